@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native libtsd hot path.
+
+Metric (BASELINE.json): Msamples/s for the 127-tap FIR on a 2^26-sample complex-float
+stream, with the dominant kernel's HBM GB/s against the 8 TB/s roofline.
+
+A "step" is one pass of the FIR (filtre_rif semantics, C ABI tsdgpu_fir_step) over one
+2^26-sample Veccf batch already resident in HBM.  With N GPUs the stream is sharded by
+contiguous chunk (weak scaling: 2^26 samples per GPU); before every step each rank receives
+its K-1-sample halo from its left neighbour over RCCL (torch.distributed send/recv) and
+installs it as the filter history -- the only exchange the path needs.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+LOG2N = 26
+K_TAPS = 127
+
+
+def design_lowpass(n, fc):
+    """Hann-windowed sinc low-pass normalised to unit DC gain (same design family as
+    libtsd's design_rif_fen(n, "lp", fc); coefficients are bench input data)."""
+    k = np.arange(n) - n // 2
+    h = 2 * fc * np.sinc(2 * fc * k)
+    w = 0.5 + 0.5 * np.cos(2 * np.pi * np.linspace(-(n // 2) / n, (n // 2) / n, n))
+    h = h * w
+    return (h / h.sum()).astype(np.float32)
+
+
+def cpu_baseline(h, seconds_target=12.0):
+    """Times the oracle (CPU restatement of FiltreRIF<cfloat,float>::step, single thread like
+    libtsd) on a bounded sample of the same workload."""
+    from oracle import pyoracle as orc
+    rng = np.random.default_rng(2)
+    n0 = 1 << 20
+    x = (rng.standard_normal(n0) + 1j * rng.standard_normal(n0)).astype(np.complex64)
+    f = orc.Fir(h)
+    t0 = time.perf_counter()
+    f.step(x)
+    dt = time.perf_counter() - t0
+    reps = max(1, min(64, int(seconds_target / max(dt, 1e-3))))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        f.step(x)
+    dt = time.perf_counter() - t0
+    return {"value": round(reps * n0 / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
+            "sample": f"{reps} x 2^20 complex samples, 127 real taps, oracle orc_fir_cf, 1 thread of {os.cpu_count()}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log2n", type=int, default=LOG2N, help="samples per GPU = 2^log2n (default: the BASELINE size)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import libtsd_amd as t
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1 or args.gpus > 1:
+        assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus}"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank)
+
+    n = 1 << args.log2n
+    h = design_lowpass(K_TAPS, 0.02)
+    g = torch.Generator(device=dev).manual_seed(2 + rank)
+    x = torch.view_as_complex(torch.randn(n, 2, device=dev, generator=g))
+    y = torch.empty_like(x)
+    halo_out = x[n - (K_TAPS - 1):].clone()
+    halo_in = torch.zeros(K_TAPS - 1, dtype=x.dtype, device=dev)
+
+    fir_auto = t.Fir(h, t.C64, t.FIR_AUTO)
+    fir_direct = t.Fir(h, t.C64, t.FIR_DIRECT)
+    method_names = {t.FIR_DIRECT: "direct", t.FIR_OVERLAP_SAVE: "overlap-save"}
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def exchange_halo(f):
+        """left-neighbour halo (K-1 samples) over RCCL send/recv; rank 0 starts from zeros."""
+        if world > 1:
+            ops = []
+            if rank + 1 < world:
+                ops.append(dist.P2POp(dist.isend, halo_out, rank + 1))
+            if rank > 0:
+                ops.append(dist.P2POp(dist.irecv, halo_in, rank - 1))
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        f.set_history(halo_in)
+
+    def run(f, steps, warmup):
+        for _ in range(warmup):
+            exchange_halo(f)
+            f.step(x, y)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            exchange_halo(f)
+            evs[i][0].record()
+            f.step(x, y)              # launched on torch's current stream (passed through the C ABI)
+            evs[i][1].record()
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+        return dt, kern_ms
+
+    dt, kern_ms = run(fir_auto, args.steps, args.warmup)
+    total_samples = float(n) * world * args.steps
+    value = total_samples / dt / 1e6
+    alg_bytes = 16.0 * n                       # 8 B read + 8 B written per complex sample
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "Msamples/s, 127-tap FIR on 2^%d cfloat stream" % args.log2n,
+            "value": round(value, 1), "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (complex64 data, real f32 taps)", "data": "synthetic",
+            "config": {"workload": "configs[1]: 127-tap FIR (design_rif_fen lp 0.02, real taps via filtrer()) "
+                                   "on 2^%d-sample Veccf per GPU, inputs resident in HBM" % args.log2n,
+                       "method": method_names[fir_auto.method], "samples_per_gpu": n,
+                       "sharding": "contiguous chunks, K-1 halo via RCCL send/recv" if world > 1 else "single GPU"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": alg_bytes},
+        }
+    # secondary line: the direct kernel on the same data (rank-local, N=1 only)
+    if world == 1:
+        dt_d, kern_d = run(fir_direct, max(3, args.steps // 4), 1)
+        out["direct"] = {"value": round(n * max(3, args.steps // 4) / dt_d / 1e6, 1), "unit": "Msamples/s",
+                         "kernel_ms": round(kern_d, 4),
+                         "hbm_frac": round(alg_bytes / (kern_d * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "valu_frac_of_157.3TF": round(4.0 * K_TAPS * n / (kern_d * 1e-3) / 157.3e12, 4)}
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(h)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

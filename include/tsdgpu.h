@@ -1,0 +1,136 @@
+/* tsdgpu.h -- C ABI of the MI355X-native streaming FIR / IIR(SOS) / FFT / resample path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, opaque handles, status codes.
+ * libtsd (the reference) has no FFI; its plug points for this path are C++ virtual
+ * interfaces and factory functions.  Each entry point below names the reference interface
+ * it stands behind (paths relative to libtsd's core/ directory); the C++ adaptors in
+ * libtsd_amd/host/ derive from those interfaces and forward here.
+ *
+ * Conventions
+ *  - every function returns a tsdgpu_status; tsdgpu_last_error() gives the message of the
+ *    last failure on the calling thread.
+ *  - data pointers (x, y) may be DEVICE pointers (hipMalloc / torch) or plain HOST
+ *    pointers; host buffers are staged through device memory by the call (H2D, kernel,
+ *    D2H) and the call returns after the result is in the host buffer.  Coefficient
+ *    pointers given to *_create are always HOST pointers and are copied.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream).  Calls with
+ *    device pointers are asynchronous on that stream.
+ *  - handles are stateful exactly like the reference's filter objects (streaming: state
+ *    is carried from one step to the next) and, like them, not thread-safe.
+ *  - complex samples are interleaved (re, im) float32 pairs == std::complex<float>.
+ */
+#ifndef TSDGPU_H
+#define TSDGPU_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  TSDGPU_OK = 0,
+  TSDGPU_ERR_INVALID = 1,      /* bad argument */
+  TSDGPU_ERR_HIP = 2,          /* a HIP runtime call failed (no device, launch failure...) */
+  TSDGPU_ERR_UNSUPPORTED = 3,  /* valid request this build cannot serve */
+  TSDGPU_ERR_ALLOC = 4
+} tsdgpu_status;
+
+typedef enum { TSDGPU_F32 = 0, TSDGPU_C64 = 1 } tsdgpu_dtype;
+
+const char *tsdgpu_last_error(void);
+/* number of visible HIP devices (0 on a CPU-only host; never fails) */
+int tsdgpu_device_count(void);
+/* "libtsd_amd x.y (gfx950)" */
+const char *tsdgpu_version(void);
+
+/* --------------------------------------------------------------------------------------
+ * FIR:  FiltreRIF<T,Tc>::step, factory filtre_rif<Tc,T>(coefs)
+ *       (src/filtrage/filtre-rt.cc:53-109,171-175; include/tsd/filtrage.hpp:1367-1368)
+ *       and the FFT-domain variant filtre_rif_fft<T> (src/fourier/fourier.cc:946-990).
+ * y[n] = sum_k h[k] x[n-k], zero initial history, history carried across steps.
+ * (data_type, tap_type) in {(F32,F32), (C64,F32), (C64,C64)} -- the reference's
+ * instantiations (filtre-rt.cc:816-818).
+ * ------------------------------------------------------------------------------------ */
+typedef struct tsdgpu_fir tsdgpu_fir;
+typedef enum {
+  TSDGPU_FIR_AUTO = 0,          /* direct for short filters, overlap-save for long ones */
+  TSDGPU_FIR_DIRECT = 1,        /* sliding dot product, same summation order as the reference */
+  TSDGPU_FIR_OVERLAP_SAVE = 2   /* block FFT convolution; output aligned with DIRECT
+                                   (no Nz-M delay, unlike the reference's OLA filter) */
+} tsdgpu_fir_method;
+
+int tsdgpu_fir_create(tsdgpu_fir **out, int data_type, int tap_type,
+                      const void *taps_host, int ntaps, int method);
+int tsdgpu_fir_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, void *stream);
+int tsdgpu_fir_reset(tsdgpu_fir *f);                     /* history <- zeros */
+/* History = the last ntaps-1 input samples (oldest first); this is the halo a multi-GPU
+ * caller exchanges between neighbouring chunks.  dst/src: host or device pointers.      */
+int tsdgpu_fir_get_history(tsdgpu_fir *f, void *dst, void *stream);
+int tsdgpu_fir_set_history(tsdgpu_fir *f, const void *src, void *stream);
+int tsdgpu_fir_method_used(const tsdgpu_fir *f);         /* DIRECT or OVERLAP_SAVE */
+int tsdgpu_fir_destroy(tsdgpu_fir *f);
+
+/* --------------------------------------------------------------------------------------
+ * FFT:  FFTPlan::configure/step, TFRPlanDefaut, tfrplan_creation / fftplan_defaut hook
+ *       (include/tsd/fourier.hpp:19-35; src/fourier/fourier.cc:61-121,360-486).
+ * Unitary scaling 1/sqrt(n) in BOTH directions, natural-order output, any n >= 1
+ * (power of two: Stockham passes; even: split recursion; odd: Bluestein).
+ * `batch` transforms of length n laid out back to back (the reference has no batch API;
+ * batch=1 is the FFTPlan::step equivalent).
+ * ------------------------------------------------------------------------------------ */
+typedef struct tsdgpu_fft tsdgpu_fft;
+int tsdgpu_fft_create(tsdgpu_fft **out, int n, int batch_hint);
+int tsdgpu_fft_step(tsdgpu_fft *p, const void *x, void *y, int batch, int forward, void *stream);
+int tsdgpu_fft_size(const tsdgpu_fft *p);
+int tsdgpu_fft_destroy(tsdgpu_fft *p);
+/* fftshift (include/tsd/fourier.hpp:232-248): pure index permutation, bit-exact */
+int tsdgpu_fftshift(const void *x, void *y, int n, int data_type, void *stream);
+
+/* --------------------------------------------------------------------------------------
+ * SOS IIR:  ChaineSOIS<T,T,T>::step over SOIS::step (DF2 / DF1) and RIIFoS::step,
+ *           factory filtre_sois<T> (src/filtrage/filtre-rt.cc:303-602).
+ * coefs: nsec rows of (b0,b1,b2,a1,a2) already normalised by a0; `gain` multiplies the
+ * output when there is no first-order section; rii1 = (b0,b1,a1) or NULL.
+ * First-call state seed: every section starts from y0=y1=(its first input sample)
+ * (filtre-rt.cc:361-365).
+ * ------------------------------------------------------------------------------------ */
+typedef struct tsdgpu_sos tsdgpu_sos;
+int tsdgpu_sos_create(tsdgpu_sos **out, int data_type, const float *coefs_host, int nsec,
+                      float gain, const float *rii1_host, int forme);
+int tsdgpu_sos_step(tsdgpu_sos *s, const void *x, void *y, int64_t n, void *stream);
+int tsdgpu_sos_reset(tsdgpu_sos *s);
+/* number of warm-up samples a chunk needs before its first output for the carried state
+ * to be exact to 2^-30 (multi-GPU halo size); -1 if the filter decays too slowly.       */
+int64_t tsdgpu_sos_halo(const tsdgpu_sos *s);
+int tsdgpu_sos_destroy(tsdgpu_sos *s);
+
+/* --------------------------------------------------------------------------------------
+ * Resampler:  AdaptationRythmeSimple<T>::step (factory filtre_itrp) over
+ *             InterpolateurRIF::step with the LUT-sinc interpolator itrp_sinc
+ *             (src/reechan/ra.cc:13-79; include/tsd/filtrage.hpp:1873-1881;
+ *             src/reechan/itrp.cc:10-55), as configured by filtre_reechan for a ratio in
+ *             [0.5,2) (ra.cc:104-156).
+ * lut_host: K x (nphases+1) float32, phase-major (lut[phase*K + i]).
+ * The output count and the (input index, LUT column) of every output follow the
+ * reference's float32 phase recurrence bit-exactly.
+ * ------------------------------------------------------------------------------------ */
+typedef struct tsdgpu_resampler tsdgpu_resampler;
+int tsdgpu_resampler_create(tsdgpu_resampler **out, int data_type, float ratio,
+                            const float *lut_host, int K, int nphases);
+/* number of outputs the next step of n inputs will produce (advances nothing) */
+int64_t tsdgpu_resampler_out_count(tsdgpu_resampler *r, int64_t n);
+int tsdgpu_resampler_step(tsdgpu_resampler *r, const void *x, int64_t n,
+                          void *y, int64_t y_capacity, int64_t *n_out, void *stream);
+int tsdgpu_resampler_reset(tsdgpu_resampler *r);
+/* jump the stream position: the next input is absolute sample `pos` of the stream
+ * (phase and output offset follow the recurrence); window history <- `hist` (K-1 samples,
+ * host or device, NULL = zeros).  This is the multi-GPU sharding hook.                   */
+int tsdgpu_resampler_seek(tsdgpu_resampler *r, int64_t pos, const void *hist, void *stream);
+int64_t tsdgpu_resampler_out_offset(const tsdgpu_resampler *r); /* outputs emitted before pos */
+int tsdgpu_resampler_destroy(tsdgpu_resampler *r);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,131 @@
+"""ctypes binding of include/tsdgpu.h.  Fails loudly when the HIP library is missing:
+there is no CPU fallback anywhere in this package."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+F32, C64 = 0, 1
+FIR_AUTO, FIR_DIRECT, FIR_OVERLAP_SAVE = 0, 1, 2
+_LIB = None
+
+
+class TsdGpuError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return os.path.join(_HERE, "lib", "libtsdgpu.so")
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise TsdGpuError(f"{p} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(make -C libtsd_amd/csrc). There is no CPU fallback.")
+        # PyTorch wheels bundle their own libamdhip64 (SONAME libamdhip64.so.7, requested by
+        # torch as "libamdhip64.so").  If ours (/opt/rocm) were loaded first the process
+        # would end up with two HIP runtimes and torch would see no GPU; importing torch
+        # first makes our DT_NEEDED libamdhip64.so.7 resolve to the copy already loaded.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        L = C.CDLL(p)
+        _declare(L)
+        _LIB = L
+    return _LIB
+
+
+def _declare(L):
+    vp, i32, i64, fl = C.c_void_p, C.c_int, C.c_int64, C.c_float
+    L.tsdgpu_last_error.restype = C.c_char_p
+    L.tsdgpu_version.restype = C.c_char_p
+    L.tsdgpu_device_count.restype = i32
+    L.tsdgpu_fir_create.argtypes = [C.POINTER(vp), i32, i32, vp, i32, i32]
+    L.tsdgpu_fir_step.argtypes = [vp, vp, vp, i64, vp]
+    L.tsdgpu_fir_reset.argtypes = [vp]
+    L.tsdgpu_fir_get_history.argtypes = [vp, vp, vp]
+    L.tsdgpu_fir_set_history.argtypes = [vp, vp, vp]
+    L.tsdgpu_fir_method_used.argtypes = [vp]
+    L.tsdgpu_fir_destroy.argtypes = [vp]
+
+
+def device_count():
+    return lib().tsdgpu_device_count()
+
+
+def _check(rc):
+    if rc != 0:
+        raise TsdGpuError(f"tsdgpu status {rc}: {lib().tsdgpu_last_error().decode()}")
+
+
+def _ptr(a):
+    """Address of a numpy array (host) or a torch tensor (host or device)."""
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    return a.data_ptr()
+
+
+def _dtype_code(a):
+    if isinstance(a, np.ndarray):
+        return C64 if np.iscomplexobj(a) else F32
+    return C64 if a.is_complex() else F32
+
+
+def _stream_of(a, stream):
+    if stream is not None:
+        return stream
+    if not isinstance(a, np.ndarray) and a.is_cuda:
+        import torch
+        return torch.cuda.current_stream(a.device).cuda_stream
+    return None
+
+
+class Fir:
+    """filtre_rif<Tc,T>(h) (filtre-rt.cc:171-175): stateful; step(x) filters one chunk."""
+
+    def __init__(self, taps, data_type, method=FIR_AUTO):
+        taps = np.ascontiguousarray(taps)
+        tt = C64 if np.iscomplexobj(taps) else F32
+        taps = taps.astype(np.complex64 if tt == C64 else np.float32)
+        self.K = len(taps)
+        self.data_type = data_type
+        self._h = C.c_void_p()
+        _check(lib().tsdgpu_fir_create(C.byref(self._h), data_type, tt, taps.ctypes.data, len(taps), method))
+
+    @property
+    def method(self):
+        return lib().tsdgpu_fir_method_used(self._h)
+
+    def step(self, x, y=None, stream=None):
+        """x: numpy array (host path) or torch tensor (device path), float32/complex64."""
+        assert _dtype_code(x) == self.data_type, "input dtype does not match the filter's data type"
+        if y is None:
+            y = np.empty_like(x) if isinstance(x, np.ndarray) else x.new_empty(x.shape)
+        _check(lib().tsdgpu_fir_step(self._h, _ptr(x), _ptr(y), x.shape[0], _stream_of(x, stream)))
+        return y
+
+    def reset(self):
+        _check(lib().tsdgpu_fir_reset(self._h))
+
+    def get_history(self, dst, stream=None):
+        _check(lib().tsdgpu_fir_get_history(self._h, _ptr(dst), _stream_of(dst, stream)))
+        return dst
+
+    def set_history(self, src, stream=None):
+        _check(lib().tsdgpu_fir_set_history(self._h, _ptr(src), _stream_of(src, stream)))
+
+    def close(self):
+        if self._h:
+            lib().tsdgpu_fir_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

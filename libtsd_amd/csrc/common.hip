@@ -1,0 +1,114 @@
+// common.hip -- error reporting and host/device staging for the C-ABI shim.
+#include "common.hpp"
+
+namespace tsdgpu {
+
+std::string &last_error_ref()
+{
+  static thread_local std::string e;
+  return e;
+}
+
+int set_err(int code, const char *fmt, ...)
+{
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  last_error_ref() = buf;
+  return code;
+}
+
+bool is_device_ptr(const void *p)
+{
+  if (!p) return false;
+  hipPointerAttribute_t attr;
+  hipError_t e = hipPointerGetAttributes(&attr, p);
+  if (e != hipSuccess) {
+    (void) hipGetLastError();  // plain host memory: clear the sticky error
+    return false;
+  }
+  return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged ||
+         attr.type == hipMemoryTypeUnified;
+}
+
+int DevBuf::reserve(size_t bytes)
+{
+  if (bytes <= cap) return TSDGPU_OK;
+  if (p) {
+    TSD_HIP(hipFree(p));
+    p = nullptr;
+    cap = 0;
+  }
+  size_t want = bytes + bytes / 8 + 256;
+  hipError_t e = hipMalloc(&p, want);
+  if (e != hipSuccess) {
+    p = nullptr;
+    return set_err(TSDGPU_ERR_ALLOC, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+  }
+  cap = want;
+  return TSDGPU_OK;
+}
+
+void DevBuf::release()
+{
+  if (p) (void) hipFree(p);
+  p = nullptr;
+  cap = 0;
+}
+
+int stage_in(const void *src, size_t bytes, DevBuf &buf, hipStream_t st, const void **dev)
+{
+  if (bytes == 0 || is_device_ptr(src)) {
+    *dev = src;
+    return TSDGPU_OK;
+  }
+  int rc = buf.reserve(bytes);
+  if (rc) return rc;
+  TSD_HIP(hipMemcpyAsync(buf.p, src, bytes, hipMemcpyHostToDevice, st));
+  *dev = buf.p;
+  return TSDGPU_OK;
+}
+
+int stage_out(void *dst, size_t bytes, DevBuf &buf, void **dev, bool *staged)
+{
+  if (bytes == 0 || is_device_ptr(dst)) {
+    *dev = dst;
+    *staged = false;
+    return TSDGPU_OK;
+  }
+  int rc = buf.reserve(bytes);
+  if (rc) return rc;
+  *dev = buf.p;
+  *staged = true;
+  return TSDGPU_OK;
+}
+
+int finish_out(void *dst, size_t bytes, const void *dev, bool staged, hipStream_t st)
+{
+  if (!staged || bytes == 0) return TSDGPU_OK;
+  TSD_HIP(hipMemcpyAsync(dst, dev, bytes, hipMemcpyDeviceToHost, st));
+  TSD_HIP(hipStreamSynchronize(st));
+  return TSDGPU_OK;
+}
+
+}  // namespace tsdgpu
+
+extern "C" {
+
+const char *tsdgpu_last_error(void) { return tsdgpu::last_error_ref().c_str(); }
+
+int tsdgpu_device_count(void)
+{
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void) hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+
+const char *tsdgpu_version(void) { return "libtsd_amd 0.1 (gfx950)"; }
+
+}  // extern "C"

@@ -1,0 +1,55 @@
+// common.hpp -- shared host-side helpers of the C-ABI shim (error reporting, host/device
+// pointer staging).  Product code: never includes or links anything under oracle/.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/tsdgpu.h"
+
+namespace tsdgpu {
+
+std::string &last_error_ref();
+int set_err(int code, const char *fmt, ...);
+
+#define TSD_HIP(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t e__ = (expr);                                                            \
+    if (e__ != hipSuccess)                                                              \
+      return ::tsdgpu::set_err(TSDGPU_ERR_HIP, "%s failed: %s (%s:%d)", #expr,          \
+                               hipGetErrorString(e__), __FILE__, __LINE__);             \
+  } while (0)
+
+#define TSD_CHECK(cond, ...)                                                            \
+  do {                                                                                  \
+    if (!(cond)) return ::tsdgpu::set_err(TSDGPU_ERR_INVALID, __VA_ARGS__);             \
+  } while (0)
+
+inline size_t dtype_size(int dt) { return dt == TSDGPU_C64 ? 8 : 4; }
+
+// true when p is memory the device can dereference in a kernel (hipMalloc'd, managed or
+// registered host memory)
+bool is_device_ptr(const void *p);
+
+// Grow-only device scratch buffer owned by a handle.
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes);
+  void release();
+  template <typename T> T *as() const { return static_cast<T *>(p); }
+};
+
+// Presents a (host or device) input as a device pointer; host data is copied to `buf`.
+int stage_in(const void *src, size_t bytes, DevBuf &buf, hipStream_t st, const void **dev);
+// Gives a device pointer to write the output to: `dst` itself when it is device memory,
+// else `buf`.  finish_out() copies back to the host buffer and synchronises when staged.
+int stage_out(void *dst, size_t bytes, DevBuf &buf, void **dev, bool *staged);
+int finish_out(void *dst, size_t bytes, const void *dev, bool staged, hipStream_t st);
+
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace tsdgpu

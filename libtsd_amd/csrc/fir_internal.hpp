@@ -1,0 +1,29 @@
+// fir_internal.hpp -- FIR handle shared by the direct (fir.hip) and overlap-save (ols.hip) paths.
+#pragma once
+#include "common.hpp"
+
+struct tsdgpu_fir {
+  int data_type = 0, tap_type = 0;
+  int K = 0;            // taps
+  int KP = 0;           // taps padded to a multiple of 2R (direct kernel); also history length
+  int method = TSDGPU_FIR_DIRECT;
+  void *d_hrev = nullptr;   // reversed zero-padded taps, KP entries of tap_type
+  void *hist[2] = {nullptr, nullptr};   // last KP input samples (double-buffered), newest last
+  int cur = 0;
+  std::vector<char> taps_host;
+  tsdgpu::DevBuf in_stage, out_stage;
+  // overlap-save plan (ols.hip)
+  void *d_H = nullptr;      // frequency response in the kernel's register order
+  int ols_N = 0;            // FFT block size
+  int ols_L = 0;            // valid outputs per block = N - (K-1)
+};
+
+namespace tsdgpu {
+int fir_direct_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, hipStream_t st);
+int fir_update_history(tsdgpu_fir *f, const void *x, int64_t n, hipStream_t st);
+// overlap-save
+bool ols_preferred(const tsdgpu_fir *f);
+int ols_plan_create(tsdgpu_fir *f);
+void ols_plan_destroy(tsdgpu_fir *f);
+int ols_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, hipStream_t st);
+}  // namespace tsdgpu

@@ -1,0 +1,49 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol
+include/tsdgpu.h declares, and fails loudly (no CPU fallback) when no GPU is present."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "tsdgpu.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(tsdgpu_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    import libtsd_amd
+    L = libtsd_amd.lib()
+    names = declared_symbols()
+    assert len(names) >= 10
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, f"declared in include/tsdgpu.h but not exported: {missing}"
+
+
+def test_no_cpu_fallback():
+    import libtsd_amd as t
+    if t.device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(t.TsdGpuError):
+        t.Fir([1.0, 2.0, 3.0], t.F32)
+
+
+def test_product_never_touches_oracle():
+    """The product path must not import, link or call anything under oracle/."""
+    bad = []
+    for base in ("libtsd_amd",):
+        for dp, _, fns in os.walk(os.path.join(ROOT, base)):
+            if "build" in dp.split(os.sep):
+                continue
+            for fn in fns:
+                if fn.endswith((".py", ".hip", ".hpp", ".h", ".cc", ".cpp", "Makefile")):
+                    txt = open(os.path.join(dp, fn), errors="ignore").read()
+                    if re.search(r"(import|from)\s+oracle|pyoracle|liborc|tsd_oracle\.h|orc_[a-z]+\(", txt):
+                        bad.append(os.path.join(dp, fn))
+    assert not bad, bad
+    out = os.popen(f"ldd {os.path.join(ROOT, 'libtsd_amd', 'lib', 'libtsdgpu.so')}").read()
+    assert "liborc" not in out

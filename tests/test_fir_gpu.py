@@ -1,0 +1,165 @@
+"""GPU parity of the FIR path (through the C ABI) against the CPU oracle.
+Tolerance for float data: max|y - y_ref| <= 1e-5 * max|y_ref|  (BASELINE.json north_star).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def relerr(y, ref):
+    return float(np.abs(y - ref).max() / max(np.abs(ref).max(), 1e-30))
+
+
+def rand(n, cplx, seed):
+    rng = np.random.default_rng(seed)
+    if cplx:
+        return (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    return rng.standard_normal(n).astype(np.float32)
+
+
+@pytest.fixture(scope="module")
+def tg():
+    import libtsd_amd as t
+    assert t.device_count() >= 1, "no GPU visible"
+    return t
+
+
+def methods(t):
+    return [t.FIR_DIRECT, t.FIR_OVERLAP_SAVE]
+
+
+# BASELINE configs[0]: 31-tap low-pass (design_rif_fen) on a 4096-sample real vector
+@pytest.mark.parametrize("method", [1, 2])
+def test_cfg1_31tap_real(tg, orc, method):
+    h = orc.design_rif_fen(31, "lp", 0.25)
+    x = rand(4096, False, 1)
+    ref = orc.fir(h, x)
+    y = tg.Fir(h, tg.F32, method).step(x)
+    assert relerr(y, ref) <= TOL
+
+
+# reference test_filtre_rif (test-filtres.cc:479-511): impulse -> taps
+@pytest.mark.parametrize("method", [1, 2])
+def test_impulse_response_is_taps(tg, method):
+    nc, n = 31, 81
+    h = np.linspace(1, nc, nc).astype(np.float32)
+    x = np.zeros(n, np.float32)
+    x[0] = 1
+    y = tg.Fir(h, tg.F32, method).step(x)
+    ref = np.concatenate([h, np.zeros(n - nc, np.float32)])
+    assert np.abs(y - ref).max() <= (1e-7 if method == 1 else 1e-5 * nc)
+
+
+@pytest.mark.parametrize("method", [1, 2])
+@pytest.mark.parametrize("cplx_data,cplx_taps", [(False, False), (True, False), (True, True)])
+@pytest.mark.parametrize("K", [1, 2, 15, 31, 127, 128, 129, 500])
+def test_fir_parity(tg, orc, method, cplx_data, cplx_taps, K):
+    n = 20000
+    h = rand(K, cplx_taps, K) / np.float32(np.sqrt(K))
+    x = rand(n, cplx_data, K + 1)
+    ref = orc.fir(h, x)
+    y = tg.Fir(h, tg.C64 if cplx_data else tg.F32, method).step(x)
+    assert y.shape == ref.shape
+    assert relerr(y, ref) <= TOL
+
+
+# filtre_par_bloc (test-filtres.cc:9-31): chunked streaming == one shot, ragged chunk sizes
+@pytest.mark.parametrize("method", [1, 2])
+@pytest.mark.parametrize("bs", [1000, 311, 80, 4, 1])
+def test_fir_streaming_chunks(tg, orc, method, bs):
+    h = orc.design_rif_fen(127, "lp", 0.02)
+    n = 5000 if bs > 1 else 300
+    x = rand(n, True, 3)
+    ref = orc.fir(h, x)
+    f = tg.Fir(h, tg.C64, method)
+    y = np.concatenate([f.step(x[o:o + bs].copy()) for o in range(0, n, bs)])
+    assert relerr(y, ref) <= TOL
+
+
+@pytest.mark.parametrize("method", [1, 2])
+def test_fir_empty_and_reset(tg, orc, method):
+    h = orc.design_rif_fen(31, "lp", 0.25)
+    f = tg.Fir(h, tg.F32, method)
+    assert f.step(np.zeros(0, np.float32)).shape == (0,)
+    x = rand(1000, False, 9)
+    y1 = f.step(x)
+    f.reset()
+    y2 = f.step(x)
+    assert np.array_equal(y1, y2)
+    assert relerr(y1, orc.fir(h, x)) <= TOL
+
+
+# device-resident path (torch tensors), in-place allowed (filtre-rt.cc:76-80), unaligned views
+@pytest.mark.parametrize("method", [1, 2])
+def test_fir_device_inplace_and_views(tg, orc, method):
+    import torch
+    h = orc.design_rif_fen(127, "lp", 0.02)
+    x = rand(70001, True, 4)
+    ref = orc.fir(h, x)
+    xd = torch.from_numpy(x).cuda()
+    f = tg.Fir(h, tg.C64, method)
+    yd = f.step(xd)
+    torch.cuda.synchronize()
+    assert relerr(yd.cpu().numpy(), ref) <= TOL
+    f.reset()
+    f.step(xd, xd)                      # in place
+    torch.cuda.synchronize()
+    assert relerr(xd.cpu().numpy(), ref) <= TOL
+    # odd offset view: 8-byte aligned only
+    xo = torch.from_numpy(x).cuda()[1:]
+    f.reset()
+    yo = f.step(xo)
+    torch.cuda.synchronize()
+    assert relerr(yo.cpu().numpy(), orc.fir(h, x[1:])) <= TOL
+
+
+# halo hook used by the multi-GPU sharding: chunk b seeded with chunk a's history
+@pytest.mark.parametrize("method", [1, 2])
+def test_fir_history_halo(tg, orc, method):
+    h = orc.design_rif_fen(127, "lp", 0.02)
+    x = rand(40000, True, 5)
+    ref = orc.fir(h, x)
+    fa, fb = tg.Fir(h, tg.C64, method), tg.Fir(h, tg.C64, method)
+    ya = fa.step(x[:20000].copy())
+    halo = fa.get_history(np.empty(126, np.complex64))
+    assert np.array_equal(halo, x[20000 - 126:20000])
+    fb.set_history(halo)
+    yb = fb.step(x[20000:].copy())
+    assert relerr(np.concatenate([ya, yb]), ref) <= TOL
+
+
+# BASELINE configs[1] at full size: 127 taps on 2^26 complex samples; oracle on a slice,
+# size-independent properties on the whole (linearity + block-shift invariance).
+@pytest.mark.parametrize("method", [1, 2])
+def test_cfg2_full_size_properties(tg, orc, method):
+    import torch
+    n = 1 << 26
+    h = orc.design_rif_fen(127, "lp", 0.02)
+    torch.cuda.init()
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(2)
+    x = torch.view_as_complex(torch.randn(n, 2, device=dev, generator=g))
+    f = tg.Fir(h, tg.C64, method)
+    y = f.step(x)
+    torch.cuda.synchronize()
+    # (a) oracle on two windows (start, and a far tile boundary region)
+    for o in (0, n - 300000):
+        lo = max(o - 126, 0)
+        seg = x[lo:o + 200000].cpu().numpy()
+        ref = orc.fir(h, seg)[o - lo:]
+        assert relerr(y[o:o + 200000].cpu().numpy(), ref) <= TOL
+    # (b) linearity: F(a*x) == a*F(x)
+    f.reset()
+    y2 = f.step(x * 2.0)
+    torch.cuda.synchronize()
+    assert float((y2 - 2.0 * y).abs().max()) <= 1e-5 * float(y.abs().max())
+    # (c) time invariance: filtering x delayed by d equals y delayed by d
+    d = 12345
+    xs = torch.cat([torch.zeros(d, dtype=x.dtype, device="cuda"), x[:n - d]])
+    f.reset()
+    ys = f.step(xs)
+    torch.cuda.synchronize()
+    assert float((ys[d:] - y[:n - d]).abs().max()) <= 1e-5 * float(y.abs().max())
