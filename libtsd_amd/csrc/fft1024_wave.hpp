@@ -1,0 +1,236 @@
+// fft1024_wave.hpp -- 1024-point complex FFT held by ONE wave64 (16 points per lane).
+//
+// 1024 = 16 x 16 x 4, decimation in frequency for the forward direction and the exact
+// mirror (decimation in time) for the inverse, so that forward followed by inverse needs
+// no reordering at all: the spectrum lives in a "register order" that only this file
+// knows (freq_index()).  Used by the overlap-save FIR (ols.hip) and as the row/column
+// transform of the large four-step FFT (fft.hip).
+//
+//   stage A  lane = n2 (0..63), reg = n1 (0..15): time index t = 64*n1 + n2.
+//            radix-16 over n1 -> k1, times W_1024^(n2*k1)
+//   xchg 1   through LDS: element (k1, n2 = 4*m1 + m2)  ->  lane (k1, m2), reg m1
+//   stage B  radix-16 over m1 -> j1, times W_64^(m2*j1)
+//   xchg 2   element (k1, j1 = 4*j1hi + j1lo, m2) -> lane (k1, j1lo), reg (j1hi, m2)
+//   stage C  radix-4 over m2 -> j2.   frequency k = k1 + 16*j1 + 256*j2.
+//
+// LDS image: 16 rows of 68 complex (64 + 4 pad) = 8704 B per wave; with the address maps
+// below every ds_write_b64 / ds_read_b64 of both exchanges, in both directions, is
+// bank-conflict free (rows shift by 4 slots, m2 planes by 17).
+//
+// Everything is plain C++ on float pairs: the same code is compiled by g++ for the
+// CPU-side structural test (tests/cpu/test_fft1024_wave.cc emulates the 64 lanes).
+#pragma once
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define TSD_HD __host__ __device__ __forceinline__
+namespace tsdgpu { using cpx = float2; }
+#else
+#include <cmath>
+#define TSD_HD inline
+namespace tsdgpu { struct cpx { float x, y; }; }
+#endif
+
+namespace tsdgpu {
+namespace w1024 {
+
+constexpr int LDS_ROW = 68;                 // complex elements per k1 row
+constexpr int LDS_ELEMS = 16 * LDS_ROW;     // 1088 complex = 8704 bytes per wave
+
+TSD_HD cpx mk(float a, float b) { cpx r; r.x = a; r.y = b; return r; }
+TSD_HD cpx cadd(cpx a, cpx b) { return mk(a.x + b.x, a.y + b.y); }
+TSD_HD cpx csub(cpx a, cpx b) { return mk(a.x - b.x, a.y - b.y); }
+TSD_HD cpx cmul(cpx a, cpx b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+TSD_HD cpx cmulc(cpx a, cpx b) { return mk(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a*conj(b)
+template <bool INV> TSD_HD cpx ctw(cpx a, cpx w) { return INV ? cmulc(a, w) : cmul(a, w); }
+// multiply by -i (forward) / +i (inverse)
+template <bool INV> TSD_HD cpx rot90(cpx a) { return INV ? mk(-a.y, a.x) : mk(a.y, -a.x); }
+
+// 4-point DFT, natural order in and out. forward: W4 = -i.
+template <bool INV> TSD_HD void dft4(cpx &a, cpx &b, cpx &c, cpx &d)
+{
+  const cpx t0 = cadd(a, c), t1 = csub(a, c), t2 = cadd(b, d), t3 = rot90<INV>(csub(b, d));
+  a = cadd(t0, t2);
+  b = cadd(t1, t3);
+  c = csub(t0, t2);
+  d = csub(t1, t3);
+}
+
+// 16-point DFT in registers, natural order in and out.
+template <bool INV> TSD_HD void dft16(cpx (&v)[16])
+{
+  constexpr float C1 = 0.92387953251128674f;   // cos(pi/8)
+  constexpr float S1 = 0.38268343236508977f;   // sin(pi/8)
+  constexpr float R2 = 0.70710678118654752f;   // sqrt(1/2)
+  // stage 1: over n1 (stride 4) for each n2:  v[4*k1 + n2] <- sum_n1 x[4*n1 + n2] W4^(n1 k1)
+#pragma unroll
+  for (int n2 = 0; n2 < 4; n2++) dft4<INV>(v[n2], v[4 + n2], v[8 + n2], v[12 + n2]);
+  // twiddles W16^(n2*k1), forward value (conjugated by ctw<INV> for the inverse)
+  v[5] = ctw<INV>(v[5], mk(C1, -S1));      // k1=1,n2=1: W16^1
+  v[6] = ctw<INV>(v[6], mk(R2, -R2));      // k1=1,n2=2: W16^2
+  v[7] = ctw<INV>(v[7], mk(S1, -C1));      // k1=1,n2=3: W16^3
+  v[9] = ctw<INV>(v[9], mk(R2, -R2));      // k1=2,n2=1: W16^2
+  v[10] = rot90<INV>(v[10]);               // k1=2,n2=2: W16^4 = -i
+  v[11] = ctw<INV>(v[11], mk(-R2, -R2));   // k1=2,n2=3: W16^6
+  v[13] = ctw<INV>(v[13], mk(S1, -C1));    // k1=3,n2=1: W16^3
+  v[14] = ctw<INV>(v[14], mk(-R2, -R2));   // k1=3,n2=2: W16^6
+  v[15] = ctw<INV>(v[15], mk(-C1, S1));    // k1=3,n2=3: W16^9
+  // stage 2: over n2 for each k1: v[4*k1 + k2] <- X[k1 + 4*k2]
+#pragma unroll
+  for (int k1 = 0; k1 < 4; k1++) dft4<INV>(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
+  // transpose to natural order: out[k1 + 4*k2] = v[4*k1 + k2]
+#pragma unroll
+  for (int a = 0; a < 4; a++)
+#pragma unroll
+    for (int b = a + 1; b < 4; b++) {
+      const cpx t = v[4 * a + b];
+      v[4 * a + b] = v[4 * b + a];
+      v[4 * b + a] = t;
+    }
+}
+
+// ---- per-lane constants ------------------------------------------------------------------
+// tw1[k1] = W_1024^(lane*k1)            (stage A, lane = n2)
+// tw2[j1] = W_64^((lane&3)*j1)          (stage B, lane = 4*k1 + m2)
+// Tables are produced on the host in double precision (fill_twiddles) and laid out
+// [16][64] so a wave reads them with coalesced loads.
+inline void fill_twiddles(cpx *tw1, cpx *tw2)
+{
+  const double PI = 3.14159265358979323846;
+  for (int r = 0; r < 16; r++)
+    for (int lane = 0; lane < 64; lane++) {
+      double a1 = -2.0 * PI * (double) (lane * r) / 1024.0;
+      tw1[r * 64 + lane] = mk((float) std::cos(a1), (float) std::sin(a1));
+      double a2 = -2.0 * PI * (double) ((lane & 3) * r) / 64.0;
+      tw2[r * 64 + lane] = mk((float) std::cos(a2), (float) std::sin(a2));
+    }
+}
+
+// frequency bin held by (lane, reg) after forward(): lane = 4*k1 + j1lo, reg = 4*j1hi + j2
+TSD_HD int freq_index(int lane, int reg)
+{
+  const int k1 = lane >> 2, j1lo = lane & 3, j1hi = reg >> 2, j2 = reg & 3;
+  return k1 + 16 * (4 * j1hi + j1lo) + 256 * j2;
+}
+// time sample held by (lane, reg) before forward() / after inverse()
+TSD_HD int time_index(int lane, int reg) { return 64 * reg + lane; }
+
+// ---- the phases.  SYNC() must order LDS writes before the following LDS reads of the
+// same wave (a __syncthreads() in a 64-lane workgroup; a no-op per-phase loop on the CPU).
+template <bool INV> TSD_HD void stageA(cpx (&v)[16], const cpx (&tw1)[16])
+{
+  if (!INV) {
+    dft16<false>(v);
+#pragma unroll
+    for (int r = 1; r < 16; r++) v[r] = cmul(v[r], tw1[r]);
+  } else {
+#pragma unroll
+    for (int r = 1; r < 16; r++) v[r] = cmulc(v[r], tw1[r]);
+    dft16<true>(v);
+  }
+}
+template <bool INV> TSD_HD void stageB(cpx (&v)[16], const cpx (&tw2)[16])
+{
+  if (!INV) {
+    dft16<false>(v);
+#pragma unroll
+    for (int r = 1; r < 16; r++) v[r] = cmul(v[r], tw2[r]);
+  } else {
+#pragma unroll
+    for (int r = 1; r < 16; r++) v[r] = cmulc(v[r], tw2[r]);
+    dft16<true>(v);
+  }
+}
+template <bool INV> TSD_HD void stageC(cpx (&v)[16])
+{
+#pragma unroll
+  for (int h = 0; h < 4; h++) dft4<INV>(v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]);
+}
+
+// exchange 1, forward direction: lane n2 / reg k1  ->  lane (k1,m2) / reg m1
+TSD_HD void x1_write_rows(const cpx (&v)[16], cpx *lds, int lane)
+{
+#pragma unroll
+  for (int r = 0; r < 16; r++) lds[LDS_ROW * r + lane] = v[r];
+}
+TSD_HD void x1_read_rows(cpx (&v)[16], const cpx *lds, int lane)
+{
+#pragma unroll
+  for (int r = 0; r < 16; r++) v[r] = lds[LDS_ROW * r + lane];
+}
+TSD_HD void x1_write_cols(const cpx (&v)[16], cpx *lds, int lane)
+{
+  const int base = LDS_ROW * (lane >> 2) + (lane & 3);
+#pragma unroll
+  for (int m1 = 0; m1 < 16; m1++) lds[base + 4 * m1] = v[m1];
+}
+TSD_HD void x1_read_cols(cpx (&v)[16], const cpx *lds, int lane)
+{
+  const int base = LDS_ROW * (lane >> 2) + (lane & 3);
+#pragma unroll
+  for (int m1 = 0; m1 < 16; m1++) v[m1] = lds[base + 4 * m1];
+}
+// exchange 2: image [k1][m2][j1] with plane stride 17
+TSD_HD void x2_write_j1(const cpx (&v)[16], cpx *lds, int lane)     // lane (k1,m2), reg j1
+{
+  const int base = LDS_ROW * (lane >> 2) + 17 * (lane & 3);
+#pragma unroll
+  for (int j1 = 0; j1 < 16; j1++) lds[base + j1] = v[j1];
+}
+TSD_HD void x2_read_j1(cpx (&v)[16], const cpx *lds, int lane)
+{
+  const int base = LDS_ROW * (lane >> 2) + 17 * (lane & 3);
+#pragma unroll
+  for (int j1 = 0; j1 < 16; j1++) v[j1] = lds[base + j1];
+}
+TSD_HD void x2_write_m2(const cpx (&v)[16], cpx *lds, int lane)     // lane (k1,j1lo), reg (j1hi,m2)
+{
+  const int base = LDS_ROW * (lane >> 2) + (lane & 3);
+#pragma unroll
+  for (int h = 0; h < 4; h++)
+#pragma unroll
+    for (int m2 = 0; m2 < 4; m2++) lds[base + 17 * m2 + 4 * h] = v[4 * h + m2];
+}
+TSD_HD void x2_read_m2(cpx (&v)[16], const cpx *lds, int lane)
+{
+  const int base = LDS_ROW * (lane >> 2) + (lane & 3);
+#pragma unroll
+  for (int h = 0; h < 4; h++)
+#pragma unroll
+    for (int m2 = 0; m2 < 4; m2++) v[4 * h + m2] = lds[base + 17 * m2 + 4 * h];
+}
+
+// Whole transforms for one lane; SYNC is a callable.  Unnormalised (the caller folds 1/N or
+// 1/sqrt(N) into a later multiply).
+template <typename SYNC>
+TSD_HD void forward(cpx (&v)[16], cpx *lds, int lane, const cpx (&tw1)[16], const cpx (&tw2)[16], SYNC sync)
+{
+  stageA<false>(v, tw1);
+  x1_write_rows(v, lds, lane);
+  sync();
+  x1_read_cols(v, lds, lane);
+  stageB<false>(v, tw2);
+  sync();
+  x2_write_j1(v, lds, lane);
+  sync();
+  x2_read_m2(v, lds, lane);
+  stageC<false>(v);
+}
+template <typename SYNC>
+TSD_HD void inverse(cpx (&v)[16], cpx *lds, int lane, const cpx (&tw1)[16], const cpx (&tw2)[16], SYNC sync)
+{
+  stageC<true>(v);
+  sync();
+  x2_write_m2(v, lds, lane);
+  sync();
+  x2_read_j1(v, lds, lane);
+  stageB<true>(v, tw2);
+  sync();
+  x1_write_cols(v, lds, lane);
+  sync();
+  x1_read_rows(v, lds, lane);
+  stageA<true>(v, tw1);
+}
+
+}  // namespace w1024
+}  // namespace tsdgpu

@@ -16,6 +16,7 @@ struct tsdgpu_fir {
   void *d_H = nullptr;      // frequency response in the kernel's register order
   int ols_N = 0;            // FFT block size
   int ols_L = 0;            // valid outputs per block = N - (K-1)
+  int ols_grid = 0;         // persistent grid size (waves)
 };
 
 namespace tsdgpu {

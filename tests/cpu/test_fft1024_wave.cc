@@ -1,0 +1,84 @@
+// CPU structural test of libtsd_amd/csrc/fft1024_wave.hpp: emulates the 64 lanes of a wave
+// phase by phase (each phase for all lanes before the next = what the LDS sync guarantees)
+// and checks forward() against a double-precision DFT and inverse(forward(x)) == N*x.
+#include <complex>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../../libtsd_amd/csrc/fft1024_wave.hpp"
+using namespace tsdgpu;
+using namespace tsdgpu::w1024;
+
+int main()
+{
+  const int N = 1024;
+  std::vector<cpx> tw1(1024), tw2(1024), lds(LDS_ELEMS);
+  fill_twiddles(tw1.data(), tw2.data());
+  std::vector<std::complex<double>> x(N), X(N);
+  srand(1);
+  for (auto &v : x) v = {rand() / (double) RAND_MAX - 0.5, rand() / (double) RAND_MAX - 0.5};
+  const double PI = 3.14159265358979323846;
+  for (int k = 0; k < N; k++) {
+    std::complex<double> s = 0;
+    for (int n = 0; n < N; n++) s += x[n] * std::polar(1.0, -2 * PI * (double) ((long) k * n % N) / N);
+    X[k] = s;
+  }
+  cpx v[64][16], t1[64][16], t2[64][16];
+  for (int l = 0; l < 64; l++)
+    for (int r = 0; r < 16; r++) {
+      auto s = x[time_index(l, r)];
+      v[l][r] = mk((float) s.real(), (float) s.imag());
+      t1[l][r] = tw1[r * 64 + l];
+      t2[l][r] = tw2[r * 64 + l];
+    }
+#define ALL(stmt) for (int l = 0; l < 64; l++) { stmt; }
+  // forward (same sequence as w1024::forward)
+  ALL(stageA<false>(v[l], t1[l]));  ALL(x1_write_rows(v[l], lds.data(), l));
+  ALL(x1_read_cols(v[l], lds.data(), l)); ALL(stageB<false>(v[l], t2[l]));
+  ALL(x2_write_j1(v[l], lds.data(), l)); ALL(x2_read_m2(v[l], lds.data(), l));
+  ALL(stageC<false>(v[l]));
+  double emax = 0, ref = 0;
+  for (int l = 0; l < 64; l++)
+    for (int r = 0; r < 16; r++) {
+      auto e = X[freq_index(l, r)];
+      emax = std::max(emax, std::abs(std::complex<double>(v[l][r].x, v[l][r].y) - e));
+      ref = std::max(ref, std::abs(e));
+    }
+  printf("forward: max err %.3e (max |X| %.3e)\n", emax, ref);
+  if (emax > 2e-6 * ref * 10) { printf("FAIL forward\n"); return 1; }
+  // every frequency index appears exactly once
+  std::vector<int> seen(N, 0);
+  for (int l = 0; l < 64; l++) for (int r = 0; r < 16; r++) seen[freq_index(l, r)]++;
+  for (int k = 0; k < N; k++) if (seen[k] != 1) { printf("FAIL freq_index not a bijection\n"); return 1; }
+  // inverse (same sequence as w1024::inverse)
+  ALL(stageC<true>(v[l])); ALL(x2_write_m2(v[l], lds.data(), l)); ALL(x2_read_j1(v[l], lds.data(), l));
+  ALL(stageB<true>(v[l], t2[l])); ALL(x1_write_cols(v[l], lds.data(), l)); ALL(x1_read_rows(v[l], lds.data(), l));
+  ALL(stageA<true>(v[l], t1[l]));
+  double e2 = 0;
+  for (int l = 0; l < 64; l++)
+    for (int r = 0; r < 16; r++) {
+      auto s = x[time_index(l, r)] * (double) N;
+      e2 = std::max(e2, std::abs(std::complex<double>(v[l][r].x, v[l][r].y) - s));
+    }
+  printf("round trip: max err %.3e (scale %d)\n", e2, N);
+  if (e2 > 1e-5 * N) { printf("FAIL inverse\n"); return 1; }
+  // bank-conflict audit of both exchanges (8-byte slots): reads in 32-lane halves over 32
+  // slots, writes in 16-lane groups over 16 slots
+  auto audit = [&](auto addr, int group, int slots, const char *name) {
+    for (int r = 0; r < 16; r++)
+      for (int g = 0; g < 64; g += group) {
+        std::vector<int> cnt(slots, 0);
+        for (int l = g; l < g + group; l++) if (++cnt[addr(l, r) % slots] > 1) { printf("FAIL bank conflict in %s\n", name); exit(1); }
+      }
+  };
+  audit([](int l, int r) { return LDS_ROW * r + l; }, 16, 16, "x1 rows write");
+  audit([](int l, int r) { return LDS_ROW * r + l; }, 32, 32, "x1 rows read");
+  audit([](int l, int r) { return LDS_ROW * (l >> 2) + (l & 3) + 4 * r; }, 16, 16, "x1 cols write");
+  audit([](int l, int r) { return LDS_ROW * (l >> 2) + (l & 3) + 4 * r; }, 32, 32, "x1 cols read");
+  audit([](int l, int r) { return LDS_ROW * (l >> 2) + 17 * (l & 3) + r; }, 16, 16, "x2 j1 write");
+  audit([](int l, int r) { return LDS_ROW * (l >> 2) + 17 * (l & 3) + r; }, 32, 32, "x2 j1 read");
+  audit([](int l, int r) { return LDS_ROW * (l >> 2) + (l & 3) + 17 * (r & 3) + 4 * (r >> 2); }, 16, 16, "x2 m2 write");
+  audit([](int l, int r) { return LDS_ROW * (l >> 2) + (l & 3) + 17 * (r & 3) + 4 * (r >> 2); }, 32, 32, "x2 m2 read");
+  printf("OK\n");
+  return 0;
+}
