@@ -137,7 +137,7 @@ static int launch_direct(const tsdgpu_fir *f, const void *x, void *y, int64_t n,
   const int64_t tiles = cdiv(n, TILE);
   if (tiles > 0x7fffffff) return set_err(TSDGPU_ERR_UNSUPPORTED, "fir: n too large for one launch");
   hipLaunchKernelGGL((fir_direct_kernel<T, TC, R, THREADS>), dim3((unsigned) tiles), dim3(THREADS),
-                     lds, st, (const T *) x, (const T *) f->hist[f->cur], (T *) y,
+                     lds, st, (const T *) x, (const T *) f->hist[f->cur] + (f->HL - KP), (T *) y,
                      (const TC *) f->d_hrev, KP, n);
   TSD_HIP(hipGetLastError());
   return TSDGPU_OK;
@@ -152,7 +152,7 @@ int fir_direct_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, hipStream_
 
 int fir_update_history(tsdgpu_fir *f, const void *x, int64_t n, hipStream_t st)
 {
-  const int H = f->KP;
+  const int H = f->HL;
   const int nxt = f->cur ^ 1;
   const int blocks = (int) cdiv(H, 256);
   if (f->data_type == TSDGPU_F32)
@@ -191,6 +191,7 @@ int tsdgpu_fir_create(tsdgpu_fir **out, int data_type, int tap_type, const void 
   f->K = ntaps;
   const int R = data_type == TSDGPU_F32 ? 16 : 8;
   f->KP = (int) (cdiv(ntaps, 2 * R) * 2 * R);
+  f->HL = (int) (cdiv(f->KP, 64) * 64);
 
   // reversed, zero-padded taps: hrev[j] = h[KP-1-j]  (zeros on the old side)
   const size_t tsz = dtype_size(tap_type);
@@ -200,7 +201,7 @@ int tsdgpu_fir_create(tsdgpu_fir **out, int data_type, int tap_type, const void 
   f->taps_host.assign((const char *) taps_host, (const char *) taps_host + (size_t) ntaps * tsz);
 
   int rc = TSDGPU_OK;
-  const size_t hbytes = (size_t) f->KP * dtype_size(data_type);
+  const size_t hbytes = (size_t) f->HL * dtype_size(data_type);
   do {
     if (hipMalloc(&f->d_hrev, hrev.size()) != hipSuccess ||
         hipMalloc(&f->hist[0], hbytes) != hipSuccess || hipMalloc(&f->hist[1], hbytes) != hipSuccess) {
@@ -259,7 +260,7 @@ int tsdgpu_fir_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, void *stre
 int tsdgpu_fir_reset(tsdgpu_fir *f)
 {
   TSD_CHECK(f != nullptr, "fir_reset: NULL handle");
-  const size_t hbytes = (size_t) f->KP * dtype_size(f->data_type);
+  const size_t hbytes = (size_t) f->HL * dtype_size(f->data_type);
   TSD_HIP(hipMemset(f->hist[f->cur], 0, hbytes));
   return TSDGPU_OK;
 }
@@ -270,7 +271,7 @@ int tsdgpu_fir_get_history(tsdgpu_fir *f, void *dst, void *stream)
   if (f->K < 2) return TSDGPU_OK;
   hipStream_t st = (hipStream_t) stream;
   const size_t sz = dtype_size(f->data_type);
-  const char *src = (const char *) f->hist[f->cur] + (size_t) (f->KP - (f->K - 1)) * sz;
+  const char *src = (const char *) f->hist[f->cur] + (size_t) (f->HL - (f->K - 1)) * sz;
   const bool dev = is_device_ptr(dst);
   TSD_HIP(hipMemcpyAsync(dst, src, (size_t) (f->K - 1) * sz, dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
   if (!dev) TSD_HIP(hipStreamSynchronize(st));
@@ -283,7 +284,7 @@ int tsdgpu_fir_set_history(tsdgpu_fir *f, const void *src, void *stream)
   if (f->K < 2) return TSDGPU_OK;
   hipStream_t st = (hipStream_t) stream;
   const size_t sz = dtype_size(f->data_type);
-  char *dst = (char *) f->hist[f->cur] + (size_t) (f->KP - (f->K - 1)) * sz;
+  char *dst = (char *) f->hist[f->cur] + (size_t) (f->HL - (f->K - 1)) * sz;
   const bool dev = is_device_ptr(src);
   TSD_HIP(hipMemcpyAsync(dst, src, (size_t) (f->K - 1) * sz, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
   if (!dev) TSD_HIP(hipStreamSynchronize(st));

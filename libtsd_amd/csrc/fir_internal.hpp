@@ -5,10 +5,11 @@
 struct tsdgpu_fir {
   int data_type = 0, tap_type = 0;
   int K = 0;            // taps
-  int KP = 0;           // taps padded to a multiple of 2R (direct kernel); also history length
+  int KP = 0;           // taps padded to a multiple of 2R (direct kernel)
+  int HL = 0;           // history length kept in hist[]: >= KP and >= the overlap-save overlap
   int method = TSDGPU_FIR_DIRECT;
   void *d_hrev = nullptr;   // reversed zero-padded taps, KP entries of tap_type
-  void *hist[2] = {nullptr, nullptr};   // last KP input samples (double-buffered), newest last
+  void *hist[2] = {nullptr, nullptr};   // last HL input samples (double-buffered), newest last
   int cur = 0;
   std::vector<char> taps_host;
   tsdgpu::DevBuf in_stage, out_stage;

@@ -15,72 +15,138 @@
 // hit) and 8 B written per sample.
 #include "fir_internal.hpp"
 #include "fft1024_wave.hpp"
+#include <cstdlib>
 
 namespace tsdgpu {
 
 using namespace w1024;
 constexpr int OLS_N = 1024;
 
-template <bool INTERIOR>
-__device__ __forceinline__ void ols_load(cpx (&v)[16], const cpx *__restrict__ x, const cpx *__restrict__ hist,
-                                         int histlen, int64_t g0, int64_t n, int lane)
+// EDGE = false: block fully inside [0, n) on both the input and the output side -- no guards,
+// straight-line code (lets hipcc use counted vmcnt waits so the prefetch and the previous
+// block's stores stay in flight).  EDGE = true: guarded loads (history / zero fill) and stores.
+#ifndef OLS_NT
+#define OLS_NT 0
+#endif
+constexpr bool NT = OLS_NT != 0;
+__device__ __forceinline__ cpx ntload(const cpx *p)
 {
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  v2f t = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(p));
+  return mk(t.x, t.y);
+}
+__device__ __forceinline__ void ntstore(cpx *p, cpx v)
+{
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  v2f t = {v.x, v.y};
+  __builtin_nontemporal_store(t, reinterpret_cast<v2f *>(p));
+}
+template <bool EDGE>
+__device__ __forceinline__ void ols_fetch(cpx (&v)[16], const cpx *__restrict__ x, const cpx *__restrict__ hist,
+                                          int histlen, int Km1, int L, int64_t n, int64_t b, int lane)
+{
+  const int64_t g0 = b * (int64_t) L - Km1;   // first input of block b
+  if (!EDGE) {
+    const cpx *xb = x + g0;
 #pragma unroll
-  for (int r = 0; r < 16; r++) {
-    const int64_t g = g0 + 64 * r + lane;
-    if (INTERIOR)
-      v[r] = x[g];
-    else
+    for (int r = 0; r < 16; r++) v[r] = NT ? ntload(xb + 64 * r + lane) : xb[64 * r + lane];
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int64_t g = g0 + 64 * r + lane;
       v[r] = g < 0 ? hist[histlen + g] : (g < n ? x[g] : mk(0.f, 0.f));
+    }
   }
 }
 
-__global__ __launch_bounds__(64) void ols_kernel(const cpx *__restrict__ x, const cpx *__restrict__ hist,
-                                                 cpx *__restrict__ y, const cpx *__restrict__ Hreg,
-                                                 const cpx *__restrict__ TW1, const cpx *__restrict__ TW2,
-                                                 int Km1, int histlen, int L, int64_t n, int64_t nblocks)
+// 2 waves per SIMD (256-register budget): twiddles + H resident (96 VGPRs), the block being
+// transformed (32) and the NEXT block's samples already in flight (32) -- the wave's own
+// prefetch, not occupancy, hides the HBM latency.
+//
+// Blocks [b_lo, b_hi) are processed with block b = b_lo + slot + i*G.  The EDGE variant is
+// launched with G = 1 per edge block.
+template <bool EDGE>
+__global__ __launch_bounds__(64, 2) void ols_kernel(const cpx *__restrict__ x, const cpx *__restrict__ hist,
+                                                    cpx *__restrict__ y, const cpx *__restrict__ Hreg,
+                                                    const cpx *__restrict__ TW1, const cpx *__restrict__ TW2,
+                                                    int Km1, int histlen, int L, int64_t n, int64_t b_lo,
+                                                    int64_t b_hi, int64_t b_edge2)
 {
   __shared__ cpx lds[LDS_ELEMS];
   const int lane = threadIdx.x;
-  cpx tw1[16], tw2[16], H[16], v[16];
+  cpx tw1[16], tw2[16], H[16];
 #pragma unroll
   for (int r = 0; r < 16; r++) {
     tw1[r] = TW1[r * 64 + lane];
     tw2[r] = TW2[r * 64 + lane];
     H[r] = Hreg[r * 64 + lane];
   }
-  auto sync = []() { __syncthreads(); };
+  // One wave per workgroup: its LDS operations execute in order, so exchanging data between
+  // lanes needs no s_barrier and -- crucially -- no vmcnt(0) drain (a __syncthreads() would
+  // wait for the prefetch loads and the previous block's stores).  Wavefront-scope fences
+  // only stop the compiler from moving LDS accesses across the exchange points.
+  auto sync = []() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
 
-  for (int64_t b = blockIdx.x; b < nblocks; b += gridDim.x) {
-    const int64_t o0 = b * (int64_t) L;       // first output of the block
-    const int64_t g0 = o0 - Km1;              // first input of the block
-    const bool interior = g0 >= 0 && g0 + OLS_N <= n;
-    if (interior)
-      ols_load<true>(v, x, hist, histlen, g0, n, lane);
-    else
-      ols_load<false>(v, x, hist, histlen, g0, n, lane);
+  // Block schedule: at iteration i the grid covers the contiguous span [i*G, (i+1)*G) of
+  // blocks (sequential HBM streams), and inside the span workgroup w -- dispatched round-robin
+  // over the 8 XCDs, so w % 8 labels its XCD -- takes block (w % 8) * G/8 + w / 8: blocks that
+  // share their K-1 overlap samples run on the same XCD at the same time and the second
+  // reader hits that XCD's L2.  Placement only affects speed, never results.
+  const int64_t G = gridDim.x;
+  const int64_t w = blockIdx.x;
+  int64_t b = b_lo + ((G % 8 == 0) ? (w % 8) * (G / 8) + w / 8 : w);
+  if (EDGE && w == 1) b = b_edge2;
+  if (b >= b_hi) return;
 
-    forward(v, lds, lane, tw1, tw2, sync);
+  // One block: prefetch the next block into `nxt`, transform `cur` in place, then store it.
+  // Memory-queue discipline (vmcnt retires in issue order and hipcc waits vmcnt(0) around the
+  // predicated stores): the wait for the prefetch is forced BEFORE this block's stores are
+  // issued -- the loads are a whole block old by then, so it costs nothing -- and afterwards
+  // nothing waits on the stores: they drain while the next block is being transformed.
+  auto process = [&](cpx (&cur)[16], cpx (&nxt)[16], int64_t blk) {
+    const bool more = !EDGE && blk + G < b_hi;
+    if (more) ols_fetch<EDGE>(nxt, x, hist, histlen, Km1, L, n, blk + G, lane);
+    forward(cur, lds, lane, tw1, tw2, sync);
 #pragma unroll
-    for (int r = 0; r < 16; r++) v[r] = cmul(v[r], H[r]);
-    inverse(v, lds, lane, tw1, tw2, sync);
-    __syncthreads();   // LDS is reused by the next block
-
+    for (int r = 0; r < 16; r++) cur[r] = cmul(cur[r], H[r]);
+    inverse(cur, lds, lane, tw1, tw2, sync);
+    sync();   // LDS is reused by the next block
+    if (more) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) asm volatile("" ::"v"(nxt[r].x), "v"(nxt[r].y));
+    }
     // sample t = 64*r + lane of the circular convolution is output o0 + t - (K-1)
-    if (interior) {
+    const int64_t o0 = blk * (int64_t) L;
+    cpx *yb = y + (o0 - Km1);
+    const int r0 = Km1 >> 6;   // Km1 is a multiple of 64: rows below r0 are overlap, the rest whole
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int t = 64 * r + lane;
-        if (t >= Km1) y[o0 + t - Km1] = v[r];
-      }
-    } else {
-#pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const int t = 64 * r + lane;
-        const int64_t o = o0 + t - Km1;
-        if (t >= Km1 && o < n) y[o] = v[r];
+    for (int r = 0; r < 16; r++) {
+      const int t = 64 * r + lane;
+      if (!EDGE) {
+        if (r >= r0) { if (NT) ntstore(yb + t, cur[r]); else yb[t] = cur[r]; }
+      } else {
+        if (r >= r0 && o0 + t - Km1 < n) yb[t] = cur[r];
       }
     }
+  };
+
+  cpx A[16], B[16];
+  ols_fetch<EDGE>(A, x, hist, histlen, Km1, L, n, b, lane);
+  if (EDGE) {
+    process(A, B, b);   // edge launches: one block per wave, no prefetch
+    return;
+  }
+  for (;;) {
+    process(A, B, b);
+    b += G;
+    if (b >= b_hi) break;
+    process(B, A, b);
+    b += G;
+    if (b >= b_hi) break;
   }
 }
 
@@ -100,7 +166,7 @@ int ols_plan_create(tsdgpu_fir *f)
   }
   const int N = OLS_N, K = f->K;
   f->ols_N = N;
-  f->ols_L = N - (K - 1);
+  f->ols_L = N - (int) (cdiv(K - 1, 64) * 64);   // see ols_kernel: overlap rounded up to whole 64-sample rows
   // H[k] = sum_n h[n] exp(-2 pi i k n / N), in double, then /N and register order
   std::vector<double> hr(K), hi(K, 0.0);
   if (f->tap_type == TSDGPU_F32) {
@@ -138,11 +204,13 @@ int ols_plan_create(tsdgpu_fir *f)
   int dev = 0, cus = 256, per_cu = 8;
   (void) hipGetDevice(&dev);
   (void) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ols_kernel, 64, 0) != hipSuccess || per_cu < 1) {
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ols_kernel<false>, 64, 0) != hipSuccess || per_cu < 1) {
     (void) hipGetLastError();
     per_cu = 8;
   }
   f->ols_grid = cus * per_cu;
+  if (const char *g = getenv("TSDGPU_OLS_WAVES_PER_CU")) f->ols_grid = cus * atoi(g);
+  if (getenv("TSDGPU_DEBUG")) fprintf(stderr, "[tsdgpu] ols plan: N=%d K=%d L=%d cus=%d occupancy/CU=%d grid=%d\n", N, K, f->ols_L, cus, per_cu, f->ols_grid);
   return TSDGPU_OK;
 }
 
@@ -156,12 +224,34 @@ int ols_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, hipStream_t st)
 {
   const int L = f->ols_L;
   const int64_t nblocks = cdiv(n, L);
-  const int64_t grid = nblocks < f->ols_grid ? nblocks : f->ols_grid;
   const cpx *d = (const cpx *) f->d_H;
-  hipLaunchKernelGGL(ols_kernel, dim3((unsigned) grid), dim3(64), 0, st, (const cpx *) x,
-                     (const cpx *) f->hist[f->cur], (cpx *) y, d, d + OLS_N, d + 2 * OLS_N, f->K - 1, f->KP, L,
-                     n, nblocks);
-  TSD_HIP(hipGetLastError());
+  // interior blocks: inputs [b*L-(K-1), b*L+L) and outputs [b*L, b*L+L) all inside [0, n)
+  const int64_t b_lo = f->K > 1 ? 1 : 0;
+  const int64_t b_hi = n / L;
+  if (b_hi > b_lo) {
+    const int64_t nint = b_hi - b_lo;
+    // balance the rounds: every wave gets ceil(nint/grid) or one fewer blocks, no tail round
+    int64_t grid = nint < f->ols_grid ? nint : f->ols_grid;
+    if (nint > grid) {
+      const int64_t rounds = cdiv(nint, grid);
+      grid = cdiv(cdiv(nint, rounds), 8) * 8;
+    }
+    hipLaunchKernelGGL(ols_kernel<false>, dim3((unsigned) grid), dim3(64), 0, st, (const cpx *) x,
+                       (const cpx *) f->hist[f->cur], (cpx *) y, d, d + OLS_N, d + 2 * OLS_N, OLS_N - L, f->HL,
+                       L, n, b_lo, b_hi, (int64_t) 0);
+    TSD_HIP(hipGetLastError());
+  }
+  // edge blocks: block 0 (history halo) and the ragged last block, one wave each
+  int64_t e[2];
+  int ne = 0;
+  if (b_lo == 1 || b_hi == 0) e[ne++] = 0;
+  if (b_hi < nblocks && b_hi > 0) e[ne++] = b_hi;
+  if (ne > 0) {
+    hipLaunchKernelGGL(ols_kernel<true>, dim3((unsigned) ne), dim3(64), 0, st, (const cpx *) x,
+                       (const cpx *) f->hist[f->cur], (cpx *) y, d, d + OLS_N, d + 2 * OLS_N, OLS_N - L, f->HL,
+                       L, n, e[0], nblocks, ne > 1 ? e[1] : e[0]);
+    TSD_HIP(hipGetLastError());
+  }
   return TSDGPU_OK;
 }
 
