@@ -52,6 +52,11 @@ def _declare(L):
     L.tsdgpu_fir_set_history.argtypes = [vp, vp, vp]
     L.tsdgpu_fir_method_used.argtypes = [vp]
     L.tsdgpu_fir_destroy.argtypes = [vp]
+    L.tsdgpu_fft_create.argtypes = [C.POINTER(vp), i32, i32]
+    L.tsdgpu_fft_step.argtypes = [vp, vp, vp, i32, i32, vp]
+    L.tsdgpu_fft_size.argtypes = [vp]
+    L.tsdgpu_fft_destroy.argtypes = [vp]
+    L.tsdgpu_fftshift.argtypes = [vp, vp, i32, i32, vp]
 
 
 def device_count():
@@ -129,3 +134,48 @@ class Fir:
             self.close()
         except Exception:
             pass
+
+
+class Fft:
+    """FFTPlan (fourier.hpp:19-32) of one size: step(x, forward) on [batch, n] complex64 data."""
+
+    def __init__(self, n, batch_hint=1):
+        self.n = int(n)
+        self._h = C.c_void_p()
+        _check(lib().tsdgpu_fft_create(C.byref(self._h), self.n, batch_hint))
+
+    def step(self, x, forward=True, y=None, stream=None):
+        assert _dtype_code(x) == C64
+        total = int(np.prod(x.shape))
+        assert total % self.n == 0
+        if y is None:
+            y = np.empty_like(x) if isinstance(x, np.ndarray) else x.new_empty(x.shape)
+        _check(lib().tsdgpu_fft_step(self._h, _ptr(x), _ptr(y), total // self.n, 1 if forward else 0,
+                                     _stream_of(x, stream)))
+        return y
+
+    def close(self):
+        if self._h:
+            lib().tsdgpu_fft_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def fft(x, forward=True):
+    """One-shot fft()/ifft() (fourier.hpp:163-205): plan per call, like the reference."""
+    p = Fft(x.shape[-1])
+    try:
+        return p.step(x, forward)
+    finally:
+        p.close()
+
+
+def fftshift(x, stream=None):
+    y = np.empty_like(x) if isinstance(x, np.ndarray) else x.new_empty(x.shape)
+    _check(lib().tsdgpu_fftshift(_ptr(x), _ptr(y), x.shape[0], _dtype_code(x), _stream_of(x, stream)))
+    return y

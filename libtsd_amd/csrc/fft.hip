@@ -1,0 +1,491 @@
+// fft.hip -- complex FFT plans for gfx950 behind FFTPlan / TFRPlanDefaut
+// (libtsd core/include/tsd/fourier.hpp:19-35; core/src/fourier/fourier.cc:61-121,360-486).
+//
+// Contract kept from the reference: unitary scaling 1/sqrt(n) in BOTH directions, natural
+// order output, any n >= 1, plan reconfigures itself per size (here: one plan per size).
+//   n = 2^p            -> Stockham-free design: in-LDS decimation-in-frequency passes with the
+//                         bit-reversal folded into the (coalesced) store; n > 4096 goes through
+//                         a four-step split n = N1*N2 (column FFTs staged through LDS in
+//                         16-column tiles so every global access is a full 128-B line)
+//   n even, not 2^p    -> even/odd split recursion (fourier.cc:438-463)
+//   n odd              -> Bluestein chirp-z on n2 = next pow2 >= 2n-1 (fourier.cc:237-255,391-400)
+// Twiddles are produced on the host in double precision and rounded once to float.
+#include "common.hpp"
+#include <cmath>
+#include <memory>
+
+namespace tsdgpu {
+
+typedef float2 cpx;
+__device__ __forceinline__ cpx cmk(float a, float b) { return make_float2(a, b); }
+__device__ __forceinline__ cpx cadd(cpx a, cpx b) { return cmk(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cpx csub(cpx a, cpx b) { return cmk(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ cpx cmul(cpx a, cpx b) { return cmk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ cpx cconj(cpx a) { return cmk(a.x, -a.y); }
+__device__ __forceinline__ cpx cscale(cpx a, float s) { return cmk(a.x * s, a.y * s); }
+
+constexpr int FFT_THREADS = 256;
+constexpr int LDS_MAX_N = 4096;      // largest transform done in one workgroup's LDS
+constexpr int COL_TILE = 16;         // columns per tile: 16 * 8 B = one 128-B line per row
+
+__device__ __forceinline__ unsigned bitrev(unsigned i, int logn) { return logn == 0 ? 0u : (__brev(i) >> (32 - logn)); }
+
+// In-place radix-2 decimation in frequency on `cols` independent length-n sequences held in
+// LDS at s[c * pitch + i].  tw[k] = exp(-2 pi i k / n), k < n/2.  Result is bit-reversed.
+__device__ __forceinline__ void dif_passes(cpx *s, int pitch, int cols, int n, int logn,
+                                           const cpx *__restrict__ tw, bool inverse)
+{
+  const int half_total = (n >> 1) * cols;
+  for (int st = 0; st < logn; st++) {
+    const int half = n >> (st + 1);           // butterfly span
+    const int tstride = 1 << st;              // twiddle index stride: W_{2*half}^j = tw[j * tstride]
+    for (int q = threadIdx.x; q < half_total; q += blockDim.x) {
+      const int c = q >> (logn - 1), b = q & ((n >> 1) - 1);
+      const int j = b & (half - 1);
+      const int i0 = ((b - j) << 1) + j;
+      cpx *p = s + c * pitch;
+      const cpx a = p[i0], d = p[i0 + half];
+      cpx w = tw[j * tstride];
+      if (inverse) w = cconj(w);
+      p[i0] = cadd(a, d);
+      p[i0 + half] = cmul(csub(a, d), w);
+    }
+    __syncthreads();
+  }
+}
+
+// One workgroup per transform (n <= 4096), contiguous in and out.
+__global__ __launch_bounds__(FFT_THREADS) void fft_rows_kernel(const cpx *__restrict__ in, cpx *__restrict__ out,
+                                                               const cpx *__restrict__ tw, int n, int logn,
+                                                               int inverse, float scale)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  cpx *s = reinterpret_cast<cpx *>(smem_raw);
+  const cpx *x = in + (size_t) blockIdx.x * n;
+  cpx *y = out + (size_t) blockIdx.x * n;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s[i] = x[i];
+  __syncthreads();
+  dif_passes(s, n, 1, n, logn, tw, inverse != 0);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) y[i] = cscale(s[bitrev(i, logn)], scale);
+}
+
+// Column FFTs of a row-major [R][C] matrix (FFT length R along the row index), COL_TILE
+// columns per workgroup staged through LDS.  blockIdx.y = batch.
+//   TRANSPOSE = true : out is [C][R]: out[c][k] = FFT_c[k] * W_N^(c*k)   (four-step pass 1)
+//   TRANSPOSE = false: out is [R][C]: out[k][c] = FFT_c[k] * scale       (four-step pass 2)
+// W_N^m is looked up as thi[m >> 12] * tlo[m & 4095].
+template <bool TRANSPOSE>
+__global__ __launch_bounds__(FFT_THREADS) void fft_cols_kernel(const cpx *__restrict__ in, cpx *__restrict__ out,
+                                                               const cpx *__restrict__ tw, int R, int logR, int C,
+                                                               const cpx *__restrict__ thi, const cpx *__restrict__ tlo,
+                                                               int inverse, float scale, int tile)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  cpx *s = reinterpret_cast<cpx *>(smem_raw);
+  const int pitch = R + 1;                         // odd pitch: column-strided LDS access stays conflict-light
+  const size_t boff = (size_t) blockIdx.y * (size_t) R * C;
+  const cpx *x = in + boff;
+  cpx *y = out + boff;
+  const int c0 = blockIdx.x * tile;
+  const int ncol = min(tile, C - c0);
+  // load: consecutive threads walk the tile's columns first (contiguous in memory)
+  for (int q = threadIdx.x; q < R * tile; q += blockDim.x) {
+    const int r = q / tile, c = q - r * tile;
+    if (c < ncol) s[c * pitch + r] = x[(size_t) r * C + c0 + c];
+  }
+  __syncthreads();
+  dif_passes(s, pitch, ncol, R, logR, tw, inverse != 0);
+  if (TRANSPOSE) {
+    for (int q = threadIdx.x; q < R * ncol; q += blockDim.x) {
+      const int c = q / R, k = q - c * R;
+      cpx v = s[c * pitch + bitrev(k, logR)];
+      const unsigned m = (unsigned) (c0 + c) * (unsigned) k;     // < N <= 2^24
+      cpx w = cmul(thi[m >> 12], tlo[m & 4095]);
+      if (inverse) w = cconj(w);
+      y[(size_t) (c0 + c) * R + k] = cmul(v, w);
+    }
+  } else {
+    for (int q = threadIdx.x; q < R * tile; q += blockDim.x) {
+      const int k = q / tile, c = q - k * tile;
+      if (c < ncol) y[(size_t) k * C + c0 + c] = cscale(s[c * pitch + bitrev(k, logR)], scale);
+    }
+  }
+}
+
+// ---- helpers for the non power-of-two paths ------------------------------------------------
+// even split: tmp[b][0..h) = x[b][0::2], tmp[b][h..n) = x[b][1::2]
+__global__ void fft_split_eo_kernel(const cpx *__restrict__ x, cpx *__restrict__ tmp, int n, int64_t total)
+{
+  const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int64_t b = i / n;
+  const int k = (int) (i - b * n), h = n >> 1;
+  tmp[i] = x[b * n + (k < h ? 2 * k : 2 * (k - h) + 1)];
+}
+// y[i] = (E[i % h] + rot[i] * O[i % h]) / sqrt(2)      (fourier.cc:451-462)
+__global__ void fft_combine_eo_kernel(const cpx *__restrict__ eo, cpx *__restrict__ y, const cpx *__restrict__ rot,
+                                      int n, int inverse, int64_t total)
+{
+  const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int64_t b = i / n;
+  const int k = (int) (i - b * n), h = n >> 1;
+  const cpx E = eo[b * n + (k % h)], O = eo[b * n + h + (k % h)];
+  cpx r = rot[k];
+  if (inverse) r = cconj(r);
+  y[i] = cscale(cadd(E, cmul(r, O)), 0.70710678118654752f);
+}
+// Bluestein: xp[b][i] = x[b][i] * chirp[n-1+i] (i < n), 0 up to n2
+__global__ void czt_pre_kernel(const cpx *__restrict__ x, cpx *__restrict__ xp, const cpx *__restrict__ chirp,
+                               int n, int n2, int64_t total)
+{
+  const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int64_t b = i / n2;
+  const int k = (int) (i - b * n2);
+  xp[i] = k < n ? cmul(x[b * n + k], chirp[n - 1 + k]) : cmk(0.f, 0.f);
+}
+__global__ void czt_mul_kernel(cpx *__restrict__ a, const cpx *__restrict__ xc, int n2, int64_t total)
+{
+  const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  a[i] = cmul(a[i], xc[i % n2]);
+}
+// y[b][k] = y2[b][n-1+k'] * chirp[n-1+k'] * g, with k' = k (forward) or (n-k)%n (inverse, tfr2itfr)
+__global__ void czt_post_kernel(const cpx *__restrict__ y2, cpx *__restrict__ y, const cpx *__restrict__ chirp,
+                                int n, int n2, float g, int inverse, int64_t total)
+{
+  const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int64_t b = i / n;
+  const int k = (int) (i - b * n);
+  const int kk = inverse ? (n - k) % n : k;
+  y[i] = cscale(cmul(y2[b * n2 + n - 1 + kk], chirp[n - 1 + kk]), g);
+}
+template <typename T>
+__global__ void fftshift_kernel(const T *__restrict__ x, T *__restrict__ y, int n)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  // res.tail(n - n/2) = X.head(n - n/2); res.head(n/2) = X.tail(n/2)   (fourier.hpp:232-248)
+  const int h = n / 2;
+  y[i] = i < h ? x[n - h + i] : x[i - h];
+}
+
+}  // namespace tsdgpu
+
+using namespace tsdgpu;
+
+struct tsdgpu_fft {
+  int n = 0;
+  enum Kind { ONE, POW2_LDS, POW2_4STEP, EVEN, ODD } kind = ONE;
+  // pow2
+  int logn = 0;
+  cpx *d_tw = nullptr;        // W_n^k, k < n/2 (LDS path) ...
+  // four-step n = N1 * N2
+  int N1 = 0, N2 = 0, logN1 = 0, logN2 = 0;
+  cpx *d_tw1 = nullptr, *d_tw2 = nullptr, *d_thi = nullptr, *d_tlo = nullptr;
+  // even / odd
+  tsdgpu_fft *sub = nullptr;
+  cpx *d_rot = nullptr;       // W_n^k, k < n (even split)
+  int n2 = 0;
+  cpx *d_chirp = nullptr, *d_xc = nullptr;   // Bluestein chirp (2n-1) and FFT of its conjugate (n2)
+  DevBuf work, work2, in_stage, out_stage;
+};
+
+namespace {
+
+int log2_exact(int n) { int l = 0; while ((1 << l) < n) l++; return l; }
+
+int upload(cpx **dst, const std::vector<cpx> &v)
+{
+  if (hipMalloc((void **) dst, v.size() * sizeof(cpx)) != hipSuccess)
+    return set_err(TSDGPU_ERR_HIP, "fft: hipMalloc failed: %s", hipGetErrorString(hipGetLastError()));
+  if (hipMemcpy(*dst, v.data(), v.size() * sizeof(cpx), hipMemcpyHostToDevice) != hipSuccess)
+    return set_err(TSDGPU_ERR_HIP, "fft: upload failed: %s", hipGetErrorString(hipGetLastError()));
+  return TSDGPU_OK;
+}
+
+std::vector<cpx> twiddle_table(int n, int count)   // exp(-2 pi i k / n), k < count
+{
+  std::vector<cpx> t((size_t) (count > 0 ? count : 1));
+  const double PI = 3.14159265358979323846;
+  for (int k = 0; k < count; k++) {
+    const double a = -2.0 * PI * (double) k / (double) n;
+    t[k] = make_float2((float) std::cos(a), (float) std::sin(a));
+  }
+  if (count == 0) t[0] = make_float2(1.f, 0.f);
+  return t;
+}
+
+// prochaine_puissance_de_2 (libtsd core/src/tsd.cc:287-291), float-log based like the reference
+int ref_next_pow2(int i)
+{
+  const int lg2 = (int) std::ceil(std::log((float) i) / std::log(2.0f));
+  return (int) (1l << lg2);
+}
+
+int plan_create(tsdgpu_fft **out, int n);
+void plan_destroy(tsdgpu_fft *p);
+
+int plan_init(tsdgpu_fft *p, int n)
+{
+  p->n = n;
+  int rc = TSDGPU_OK;
+  if (n == 1) {
+    p->kind = tsdgpu_fft::ONE;
+  } else if ((n & (n - 1)) == 0) {
+    p->logn = log2_exact(n);
+    if (n <= LDS_MAX_N) {
+      p->kind = tsdgpu_fft::POW2_LDS;
+      rc = upload(&p->d_tw, twiddle_table(n, n / 2));
+    } else {
+      TSD_CHECK(p->logn <= 24, "fft: n = %d exceeds the four-step limit 2^24", n);
+      p->kind = tsdgpu_fft::POW2_4STEP;
+      p->logN1 = p->logn / 2;
+      p->logN2 = p->logn - p->logN1;
+      p->N1 = 1 << p->logN1;
+      p->N2 = 1 << p->logN2;
+      if ((rc = upload(&p->d_tw1, twiddle_table(p->N1, p->N1 / 2)))) return rc;
+      if ((rc = upload(&p->d_tw2, twiddle_table(p->N2, p->N2 / 2)))) return rc;
+      // W_n^m = thi[m >> 12] * tlo[m & 4095]
+      std::vector<cpx> hi((size_t) (n >> 12)), lo(4096);
+      const double PI = 3.14159265358979323846;
+      for (int a = 0; a < (n >> 12); a++) {
+        const double ang = -2.0 * PI * ((double) a * 4096.0) / (double) n;
+        hi[a] = make_float2((float) std::cos(ang), (float) std::sin(ang));
+      }
+      for (int b = 0; b < 4096; b++) {
+        const double ang = -2.0 * PI * (double) b / (double) n;
+        lo[b] = make_float2((float) std::cos(ang), (float) std::sin(ang));
+      }
+      if ((rc = upload(&p->d_thi, hi))) return rc;
+      if ((rc = upload(&p->d_tlo, lo))) return rc;
+      // the column tiles use up to ~150 KiB of the CU's 160 KiB LDS
+      (void) hipFuncSetAttribute((const void *) fft_cols_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void) hipFuncSetAttribute((const void *) fft_cols_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void) hipGetLastError();
+    }
+  } else if ((n & 1) == 0) {
+    p->kind = tsdgpu_fft::EVEN;
+    if ((rc = plan_create(&p->sub, n / 2))) return rc;
+    // tfr_rotation_rapide (fourier.cc:32-46): double-precision recurrence r *= w0, rounded to float
+    std::vector<cpx> rot((size_t) n);
+    const double PI = 3.14159265358979323846;
+    double rr = 1.0, ri = 0.0;
+    const double wr = std::cos(-2 * PI / n), wi = std::sin(-2 * PI / n);
+    for (int i = 0; i < n; i++) {
+      rot[i] = make_float2((float) rr, (float) ri);
+      const double tr = rr * wr - ri * wi, ti = rr * wi + ri * wr;
+      rr = tr; ri = ti;
+    }
+    rc = upload(&p->d_rot, rot);
+  } else {
+    p->kind = tsdgpu_fft::ODD;
+    p->n2 = ref_next_pow2(2 * n - 1);
+    if ((rc = plan_create(&p->sub, p->n2))) return rc;
+    // chirp = polar(square(linspace(-(n-1), n-1, 2n-1)) / 2 * (-2 pi / n)), all in float like
+    // the reference (fourier.cc:396-399): the float rounding of the angle is part of its result
+    std::vector<cpx> chirp((size_t) (2 * n - 1)), icp((size_t) p->n2, make_float2(0.f, 0.f));
+    const double step = ((double) (float) (n - 1) - (double) (float) -(n - 1)) / (2 * n - 2);
+    const float mul = (float) (-2 * 3.14159265358979323846 / n);
+    for (int i = 0; i < 2 * n - 1; i++) {
+      const float t = i == 0 ? (float) -(n - 1) : (float) ((double) (float) -(n - 1) + step * i);
+      float v = (t * t) / 2;
+      v *= mul;
+      chirp[i] = make_float2(std::cos(v), std::sin(v));
+      icp[i] = make_float2(chirp[i].x, -chirp[i].y);
+    }
+    if ((rc = upload(&p->d_chirp, chirp))) return rc;
+    cpx *d_icp = nullptr;
+    if ((rc = upload(&d_icp, icp))) return rc;
+    if (hipMalloc((void **) &p->d_xc, (size_t) p->n2 * sizeof(cpx)) != hipSuccess) {
+      (void) hipFree(d_icp);
+      return set_err(TSDGPU_ERR_HIP, "fft: hipMalloc failed");
+    }
+    rc = tsdgpu_fft_step(p->sub, d_icp, p->d_xc, 1, 1, nullptr);
+    (void) hipDeviceSynchronize();
+    (void) hipFree(d_icp);
+  }
+  return rc;
+}
+
+int plan_create(tsdgpu_fft **out, int n)
+{
+  tsdgpu_fft *p = new tsdgpu_fft();
+  const int rc = plan_init(p, n);
+  if (rc) {
+    plan_destroy(p);
+    return rc;
+  }
+  *out = p;
+  return TSDGPU_OK;
+}
+
+void plan_destroy(tsdgpu_fft *p)
+{
+  if (!p) return;
+  if (p->sub) plan_destroy(p->sub);
+  for (cpx *q : {p->d_tw, p->d_tw1, p->d_tw2, p->d_thi, p->d_tlo, p->d_rot, p->d_chirp, p->d_xc})
+    if (q) (void) hipFree(q);
+  p->work.release();
+  p->work2.release();
+  p->in_stage.release();
+  p->out_stage.release();
+  delete p;
+}
+
+inline unsigned blocks_for(int64_t total) { return (unsigned) cdiv(total, 256); }
+
+// device pointers in, device pointers out; x == y allowed
+int step_device(tsdgpu_fft *p, const cpx *x, cpx *y, int batch, int forward, hipStream_t st)
+{
+  const int n = p->n;
+  const int inverse = forward ? 0 : 1;
+  const int64_t total = (int64_t) n * batch;
+  switch (p->kind) {
+    case tsdgpu_fft::ONE:
+      if (x != y) TSD_HIP(hipMemcpyAsync(y, x, (size_t) total * sizeof(cpx), hipMemcpyDeviceToDevice, st));
+      return TSDGPU_OK;
+    case tsdgpu_fft::POW2_LDS: {
+      const float scale = 1.0f / std::sqrt((float) n);
+      hipLaunchKernelGGL(fft_rows_kernel, dim3((unsigned) batch), dim3(FFT_THREADS), (size_t) n * sizeof(cpx), st, x,
+                         y, p->d_tw, n, p->logn, inverse, scale);
+      TSD_HIP(hipGetLastError());
+      return TSDGPU_OK;
+    }
+    case tsdgpu_fft::POW2_4STEP: {
+      TSD_CHECK(batch <= 65535, "fft_step: batch %d too large for the four-step path (max 65535 per call)", batch);
+      int rc = p->work.reserve((size_t) total * sizeof(cpx));
+      if (rc) return rc;
+      cpx *z = p->work.as<cpx>();
+      const float scale = 1.0f / std::sqrt((float) n);
+      // x viewed [N1][N2]: pass 1 = column FFTs (length N1) + twiddle, stored transposed [N2][N1]
+      int tile1 = COL_TILE, tile2 = COL_TILE;
+      while ((size_t) tile1 * (p->N1 + 1) * sizeof(cpx) > 150 * 1024) tile1 >>= 1;
+      while ((size_t) tile2 * (p->N2 + 1) * sizeof(cpx) > 150 * 1024) tile2 >>= 1;
+      hipLaunchKernelGGL(fft_cols_kernel<true>, dim3((unsigned) cdiv(p->N2, tile1), (unsigned) batch), dim3(FFT_THREADS),
+                         (size_t) tile1 * (p->N1 + 1) * sizeof(cpx), st, x, z, p->d_tw1, p->N1, p->logN1, p->N2,
+                         p->d_thi, p->d_tlo, inverse, 1.0f, tile1);
+      TSD_HIP(hipGetLastError());
+      // z viewed [N2][N1]: pass 2 = column FFTs (length N2), natural store: y[k2 * N1 + k1]
+      hipLaunchKernelGGL(fft_cols_kernel<false>, dim3((unsigned) cdiv(p->N1, tile2), (unsigned) batch), dim3(FFT_THREADS),
+                         (size_t) tile2 * (p->N2 + 1) * sizeof(cpx), st, z, y, p->d_tw2, p->N2, p->logN2, p->N1,
+                         p->d_thi, p->d_tlo, inverse, scale, tile2);
+      TSD_HIP(hipGetLastError());
+      return TSDGPU_OK;
+    }
+    case tsdgpu_fft::EVEN: {
+      int rc = p->work.reserve((size_t) total * sizeof(cpx));
+      if (rc) return rc;
+      rc = p->work2.reserve((size_t) total * sizeof(cpx));
+      if (rc) return rc;
+      cpx *t1 = p->work.as<cpx>(), *t2 = p->work2.as<cpx>();
+      hipLaunchKernelGGL(fft_split_eo_kernel, dim3(blocks_for(total)), dim3(256), 0, st, x, t1, n, total);
+      TSD_HIP(hipGetLastError());
+      rc = step_device(p->sub, t1, t2, 2 * batch, forward, st);
+      if (rc) return rc;
+      hipLaunchKernelGGL(fft_combine_eo_kernel, dim3(blocks_for(total)), dim3(256), 0, st, t2, y, p->d_rot, n, inverse,
+                         total);
+      TSD_HIP(hipGetLastError());
+      return TSDGPU_OK;
+    }
+    case tsdgpu_fft::ODD: {
+      const int n2 = p->n2;
+      const int64_t tot2 = (int64_t) n2 * batch;
+      int rc = p->work.reserve((size_t) tot2 * sizeof(cpx));
+      if (rc) return rc;
+      rc = p->work2.reserve((size_t) tot2 * sizeof(cpx));
+      if (rc) return rc;
+      cpx *a = p->work.as<cpx>(), *b = p->work2.as<cpx>();
+      hipLaunchKernelGGL(czt_pre_kernel, dim3(blocks_for(tot2)), dim3(256), 0, st, x, a, p->d_chirp, n, n2, tot2);
+      TSD_HIP(hipGetLastError());
+      rc = step_device(p->sub, a, b, batch, 1, st);
+      if (rc) return rc;
+      hipLaunchKernelGGL(czt_mul_kernel, dim3(blocks_for(tot2)), dim3(256), 0, st, b, p->d_xc, n2, tot2);
+      TSD_HIP(hipGetLastError());
+      rc = step_device(p->sub, b, a, batch, 0, st);
+      if (rc) return rc;
+      const float g = std::sqrt((float) n2) / std::sqrt((float) n);
+      hipLaunchKernelGGL(czt_post_kernel, dim3(blocks_for(total)), dim3(256), 0, st, a, y, p->d_chirp, n, n2, g, inverse,
+                         total);
+      TSD_HIP(hipGetLastError());
+      return TSDGPU_OK;
+    }
+  }
+  return TSDGPU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tsdgpu_fft_create(tsdgpu_fft **out, int n, int batch_hint)
+{
+  (void) batch_hint;
+  TSD_CHECK(out != nullptr, "fft_create: out is NULL");
+  *out = nullptr;
+  TSD_CHECK(n >= 1, "fft_create: n must be >= 1 (got %d)", n);
+  TSD_CHECK(n <= (1 << 24), "fft_create: n = %d too large", n);
+  return plan_create(out, n);
+}
+
+int tsdgpu_fft_step(tsdgpu_fft *p, const void *x, void *y, int batch, int forward, void *stream)
+{
+  TSD_CHECK(p != nullptr, "fft_step: NULL plan");
+  TSD_CHECK(batch >= 0, "fft_step: negative batch");
+  if (batch == 0) return TSDGPU_OK;
+  TSD_CHECK(x != nullptr && y != nullptr, "fft_step: NULL buffer");
+  hipStream_t st = (hipStream_t) stream;
+  const size_t bytes = (size_t) p->n * batch * sizeof(cpx);
+  const void *dx = nullptr;
+  void *dy = nullptr;
+  bool staged = false;
+  int rc = stage_in(x, bytes, p->in_stage, st, &dx);
+  if (rc) return rc;
+  rc = stage_out(y, bytes, p->out_stage, &dy, &staged);
+  if (rc) return rc;
+  rc = step_device(p, (const cpx *) dx, (cpx *) dy, batch, forward, st);
+  if (rc) return rc;
+  return finish_out(y, bytes, dy, staged, st);
+}
+
+int tsdgpu_fft_size(const tsdgpu_fft *p) { return p ? p->n : -1; }
+
+int tsdgpu_fft_destroy(tsdgpu_fft *p)
+{
+  plan_destroy(p);
+  return TSDGPU_OK;
+}
+
+int tsdgpu_fftshift(const void *x, void *y, int n, int data_type, void *stream)
+{
+  TSD_CHECK(n >= 0, "fftshift: negative length");
+  if (n == 0) return TSDGPU_OK;
+  TSD_CHECK(x != nullptr && y != nullptr && x != y, "fftshift: needs distinct non-NULL buffers");
+  hipStream_t st = (hipStream_t) stream;
+  const size_t bytes = (size_t) n * dtype_size(data_type);
+  DevBuf a, b;
+  const void *dx = nullptr;
+  void *dy = nullptr;
+  bool staged = false;
+  int rc = stage_in(x, bytes, a, st, &dx);
+  if (!rc) rc = stage_out(y, bytes, b, &dy, &staged);
+  if (!rc) {
+    if (data_type == TSDGPU_C64)
+      hipLaunchKernelGGL(fftshift_kernel<float2>, dim3((unsigned) cdiv(n, 256)), dim3(256), 0, st, (const float2 *) dx,
+                         (float2 *) dy, n);
+    else
+      hipLaunchKernelGGL(fftshift_kernel<float>, dim3((unsigned) cdiv(n, 256)), dim3(256), 0, st, (const float *) dx,
+                         (float *) dy, n);
+    if (hipGetLastError() != hipSuccess) rc = set_err(TSDGPU_ERR_HIP, "fftshift launch failed");
+  }
+  if (!rc) rc = finish_out(y, bytes, dy, staged, st);
+  if (rc == TSDGPU_OK && !staged) { /* async on the caller's stream */ }
+  else (void) hipStreamSynchronize(st);
+  a.release();
+  b.release();
+  return rc;
+}
+
+}  // extern "C"
