@@ -52,6 +52,12 @@ def _declare(L):
     L.tsdgpu_fir_set_history.argtypes = [vp, vp, vp]
     L.tsdgpu_fir_method_used.argtypes = [vp]
     L.tsdgpu_fir_destroy.argtypes = [vp]
+    L.tsdgpu_sos_create.argtypes = [C.POINTER(vp), i32, vp, i32, fl, vp, i32]
+    L.tsdgpu_sos_step.argtypes = [vp, vp, vp, i64, vp]
+    L.tsdgpu_sos_reset.argtypes = [vp]
+    L.tsdgpu_sos_halo.argtypes = [vp]
+    L.tsdgpu_sos_halo.restype = i64
+    L.tsdgpu_sos_destroy.argtypes = [vp]
     L.tsdgpu_fft_create.argtypes = [C.POINTER(vp), i32, i32]
     L.tsdgpu_fft_step.argtypes = [vp, vp, vp, i32, i32, vp]
     L.tsdgpu_fft_size.argtypes = [vp]
@@ -179,3 +185,41 @@ def fftshift(x, stream=None):
     y = np.empty_like(x) if isinstance(x, np.ndarray) else x.new_empty(x.shape)
     _check(lib().tsdgpu_fftshift(_ptr(x), _ptr(y), x.shape[0], _dtype_code(x), _stream_of(x, stream)))
     return y
+
+
+class Sos:
+    """filtre_sois<T> (filtre-rt.cc:574-602) from already-paired sections:
+    coefs [nsec,5] = (b0,b1,b2,a1,a2) normalised by a0; gain; optional first-order (b0,b1,a1)."""
+
+    def __init__(self, coefs, gain, data_type, rii1=None, forme=2):
+        coefs = np.ascontiguousarray(coefs, dtype=np.float32).reshape(-1, 5)
+        self.data_type = data_type
+        self._h = C.c_void_p()
+        r1 = None if rii1 is None else np.ascontiguousarray(rii1, dtype=np.float32)
+        _check(lib().tsdgpu_sos_create(C.byref(self._h), data_type, coefs.ctypes.data, coefs.shape[0],
+                                       float(gain), None if r1 is None else r1.ctypes.data, forme))
+
+    @property
+    def halo(self):
+        return lib().tsdgpu_sos_halo(self._h)
+
+    def step(self, x, y=None, stream=None):
+        assert _dtype_code(x) == self.data_type
+        if y is None:
+            y = np.empty_like(x) if isinstance(x, np.ndarray) else x.new_empty(x.shape)
+        _check(lib().tsdgpu_sos_step(self._h, _ptr(x), _ptr(y), x.shape[0], _stream_of(x, stream)))
+        return y
+
+    def reset(self):
+        _check(lib().tsdgpu_sos_reset(self._h))
+
+    def close(self):
+        if self._h:
+            lib().tsdgpu_sos_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

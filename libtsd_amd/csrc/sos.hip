@@ -1,0 +1,463 @@
+// sos.hip -- cascade of second-order IIR sections (biquads) as a block-parallel recursion.
+//
+// Stands behind ChaineSOIS<T,T,T>::step / filtre_sois<T>  (libtsd core/src/filtrage/
+// filtre-rt.cc:303-400,407-437,440-602): direct-form-II biquads
+//     d = x - a1*d1 - a2*d2;  y = b0*d + b1*d1 + b2*d2        (:373-379)
+// chained section after section, each section seeded on the very first sample of the stream
+// with d1 = d2 = (its own first input) (:361-365), then `y *= gain` or a trailing first-order
+// section (:567-570).  The reference makes one sequential pass over the vector per section;
+// here ALL sections are applied in ONE pass over HBM (8 B/sample for float data).
+//
+// Parallel formulation (exact linear algebra, not an approximation of the recurrence):
+//  * a wave64 owns a sub-tile of 2048 floats; each lane holds 32 consecutive floats in
+//    registers (complex data = two interleaved real channels, the coefficients being real);
+//  * per section the lane runs the recurrence from ZERO state over its samples, the 64
+//    zero-state end states are combined by a Kogge-Stone scan of affine maps over the wave
+//    (wave shuffles; all maps share the linear part M^L, so the scan only carries the two
+//    state values), and every sample is corrected by the zero-input response of the lane's
+//    true start state (two FMAs against tabulated responses).  The corrected outputs are the
+//    next section's inputs, still in registers;
+//  * a wave walks a chunk of consecutive sub-tiles carrying the state exactly; chunk 0 starts
+//    from the stream state carried by the handle, every other chunk starts W samples early
+//    from zero state, W chosen on the host so that the cascade's state-transition matrix
+//    satisfies ||Phi^W||_inf <= 1e-9 (chunks are >= 8 W long; a filter that decays slowly
+//    simply gets fewer, longer chunks -- down to a single sequential one);
+//  * global accesses are 16 B per lane, transposed lane<->sample through padded LDS.
+#include "common.hpp"
+#include <cmath>
+
+namespace tsdgpu {
+
+constexpr int SOS_MAX_SEC = 32;
+constexpr int SUB_FLOATS = 2048;      // floats per sub-tile (64 lanes x 32)
+constexpr int LANE_FLOATS = 32;
+constexpr int LDS_LANE_PITCH = 36;    // floats: 32 + 4 pad -> conflict-free b128 both ways
+
+struct SosSection {
+  float b0, b1, b2, a1, a2;
+  float seed;                 // 1: first-sample seed d1 = d2 = x0 (SOIS), 0: zero start (RIIFoS)
+  float pad0, pad1;
+  float A[6][4];              // (M^L)^(2^k), k = 0..5, row-major 2x2, M = [[-a1,-a2],[1,0]]
+  float c1[LANE_FLOATS];      // output response to start state d1 (per in-lane sample index)
+  float c2[LANE_FLOATS];      // output response to start state d2
+};
+
+// state buffer layout (floats): [0] = seeded flag, then per section per channel (d1, d2)
+__host__ __device__ inline int state_index(int sec, int ch) { return 1 + (sec * 2 + ch) * 2; }
+constexpr int STATE_FLOATS = 1 + SOS_MAX_SEC * 4;
+
+__device__ __forceinline__ void wave_sync()
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// NCH = 1: real samples; NCH = 2: interleaved complex (two real channels).
+template <int NCH>
+__global__ __launch_bounds__(64) void sos_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                 const SosSection *__restrict__ sec, int nsec, float gain,
+                                                 const float *__restrict__ st_in, float *__restrict__ st_out,
+                                                 int64_t n_sub, int spc, int warm_sub)
+{
+  constexpr int L = LANE_FLOATS / NCH;           // samples per lane
+  __shared__ __attribute__((aligned(16))) float lds[64 * LDS_LANE_PITCH];
+  __shared__ float sst[SOS_MAX_SEC * 4];          // running (d1,d2) per section and channel
+  const int lane = threadIdx.x;
+  const int64_t chunk = blockIdx.x;
+  const int64_t t_first = chunk * spc;                         // first sub-tile whose output we own
+  const int64_t t_last = min(t_first + spc, n_sub);            // exclusive
+  const bool first_chunk = chunk == 0;
+  int64_t t = first_chunk ? 0 : t_first - warm_sub;            // warm-up sub-tiles precede the chunk
+  const bool seeded = st_in[0] != 0.f;
+
+  // running state per section and channel: wave-uniform, kept in LDS (indexed by the
+  // runtime section number; a register array would go to scratch)
+  for (int i = lane; i < nsec * 4; i += 64) {
+    const int sc = i >> 1;                                     // (section*2 + channel)
+    sst[i] = first_chunk ? st_in[1 + sc * 2 + (i & 1)] : 0.f;
+  }
+  wave_sync();
+
+  for (; t < t_last; t++) {
+    const float *xt = x + t * SUB_FLOATS;
+    // ---- load 16 B per lane, transpose through LDS: lane gets floats [32*lane, 32*lane+32)
+    float v[LANE_FLOATS];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int p = 4 * (i * 64 + lane);                       // float index in the sub-tile
+      const float4 q = *reinterpret_cast<const float4 *>(xt + p);
+      *reinterpret_cast<float4 *>(&lds[(p >> 5) * LDS_LANE_PITCH + (p & 31)]) = q;
+    }
+    wave_sync();
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const float4 q = *reinterpret_cast<const float4 *>(&lds[lane * LDS_LANE_PITCH + 4 * i]);
+      v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w;
+    }
+    wave_sync();
+
+    const bool do_seed = first_chunk && !seeded && t == 0;
+#pragma unroll 1
+    for (int s = 0; s < nsec; s++) {
+      const SosSection &k = sec[s];
+      const float b0 = k.b0, b1 = k.b1, b2 = k.b2, a1 = k.a1, a2 = k.a2;
+#pragma unroll
+      for (int c = 0; c < NCH; c++) {
+        float sin1 = sst[(s * 2 + c) * 2], sin0 = sst[(s * 2 + c) * 2 + 1];
+        if (do_seed && k.seed != 0.f) {
+          // premier_appel: d1 = d2 = the section's own first input sample (filtre-rt.cc:361-365)
+          const float x0 = __shfl(v[c], 0);
+          sin1 = x0;
+          sin0 = x0;
+        }
+        // zero-state run over the lane's L samples
+        float d1 = 0.f, d2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < L; i++) {
+          const float xin = v[i * NCH + c];
+          const float d = fmaf(-a2, d2, fmaf(-a1, d1, xin));
+          v[i * NCH + c] = fmaf(b2, d2, fmaf(b1, d1, b0 * d));
+          d2 = d1;
+          d1 = d;
+        }
+        // lane 0 absorbs the sub-tile's start state: P = M^L * S_in + Z
+        float p1 = d1, p0 = d2;
+        if (lane == 0) {
+          p1 = fmaf(k.A[0][0], sin1, fmaf(k.A[0][1], sin0, p1));
+          p0 = fmaf(k.A[0][2], sin1, fmaf(k.A[0][3], sin0, p0));
+        }
+        // inclusive Kogge-Stone scan over the 64 lanes: P_l = sum_j (M^L)^(l-j) Z_j
+#pragma unroll
+        for (int kk = 0; kk < 6; kk++) {
+          const int dd = 1 << kk;
+          const float q1 = __shfl_up(p1, dd), q0 = __shfl_up(p0, dd);
+          if (lane >= dd) {
+            p1 = fmaf(k.A[kk][0], q1, fmaf(k.A[kk][1], q0, p1));
+            p0 = fmaf(k.A[kk][2], q1, fmaf(k.A[kk][3], q0, p0));
+          }
+        }
+        // true start state of this lane = end state of the previous lane
+        float s1 = __shfl_up(p1, 1), s0 = __shfl_up(p0, 1);
+        if (lane == 0) { s1 = sin1; s0 = sin0; }
+        // zero-input correction of every output of the lane
+#pragma unroll
+        for (int i = 0; i < L; i++) v[i * NCH + c] = fmaf(k.c1[i], s1, fmaf(k.c2[i], s0, v[i * NCH + c]));
+        // state after the sub-tile's last sample, carried to the next sub-tile
+        if (lane == 63) {
+          sst[(s * 2 + c) * 2] = p1;
+          sst[(s * 2 + c) * 2 + 1] = p0;
+        }
+      }
+      wave_sync();
+    }
+
+    if (t >= t_first) {
+      // ---- gain, transpose back, store 16 B per lane
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const float4 q = make_float4(v[4 * i] * gain, v[4 * i + 1] * gain, v[4 * i + 2] * gain, v[4 * i + 3] * gain);
+        *reinterpret_cast<float4 *>(&lds[lane * LDS_LANE_PITCH + 4 * i]) = q;
+      }
+      wave_sync();
+      float *yt = y + t * SUB_FLOATS;
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        const int p = 4 * (i * 64 + lane);
+        *reinterpret_cast<float4 *>(yt + p) = *reinterpret_cast<const float4 *>(&lds[(p >> 5) * LDS_LANE_PITCH + (p & 31)]);
+      }
+      wave_sync();
+    }
+  }
+
+  // the wave that owns the last sub-tile publishes the stream state
+  if (t_last == n_sub && t_last > t_first) {
+    if (lane == 0) st_out[0] = 1.f;
+    for (int i = lane; i < nsec * 4; i += 64) st_out[1 + i] = sst[i];
+  }
+}
+
+// Sequential tail (fewer samples than one sub-tile, or a ragged end): one lane per channel
+// applies the reference recurrence literally from the carried state and updates it.
+template <int NCH>
+__global__ void sos_tail_kernel(const float *__restrict__ x, float *__restrict__ y, const SosSection *__restrict__ sec,
+                                int nsec, float gain, float *__restrict__ st, int64_t n0, int64_t n1)
+{
+  const int c = threadIdx.x;
+  if (c >= NCH) return;
+  const bool seeded = st[0] != 0.f;
+  for (int s = 0; s < nsec; s++) {
+    const SosSection k = sec[s];
+    float d1 = st[state_index(s, c)], d2 = st[state_index(s, c) + 1];
+    for (int64_t i = n0; i < n1; i++) {
+      const float xin = (s == 0 ? x : y)[i * NCH + c];
+      if (i == n0 && !seeded && k.seed != 0.f) d1 = d2 = xin;
+      const float d = fmaf(-k.a2, d2, fmaf(-k.a1, d1, xin));
+      float o = fmaf(k.b2, d2, fmaf(k.b1, d1, k.b0 * d));
+      if (s == nsec - 1) o *= gain;
+      y[i * NCH + c] = o;
+      d2 = d1;
+      d1 = d;
+    }
+    st[state_index(s, c)] = d1;
+    st[state_index(s, c) + 1] = d2;
+  }
+  __syncthreads();
+  if (c == 0 && n1 > n0) st[0] = 1.f;
+}
+
+}  // namespace tsdgpu
+
+using namespace tsdgpu;
+
+struct tsdgpu_sos {
+  int data_type = 0, nsec = 0, nch = 1;
+  float gain = 1.f;
+  SosSection *d_sec = nullptr;
+  float *d_state[2] = {nullptr, nullptr};
+  int cur = 0;
+  int64_t halo = 0;             // W: samples after which the state transition is below 1e-9
+  DevBuf in_stage, out_stage;
+};
+
+namespace {
+
+// one step of the whole cascade in double on a state vector (2 per section), input u
+double cascade_step(const std::vector<SosSection> &sec, std::vector<double> &st, double u)
+{
+  double v = u;
+  for (size_t s = 0; s < sec.size(); s++) {
+    const double d1 = st[2 * s], d2 = st[2 * s + 1];
+    const double d = v - (double) sec[s].a1 * d1 - (double) sec[s].a2 * d2;
+    v = (double) sec[s].b0 * d + (double) sec[s].b1 * d1 + (double) sec[s].b2 * d2;
+    st[2 * s + 1] = d1;
+    st[2 * s] = d;
+  }
+  return v;
+}
+
+int64_t compute_halo(const std::vector<SosSection> &sec)
+{
+  const int m = 2 * (int) sec.size();
+  if (m == 0) return 0;
+  // Phi = one-step zero-input state transition, column by column
+  std::vector<double> P((size_t) m * m, 0.0);
+  for (int j = 0; j < m; j++) {
+    std::vector<double> st((size_t) m, 0.0);
+    st[j] = 1.0;
+    cascade_step(sec, st, 0.0);
+    for (int i = 0; i < m; i++) P[(size_t) i * m + j] = st[i];
+  }
+  int64_t W = 1;
+  for (int it = 0; it < 40; it++) {
+    double nrm = 0;
+    for (int i = 0; i < m; i++) {
+      double r = 0;
+      for (int j = 0; j < m; j++) r += std::fabs(P[(size_t) i * m + j]);
+      nrm = std::max(nrm, r);
+    }
+    if (!(nrm > 1e-9)) return W;
+    if (!std::isfinite(nrm)) break;
+    std::vector<double> Q((size_t) m * m, 0.0);
+    for (int i = 0; i < m; i++)
+      for (int k = 0; k < m; k++) {
+        const double a = P[(size_t) i * m + k];
+        if (a == 0) continue;
+        for (int j = 0; j < m; j++) Q[(size_t) i * m + j] += a * P[(size_t) k * m + j];
+      }
+    P.swap(Q);
+    W *= 2;
+  }
+  return -1;   // does not decay (unstable or marginal filter)
+}
+
+void fill_tables(SosSection &k, int L)
+{
+  const double a1 = k.a1, a2 = k.a2, b0 = k.b0, b1 = k.b1, b2 = k.b2;
+  // zero-input responses from unit start states (d1,d2) = (1,0) and (0,1)
+  for (int which = 0; which < 2; which++) {
+    double d1 = which == 0 ? 1.0 : 0.0, d2 = which == 0 ? 0.0 : 1.0;
+    for (int i = 0; i < LANE_FLOATS; i++) {
+      double o = 0;
+      if (i < L) {
+        const double d = -a1 * d1 - a2 * d2;
+        o = b0 * d + b1 * d1 + b2 * d2;
+        d2 = d1;
+        d1 = d;
+      }
+      (which == 0 ? k.c1 : k.c2)[i] = (float) o;
+    }
+  }
+  // M^L by L-fold application, then repeated squaring for the scan
+  double A[4] = {1, 0, 0, 1};
+  const double M[4] = {-a1, -a2, 1, 0};
+  for (int i = 0; i < L; i++) {
+    const double t[4] = {M[0] * A[0] + M[1] * A[2], M[0] * A[1] + M[1] * A[3], M[2] * A[0] + M[3] * A[2],
+                         M[2] * A[1] + M[3] * A[3]};
+    for (int j = 0; j < 4; j++) A[j] = t[j];
+  }
+  for (int kk = 0; kk < 6; kk++) {
+    for (int j = 0; j < 4; j++) k.A[kk][j] = (float) A[j];
+    const double t[4] = {A[0] * A[0] + A[1] * A[2], A[0] * A[1] + A[1] * A[3], A[2] * A[0] + A[3] * A[2],
+                         A[2] * A[1] + A[3] * A[3]};
+    for (int j = 0; j < 4; j++) A[j] = t[j];
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int tsdgpu_sos_create(tsdgpu_sos **out, int data_type, const float *coefs_host, int nsec, float gain,
+                      const float *rii1_host, int forme)
+{
+  TSD_CHECK(out != nullptr, "sos_create: out is NULL");
+  *out = nullptr;
+  TSD_CHECK(data_type == TSDGPU_F32 || data_type == TSDGPU_C64, "sos_create: bad data_type %d", data_type);
+  TSD_CHECK(nsec >= 0 && nsec + (rii1_host ? 1 : 0) <= SOS_MAX_SEC, "sos_create: %d sections unsupported (max %d)",
+            nsec, SOS_MAX_SEC);
+  TSD_CHECK(nsec == 0 || coefs_host != nullptr, "sos_create: NULL coefficients");
+  if (forme != 2)
+    return set_err(TSDGPU_ERR_UNSUPPORTED, "sos_create: only FormeDirecte2 (the reference default) is built; got %d", forme);
+
+  tsdgpu_sos *s = new tsdgpu_sos();
+  s->data_type = data_type;
+  s->nch = data_type == TSDGPU_C64 ? 2 : 1;
+  const int L = LANE_FLOATS / s->nch;
+  std::vector<SosSection> sec;
+  for (int i = 0; i < nsec; i++) {
+    SosSection k{};
+    k.b0 = coefs_host[5 * i]; k.b1 = coefs_host[5 * i + 1]; k.b2 = coefs_host[5 * i + 2];
+    k.a1 = coefs_host[5 * i + 3]; k.a2 = coefs_host[5 * i + 4];
+    k.seed = 1.f;
+    fill_tables(k, L);
+    sec.push_back(k);
+  }
+  if (rii1_host) {
+    // RIIFoS (filtre-rt.cc:407-437): y = -a1*y1 + b0*x0 + b1*x1 from zero memory == the
+    // biquad (b0,b1,0 ; a1,0) from zero state; it carries the gain, so `gain` is not applied
+    SosSection k{};
+    k.b0 = rii1_host[0]; k.b1 = rii1_host[1]; k.b2 = 0.f; k.a1 = rii1_host[2]; k.a2 = 0.f;
+    k.seed = 0.f;
+    fill_tables(k, L);
+    sec.push_back(k);
+    s->gain = 1.f;
+  } else {
+    s->gain = gain;
+  }
+  if (sec.empty()) {
+    // order-0 chain: y = x * gain, expressed as an identity section with zero state
+    SosSection k{};
+    k.b0 = 1.f;
+    fill_tables(k, L);
+    sec.push_back(k);
+  }
+  s->nsec = (int) sec.size();
+  s->halo = compute_halo(sec);
+
+  int rc = TSDGPU_OK;
+  do {
+    const size_t sb = std::max<size_t>(1, sec.size()) * sizeof(SosSection);
+    if (hipMalloc((void **) &s->d_sec, sb) != hipSuccess || hipMalloc((void **) &s->d_state[0], STATE_FLOATS * 4) != hipSuccess ||
+        hipMalloc((void **) &s->d_state[1], STATE_FLOATS * 4) != hipSuccess) {
+      rc = set_err(TSDGPU_ERR_HIP, "sos_create: hipMalloc failed: %s", hipGetErrorString(hipGetLastError()));
+      break;
+    }
+    if ((!sec.empty() && hipMemcpy(s->d_sec, sec.data(), sec.size() * sizeof(SosSection), hipMemcpyHostToDevice) != hipSuccess) ||
+        hipMemset(s->d_state[0], 0, STATE_FLOATS * 4) != hipSuccess || hipMemset(s->d_state[1], 0, STATE_FLOATS * 4) != hipSuccess) {
+      rc = set_err(TSDGPU_ERR_HIP, "sos_create: upload failed: %s", hipGetErrorString(hipGetLastError()));
+      break;
+    }
+  } while (0);
+  if (rc) {
+    tsdgpu_sos_destroy(s);
+    return rc;
+  }
+  *out = s;
+  return TSDGPU_OK;
+}
+
+int tsdgpu_sos_step(tsdgpu_sos *s, const void *x, void *y, int64_t n, void *stream)
+{
+  TSD_CHECK(s != nullptr, "sos_step: NULL handle");
+  TSD_CHECK(n >= 0, "sos_step: negative length");
+  if (n == 0) return TSDGPU_OK;
+  TSD_CHECK(x != nullptr && y != nullptr, "sos_step: NULL buffer");
+  hipStream_t st = (hipStream_t) stream;
+  const size_t bytes = (size_t) n * dtype_size(s->data_type);
+  const void *dx = nullptr;
+  void *dy = nullptr;
+  bool staged = false;
+  int rc = stage_in(x, bytes, s->in_stage, st, &dx);
+  if (rc) return rc;
+  rc = stage_out(y, bytes, s->out_stage, &dy, &staged);
+  if (rc) return rc;
+  if (dx == dy) {
+    // in place (filtre-rt.cc:354-355): chunks re-read their predecessors' inputs for the warm-up
+    rc = s->in_stage.reserve(bytes);
+    if (rc) return rc;
+    TSD_HIP(hipMemcpyAsync(s->in_stage.p, dx, bytes, hipMemcpyDeviceToDevice, st));
+    dx = s->in_stage.p;
+  }
+  const int nch = s->nch;
+  const int64_t nfl = n * nch;                              // floats
+  const bool aligned = (((uintptr_t) dx | (uintptr_t) dy) & 15) == 0;
+  const int64_t n_sub = aligned ? nfl / SUB_FLOATS : 0;     // whole sub-tiles go to the wave kernel
+  float *st_in = s->d_state[s->cur], *st_out = s->d_state[s->cur ^ 1];
+  if (n_sub > 0) {
+    const int64_t sub_samples = SUB_FLOATS / nch;
+    int64_t warm_sub, spc;
+    if (s->halo < 0) {
+      warm_sub = 0;
+      spc = n_sub;                                          // no decay: one sequential chunk
+    } else {
+      warm_sub = cdiv(s->halo, sub_samples);
+      spc = std::max<int64_t>(16, 8 * warm_sub);
+    }
+    const int64_t nchunks = cdiv(n_sub, spc);
+    TSD_CHECK(nchunks <= 0x7fffffff, "sos_step: too many chunks");
+    if (nch == 1)
+      hipLaunchKernelGGL(sos_kernel<1>, dim3((unsigned) nchunks), dim3(64), 0, st, (const float *) dx, (float *) dy,
+                         s->d_sec, s->nsec, s->gain, st_in, st_out, n_sub, (int) spc, (int) warm_sub);
+    else
+      hipLaunchKernelGGL(sos_kernel<2>, dim3((unsigned) nchunks), dim3(64), 0, st, (const float *) dx, (float *) dy,
+                         s->d_sec, s->nsec, s->gain, st_in, st_out, n_sub, (int) spc, (int) warm_sub);
+    TSD_HIP(hipGetLastError());
+    s->cur ^= 1;
+  }
+  const int64_t n0 = n_sub * (SUB_FLOATS / nch);
+  if (n0 < n) {
+    float *stc = s->d_state[s->cur];
+    if (nch == 1)
+      hipLaunchKernelGGL(sos_tail_kernel<1>, dim3(1), dim3(64), 0, st, (const float *) dx, (float *) dy, s->d_sec, s->nsec,
+                         s->gain, stc, n0, n);
+    else
+      hipLaunchKernelGGL(sos_tail_kernel<2>, dim3(1), dim3(64), 0, st, (const float *) dx, (float *) dy, s->d_sec, s->nsec,
+                         s->gain, stc, n0, n);
+    TSD_HIP(hipGetLastError());
+  }
+  return finish_out(y, bytes, dy, staged, st);
+}
+
+int tsdgpu_sos_reset(tsdgpu_sos *s)
+{
+  TSD_CHECK(s != nullptr, "sos_reset: NULL handle");
+  TSD_HIP(hipMemset(s->d_state[s->cur], 0, STATE_FLOATS * 4));
+  return TSDGPU_OK;
+}
+
+int64_t tsdgpu_sos_halo(const tsdgpu_sos *s) { return s ? s->halo : -1; }
+
+int tsdgpu_sos_destroy(tsdgpu_sos *s)
+{
+  if (!s) return TSDGPU_OK;
+  if (s->d_sec) (void) hipFree(s->d_sec);
+  if (s->d_state[0]) (void) hipFree(s->d_state[0]);
+  if (s->d_state[1]) (void) hipFree(s->d_state[1]);
+  s->in_stage.release();
+  s->out_stage.release();
+  delete s;
+  return TSDGPU_OK;
+}
+
+}  // extern "C"

@@ -97,6 +97,7 @@ def _declare(L):
     L.orc_sos_state_init_c.argtypes = [vp]
     L.orc_sos_step_f.argtypes = [vp, vp, vp, vp, i64]
     L.orc_sos_step_c.argtypes = [vp, vp, vp, vp, i64]
+    L.orc_sos_run_f64.argtypes = [vp, vp, vp, i64]
     L.orc_fft.argtypes = [vp, vp, i32, i32]
     L.orc_fft_twiddles.argtypes = [vp, i32]
     L.orc_rfft.argtypes = [vp, vp, i32]
@@ -201,6 +202,13 @@ class SosChain:
         a = np.array([[b.b0, b.b1, b.b2, b.a1, b.a2] for b in self.s.sec[: self.s.nsec]], dtype=f32)
         r1 = (self.s.r_b0, self.s.r_b1, self.s.r_a1) if self.s.avec_rii1 else None
         return a.reshape(-1, 5), np.float32(self.s.gain), r1
+
+    def run_f64(self, x):
+        """Same recurrence in double (real data, one shot): conditioning yardstick."""
+        x = np.ascontiguousarray(x, dtype=f32)
+        y = np.empty(len(x), np.float64)
+        lib().orc_sos_run_f64(C.byref(self.s), _p(x), _p(y), len(x))
+        return y
 
     def step(self, x):
         x = np.ascontiguousarray(x)

@@ -289,6 +289,33 @@ void orc_sos_step_c(const orc_sos *s, orc_sos_state_c *st, const orc_cf *x, orc_
   }
 }
 
+/* Same chain (DF2, first-sample seed, gain / first-order tail) evaluated in double: NOT a
+ * reference path -- the conditioning yardstick the parity tests use to tell float32 rounding
+ * noise of the recurrence itself from an implementation error. One-shot (no carried state). */
+void orc_sos_run_f64(const orc_sos *s, const float *x, double *y, int64_t n)
+{
+  for (int64_t i = 0; i < n; i++) y[i] = x[i];
+  for (int k = 0; k < s->nsec; k++) {
+    const double b0 = s->sec[k].b0, b1 = s->sec[k].b1, b2 = s->sec[k].b2, a1 = s->sec[k].a1, a2 = s->sec[k].a2;
+    double y0 = n ? y[0] : 0, y1 = y0;
+    for (int64_t i = 0; i < n; i++) {
+      double d2 = y[i] - a1 * y1 - a2 * y0;
+      y[i] = b0 * d2 + b1 * y1 + b2 * y0;
+      y0 = y1; y1 = d2;
+    }
+  }
+  if (s->avec_rii1) {
+    double x1 = 0, y1 = 0;
+    for (int64_t i = 0; i < n; i++) {
+      double x0 = y[i];
+      y1 = -(double) s->r_a1 * y1 + (double) s->r_b0 * x0 + (double) s->r_b1 * x1;
+      y[i] = y1; x1 = x0;
+    }
+  } else {
+    for (int64_t i = 0; i < n; i++) y[i] *= (double) s->gain;
+  }
+}
+
 /* ======================================================================================
  * FFT -- src/fourier/fourier.cc
  * ==================================================================================== */

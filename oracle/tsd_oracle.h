@@ -72,6 +72,8 @@ void orc_sos_state_init_c(orc_sos_state_c *st);
 /* ChaineSOIS::step (:562-571) over SOIS::step (:347-397) and RIIFoS::step (:422-436).     */
 void orc_sos_step_f(const orc_sos *s, orc_sos_state_f *st, const float *x, float *y, int64_t n);
 void orc_sos_step_c(const orc_sos *s, orc_sos_state_c *st, const orc_cf *x, orc_cf *y, int64_t n);
+/* the same chain in double precision, one shot: conditioning yardstick only (not a reference path) */
+void orc_sos_run_f64(const orc_sos *s, const float *x, double *y, int64_t n);
 
 /* ---- FFT, src/fourier/fourier.cc:32-46,61-121,237-278,360-467 --------------------------
  * TFRPlanDefaut: pow2 -> radix-2 Stockham; even -> split recursion; odd -> Bluestein.
