@@ -58,6 +58,15 @@ def _declare(L):
     L.tsdgpu_sos_halo.argtypes = [vp]
     L.tsdgpu_sos_halo.restype = i64
     L.tsdgpu_sos_destroy.argtypes = [vp]
+    L.tsdgpu_resampler_create.argtypes = [C.POINTER(vp), i32, fl, vp, i32, i32]
+    L.tsdgpu_resampler_out_count.argtypes = [vp, i64]
+    L.tsdgpu_resampler_out_count.restype = i64
+    L.tsdgpu_resampler_step.argtypes = [vp, vp, i64, vp, i64, C.POINTER(i64), vp]
+    L.tsdgpu_resampler_reset.argtypes = [vp]
+    L.tsdgpu_resampler_seek.argtypes = [vp, i64, vp, vp]
+    L.tsdgpu_resampler_out_offset.argtypes = [vp]
+    L.tsdgpu_resampler_out_offset.restype = i64
+    L.tsdgpu_resampler_destroy.argtypes = [vp]
     L.tsdgpu_fft_create.argtypes = [C.POINTER(vp), i32, i32]
     L.tsdgpu_fft_step.argtypes = [vp, vp, vp, i32, i32, vp]
     L.tsdgpu_fft_size.argtypes = [vp]
@@ -216,6 +225,79 @@ class Sos:
     def close(self):
         if self._h:
             lib().tsdgpu_sos_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def itrp_sinc_lut(K=15, nphases=256, fcut=0.4):
+    """Host-side design helper: the LUT of itrp_sinc{K, nphases, fcut, "hn"} (itrp.cc:24-54),
+    float32 arithmetic, returned phase-major [nphases+1, K]."""
+    f = np.float32
+    i = np.arange(K)
+    step = (float((K - 1) // 2) - float(-(K // 2))) / (K - 1) if K > 1 else 0.0
+    ls = np.array([f(-(K // 2))] + [f(-(K // 2) + step * j) for j in range(1, K)], dtype=f)   # linspace (tsd.hpp:916-931)
+    lut = np.empty((nphases + 1, K), f)
+    pi_f = f(np.pi)
+    for j in range(nphases + 1):
+        tau = f((1.0 * j) / nphases)
+        t = (i - K // 2).astype(f) - tau
+        a = pi_f * f(2 * f(fcut)) * t                                    # sinc(T, f) (divers.cc:6-12)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            h = np.where(np.abs(a) < f(1e-7), f(2 * f(fcut)), np.sin(a, dtype=f) / (pi_f * t))
+        w = f(0.5) + f(2) * f(0.25) * np.cos((ls - tau) * f(2 * np.pi / K), dtype=f)
+        lut[j] = (h.astype(f) * w.astype(f)).astype(f)
+    return lut
+
+
+class Resampler:
+    """filtre_itrp<T>(ratio, itrp_sinc{K,nphases,fcut,"hn"}) (ra.cc:13-79,185-188).  With the
+    defaults this is the interpolator filtre_reechan configures for a ratio in [0.5,2)."""
+
+    def __init__(self, ratio, data_type, K=15, nphases=256, fcut=None, lut=None):
+        ratio = float(np.float32(ratio))
+        if lut is None:
+            if fcut is None:
+                fcut = float(min(np.float32(0.4), np.float32(ratio) / np.float32(2)))      # ra.cc:149
+            lut = itrp_sinc_lut(K, nphases, fcut)
+        lut = np.ascontiguousarray(lut, dtype=np.float32)
+        assert lut.shape == (nphases + 1, K)
+        self.ratio, self.K, self.data_type = ratio, K, data_type
+        self._h = C.c_void_p()
+        _check(lib().tsdgpu_resampler_create(C.byref(self._h), data_type, ratio, lut.ctypes.data, K, nphases))
+
+    def out_count(self, n):
+        return lib().tsdgpu_resampler_out_count(self._h, n)
+
+    @property
+    def out_offset(self):
+        return lib().tsdgpu_resampler_out_offset(self._h)
+
+    def step(self, x, y=None, stream=None):
+        assert _dtype_code(x) == self.data_type
+        n = x.shape[0]
+        nout = self.out_count(n)
+        if y is None:
+            y = np.empty(nout, x.dtype) if isinstance(x, np.ndarray) else x.new_empty(nout)
+        got = C.c_int64(0)
+        _check(lib().tsdgpu_resampler_step(self._h, _ptr(x), n, _ptr(y), y.shape[0], C.byref(got),
+                                           _stream_of(x, stream)))
+        return y[: got.value]
+
+    def reset(self):
+        _check(lib().tsdgpu_resampler_reset(self._h))
+
+    def seek(self, pos, hist=None, stream=None):
+        _check(lib().tsdgpu_resampler_seek(self._h, pos, None if hist is None else _ptr(hist),
+                                           None if hist is None else _stream_of(hist, stream)))
+
+    def close(self):
+        if self._h:
+            lib().tsdgpu_resampler_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

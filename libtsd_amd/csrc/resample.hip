@@ -1,0 +1,477 @@
+// resample.hip -- fractional resampler: LUT-sinc interpolator driven by libtsd's float32
+// phase accumulator, reproduced bit-exactly and evaluated tile-parallel.
+//
+// Stands behind AdaptationRythmeSimple<T>::step / filtre_itrp<T> (libtsd core/src/reechan/
+// ra.cc:13-79) with InterpolateurRIF::step (core/include/tsd/filtrage.hpp:1873-1881) and the
+// sinc LUT of itrp_sinc (core/src/reechan/itrp.cc:10-55), i.e. what filtre_reechan builds for
+// a ratio in [0.5,2) (ra.cc:104-156).  Per input sample the reference does
+//     window <- shift in x;  while (phase < 1) { emit sum_i lut[i][(int)(phase*nphases)] * window[i];
+//                                               phase += 1/ratio; }  phase -= 1;
+// with `phase` a float32: the number of outputs and the (input index, LUT column) of each one
+// are an index/permute result and are matched BIT-EXACTLY (same float additions, in the same
+// order, on host and device).
+//
+// The recurrence is sequential, so it is cut with checkpoints: the host simulates it once per
+// handle (lazily, only as far as the stream has advanced), records (phase, outputs so far)
+// every 16 inputs and runs Brent's cycle detection on the phase at input boundaries -- the
+// state space is finite, so the sequence becomes periodic (ratio 160/147: period 3 853 516
+// inputs <-> 4 194 303 outputs) and from then on any stream position is a table lookup.
+// On the device every lane restarts from the checkpoint at or below its 8-input segment,
+// replays at most 15+8 inputs, and writes one (input, column) record per output into LDS;
+// then the workgroup evaluates all outputs of the tile in parallel (15 taps x window from
+// LDS) and stores them coalesced.  HBM traffic: 8 B in + 8*ratio B out per complex sample.
+#include "common.hpp"
+#include <cmath>
+
+namespace tsdgpu {
+
+constexpr int RS_THREADS = 256;
+constexpr int RS_SEG = 8;                       // inputs per lane
+constexpr int RS_TI = RS_THREADS * RS_SEG;      // inputs per tile (2048)
+constexpr int RS_CK = 16;                       // checkpoint spacing (inputs)
+
+struct RsParams {
+  int64_t pos;        // absolute index of x[0]
+  int64_t n;          // inputs in this call
+  int64_t tile0;      // absolute start of the first tile (multiple of RS_TI, <= pos)
+  int64_t mu, lambda; // cycle of the phase sequence (lambda = 0: not found yet, table covers the call)
+  int64_t opp;        // outputs per period
+  int64_t cum_pos;    // outputs emitted before `pos`
+  float inc;          // 1/ratio as float (ra.cc:29)
+  int K, nph, lstride, rec_cap;
+};
+
+struct RsCk { uint32_t phase_bits; uint32_t cum; };   // cum = outputs before this input (canonical index space)
+
+__host__ __device__ inline float bits2f(uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __uint_as_float(b);
+#else
+  float f; memcpy(&f, &b, 4); return f;
+#endif
+}
+__host__ __device__ inline uint32_t f2bits(float f)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __float_as_uint(f);
+#else
+  uint32_t b; memcpy(&b, &f, 4); return b;
+#endif
+}
+
+__device__ __forceinline__ float zero_of(float) { return 0.f; }
+__device__ __forceinline__ float2 zero_of(float2) { return make_float2(0.f, 0.f); }
+__device__ __forceinline__ float tap_mac(float acc, float h, float x) { return fmaf(h, x, acc); }
+__device__ __forceinline__ float2 tap_mac(float2 acc, float h, float2 x)
+{
+  return make_float2(fmaf(h, x.x, acc.x), fmaf(h, x.y, acc.y));
+}
+
+template <typename T, int KT>
+__global__ __launch_bounds__(RS_THREADS) void resample_kernel(const T *__restrict__ x, const T *__restrict__ hist,
+                                                              T *__restrict__ y, const float *__restrict__ lut,
+                                                              const RsCk *__restrict__ ck, RsParams P)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int K = KT > 0 ? KT : P.K;      // KT = 15: the filtre_reechan interpolator, fully unrolled
+  T *tile = reinterpret_cast<T *>(smem_raw);                              // RS_TI + K - 1 samples
+  uint32_t *rec = reinterpret_cast<uint32_t *>(tile + (RS_TI + K - 1 + 1));
+  float *lut_s = reinterpret_cast<float *>(rec + P.rec_cap);
+  __shared__ long long s_cum_t0;
+  __shared__ int s_o_end;
+
+  const int tid = threadIdx.x;
+  const int64_t T0 = P.tile0 + (int64_t) blockIdx.x * RS_TI;
+  if (tid == 0) s_o_end = 0;
+
+  // ---- stage the LUT (phase-major, padded to an odd stride) and the input tile
+  const int lut_n = (P.nph + 1) * K;
+  for (int i = tid; i < lut_n; i += RS_THREADS) {
+    const int c = i / K, k = i - c * K;
+    lut_s[c * P.lstride + k] = lut[i];
+  }
+  for (int s = tid; s < RS_TI + K - 1; s += RS_THREADS) {
+    const int64_t rel = T0 - (K - 1) + s - P.pos;
+    T v = zero_of(T{});
+    if (rel < 0) {
+      if (rel >= -(int64_t) (K - 1)) v = hist[(K - 1) + rel];
+    } else if (rel < P.n) {
+      v = x[rel];
+    }
+    tile[s] = v;
+  }
+
+  // ---- replay the phase recurrence for this lane's 8 inputs
+  const int64_t i_abs = T0 + (int64_t) tid * RS_SEG;
+  int64_t ic = i_abs, q = 0;
+  if (P.lambda > 0 && i_abs >= P.mu + P.lambda) {
+    const int64_t d = i_abs - P.mu;
+    q = d / P.lambda;
+    ic = P.mu + (d - q * P.lambda);
+  }
+  const bool in_call = i_abs < P.pos + P.n;              // lanes past the end of the call do nothing
+  const float inc = P.inc;
+  float phase = 2.f;
+  int64_t cum = 0;
+  if (in_call) {
+    const RsCk c0 = ck[ic / RS_CK];
+    phase = bits2f(c0.phase_bits);
+    cum = (int64_t) c0.cum + q * P.opp;
+    for (int s = (int) (ic % RS_CK); s > 0; s--) {      // catch up from the checkpoint
+      while (phase < 1.f) { phase = phase + inc; cum++; }
+      phase = phase - 1.f;
+    }
+  }
+  if (tid == 0) s_cum_t0 = cum;
+  __syncthreads();
+  const int64_t cum_t0 = s_cum_t0;
+  const float fnph = (float) P.nph;
+  int last = 0;
+  for (int s = 0; s < RS_SEG && in_call; s++) {
+    const int64_t i = i_abs + s;
+    const bool live = i >= P.pos && i < P.pos + P.n;
+    while (phase < 1.f) {
+      if (live) {
+        const int o = (int) (cum - cum_t0);
+        rec[o] = ((uint32_t) (tid * RS_SEG + s) << 9) | (uint32_t) (int) (phase * fnph);   // itrp.cc:19
+        last = o + 1;
+      }
+      phase = phase + inc;                                // ra.cc:71, float32 add
+      cum++;
+    }
+    phase = phase - 1.f;                                  // ra.cc:73
+  }
+  if (last > 0) atomicMax(&s_o_end, last);
+  __syncthreads();
+
+  // ---- evaluate the tile's outputs in parallel
+  const int o_begin = (int) max((int64_t) 0, P.cum_pos - cum_t0);
+  const int o_end = s_o_end;
+  T *yt = y + (cum_t0 - P.cum_pos);
+  for (int o = o_begin + tid; o < o_end; o += RS_THREADS) {
+    const uint32_t r = rec[o];
+    const T *w = tile + (r >> 9);                         // window: x[i-K+1 .. i], oldest first
+    const float *h = lut_s + (r & 511u) * P.lstride;
+    T acc = zero_of(T{});
+#pragma unroll
+    for (int k = 0; k < K; k++) acc = tap_mac(acc, h[k], w[k]);   // filtrage.hpp:1877-1879 order
+    yt[o] = acc;
+  }
+}
+
+// new_hist = last H samples of (old_hist ++ x[0..n))
+template <typename T>
+__global__ void rs_hist_update_kernel(const T *__restrict__ x, const T *__restrict__ old_hist, T *__restrict__ new_hist,
+                                      int H, int64_t n)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= H) return;
+  const int64_t g = n - H + i;
+  new_hist[i] = g < 0 ? old_hist[H + g] : x[g];
+}
+
+}  // namespace tsdgpu
+
+using namespace tsdgpu;
+
+struct tsdgpu_resampler {
+  int data_type = 0, K = 0, nph = 0, lstride = 0;
+  float ratio = 1.f, inc = 1.f;
+  float *d_lut = nullptr;
+  void *d_hist[2] = {nullptr, nullptr};
+  int cur = 0;
+  // stream position
+  int64_t pos = 0, cum_pos = 0;
+  // host schedule: checkpoints every RS_CK inputs of the canonical sequence
+  std::vector<RsCk> ck;
+  int64_t sim_i = 0;          // inputs simulated so far (canonical)
+  float sim_phase = 0.f;
+  int64_t sim_cum = 0;
+  // Brent cycle detection on the phase at input boundaries
+  uint32_t tort_bits = 0;
+  int64_t brent_power = 1, brent_lam = 0;
+  bool cyc = false;
+  int64_t mu = 0, lambda = 0, opp = 0;
+  RsCk *d_ck = nullptr;
+  size_t d_ck_cap = 0, d_ck_n = 0;
+  DevBuf in_stage, out_stage;
+};
+
+namespace {
+
+inline void sim_one(float &phase, int64_t &cum, float inc)
+{
+  // volatile: keep every addition an IEEE binary32 operation whatever the optimiser prefers
+  volatile float p = phase;
+  while (p < 1.f) { p = p + inc; cum++; }
+  p = p - 1.f;
+  phase = p;
+}
+
+// state (phase, outputs before) at canonical input index ic, ic <= sim_i
+void state_at_canonical(const tsdgpu_resampler *r, int64_t ic, float *phase, int64_t *cum)
+{
+  const RsCk &c = r->ck[(size_t) (ic / RS_CK)];
+  float p = bits2f(c.phase_bits);
+  int64_t cu = c.cum;
+  for (int64_t s = ic % RS_CK; s > 0; s--) sim_one(p, cu, r->inc);
+  *phase = p;
+  *cum = cu;
+}
+
+// advance the host simulation until it covers canonical index `upto` or the cycle is known
+void extend(tsdgpu_resampler *r, int64_t upto)
+{
+  while (!r->cyc && r->sim_i < upto + RS_CK) {
+    if (r->sim_i % RS_CK == 0) r->ck.push_back(RsCk{f2bits(r->sim_phase), (uint32_t) r->sim_cum});
+    // Brent: compare the state at this input boundary with the tortoise
+    const uint32_t bits = f2bits(r->sim_phase);
+    if (r->sim_i == 0) {
+      r->tort_bits = bits;
+    } else {
+      r->brent_lam++;
+      if (bits == r->tort_bits) {
+        r->lambda = r->brent_lam;
+        // mu = first index whose state recurs lambda inputs later
+        float pa = 0.f, pb;
+        int64_t ca = 0, cb;
+        state_at_canonical(r, r->lambda, &pb, &cb);
+        int64_t m = 0;
+        while (f2bits(pa) != f2bits(pb)) {
+          sim_one(pa, ca, r->inc);
+          sim_one(pb, cb, r->inc);
+          m++;
+        }
+        r->mu = m;
+        r->opp = cb - ca;
+        r->cyc = true;
+        // make sure the table covers [0, mu + lambda + RS_CK)
+        while (r->sim_i < r->mu + r->lambda + 2 * RS_CK) {
+          sim_one(r->sim_phase, r->sim_cum, r->inc);
+          r->sim_i++;
+          if (r->sim_i % RS_CK == 0) r->ck.push_back(RsCk{f2bits(r->sim_phase), (uint32_t) r->sim_cum});
+        }
+        return;
+      }
+      if (r->brent_lam == r->brent_power) {
+        r->tort_bits = bits;
+        r->brent_power *= 2;
+        r->brent_lam = 0;
+      }
+    }
+    sim_one(r->sim_phase, r->sim_cum, r->inc);
+    r->sim_i++;
+  }
+}
+
+// outputs emitted before absolute input index i (and the phase there)
+void state_at(tsdgpu_resampler *r, int64_t i, float *phase, int64_t *cum)
+{
+  extend(r, i);
+  int64_t ic = i, q = 0;
+  if (r->cyc && i >= r->mu + r->lambda) {
+    const int64_t d = i - r->mu;
+    q = d / r->lambda;
+    ic = r->mu + d % r->lambda;
+  }
+  state_at_canonical(r, ic, phase, cum);
+  *cum += q * r->opp;
+}
+
+int sync_table(tsdgpu_resampler *r, hipStream_t st)
+{
+  if (r->d_ck_n == r->ck.size()) return TSDGPU_OK;
+  if (r->ck.size() > r->d_ck_cap) {
+    RsCk *nd = nullptr;
+    const size_t cap = r->ck.size() + r->ck.size() / 2 + 1024;
+    if (hipMalloc((void **) &nd, cap * sizeof(RsCk)) != hipSuccess)
+      return set_err(TSDGPU_ERR_ALLOC, "resampler: schedule table alloc failed");
+    TSD_HIP(hipStreamSynchronize(st));
+    if (r->d_ck) (void) hipFree(r->d_ck);
+    r->d_ck = nd;
+    r->d_ck_cap = cap;
+    r->d_ck_n = 0;
+  }
+  TSD_HIP(hipMemcpyAsync(r->d_ck + r->d_ck_n, r->ck.data() + r->d_ck_n, (r->ck.size() - r->d_ck_n) * sizeof(RsCk),
+                         hipMemcpyHostToDevice, st));
+  TSD_HIP(hipStreamSynchronize(st));    // the vector may grow (reallocate) before the copy has run
+  r->d_ck_n = r->ck.size();
+  return TSDGPU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tsdgpu_resampler_create(tsdgpu_resampler **out, int data_type, float ratio, const float *lut_host, int K,
+                            int nphases)
+{
+  TSD_CHECK(out != nullptr, "resampler_create: out is NULL");
+  *out = nullptr;
+  TSD_CHECK(data_type == TSDGPU_F32 || data_type == TSDGPU_C64, "resampler_create: bad data_type %d", data_type);
+  TSD_CHECK(lut_host != nullptr, "resampler_create: NULL lut");
+  TSD_CHECK(std::isfinite(ratio) && ratio > 0.f, "resampler_create: invalid ratio %g", (double) ratio);
+  if (ratio > 8.f || ratio < 1.f / 64.f)
+    return set_err(TSDGPU_ERR_UNSUPPORTED, "resampler_create: ratio %g outside [1/64, 8] (filtre_reechan folds "
+                   "ratios into [0.5,2) with half-band stages first)", (double) ratio);
+  if (K < 1 || K > 32 || nphases < 1 || nphases > 511)
+    return set_err(TSDGPU_ERR_UNSUPPORTED, "resampler_create: K=%d nphases=%d unsupported (K <= 32, nphases <= 511)", K, nphases);
+  tsdgpu_resampler *r = new tsdgpu_resampler();
+  r->data_type = data_type;
+  r->K = K;
+  r->nph = nphases;
+  r->lstride = (K % 2 == 0) ? K + 1 : K + 2;
+  r->ratio = ratio;
+  r->inc = 1.f / ratio;                      // ra.cc:29
+  const size_t lut_bytes = (size_t) (nphases + 1) * K * sizeof(float);
+  const size_t hb = (size_t) std::max(K - 1, 1) * dtype_size(data_type);
+  int rc = TSDGPU_OK;
+  if (hipMalloc((void **) &r->d_lut, lut_bytes) != hipSuccess || hipMalloc(&r->d_hist[0], hb) != hipSuccess ||
+      hipMalloc(&r->d_hist[1], hb) != hipSuccess)
+    rc = set_err(TSDGPU_ERR_HIP, "resampler_create: hipMalloc failed: %s", hipGetErrorString(hipGetLastError()));
+  else if (hipMemcpy(r->d_lut, lut_host, lut_bytes, hipMemcpyHostToDevice) != hipSuccess ||
+           hipMemset(r->d_hist[0], 0, hb) != hipSuccess || hipMemset(r->d_hist[1], 0, hb) != hipSuccess)
+    rc = set_err(TSDGPU_ERR_HIP, "resampler_create: upload failed: %s", hipGetErrorString(hipGetLastError()));
+  if (rc) {
+    tsdgpu_resampler_destroy(r);
+    return rc;
+  }
+  (void) hipFuncSetAttribute((const void *) resample_kernel<float, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void) hipFuncSetAttribute((const void *) resample_kernel<float2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void) hipFuncSetAttribute((const void *) resample_kernel<float, 15>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void) hipFuncSetAttribute((const void *) resample_kernel<float2, 15>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void) hipGetLastError();
+  *out = r;
+  return TSDGPU_OK;
+}
+
+int64_t tsdgpu_resampler_out_count(tsdgpu_resampler *r, int64_t n)
+{
+  if (!r || n < 0) return -1;
+  float ph;
+  int64_t c;
+  state_at(r, r->pos + n, &ph, &c);
+  return c - r->cum_pos;
+}
+
+int tsdgpu_resampler_step(tsdgpu_resampler *r, const void *x, int64_t n, void *y, int64_t y_capacity, int64_t *n_out,
+                          void *stream)
+{
+  TSD_CHECK(r != nullptr, "resampler_step: NULL handle");
+  TSD_CHECK(n >= 0, "resampler_step: negative length");
+  if (n_out) *n_out = 0;
+  if (n == 0) return TSDGPU_OK;
+  TSD_CHECK(x != nullptr, "resampler_step: NULL input");
+  hipStream_t st = (hipStream_t) stream;
+  float ph_end;
+  int64_t cum_end;
+  state_at(r, r->pos + n, &ph_end, &cum_end);
+  const int64_t nout = cum_end - r->cum_pos;
+  TSD_CHECK(nout <= y_capacity, "resampler_step: output needs %lld samples, capacity is %lld", (long long) nout,
+            (long long) y_capacity);
+  TSD_CHECK(nout == 0 || y != nullptr, "resampler_step: NULL output");
+  int rc = sync_table(r, st);
+  if (rc) return rc;
+  const size_t sz = dtype_size(r->data_type);
+  const void *dx = nullptr;
+  void *dy = nullptr;
+  bool staged = false;
+  rc = stage_in(x, (size_t) n * sz, r->in_stage, st, &dx);
+  if (rc) return rc;
+  rc = stage_out(y, (size_t) nout * sz, r->out_stage, &dy, &staged);
+  if (rc) return rc;
+
+  RsParams P;
+  P.pos = r->pos;
+  P.n = n;
+  P.tile0 = (r->pos / RS_TI) * RS_TI;
+  P.mu = r->cyc ? r->mu : 0;
+  P.lambda = r->cyc ? r->lambda : 0;
+  P.opp = r->opp;
+  P.cum_pos = r->cum_pos;
+  P.inc = r->inc;
+  P.K = r->K;
+  P.nph = r->nph;
+  P.lstride = r->lstride;
+  // at most floor(1/inc)+1 outputs per input
+  // outputs are spaced 1/ratio apart in input time (up to float32 rounding of the adds)
+  P.rec_cap = (int) ((double) RS_TI * (double) r->ratio * 1.0001) + 32;
+  const int64_t tiles = cdiv(r->pos + n - P.tile0, RS_TI);
+  TSD_CHECK(tiles <= 0x7fffffff, "resampler_step: n too large for one launch");
+  const size_t lds = (size_t) (RS_TI + r->K) * sz + (size_t) P.rec_cap * 4 + (size_t) (r->nph + 1) * r->lstride * 4 + 64;
+  TSD_CHECK(lds <= 158 * 1024, "resampler_step: configuration needs %zu bytes of LDS", lds);
+#define RS_LAUNCH(T, KT)                                                                                            \
+  hipLaunchKernelGGL((resample_kernel<T, KT>), dim3((unsigned) tiles), dim3(RS_THREADS), lds, st, (const T *) dx, \
+                     (const T *) r->d_hist[r->cur], (T *) dy, r->d_lut, r->d_ck, P)
+  if (r->data_type == TSDGPU_C64) {
+    if (r->K == 15) RS_LAUNCH(float2, 15); else RS_LAUNCH(float2, 0);
+  } else {
+    if (r->K == 15) RS_LAUNCH(float, 15); else RS_LAUNCH(float, 0);
+  }
+#undef RS_LAUNCH
+  TSD_HIP(hipGetLastError());
+  if (r->K > 1) {
+    const int H = r->K - 1, nxt = r->cur ^ 1;
+    if (r->data_type == TSDGPU_C64)
+      hipLaunchKernelGGL(rs_hist_update_kernel<float2>, dim3(1), dim3(64), 0, st, (const float2 *) dx,
+                         (const float2 *) r->d_hist[r->cur], (float2 *) r->d_hist[nxt], H, n);
+    else
+      hipLaunchKernelGGL(rs_hist_update_kernel<float>, dim3(1), dim3(64), 0, st, (const float *) dx,
+                         (const float *) r->d_hist[r->cur], (float *) r->d_hist[nxt], H, n);
+    TSD_HIP(hipGetLastError());
+    r->cur = nxt;
+  }
+  r->pos += n;
+  r->cum_pos = cum_end;
+  if (n_out) *n_out = nout;
+  return finish_out(y, (size_t) nout * sz, dy, staged, st);
+}
+
+int tsdgpu_resampler_reset(tsdgpu_resampler *r)
+{
+  TSD_CHECK(r != nullptr, "resampler_reset: NULL handle");
+  r->pos = 0;
+  r->cum_pos = 0;
+  const size_t hb = (size_t) std::max(r->K - 1, 1) * dtype_size(r->data_type);
+  TSD_HIP(hipMemset(r->d_hist[r->cur], 0, hb));
+  return TSDGPU_OK;
+}
+
+int tsdgpu_resampler_seek(tsdgpu_resampler *r, int64_t pos, const void *hist, void *stream)
+{
+  TSD_CHECK(r != nullptr && pos >= 0, "resampler_seek: bad argument");
+  hipStream_t st = (hipStream_t) stream;
+  float ph;
+  int64_t c;
+  state_at(r, pos, &ph, &c);
+  r->pos = pos;
+  r->cum_pos = c;
+  const size_t hb = (size_t) std::max(r->K - 1, 1) * dtype_size(r->data_type);
+  if (hist && r->K > 1) {
+    const bool dev = is_device_ptr(hist);
+    TSD_HIP(hipMemcpyAsync(r->d_hist[r->cur], hist, (size_t) (r->K - 1) * dtype_size(r->data_type),
+                           dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    if (!dev) TSD_HIP(hipStreamSynchronize(st));
+  } else {
+    TSD_HIP(hipMemsetAsync(r->d_hist[r->cur], 0, hb, st));
+  }
+  return TSDGPU_OK;
+}
+
+int64_t tsdgpu_resampler_out_offset(const tsdgpu_resampler *r) { return r ? r->cum_pos : -1; }
+
+int tsdgpu_resampler_destroy(tsdgpu_resampler *r)
+{
+  if (!r) return TSDGPU_OK;
+  if (r->d_lut) (void) hipFree(r->d_lut);
+  if (r->d_hist[0]) (void) hipFree(r->d_hist[0]);
+  if (r->d_hist[1]) (void) hipFree(r->d_hist[1]);
+  if (r->d_ck) (void) hipFree(r->d_ck);
+  r->in_stage.release();
+  r->out_stage.release();
+  delete r;
+  return TSDGPU_OK;
+}
+
+}  // extern "C"

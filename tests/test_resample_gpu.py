@@ -1,0 +1,125 @@
+"""GPU parity of the fractional resampler (C ABI tsdgpu_resampler_*) against the CPU oracle
+(restatement of AdaptationRythmeSimple / InterpolateurRIF / itrp_sinc, ra.cc:13-79).
+Index results (output count, input index and LUT column of every output) must be BIT-EXACT;
+sample values within 1e-5 relative."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+R160 = np.float32(160.0) / np.float32(147.0)
+
+
+def relerr(y, ref):
+    return float(np.abs(y - ref).max() / max(np.abs(ref).max(), 1e-30))
+
+
+def rand(n, cplx, seed):
+    rng = np.random.default_rng(seed)
+    if cplx:
+        return (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    return rng.standard_normal(n).astype(np.float32)
+
+
+@pytest.fixture(scope="module")
+def tg():
+    import libtsd_amd as t
+    assert t.device_count() >= 1
+    return t
+
+
+RATIOS = [R160, 1.5, 0.5, 1.2, 1.999, 0.7, float(np.pi / 2), 1.0000001, 147.0 / 160.0]
+
+
+@pytest.mark.parametrize("ratio", RATIOS)
+@pytest.mark.parametrize("cplx", [True, False])
+def test_resample_values(tg, orc, ratio, cplx):
+    n = 50000
+    x = rand(n, cplx, 7)
+    ref = orc.Resampler(ratio)
+    yref = ref.step(x)
+    g = tg.Resampler(ratio, tg.C64 if cplx else tg.F32, lut=ref.lut)     # identical LUT data on both sides
+    y = g.step(x)
+    assert len(y) == len(yref)                                           # exact output count
+    assert relerr(y, yref) <= TOL
+
+
+# Bit-exact schedule: with a LUT that is 1 on the newest tap the output IS the input sample
+# selected (x = ramp -> input index); with LUT[col][newest] = col and x = 1 the output IS the column.
+@pytest.mark.parametrize("ratio", RATIOS)
+def test_resample_schedule_bit_exact(tg, orc, ratio):
+    n, K, nph = 70000, 15, 256
+    ref = orc.Resampler(ratio)
+    nout, idx, col = ref.schedule(n)
+    lut_idx = np.zeros((nph + 1, K), np.float32)
+    lut_idx[:, K - 1] = 1
+    y = tg.Resampler(ratio, tg.F32, lut=lut_idx).step(np.arange(n, dtype=np.float32))
+    assert len(y) == nout
+    assert np.array_equal(y.astype(np.int64), idx)
+    lut_col = np.zeros((nph + 1, K), np.float32)
+    lut_col[:, K - 1] = np.arange(nph + 1)
+    y = tg.Resampler(ratio, tg.F32, lut=lut_col).step(np.ones(n, np.float32))
+    assert np.array_equal(y.astype(np.int32), col)
+
+
+# streaming: ragged chunks carry phase, window history and output offset
+@pytest.mark.parametrize("bs", [20000, 4096, 1000, 311, 1])
+def test_resample_streaming(tg, orc, bs):
+    n = 60000 if bs > 1 else 300
+    x = rand(n, True, 8)
+    ref = orc.Resampler(R160)
+    yref = ref.step(x)
+    g = tg.Resampler(R160, tg.C64, lut=ref.lut)
+    y = np.concatenate([g.step(x[o:o + bs].copy()) for o in range(0, n, bs)])
+    assert len(y) == len(yref) and relerr(y, yref) <= TOL
+    g.reset()
+    assert np.array_equal(g.step(x), y)
+
+
+# the multi-GPU sharding hook: a shard seeks to its absolute position with its 14-sample halo
+def test_resample_seek_shards(tg, orc):
+    n, parts = 400000, 4
+    x = rand(n, True, 9)
+    ref = orc.Resampler(R160)
+    yref = ref.step(x)
+    out = np.zeros_like(yref)
+    for p in range(parts):
+        lo, hi = p * n // parts, (p + 1) * n // parts
+        g = tg.Resampler(R160, tg.C64, lut=ref.lut)
+        halo = np.zeros(14, np.complex64)
+        if lo:
+            halo[:] = x[lo - 14:lo]
+        g.seek(lo, halo if lo else None)
+        off = g.out_offset
+        yp = g.step(x[lo:hi].copy())
+        out[off:off + len(yp)] = yp
+    assert relerr(out, yref) <= TOL
+
+
+# known-answer counts of the float32 recurrence -- host schedule only
+def test_resample_counts_known_answers(tg):
+    g = tg.Resampler(R160, tg.C64)
+    assert g.out_count(1 << 20) == 1141308
+    assert g.out_count(1 << 26) == 73043660
+    assert g.out_count(1 << 30) == 1168698548
+
+
+def test_resample_device_large(tg, orc):
+    import torch
+    n = 1 << 24
+    gen = torch.Generator(device="cuda:0").manual_seed(5)
+    xd = torch.view_as_complex(torch.randn(n, 2, device="cuda:0", generator=gen))
+    ref = orc.Resampler(R160)
+    g = tg.Resampler(R160, tg.C64, lut=ref.lut)
+    yd = g.step(xd)
+    torch.cuda.synchronize()
+    yref = ref.step(xd.cpu().numpy())
+    assert yd.shape[0] == len(yref)
+    assert relerr(yd.cpu().numpy(), yref) <= TOL
+
+
+def test_resample_bad_arguments(tg):
+    with pytest.raises(tg.TsdGpuError):
+        tg.Resampler(0.0, tg.F32)
+    with pytest.raises(tg.TsdGpuError):
+        tg.Resampler(1.5, tg.F32, K=127, nphases=256, fcut=0.5)       # documented gap: K <= 32
