@@ -1,0 +1,53 @@
+// dsp/dsp.hpp -- English names of the hot-path API (libtsd core/include/dsp/*.hpp forwards
+// every call to its French twin; SURVEY.md Appendix A lists the pairs).  Here the English
+// API is the same objects under aliases, so dsp:: and tsd:: code can be mixed freely.
+#pragma once
+#include "tsd/tsd.hpp"
+#include "tsd/filtrage.hpp"
+#include "tsd/fourier.hpp"
+
+namespace dsp {
+using tsd::cfloat;
+using tsd::sptr;
+template <typename T> using Vector = tsd::Vecteur<T>;
+using Vecf = tsd::Vecf;
+using Veccf = tsd::Veccf;
+template <typename Te, typename Ts = Te> using FilterGen = tsd::FiltreGen<Te, Ts>;   // dsp/dsp.hpp:462-472
+template <typename Te, typename Ts = Te, typename Tc = tsd::Void> using Filter = tsd::Filtre<Te, Ts, Tc>;
+using tsd::linspace;
+// dsp::resample (dsp/dsp.hpp:499-503)
+template <typename T> Vector<T> resample(const Vector<T> &x, float ratio) { return tsd::rééchan(x, ratio); }
+
+namespace filter {
+using tsd::filtrage::Design;
+using tsd::filtrage::FRat;
+using tsd::filtrage::RIIStructure;
+using tsd::filtrage::FormeDirecte1;
+using tsd::filtrage::FormeDirecte2;
+inline Vecf window(const std::string &type, int n, bool symetrical = true) { return tsd::filtrage::fenêtre(type, n, symetrical); }
+inline Vecf design_fir_wnd(int n, const std::string &type, float fc, const std::string &wnd = "hn", float fc2 = 0)
+{ return tsd::filtrage::design_rif_fen(n, type, fc, wnd, fc2); }
+inline FRat<cfloat> design_iira(int n, const std::string &type, const std::string &prototype, float fc, float δ_bp = 0.1f, float δ_bc = 60)
+{ return tsd::filtrage::design_riia(n, type, prototype, fc, δ_bp, δ_bc); }
+template <typename Tc, typename T = Tc> sptr<FilterGen<T>> filter_fir(const Vector<Tc> &h) { return tsd::filtrage::filtre_rif<Tc, T>(h); }
+template <typename T> sptr<FilterGen<T>> filter_fir_fft(const Vecf &h) { return tsd::filtrage::filtre_rif_fft<T>(h); }
+template <typename T> sptr<FilterGen<T>> filter_sois(const FRat<cfloat> &h, RIIStructure s = FormeDirecte2) { return tsd::filtrage::filtre_sois<T>(h, s); }
+template <typename T> sptr<FilterGen<T>> filter_sois(const FRat<float> &h, RIIStructure s = FormeDirecte2) { return tsd::filtrage::filtre_sois<T>(h, s); }
+template <typename T> sptr<Filter<T, T, float>> filter_resample(float ratio) { return tsd::filtrage::filtre_reechan<T>(ratio); }
+template <typename T> Vector<T> filter(const Design &d, const Vector<T> &x) { return tsd::filtrage::filtrer<T>(d, x); }
+template <typename T> Vector<T> filtfilt(const Design &d, const Vector<T> &x) { return tsd::filtrage::filtfilt<T>(d, x); }
+template <typename T, typename Tc> Vector<T> convol(const Vector<Tc> &h, const Vector<T> &x) { return tsd::filtrage::convol<T, Tc>(h, x); }
+}  // namespace filter
+
+namespace fourier {
+using tsd::fourier::FFTPlan;
+using tsd::fourier::fftplan_defaut;
+inline sptr<FFTPlan> fftplan_new(int n = -1, bool forward = true, bool normalize = true) { return tsd::fourier::tfrplan_création(n, forward, normalize); }
+inline sptr<FilterGen<float, cfloat>> rfftplan_new(int n = -1) { return tsd::fourier::rtfrplan_création(n); }
+template <typename T> Veccf fft(const Vector<T> &x) { return tsd::fourier::fft(x); }
+template <typename T> Veccf ifft(const Vector<T> &X) { return tsd::fourier::ifft(X); }
+inline Veccf rfft(const Vecf &x) { return tsd::fourier::rfft(x); }
+template <typename T> Vector<T> fftshift(const Vector<T> &X) { return tsd::fourier::fftshift(X); }
+template <typename T> void force_csym(Vector<T> &X) { tsd::fourier::csym_forçage(X); }
+}  // namespace fourier
+}  // namespace dsp

@@ -1,0 +1,143 @@
+// tsd/filtrage.hpp -- host-side mirror of libtsd's filtering API for the streaming hot path
+// (namespace tsd::filtrage), backed by the MI355X C ABI.  Same names / argument meaning as
+//   core/include/tsd/filtrage.hpp:24-85 (Design), :839 (design_rif_fen), :700 (design_riia),
+//   :1367 (filtre_rif), :1402 (filtre_rif_fft), :1585-1590 (filtre_sois), :1684-1780
+//   (filtrer / filtfilt / convol), :1814-1943 (Interpolateur, itrp_sinc), :2029-2039
+//   (filtre_reechan, filtre_itrp);  core/include/tsd/filtrage/frat.hpp (FRat / Poly subset).
+#pragma once
+#include "tsd/tsd.hpp"
+
+namespace tsd::filtrage {
+
+// ---- rational transfer functions (subset of frat.hpp:16,501) ---------------------------------
+// A polynomial is either a coefficient list (ascending powers) or, in "mode_racines", a list
+// of roots with a leading multiplier `mlt`: mlt * prod (z - coefs[i]).
+template <typename T> struct Poly {
+  Vecteur<T> coefs;
+  T mlt = T(1);
+  bool mode_racines = false;
+  std::string vname = "z";
+  static Poly from_roots(const Vecteur<T> &r)
+  {
+    Poly p;
+    p.coefs = r;
+    p.mode_racines = true;
+    return p;
+  }
+  // roots of the polynomial (identity in mode_racines, frat.cc:43-46; companion-free
+  // Durand-Kerner iteration otherwise -- the reference uses Eigen's PolynomialSolver there)
+  Vecteur<std::complex<float>> roots() const;
+};
+
+template <typename T> struct FRat {
+  Poly<T> numer, denom;
+  // H(z^-1) = (a0 + a1 z^-1 + ...) / (b0 + b1 z^-1 + ...), coefficient form
+  static FRat rii(const Vecteur<T> &numer, const Vecteur<T> &denom)
+  {
+    FRat h;
+    h.numer.coefs = numer;
+    h.numer.vname = "z^-1";
+    h.denom.coefs = denom;
+    h.denom.vname = "z^-1";
+    return h;
+  }
+  static FRat rif(const Vecteur<T> &c)
+  {
+    FRat h = rii(c, Vecteur<T>::ones(1));
+    return h;
+  }
+  bool est_rif() const { return !denom.mode_racines && denom.coefs.rows() == 1; }
+};
+
+// ---- Design (filtrage.hpp:24-85) ---------------------------------------------------------------
+struct Design {
+  Design(const FRat<cfloat> &f) : est_complexe(true), est_rif(false), frat_c(f) {}
+  Design(const FRat<float> &f) : est_complexe(false), est_rif(false), frat(f) {}
+  Design(const Vecf &c) : est_complexe(false), est_rif(true), coefs(c) {}
+  Design() {}
+  bool est_complexe = false, est_rif = false;
+  FRat<float> frat;
+  FRat<cfloat> frat_c;
+  Vecf coefs;
+};
+
+typedef enum { FormeDirecte1, FormeDirecte2 } RIIStructure;
+
+// ---- design helpers (run once on the host) ---------------------------------------------------
+Vecf fenêtre(cstring type, entier n, bouléen symetrique = true);                       // "hn","hm","re","tr"
+Vecf design_rif_fen(entier n, cstring type, float fc, cstring fen = "hn", float fc2 = 0);
+Vecf design_rif_prod(const Vecf &h1, const Vecf &h2);
+FRat<cfloat> design_riia(entier n, cstring type, cstring prototype, float fc, float δ_bp = 0.1f, float δ_bc = 60);
+float sinc(float T, float f);
+
+// ---- stateful operators (factories) ------------------------------------------------------------
+template <typename Tc, typename T = Tc> sptr<FiltreGen<T>> filtre_rif(const Vecteur<Tc> &h);
+template <typename T> sptr<FiltreGen<T>> filtre_rif_fft(const Vecf &h);
+template <typename T> sptr<FiltreGen<T>> filtre_sois(const FRat<cfloat> &h, RIIStructure structure = FormeDirecte2);
+template <typename T> sptr<FiltreGen<T>> filtre_sois(const FRat<float> &h, RIIStructure structure = FormeDirecte2);
+
+// ---- interpolators / resampling (filtrage.hpp:1814-1943,2029-2039) -----------------------------
+template <typename T> struct Interpolateur {
+  entier K = 0;
+  float delais = 0;
+  std::string nom;
+  virtual ~Interpolateur() {}
+  virtual T step(const Vecteur<T> &x, entier k, float τ) = 0;
+};
+template <typename T> struct InterpolateurRIF : Interpolateur<T> {
+  virtual Vecf coefs(float τ) = 0;
+  T step(const Vecteur<T> &x, entier k, float τ) override
+  {
+    const Vecf h = coefs(τ);
+    T res = T(0);
+    for (entier i = 0; i < this->K; i++) res += h(i) * x((i + k) % this->K);
+    return res;
+  }
+};
+struct InterpolateurSincConfig {
+  entier ncoefs = 31;
+  entier nphases = 256;
+  float fcut = 0.5;
+  std::string fenetre = "hn";
+};
+// LUT-sinc interpolator; exposes its table so the GPU resampler can take it as is
+template <typename T> struct InterpolateurSinc : InterpolateurRIF<T> {
+  InterpolateurSincConfig config;
+  std::vector<float> lut;   // phase-major [(nphases+1) x K]
+  explicit InterpolateurSinc(const InterpolateurSincConfig &c);
+  Vecf coefs(float τ) override;
+};
+template <typename T> sptr<Interpolateur<T>> itrp_sinc(const InterpolateurSincConfig &config);
+template <typename T> sptr<FiltreGen<T>> filtre_itrp(float ratio, sptr<Interpolateur<T>> itrp);
+template <typename T> sptr<Filtre<T, T, float>> filtre_reechan(float ratio);
+
+// ---- one-shot API (filtrage.hpp:1684-1780) -----------------------------------------------------
+template <typename T> Vecteur<T> filtrer(const Design &d, const Vecteur<T> &x)
+{
+  if (d.est_rif) {
+    auto f = filtre_rif<float, T>(d.coefs);
+    return f->step(x);
+  }
+  if (d.est_complexe) {
+    auto f = filtre_sois<T>(d.frat_c);
+    return f->step(x);
+  }
+  if (d.frat.est_rif()) {
+    // coefficient-form FIR: the reference reverses the numerator here (filtrage.hpp:1702-1704)
+    auto f = filtre_rif<float, T>(d.frat.numer.coefs.reverse());
+    return f->step(x);
+  }
+  auto f = filtre_sois<T>(d.frat);
+  return f->step(x);
+}
+template <typename T> Vecteur<T> filtfilt(const Design &h, const Vecteur<T> &x)
+{
+  return filtrer(h, filtrer<T>(h, x).reverse()).reverse();
+}
+template <typename T, typename Tc> Vecteur<T> convol(const Vecteur<Tc> &h, const Vecteur<T> &x)
+{
+  auto f = filtre_rif<Tc, T>(h);
+  return f->step(x);
+}
+
+}  // namespace tsd::filtrage

@@ -1,0 +1,69 @@
+// tsd/fourier.hpp -- host-side mirror of libtsd's FFT API for the hot path (namespace
+// tsd::fourier), backed by the MI355X C ABI.  Same names / meaning as
+//   core/include/tsd/fourier.hpp:19-35 (FFTPlan, fftplan_defaut), :69,:99 (tfrplan_création,
+//   rtfrplan_création), :116-205 (rfft, fft, ifft), :232-282 (fftshift, csym_forçage).
+// Unitary scaling 1/sqrt(n) in both directions, whatever `normalize` says -- that is what
+// TFRPlanDefaut does (fourier.cc:362,372-376,120).
+#pragma once
+#include "tsd/tsd.hpp"
+
+namespace tsd::fourier {
+
+struct FFTPlan {
+  virtual ~FFTPlan() {}
+  virtual void configure(entier n, bouléen avant, bouléen normalize = true) = 0;
+  virtual void step(const Veccf &x, Veccf &y, bouléen avant = true) = 0;
+  Veccf step(const Veccf &x, bouléen avant = true)
+  {
+    Veccf y;
+    step(x, y, avant);
+    return y;
+  }
+};
+
+// The run-time plug point: every fft()/ifft() asks this factory for its plan
+// (fourier.cc:469-481).  Default: the MI355X plan.
+extern fonction<sptr<FFTPlan>()> fftplan_defaut;
+sptr<FFTPlan> tfrplan_création(entier n = -1, bouléen avant = true, bouléen normalize = true);
+sptr<FiltreGen<float, cfloat>> rtfrplan_création(entier n = -1);
+
+void csym_forçage_impl(Veccf &X);
+template <typename T> void csym_forçage(Vecteur<T> &X)
+{
+  if constexpr (est_complexe<T>()) csym_forçage_impl(X);
+}
+
+template <typename T> Veccf fft(const Vecteur<T> &x)
+{
+  if constexpr (est_complexe<T>()) {
+    return tfrplan_création()->step(x, true);
+  } else {
+    // real input goes through the real-FFT plan like the reference (fourier.hpp:163-170)
+    return rtfrplan_création()->step(x);
+  }
+}
+template <typename T> Veccf ifft(const Vecteur<T> &X)
+{
+  if constexpr (est_complexe<T>())
+    return tfrplan_création()->step(X, false);
+  else
+    return tfrplan_création()->step(X.as_complex(), false);
+}
+inline Veccf rfft(const Vecf &x) { return rtfrplan_création()->step(x); }
+
+// fftshift (fourier.hpp:232-248): pure index permutation
+template <typename T> Vecteur<T> fftshift(const Vecteur<T> &X)
+{
+  const entier n = X.rows();
+  Vecteur<T> res = Vecteur<T>::zeros(n);
+  if ((n & 1) == 0) {
+    res.tail(n / 2) = X.head(n / 2);
+    res.head(n / 2) = X.tail(n / 2);
+  } else {
+    res.tail(1 + n / 2) = X.head(1 + n / 2);
+    res.head(n / 2) = X.tail(n / 2);
+  }
+  return res;
+}
+
+}  // namespace tsd::fourier

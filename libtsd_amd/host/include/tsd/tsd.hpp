@@ -1,0 +1,389 @@
+// tsd/tsd.hpp -- host-side mirror of the part of libtsd's root API (namespace tsd) that the
+// streaming FIR / IIR / FFT / resample path touches, backed by the MI355X C ABI
+// (include/tsdgpu.h).  Written from scratch; it keeps libtsd's NAMES, argument meaning and
+// error behaviour for this path so existing call sites compile unchanged:
+//   Vecteur<T> / Vecf / Veccf          core/include/tsd/tableau.hpp:290-1445 (subset)
+//   FiltreGen / Filtre / Configurable  core/include/tsd/tsd.hpp:544-579,626-668
+//   rééchan                            core/include/tsd/tsd.hpp:700-705
+//   linspace, sigimp, randn ...        core/include/tsd/tsd.hpp:916-931, core/src/tsd.cc:179-483
+// Not a reimplementation of libtsd's array runtime: only what the hot path and its tests use.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <initializer_list>
+#include <memory>
+#include <random>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace tsd {
+
+using entier = int;
+using bouléen = bool;
+using cfloat = std::complex<float>;
+using cdouble = std::complex<double>;
+template <typename T> using sptr = std::shared_ptr<T>;
+template <typename T> using fonction = std::function<T>;
+using cstring = const std::string &;
+static const double π = 3.14159265358979323846;
+static const float π_f = 3.14159265358979323846f;
+struct Void {};
+
+// ---- errors and logging (core/include/tsd/commun.hpp:41-54,132-178) -----------------------
+// logger(niveau, message): niveau 0..5; échec() logs at level 4 then throws std::runtime_error
+// (what libtsd's default logger does, core/src/tsd.cc:114-118).
+using logger_t = std::function<void(int niveau, const std::string &msg)>;
+logger_t &get_logger();
+void set_logger(logger_t l);
+
+namespace detail {
+inline void fmt_rec(std::ostringstream &os, const char *f)
+{
+  os << f;
+}
+template <typename A, typename... R> void fmt_rec(std::ostringstream &os, const char *f, const A &a, const R &...r)
+{
+  for (; *f; f++) {
+    if (f[0] == '{') {
+      const char *e = std::strchr(f, '}');
+      if (e) {
+        os << a;
+        fmt_rec(os, e + 1, r...);
+        return;
+      }
+    }
+    os << *f;
+  }
+}
+template <typename... A> std::string fmt(const char *f, const A &...a)
+{
+  std::ostringstream os;
+  fmt_rec(os, f, a...);
+  return os.str();
+}
+}  // namespace detail
+
+template <typename... A> void msg(const char *f, const A &...a)
+{
+  if (get_logger()) get_logger()(1, detail::fmt(f, a...));
+}
+template <typename... A> [[noreturn]] void échec(const char *f, const A &...a)
+{
+  const std::string m = detail::fmt(f, a...);
+  if (get_logger()) get_logger()(4, m);
+  throw std::runtime_error(m);
+}
+#define tsd_assertion(cond)                                                                  \
+  do {                                                                                       \
+    if (!(cond)) ::tsd::échec("assertion failed: {} ({}:{})", #cond, __FILE__, __LINE__);    \
+  } while (0)
+
+template <typename T> constexpr bool est_complexe()
+{
+  return std::is_same_v<T, cfloat> || std::is_same_v<T, cdouble>;
+}
+
+// ---- Vecteur<T>: contiguous column vector, int-indexed -------------------------------------
+// Semantics kept from TabT<T,1> (tableau.hpp:530-592, pinned by core/tests/test-tab.cc):
+// copy construction = deep copy, move = steal, head/tail/segment = views aliasing the parent,
+// assignment INTO a view = element copy into the parent, map() wraps foreign memory.
+template <typename T> class Vecteur {
+  std::shared_ptr<T[]> buf_;
+  T *p_ = nullptr;
+  entier n_ = 0;
+  bool vue_ = false;
+
+ public:
+  using Scalar = T;
+  Vecteur() = default;
+  explicit Vecteur(entier n) { alloc(n); }
+  Vecteur(const Vecteur &o)
+  {
+    alloc(o.n_);
+    std::copy(o.p_, o.p_ + o.n_, p_);
+  }
+  Vecteur(Vecteur &&o) noexcept : buf_(std::move(o.buf_)), p_(o.p_), n_(o.n_), vue_(o.vue_)
+  {
+    o.p_ = nullptr;
+    o.n_ = 0;
+    o.vue_ = false;
+  }
+  // widening: real -> complex (tableau.hpp:515-521)
+  template <typename U, typename = std::enable_if_t<!std::is_same_v<U, T> && std::is_convertible_v<U, T>>>
+  Vecteur(const Vecteur<U> &o)
+  {
+    alloc(o.rows());
+    for (entier i = 0; i < n_; i++) p_[i] = (T) o.data()[i];
+  }
+  Vecteur &operator=(const Vecteur &o)
+  {
+    if (this == &o) return *this;
+    if (vue_) {
+      if (o.n_ != n_) échec("Vecteur: assignment into a view of {} elements from {} elements", n_, o.n_);
+      std::copy(o.p_, o.p_ + n_, p_);
+    } else {
+      if (o.n_ != n_) alloc(o.n_);
+      std::copy(o.p_, o.p_ + n_, p_);
+    }
+    return *this;
+  }
+  Vecteur &operator=(Vecteur &&o)
+  {
+    if (this == &o) return *this;
+    if (vue_) return *this = static_cast<const Vecteur &>(o);
+    buf_ = std::move(o.buf_);
+    p_ = o.p_;
+    n_ = o.n_;
+    vue_ = o.vue_;
+    o.p_ = nullptr;
+    o.n_ = 0;
+    o.vue_ = false;
+    return *this;
+  }
+
+  static Vecteur map(T *ptr, entier n)
+  {
+    Vecteur v;
+    v.p_ = ptr;
+    v.n_ = n;
+    v.vue_ = true;
+    return v;
+  }
+  static Vecteur zeros(entier n)
+  {
+    Vecteur v(n);
+    v.setZero();
+    return v;
+  }
+  static Vecteur ones(entier n)
+  {
+    Vecteur v(n);
+    v.setConstant((T) 1);
+    return v;
+  }
+  static Vecteur valeurs(std::initializer_list<T> l)
+  {
+    Vecteur v((entier) l.size());
+    std::copy(l.begin(), l.end(), v.p_);
+    return v;
+  }
+  template <typename F> static Vecteur int_expr(entier n, F f)
+  {
+    Vecteur v(n);
+    for (entier i = 0; i < n; i++) v.p_[i] = (T) f(i);
+    return v;
+  }
+
+  T *data() { return p_; }
+  const T *data() const { return p_; }
+  entier rows() const { return n_; }
+  entier dim() const { return n_; }
+  bool est_vide() const { return n_ == 0; }
+  void resize(entier n)
+  {
+    if (n == n_) return;
+    if (vue_) échec("Vecteur::resize on a view");
+    alloc(n);
+  }
+  void setZero() { std::fill(p_, p_ + n_, T()); }
+  void setZero(entier n)
+  {
+    resize(n);
+    setZero();
+  }
+  void setConstant(T v) { std::fill(p_, p_ + n_, v); }
+  Vecteur clone() const { return Vecteur(*this); }
+
+  T &operator()(entier i)
+  {
+    if (i < 0 || i >= n_) échec("Vecteur: index {} out of range (dim = {})", i, n_);
+    return p_[i];
+  }
+  const T &operator()(entier i) const
+  {
+    if (i < 0 || i >= n_) échec("Vecteur: index {} out of range (dim = {})", i, n_);
+    return p_[i];
+  }
+
+  Vecteur segment(entier i, entier n) const
+  {
+    if (i < 0 || n < 0 || i + n > n_) échec("Vecteur::segment({}, {}) out of range (dim = {})", i, n, n_);
+    Vecteur v;
+    v.buf_ = buf_;
+    v.p_ = p_ + i;
+    v.n_ = n;
+    v.vue_ = true;
+    return v;
+  }
+  Vecteur head(entier n) const { return segment(0, n); }
+  Vecteur tail(entier n) const { return segment(n_ - n, n); }
+  Vecteur reverse() const
+  {
+    Vecteur v(n_);
+    for (entier i = 0; i < n_; i++) v.p_[i] = p_[n_ - 1 - i];
+    return v;
+  }
+  Vecteur<cfloat> as_complex() const
+  {
+    Vecteur<cfloat> v(n_);
+    for (entier i = 0; i < n_; i++) v.data()[i] = cfloat(p_[i]);
+    return v;
+  }
+  template <typename U> Vecteur<U> as() const
+  {
+    Vecteur<U> v(n_);
+    for (entier i = 0; i < n_; i++) v.data()[i] = (U) p_[i];
+    return v;
+  }
+
+  // element-wise arithmetic used around the hot path
+  Vecteur &operator*=(T s) { for (entier i = 0; i < n_; i++) p_[i] *= s; return *this; }
+  Vecteur &operator/=(T s) { for (entier i = 0; i < n_; i++) p_[i] /= s; return *this; }
+  Vecteur &operator+=(const Vecteur &o) { chk(o); for (entier i = 0; i < n_; i++) p_[i] += o.p_[i]; return *this; }
+  Vecteur &operator-=(const Vecteur &o) { chk(o); for (entier i = 0; i < n_; i++) p_[i] -= o.p_[i]; return *this; }
+  Vecteur &operator*=(const Vecteur &o) { chk(o); for (entier i = 0; i < n_; i++) p_[i] *= o.p_[i]; return *this; }
+  Vecteur operator-() const { Vecteur v(*this); for (entier i = 0; i < n_; i++) v.p_[i] = -v.p_[i]; return v; }
+  friend Vecteur operator+(const Vecteur &a, const Vecteur &b) { Vecteur v(a); v += b; return v; }
+  friend Vecteur operator-(const Vecteur &a, const Vecteur &b) { Vecteur v(a); v -= b; return v; }
+  friend Vecteur operator*(const Vecteur &a, const Vecteur &b) { Vecteur v(a); v *= b; return v; }
+  friend Vecteur operator*(const Vecteur &a, T s) { Vecteur v(a); v *= s; return v; }
+  friend Vecteur operator*(T s, const Vecteur &a) { Vecteur v(a); v *= s; return v; }
+  friend Vecteur operator/(const Vecteur &a, T s) { Vecteur v(a); v /= s; return v; }
+
+  // reductions accumulate in double (tableau.hpp:656-717)
+  T somme() const
+  {
+    if constexpr (est_complexe<T>()) {
+      cdouble s = 0;
+      for (entier i = 0; i < n_; i++) s += cdouble(p_[i]);
+      return T(s);
+    } else {
+      double s = 0;
+      for (entier i = 0; i < n_; i++) s += p_[i];
+      return (T) s;
+    }
+  }
+  T moyenne() const { return n_ ? somme() / (T) n_ : T(); }
+  T valeur_max() const { tsd_assertion(n_ > 0); return *std::max_element(p_, p_ + n_); }
+  T valeur_min() const { tsd_assertion(n_ > 0); return *std::min_element(p_, p_ + n_); }
+  entier index_max() const { return n_ ? (entier) (std::max_element(p_, p_ + n_) - p_) : -1; }
+
+ private:
+  void alloc(entier n)
+  {
+    if (n < 0) échec("Vecteur: negative size {}", n);
+    buf_ = n ? std::shared_ptr<T[]>(new T[(size_t) n]) : nullptr;
+    p_ = buf_.get();
+    n_ = n;
+    vue_ = false;
+  }
+  void chk(const Vecteur &o) const
+  {
+    if (o.n_ != n_) échec("Vecteur: size mismatch ({} vs {})", n_, o.n_);
+  }
+};
+
+using Vecf = Vecteur<float>;
+using Vecd = Vecteur<double>;
+using Veccf = Vecteur<cfloat>;
+using Veci = Vecteur<int32_t>;
+
+template <typename T> Vecteur<float> abs(const Vecteur<T> &x)
+{
+  Vecteur<float> y(x.rows());
+  for (entier i = 0; i < x.rows(); i++) y.data()[i] = std::abs(x.data()[i]);
+  return y;
+}
+inline Vecf real(const Veccf &x) { return Vecf::int_expr(x.rows(), [&](entier i) { return x.data()[i].real(); }); }
+inline Vecf imag(const Veccf &x) { return Vecf::int_expr(x.rows(), [&](entier i) { return x.data()[i].imag(); }); }
+template <typename T> Vecteur<T> vconcat(const Vecteur<T> &a, const Vecteur<T> &b)
+{
+  Vecteur<T> v(a.rows() + b.rows());
+  std::copy(a.data(), a.data() + a.rows(), v.data());
+  std::copy(b.data(), b.data() + b.rows(), v.data() + a.rows());
+  return v;
+}
+
+// linspace (tsd.hpp:916-931): step in double, samples rounded to float
+inline Vecf linspace(float a, float b, entier n)
+{
+  Vecf x(n);
+  if (n > 0) x(0) = a;
+  if (n > 1) {
+    const double step = ((double) b - a) / (n - 1);
+    for (entier i = 1; i < n; i++) x(i) = (float) (a + step * i);
+  }
+  return x;
+}
+// sigimp (core/src/tsd.cc): unit impulse at position p
+inline Vecf sigimp(entier n, entier p = 0)
+{
+  Vecf x = Vecf::zeros(n);
+  if (n > 0) x(p) = 1;
+  return x;
+}
+// randn / randcn on a default-seeded engine (core/src/tsd.cc:173,410-483)
+std::default_random_engine &generateur_aleatoire();
+Vecf randn(entier n);
+Veccf randcn(entier n);
+// prochaine_puissance_de_2 (core/src/tsd.cc:287-291), float-log based like the reference
+entier prochaine_puissance_de_2(entier i);
+
+// ---- operator interfaces (tsd.hpp:544-579,626-668) -------------------------------------------
+template <typename C> struct Configurable {
+  virtual ~Configurable() {}
+  void configure(const C &c)
+  {
+    if (callback_modif) callback_modif(c);
+    configure_impl(c);
+    config = c;
+  }
+  virtual void configure_impl(const C &c) = 0;
+  const C &lis_config() const { return config; }
+  fonction<void(const C &)> callback_modif;
+
+ protected:
+  C config;
+};
+
+template <typename Te, typename Ts = Te> struct FiltreGen {
+  virtual ~FiltreGen() {}
+  virtual void step(const Vecteur<Te> &x, Vecteur<Ts> &y) = 0;
+  Vecteur<Ts> step(const Vecteur<Te> &x)
+  {
+    Vecteur<Ts> y;
+    step(x, y);
+    return y;
+  }
+  Ts step(Te x)
+  {
+    Vecteur<Te> vx(1);
+    Vecteur<Ts> vy(1);
+    vx(0) = x;
+    step(vx, vy);
+    return vy(0);
+  }
+};
+
+template <typename Te, typename Ts = Te, typename Tc = Void> struct Filtre : Configurable<Tc>, FiltreGen<Te, Ts> {
+  virtual ~Filtre() {}
+};
+
+namespace filtrage {
+template <typename T> sptr<Filtre<T, T, float>> filtre_reechan(float ratio);
+}
+
+// rééchan (tsd.hpp:700-705): one-shot resampling through filtre_reechan
+template <typename T> Vecteur<T> rééchan(const Vecteur<T> &x, float ratio)
+{
+  auto f = filtrage::filtre_reechan<T>(ratio);
+  return f->FiltreGen<T, T>::step(x);
+}
+
+}  // namespace tsd

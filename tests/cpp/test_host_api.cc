@@ -1,0 +1,294 @@
+// Reference-style tests of the C++ host layer (tsd:: / dsp:: API on the MI355X C ABI).
+// They read like libtsd's own tests (core/tests/test-filtres.cc, test-fourier.cc, test-ra.cc,
+// test-tab.cc, test-dsp.cc) and use the CPU oracle only as the checker.
+//   usage: test_host_api            -> runs everything (needs a GPU)
+//          test_host_api --no-gpu   -> checks that the factories fail loudly without a GPU
+#include <cstdio>
+#include <cstring>
+#include "dsp/dsp.hpp"
+#include "../../oracle/tsd_oracle.h"
+
+using namespace tsd;
+using namespace tsd::filtrage;
+using namespace tsd::fourier;
+
+static int nfail = 0;
+#define CHECK(cond, ...)                                                     \
+  do {                                                                       \
+    if (!(cond)) {                                                           \
+      nfail++;                                                               \
+      printf("FAIL %s:%d  %s  -- ", __FILE__, __LINE__, #cond);              \
+      printf(__VA_ARGS__);                                                   \
+      printf("\n");                                                          \
+    }                                                                        \
+  } while (0)
+
+template <typename T> static float maxabs(const Vecteur<T> &v)
+{
+  float m = 0;
+  for (int i = 0; i < v.rows(); i++) m = std::max(m, std::abs(v(i)));
+  return m;
+}
+
+// test-filtres.cc:9-31
+template <typename T> static Vecteur<T> filtre_par_bloc(sptr<FiltreGen<T>> f, const Vecteur<T> &x, int BS)
+{
+  std::vector<Vecteur<T>> lst;
+  int N = x.rows(), offset = 0, n = 0;
+  while (offset < N) {
+    int nl = std::min(BS, N - offset);
+    Vecteur<T> xp = x.segment(offset, nl).clone();
+    Vecteur<T> yp = f->step(xp);
+    offset += nl;
+    n += yp.rows();
+    lst.push_back(yp);
+  }
+  Vecteur<T> y(n);
+  offset = 0;
+  for (auto &v : lst) {
+    y.segment(offset, v.rows()) = v;
+    offset += v.rows();
+  }
+  return y;
+}
+
+static void test_tab()   // test-tab.cc:53-137 semantics
+{
+  Vecf a = linspace(0, 9, 10);
+  Vecf b = a;                 // deep copy
+  b(0) = 42;
+  CHECK(a(0) == 0, "copy must be deep");
+  Vecf v = a.segment(2, 3);   // view
+  v(0) = -1;
+  CHECK(a(2) == -1, "segment must alias its parent");
+  a.tail(2) = Vecf::valeurs({7, 8});
+  CHECK(a(8) == 7 && a(9) == 8, "assignment into a view copies elements");
+  Vecf c = std::move(b);
+  CHECK(c(0) == 42 && b.rows() == 0, "move steals");
+  float raw[3] = {1, 2, 3};
+  Vecf m = Vecf::map(raw, 3);
+  m(1) = 5;
+  CHECK(raw[1] == 5, "map wraps foreign memory");
+  bool threw = false;
+  try { a(10) = 0; } catch (const std::runtime_error &) { threw = true; }
+  CHECK(threw, "out-of-range access must throw through échec");
+  CHECK(prochaine_puissance_de_2(3) == 4 && prochaine_puissance_de_2(65535) == 65536 && prochaine_puissance_de_2(1) == 1, "pp2");
+}
+
+static void test_filtre_rif()   // test-filtres.cc:479-511
+{
+  int nc = 31, n = nc + 50;
+  Vecf h = linspace(1, nc, nc);
+  auto f = filtre_rif<float, float>(h);
+  Vecf y = f->step(sigimp(n));
+  CHECK(y.rows() == n, "n=%d rows=%d", n, y.rows());
+  Vecf verr = y - vconcat(h, Vecf::zeros(n - nc));
+  CHECK(maxabs(verr) <= 1e-7f, "err=%g", maxabs(verr));
+}
+
+static void test_retard(int d)   // test-filtres.cc:450-476
+{
+  Vecf h = Vecf::ones(d), x = sigimp(20, 3);
+  Vecf y = filtrer<float>(h, x), y2 = filtrer<float>(h, y);
+  CHECK(y2.index_max() == 3 + d - 1, "d=%d index=%d", d, y2.index_max());
+}
+
+static void test_design_rif_prod(int n1, int n2)   // test-filtres.cc:33-71
+{
+  Vecf h1 = randn(n1), h2 = randn(n2), hp = design_rif_prod(h1, h2);
+  CHECK(hp.rows() == n1 + n2 - 1, "rows");
+  Vecf x = sigimp(n1 + n2);
+  Vecf y2 = filtrer<float>(h2, filtrer<float>(h1, x)), yp = filtrer<float>(hp, x);
+  CHECK(maxabs(y2 - yp) < 1e-5f, "n1=%d n2=%d err=%g", n1, n2, maxabs(y2 - yp));
+}
+
+static void test_rif_vs_rif_fft()   // test-filtres.cc:514-554
+{
+  Vecf h = design_rif_fen(127, "lp", 0.02f);
+  Vecf x = randn(5000);
+  auto f1 = filtre_rif<float, float>(h);
+  auto f2 = filtre_rif_fft<float>(h);
+  Vecf y1 = filtre_par_bloc<float>(f1, x, 1000), y2 = filtre_par_bloc<float>(f2, x, 1000);
+  // the OLA filter's output is the direct one delayed by Nz - M = 385 samples
+  const int d = 385;
+  float err = 0;
+  for (int i = 0; i + d < 5000 - 4 * 127; i++) err = std::max(err, std::abs(y2(i + d) - y1(i)));
+  CHECK(err <= 1e-6f, "err=%g", err);
+  CHECK(maxabs(y2.head(d)) == 0.f, "the first %d outputs of filtre_rif_fft are the delay line's zeros", d);
+  // complex instantiation: real part only (fourier.cc:976)
+  Veccf xc = randcn(3000);
+  Veccf yc = filtre_rif_fft<cfloat>(h)->step(xc);
+  CHECK(maxabs(imag(yc)) == 0.f, "filtre_rif_fft<cfloat> keeps only the real part, like the reference");
+}
+
+static void test_fir_vs_oracle()
+{
+  Vecf h = design_rif_fen(127, "lp", 0.02f);
+  Veccf x = randcn(20000);
+  Veccf y = filtrer<cfloat>(h, x);
+  std::vector<orc_cf> fen(127, orc_cf{0, 0}), yr(20000);
+  int idx = 0;
+  orc_fir_cf(h.data(), 127, fen.data(), &idx, (const orc_cf *) x.data(), yr.data(), 20000);
+  float err = 0, ref = 0;
+  for (int i = 0; i < 20000; i++) {
+    err = std::max(err, std::abs(y(i) - cfloat(yr[i].re, yr[i].im)));
+    ref = std::max(ref, std::abs(cfloat(yr[i].re, yr[i].im)));
+  }
+  CHECK(err <= 1e-5f * ref, "filtrer(Veccf) vs oracle: err=%g ref=%g", err, ref);
+  // design parity with the oracle's restatement of design_rif_fen
+  std::vector<float> ho(127);
+  orc_design_rif_fen_hann(127, 0, 0.02f, ho.data());
+  float dh = 0;
+  for (int i = 0; i < 127; i++) dh = std::max(dh, std::abs(ho[i] - h(i)));
+  CHECK(dh <= 1e-7f, "design_rif_fen vs oracle: %g", dh);
+  // dsp:: spelling reaches the same objects (test-dsp.cc is a compile check)
+  dsp::Vecf h2 = dsp::filter::design_fir_wnd(127, "lp", 0.02f);
+  dsp::Veccf y2 = dsp::filter::filter<cfloat>(h2, x);
+  CHECK(maxabs(y2 - y) == 0.f, "dsp::filter::filter == tsd::filtrage::filtrer");
+}
+
+static void test_sois()   // design_riia(12,"lp","butt",0.25) -> 6 sections (test-filtres.cc:668-679)
+{
+  auto h = design_riia(12, "lp", "butt", 0.25f);
+  Vecf x = randn(100000);
+  Vecf y = filtrer<float>(Design(h), x);
+  // oracle: same design, same pairing, sequential recurrence
+  std::vector<orc_cf> z(12), p(12);
+  orc_cf mn, md;
+  orc_design_butter_lp(12, 0.25f, z.data(), p.data(), &mn, &md);
+  orc_sos s;
+  orc_sos_from_zpk(&s, z.data(), p.data(), 12, mn, md, 2);
+  CHECK(s.nsec == 6, "nsec=%d", s.nsec);
+  orc_sos_state_f st;
+  orc_sos_state_init_f(&st);
+  std::vector<float> yr(100000);
+  orc_sos_step_f(&s, &st, x.data(), yr.data(), 100000);
+  float err = 0, ref = 0;
+  for (int i = 0; i < 100000; i++) { err = std::max(err, std::abs(y(i) - yr[i])); ref = std::max(ref, std::abs(yr[i])); }
+  CHECK(err <= 1e-5f * ref, "filtrer(design_riia) vs oracle: err=%g ref=%g", err, ref);
+  // streaming through the FiltreGen interface
+  auto f = filtre_sois<float>(h);
+  Vecf yb = filtre_par_bloc<float>(f, x, 311);
+  CHECK(maxabs(yb - y) <= 1e-5f * ref, "chunked SOS differs: %g", maxabs(yb - y));
+}
+
+static void test_fft_valide(int n, bool inv)   // test-fourier.cc:181-272
+{
+  Veccf x = randcn(n);
+  Veccf X = inv ? ifft(x) : fft(x);
+  CHECK(X.rows() == n, "rows");
+  float err = 0;
+  for (int i = 0; i < n; i++) {
+    cdouble s = 0;
+    const double signe = inv ? 1 : -1;
+    for (int k = 0; k < n; k++) s += cdouble(x(k)) * std::polar(1.0, signe * (2 * π * ((long) k * i % n)) / n);
+    s /= std::sqrt((double) n);
+    err = std::max(err, (float) std::abs(cdouble(X(i)) - s));
+  }
+  CHECK(err < 1e-2f, "n=%d inv=%d err=%g", n, (int) inv, err);
+  CHECK(err < ((n & 1) && n > 1 ? 2e-4f : 2e-5f) * std::sqrt((float) n) + 1e-6f, "n=%d inv=%d err=%g (tight)", n, (int) inv, err);
+}
+
+static void test_fft_misc()
+{
+  // test_fft (test-fourier.cc:275-312): ifft(fft(x)) rms error
+  int n = 1024;
+  Vecf x = Vecf::int_expr(n, [&](int i) { return std::cos(8 * 2 * π * i / (n - 1)); });
+  Veccf X = fft(x);
+  Vecf x2 = real(ifft(X));
+  double e = 0;
+  for (int i = 0; i < n; i++) e += (x2(i) - x(i)) * (x2(i) - x(i));
+  CHECK(std::sqrt(e / n) <= 5e-6, "rfft + ifft rms err=%g", std::sqrt(e / n));
+  // rfft == fft of the widened signal (test_fft_valide<float,cfloat>)
+  for (int m : {16, 2, 4, 8, 10, 128, 1024, 17, 5, 3}) {
+    Vecf xr = randn(m);
+    Veccf A = rfft(xr), B = fft(Veccf(xr.as_complex()));
+    CHECK(maxabs(A - B) <= 2e-5f * std::sqrt((float) m) * 4, "rfft(%d) err=%g", m, maxabs(A - B));
+  }
+  // test_fftplan (test-fourier.cc:6-37): plan == fft()
+  for (int m : {8, 16, 18, 19, 101}) {
+    Veccf xc = randcn(m);
+    auto plan = tfrplan_création(m);
+    CHECK(maxabs(plan->step(xc) - fft(xc)) <= 1e-6f, "plan(%d)", m);
+  }
+  // test_fftshift (test-fourier.cc:39-72)
+  for (int m : {15, 16}) {
+    Vecf y = fftshift(linspace(0, m - 1, m));
+    int h = m / 2;
+    Vecf yref(m);
+    if (m & 1) { yref.head(h) = linspace(h + 1, m - 1, h); yref.tail(h + 1) = linspace(0, h, h + 1); }
+    else { yref.head(h) = linspace(h, m - 1, h); yref.tail(h) = linspace(0, h - 1, h); }
+    CHECK(maxabs(y - yref) == 0.f, "fftshift(%d)", m);
+  }
+  // the plug point: a user-installed factory is what fft() uses (fourier.cc:469-481)
+  struct Compte : FFTPlan {
+    sptr<FFTPlan> inner;
+    int *cnt;
+    void configure(entier n, bouléen a, bouléen no) override { inner->configure(n, a, no); }
+    void step(const Veccf &x, Veccf &y, bouléen a) override { (*cnt)++; inner->step(x, y, a); }
+  };
+  auto sauvegarde = fftplan_defaut;
+  int cnt = 0;
+  fftplan_defaut = [&]() -> sptr<FFTPlan> { auto p = std::make_shared<Compte>(); p->inner = sauvegarde(); p->cnt = &cnt; return p; };
+  (void) fft(randcn(64));
+  fftplan_defaut = sauvegarde;
+  CHECK(cnt == 1, "fftplan_defaut hook not consulted (cnt=%d)", cnt);
+}
+
+static void test_reechan()   // test-ra.cc:55-160 style checks on rééchan / filtre_reechan
+{
+  for (float ratio : {1.0f, 1.5f, 0.5f, 1.2f, 160.f / 147.f}) {
+    const float fe = 100e3f, f2 = 2e3f;
+    Vecf x = Vecf::int_expr(1000, [&](int i) { return std::sin(2 * π * f2 * i / fe); });
+    Vecf y = rééchan(x, ratio);
+    const double err = 100.0 * std::abs((y.rows() - ratio * x.rows()) / x.rows());
+    CHECK(err < 1, "ratio=%g rows=%d", ratio, y.rows());
+    const float amp1 = x.valeur_max() - x.valeur_min(), amp2 = y.valeur_max() - y.valeur_min();
+    CHECK(100 * (amp1 - amp2) / amp1 < 10, "ratio=%g amplitude %g -> %g", ratio, amp1, amp2);
+    // exact parity with the oracle (count and samples)
+    if (ratio != 1.0f) {
+      int nd, nu; float post, fcut;
+      orc_reechan_config(ratio, &nd, &nu, &post, &fcut);
+      std::vector<float> lut(257 * 15), yr(2100);
+      orc_itrp_sinc_lut(15, 256, fcut, lut.data());
+      orc_ra r;
+      orc_ra_init(&r, post, 15, 256, lut.data());
+      const int64_t no = orc_ra_step_f(&r, x.data(), 1000, yr.data());
+      CHECK(no == y.rows(), "ratio=%g: %lld outputs vs oracle %d", ratio, (long long) no, y.rows());
+      float e = 0;
+      for (int i = 0; i < std::min<int64_t>(no, y.rows()); i++) e = std::max(e, std::abs(y(i) - yr[i]));
+      CHECK(e <= 1e-5f, "ratio=%g err=%g", ratio, e);
+    }
+  }
+  bool threw = false;
+  try { (void) filtre_reechan<float>(4.0f); } catch (const std::runtime_error &) { threw = true; }
+  CHECK(threw, "ratio outside [0.5,2) must fail loudly until the half-band stages are built");
+  // dsp::resample spelling
+  dsp::Veccf xc = randcn(2000);
+  CHECK(dsp::resample(xc, 1.25f).rows() == rééchan(xc, 1.25f).rows(), "dsp::resample");
+}
+
+int main(int argc, char **argv)
+{
+  if (argc > 1 && !std::strcmp(argv[1], "--no-gpu")) {
+    bool threw = false;
+    try { (void) filtre_rif<float, float>(Vecf::ones(3)); } catch (const std::runtime_error &e) { threw = true; printf("expected failure: %s\n", e.what()); }
+    test_tab();
+    CHECK(threw, "filtre_rif must throw without a GPU (no CPU fallback)");
+    printf(nfail ? "FAILED (%d)\n" : "OK\n", nfail);
+    return nfail ? 1 : 0;
+  }
+  test_tab();
+  test_filtre_rif();
+  test_retard(3);
+  test_retard(4);
+  for (int i : {10, 11, 15, 20}) for (int j : {10, 11, 15, 20}) test_design_rif_prod(i, j);
+  test_rif_vs_rif_fft();
+  test_fir_vs_oracle();
+  test_sois();
+  for (int n : {16, 1, 2, 3, 4, 5, 8, 10, 17, 128, 129, 1024}) { test_fft_valide(n, false); test_fft_valide(n, true); }
+  test_fft_misc();
+  test_reechan();
+  printf(nfail ? "FAILED (%d)\n" : "ALL C++ HOST TESTS OK\n", nfail);
+  return nfail ? 1 : 0;
+}

@@ -1,0 +1,45 @@
+"""C++ host layer (tsd:: / dsp:: mirror on the C ABI): builds on CPU, fails loudly without a
+GPU, and passes its reference-style test-suite on the GPU (tests/cpp/test_host_api.cc)."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "tests", "cpp", "build", "test_host_api")
+
+
+def build():
+    subprocess.run(["make", "-C", os.path.join(ROOT, "libtsd_amd", "host")], check=True, capture_output=True)
+    subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "cpp")], check=True, capture_output=True)
+
+
+def test_host_layer_builds_and_refuses_cpu():
+    build()
+    r = subprocess.run([BIN, "--no-gpu"], capture_output=True, text=True)
+    import libtsd_amd
+    if libtsd_amd.device_count() == 0:
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "OK" in r.stdout
+
+
+def test_host_library_exports_factories():
+    build()
+    out = subprocess.run(["nm", "-DC", os.path.join(ROOT, "libtsd_amd", "lib", "libtsd_host.so")],
+                         capture_output=True, text=True).stdout
+    for sym in ["tsd::filtrage::filtre_rif<float, float>", "tsd::filtrage::filtre_rif<float, std::complex<float> >",
+                "tsd::filtrage::filtre_rif<std::complex<float>, std::complex<float> >",
+                "tsd::filtrage::filtre_rif_fft<float>", "tsd::filtrage::filtre_sois<float>",
+                "tsd::filtrage::filtre_reechan<std::complex<float> >", "tsd::filtrage::filtre_itrp<float>",
+                "tsd::filtrage::design_rif_fen", "tsd::filtrage::design_riia",
+                "tsd::fourier::fftplan_defaut", "tsd::fourier::tfrplan_cr", "tsd::fourier::rtfrplan_cr"]:
+        assert sym in out, f"{sym} not exported by libtsd_host.so"
+
+
+@pytest.mark.gpu
+def test_host_layer_gpu_suite():
+    if not os.path.exists(BIN):
+        build()
+    r = subprocess.run([BIN], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+    assert "ALL C++ HOST TESTS OK" in r.stdout
