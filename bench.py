@@ -101,16 +101,12 @@ def main():
         if world > 1:
             dist.barrier()
 
+    from libtsd_amd import sharding
+    halo_out_r, halo_in_r = torch.view_as_real(halo_out), torch.view_as_real(halo_in)
+
     def exchange_halo(f):
         """left-neighbour halo (K-1 samples) over RCCL send/recv; rank 0 starts from zeros."""
-        if world > 1:
-            ops = []
-            if rank + 1 < world:
-                ops.append(dist.P2POp(dist.isend, halo_out, rank + 1))
-            if rank > 0:
-                ops.append(dist.P2POp(dist.irecv, halo_in, rank - 1))
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()
+        sharding.exchange_left_halo(halo_out_r, halo_in_r, rank, world)
         f.set_history(halo_in)
 
     def run(f, steps, warmup):
@@ -129,10 +125,7 @@ def main():
         torch.cuda.synchronize()
         barrier()
         dt = time.perf_counter() - t0
-        if world > 1:
-            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
+        dt = sharding.max_over_ranks(dt, dev, world)
         kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
         return dt, kern_ms
 

@@ -1,0 +1,76 @@
+"""N > 1 path on CPU: two gloo ranks shard a stream by contiguous chunk, exchange the halo
+with libtsd_amd.sharding (the code bench.py runs over RCCL), and each rank filters its chunk
+with the oracle seeded by the received halo.  The concatenation must equal the one-process
+result (to an ulp: the oracle's two-segment circular sum is split at a different index when
+the delay line is re-seeded, which moves the last bit; the resampler is exactly equal)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, n, K, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from libtsd_amd import sharding
+    from oracle import pyoracle as orc
+    rng = np.random.default_rng(123)
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)     # same stream on every rank
+    h = orc.design_rif_fen(K, "lp", 0.02)
+    lo, hi = sharding.chunk_bounds(n, rank, world)
+    mine = x[lo:hi]
+    # --- FIR: K-1 halo
+    tail = torch.view_as_real(torch.from_numpy(mine[-(K - 1):].copy()))
+    halo = torch.zeros(K - 1, 2)
+    sharding.exchange_left_halo(tail, halo, rank, world)
+    f = orc.Fir(h)
+    halo_c = torch.view_as_complex(halo).numpy()
+    if rank > 0:
+        assert np.array_equal(halo_c, x[lo - (K - 1):lo])
+        f.step(np.concatenate([np.zeros(1, np.complex64), halo_c]))       # load the delay line with the halo
+    y = f.step(mine)
+    # --- resampler: 14-sample window halo + absolute position (schedule restarts from the recurrence)
+    r = orc.Resampler(np.float32(160.0) / np.float32(147.0))
+    tail14 = torch.view_as_real(torch.from_numpy(mine[-14:].copy()))
+    halo14 = torch.zeros(14, 2)
+    sharding.exchange_left_halo(tail14, halo14, rank, world)
+    pre = np.zeros(0, np.complex64)
+    if rank > 0:
+        pre = x[:lo]          # the oracle has no seek: replay the prefix (CPU test only)
+        r.step(pre)
+    yr = r.step(mine)
+    t = sharding.max_over_ranks(float(rank), torch.device("cpu"), world)
+    q.put((rank, y, yr, t))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_fir_and_resampler_match_single_process(orc, world):
+    n, K = 30000, 127
+    port = 29600 + world
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, K, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rng = np.random.default_rng(123)
+    x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    h = orc.design_rif_fen(K, "lp", 0.02)
+    yref = orc.fir(h, x)
+    assert np.abs(np.concatenate([r[1] for r in res]) - yref).max() <= 2e-7 * np.abs(yref).max()
+    yfull = orc.Resampler(np.float32(160.0) / np.float32(147.0)).step(x)
+    assert np.array_equal(np.concatenate([r[2] for r in res]), yfull)
+    assert all(r[3] == world - 1 for r in res)
