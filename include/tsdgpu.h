@@ -130,6 +130,34 @@ int tsdgpu_resampler_seek(tsdgpu_resampler *r, int64_t pos, const void *hist, vo
 int64_t tsdgpu_resampler_out_offset(const tsdgpu_resampler *r); /* outputs emitted before pos */
 int tsdgpu_resampler_destroy(tsdgpu_resampler *r);
 
+/* --------------------------------------------------------------------------------------
+ * Integer-rate polyphase stages (what filtre_reechan chains for ratios outside [0.5,2)) and
+ * the plain decimator:
+ *   TSDGPU_POLY_DECIM     FiltreRIFDecim<T,float>     src/reechan/polyphase.cc:156-239
+ *                         (taps applied in FORWARD order against the oldest->newest window)
+ *   TSDGPU_POLY_HALFBAND  FiltreRIFDemiBande<T,float> polyphase.cc:54-149 (even taps + 0.5 centre, R = 2)
+ *   TSDGPU_POLY_UPS       FiltreRIFUps<T,float>       polyphase.cc:246-341 (taps * R, R outputs per input)
+ *   TSDGPU_POLY_PICK      Decimateur<T>               src/filtrage/filtre-rt.cc:127-169 (no taps)
+ * ------------------------------------------------------------------------------------ */
+typedef struct tsdgpu_polyfir tsdgpu_polyfir;
+typedef enum { TSDGPU_POLY_DECIM = 0, TSDGPU_POLY_HALFBAND = 1, TSDGPU_POLY_UPS = 2, TSDGPU_POLY_PICK = 3 } tsdgpu_poly_kind;
+int tsdgpu_polyfir_create(tsdgpu_polyfir **out, int kind, int data_type, const float *taps_host, int ntaps, int R);
+int64_t tsdgpu_polyfir_out_count(tsdgpu_polyfir *p, int64_t n);
+int tsdgpu_polyfir_step(tsdgpu_polyfir *p, const void *x, int64_t n, void *y, int64_t y_capacity,
+                        int64_t *n_out, void *stream);
+int tsdgpu_polyfir_reset(tsdgpu_polyfir *p);
+int tsdgpu_polyfir_destroy(tsdgpu_polyfir *p);
+
+/* --------------------------------------------------------------------------------------
+ * Generic direct-form-I IIR: FiltreRII<T,float>::step, factory filtre_rii
+ * (src/filtrage/filtre-rt.cc:177-289).  numer[Kx], denom[Kd] in powers of z^-1.
+ * ------------------------------------------------------------------------------------ */
+typedef struct tsdgpu_rii tsdgpu_rii;
+int tsdgpu_rii_create(tsdgpu_rii **out, int data_type, const float *numer_host, int Kx,
+                      const float *denom_host, int Kd);
+int tsdgpu_rii_step(tsdgpu_rii *r, const void *x, void *y, int64_t n, void *stream);
+int tsdgpu_rii_destroy(tsdgpu_rii *r);
+
 #ifdef __cplusplus
 }
 #endif

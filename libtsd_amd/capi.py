@@ -67,6 +67,15 @@ def _declare(L):
     L.tsdgpu_resampler_out_offset.argtypes = [vp]
     L.tsdgpu_resampler_out_offset.restype = i64
     L.tsdgpu_resampler_destroy.argtypes = [vp]
+    L.tsdgpu_polyfir_create.argtypes = [C.POINTER(vp), i32, i32, vp, i32, i32]
+    L.tsdgpu_polyfir_out_count.argtypes = [vp, i64]
+    L.tsdgpu_polyfir_out_count.restype = i64
+    L.tsdgpu_polyfir_step.argtypes = [vp, vp, i64, vp, i64, C.POINTER(i64), vp]
+    L.tsdgpu_polyfir_reset.argtypes = [vp]
+    L.tsdgpu_polyfir_destroy.argtypes = [vp]
+    L.tsdgpu_rii_create.argtypes = [C.POINTER(vp), i32, vp, i32, vp, i32]
+    L.tsdgpu_rii_step.argtypes = [vp, vp, vp, i64, vp]
+    L.tsdgpu_rii_destroy.argtypes = [vp]
     L.tsdgpu_fft_create.argtypes = [C.POINTER(vp), i32, i32]
     L.tsdgpu_fft_step.argtypes = [vp, vp, vp, i32, i32, vp]
     L.tsdgpu_fft_size.argtypes = [vp]
@@ -303,5 +312,64 @@ class Resampler:
     def __del__(self):
         try:
             self.close()
+        except Exception:
+            pass
+
+
+POLY_DECIM, POLY_HALFBAND, POLY_UPS, POLY_PICK = 0, 1, 2, 3
+
+
+class PolyFir:
+    """filtre_rif_decim / filtre_rif_demi_bande / filtre_rif_ups / decimateur
+    (polyphase.cc:54-341, filtre-rt.cc:127-169)."""
+
+    def __init__(self, kind, data_type, taps=None, R=2):
+        self.data_type = data_type
+        self._h = C.c_void_p()
+        t = None if taps is None else np.ascontiguousarray(taps, dtype=np.float32)
+        _check(lib().tsdgpu_polyfir_create(C.byref(self._h), kind, data_type, None if t is None else t.ctypes.data,
+                                           0 if t is None else len(t), R))
+
+    def step(self, x, stream=None):
+        assert _dtype_code(x) == self.data_type
+        n = x.shape[0]
+        nout = lib().tsdgpu_polyfir_out_count(self._h, n)
+        y = np.empty(nout, x.dtype) if isinstance(x, np.ndarray) else x.new_empty(nout)
+        got = C.c_int64(0)
+        _check(lib().tsdgpu_polyfir_step(self._h, _ptr(x), n, _ptr(y), nout, C.byref(got), _stream_of(x, stream)))
+        return y[: got.value]
+
+    def reset(self):
+        _check(lib().tsdgpu_polyfir_reset(self._h))
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().tsdgpu_polyfir_destroy(self._h)
+        except Exception:
+            pass
+
+
+class Rii:
+    """filtre_rii<float,T> (filtre-rt.cc:177-289): numer / denom in powers of z^-1."""
+
+    def __init__(self, numer, denom, data_type):
+        nu = np.ascontiguousarray(numer, dtype=np.float32)
+        de = np.ascontiguousarray(denom, dtype=np.float32)
+        self.data_type = data_type
+        self._h = C.c_void_p()
+        _check(lib().tsdgpu_rii_create(C.byref(self._h), data_type, nu.ctypes.data, len(nu), de.ctypes.data, len(de)))
+
+    def step(self, x, y=None, stream=None):
+        assert _dtype_code(x) == self.data_type
+        if y is None:
+            y = np.empty_like(x) if isinstance(x, np.ndarray) else x.new_empty(x.shape)
+        _check(lib().tsdgpu_rii_step(self._h, _ptr(x), _ptr(y), x.shape[0], _stream_of(x, stream)))
+        return y
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().tsdgpu_rii_destroy(self._h)
         except Exception:
             pass

@@ -76,6 +76,35 @@ template <typename T> sptr<FiltreGen<T>> filtre_rif_fft(const Vecf &h);
 template <typename T> sptr<FiltreGen<T>> filtre_sois(const FRat<cfloat> &h, RIIStructure structure = FormeDirecte2);
 template <typename T> sptr<FiltreGen<T>> filtre_sois(const FRat<float> &h, RIIStructure structure = FormeDirecte2);
 
+template <typename Tc, typename T = Tc> sptr<FiltreGen<T>> filtre_rii(const FRat<Tc> &h);   // filtrage.hpp:1428-1429
+
+// ---- integer-rate stages (filtrage.hpp:1968-1998; src/reechan/polyphase.cc; filtre-rt.cc:127-169)
+template <typename T> sptr<FiltreGen<T>> decimateur(entier R);
+template <typename Tc, typename T = Tc> sptr<FiltreGen<T>> filtre_rif_decim(const Vecteur<Tc> &h, entier R);
+template <typename Tc, typename T = Tc> sptr<FiltreGen<T>> filtre_rif_demi_bande(const Vecteur<Tc> &h);
+template <typename Tc, typename T = Tc> sptr<FiltreGen<T>> filtre_rif_ups(const Vecteur<Tc> &h, entier R);
+float filtre_rif_ups_délais(entier nc, entier R);
+float rif_delais(entier nc);
+// forme_polyphase (polyphase.cc:16-46): zero-pad to a multiple of M and view as M rows x n/M
+// columns, column-major -- a pure index permutation (here: the identity on memory).
+template <typename T> struct TabPoly {
+  entier lignes = 0, colonnes = 0;
+  Vecteur<T> données;                                   // column-major
+  T &operator()(entier i, entier j) { return données(i + j * lignes); }
+};
+template <typename T> TabPoly<T> forme_polyphase(const Vecteur<T> &x, entier M)
+{
+  TabPoly<T> X;
+  const entier n = x.rows();
+  if (n == 0) return X;
+  const entier r = n % M;
+  X.données = r ? vconcat(x, Vecteur<T>::zeros(M - r)) : x.clone();
+  X.lignes = M;
+  X.colonnes = X.données.rows() / M;
+  return X;
+}
+template <typename T> Vecteur<T> iforme_polyphase(const TabPoly<T> &X) { return X.données.clone(); }
+
 // ---- interpolators / resampling (filtrage.hpp:1814-1943,2029-2039) -----------------------------
 template <typename T> struct Interpolateur {
   entier K = 0;

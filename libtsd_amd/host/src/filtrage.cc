@@ -331,6 +331,76 @@ template sptr<FiltreGen<cfloat>> filtre_sois<cfloat>(const FRat<cfloat> &, RIISt
 template sptr<FiltreGen<float>> filtre_sois<float>(const FRat<float> &, RIIStructure);
 template sptr<FiltreGen<cfloat>> filtre_sois<cfloat>(const FRat<float> &, RIIStructure);
 
+// ---- integer-rate stages and the generic IIR ---------------------------------------------
+template <typename T> struct PolyFirGpu : FiltreGen<T> {
+  tsdgpu_polyfir *h = nullptr;
+  PolyFirGpu(int kind, const float *taps, int K, int R)
+  {
+    if (tsdgpu_polyfir_create(&h, kind, dtype_of<T>(), taps, K, R)) gpu_fail("filtre_rif_decim/_demi_bande/_ups/decimateur");
+  }
+  ~PolyFirGpu() override { tsdgpu_polyfir_destroy(h); }
+  void step(const Vecteur<T> &x, Vecteur<T> &y) override
+  {
+    const entier n = x.rows();
+    const int64_t cap = tsdgpu_polyfir_out_count(h, n);
+    if (cap < 0 || cap > 0x7fffffff) échec("polyphase stage: output size {} not representable", (long long) cap);
+    Vecteur<T> out((entier) cap);
+    int64_t got = 0;
+    if (n > 0 && tsdgpu_polyfir_step(h, x.data(), n, out.data(), cap, &got, nullptr)) gpu_fail("polyphase stage step");
+    y = std::move(out);
+  }
+};
+template <typename T> sptr<FiltreGen<T>> decimateur(entier R) { return std::make_shared<PolyFirGpu<T>>(TSDGPU_POLY_PICK, nullptr, 0, R); }
+template <typename Tc, typename T> sptr<FiltreGen<T>> filtre_rif_decim(const Vecteur<Tc> &c, entier R)
+{
+  return std::make_shared<PolyFirGpu<T>>(TSDGPU_POLY_DECIM, c.data(), c.rows(), R);
+}
+template <typename Tc, typename T> sptr<FiltreGen<T>> filtre_rif_demi_bande(const Vecteur<Tc> &c)
+{
+  return std::make_shared<PolyFirGpu<T>>(TSDGPU_POLY_HALFBAND, c.data(), c.rows(), 2);
+}
+template <typename Tc, typename T> sptr<FiltreGen<T>> filtre_rif_ups(const Vecteur<Tc> &c, entier R)
+{
+  return std::make_shared<PolyFirGpu<T>>(TSDGPU_POLY_UPS, c.data(), c.rows(), R);
+}
+template sptr<FiltreGen<float>> decimateur<float>(entier);
+template sptr<FiltreGen<cfloat>> decimateur<cfloat>(entier);
+template sptr<FiltreGen<float>> filtre_rif_decim<float, float>(const Vecf &, entier);
+template sptr<FiltreGen<cfloat>> filtre_rif_decim<float, cfloat>(const Vecf &, entier);
+template sptr<FiltreGen<float>> filtre_rif_demi_bande<float, float>(const Vecf &);
+template sptr<FiltreGen<cfloat>> filtre_rif_demi_bande<float, cfloat>(const Vecf &);
+template sptr<FiltreGen<float>> filtre_rif_ups<float, float>(const Vecf &, entier);
+template sptr<FiltreGen<cfloat>> filtre_rif_ups<float, cfloat>(const Vecf &, entier);
+float filtre_rif_ups_délais(entier nc, entier R)     // polyphase.cc:363-369
+{
+  entier pad = 0;
+  if ((nc % R) != 0) pad = R - (nc % R);
+  return (float) ((nc - 1) / 2.0 + pad);
+}
+float rif_delais(entier nc) { return (nc - 1) / 2.0f; }
+
+// FiltreRII (filtre-rt.cc:177-289) from a coefficient-form H(z^-1)
+template <typename T> struct FiltreRIIGpu : FiltreGen<T> {
+  tsdgpu_rii *h = nullptr;
+  explicit FiltreRIIGpu(const FRat<float> &f)
+  {
+    if (f.numer.mode_racines || f.denom.mode_racines)
+      échec("filtre_rii: give the transfer function in coefficient form (FRat::rii); pole/zero forms go through filtre_sois");
+    if (tsdgpu_rii_create(&h, dtype_of<T>(), f.numer.coefs.data(), f.numer.coefs.rows(), f.denom.coefs.data(), f.denom.coefs.rows()))
+      gpu_fail("filtre_rii");
+  }
+  ~FiltreRIIGpu() override { tsdgpu_rii_destroy(h); }
+  void step(const Vecteur<T> &x, Vecteur<T> &y) override
+  {
+    const entier n = x.rows();
+    if (x.data() != y.data()) y.resize(n);
+    if (n > 0 && tsdgpu_rii_step(h, x.data(), y.data(), n, nullptr)) gpu_fail("filtre_rii::step");
+  }
+};
+template <typename Tc, typename T> sptr<FiltreGen<T>> filtre_rii(const FRat<Tc> &h) { return std::make_shared<FiltreRIIGpu<T>>(h); }
+template sptr<FiltreGen<float>> filtre_rii<float, float>(const FRat<float> &);
+template sptr<FiltreGen<cfloat>> filtre_rii<float, cfloat>(const FRat<float> &);
+
 // ---- resampling: itrp_sinc / filtre_itrp / filtre_reechan -----------------------------------
 template <typename T> InterpolateurSinc<T>::InterpolateurSinc(const InterpolateurSincConfig &c) : config(c)
 {
@@ -401,6 +471,7 @@ template sptr<FiltreGen<cfloat>> filtre_itrp<cfloat>(float, sptr<Interpolateur<c
 // AdaptationRythmeArbitraire (ra.cc:84-183)
 template <typename T> struct AdaptationRythmeArbitraireGpu : Filtre<T, T, float> {
   sptr<FiltreGen<T>> interpolateur;
+  std::vector<sptr<FiltreGen<T>>> décimateurs, suréchantilloneurs;
   float facteur_post_interpolation = 1, ratio = 1;
   explicit AdaptationRythmeArbitraireGpu(float r) { Configurable<float>::configure(r); }
   void configure_impl(const float &ratio_) override
@@ -414,20 +485,24 @@ template <typename T> struct AdaptationRythmeArbitraireGpu : Filtre<T, T, float>
     entier nb_sur = 0, nb_dec = 0;
     while (facteur_post_interpolation < 0.5) { nb_dec++; facteur_post_interpolation *= 2; }
     while (facteur_post_interpolation >= 2) { nb_sur++; facteur_post_interpolation /= 2; }
-    if (nb_dec || nb_sur)
-      échec("filtre_reechan: ratio {} needs {} half-band decimator(s) / {} x2 upsampler(s) (ra.cc:122-144); those "
-            "polyphase stages are the next row of the hot-path scope and are not built yet", ratio, nb_dec, nb_sur);
+    // half-band cascade around the interpolator (ra.cc:136-144): 15-tap Hann, fc = 0.25
+    const Vecf coefs = design_rif_fen(15, "lp", 0.25f, "hn");
+    décimateurs.clear();
+    suréchantilloneurs.clear();
+    for (entier i = 0; i < nb_dec; i++) décimateurs.push_back(filtre_rif_demi_bande<float, T>(coefs));
+    for (entier i = 0; i < nb_sur; i++) suréchantilloneurs.push_back(filtre_rif_ups<float, T>(coefs, 2));
     const float fcut = std::min(0.4f, facteur_post_interpolation / 2);
     auto itrp = itrp_sinc<T>({15, 256, fcut, "hn"});
     interpolateur = filtre_itrp<T>(facteur_post_interpolation, itrp);
   }
   void step(const Vecteur<T> &x, Vecteur<T> &y) override
   {
-    if (ratio == 1 || std::abs(facteur_post_interpolation - 1) < 1e-6f) {   // bypass (ra.cc:162-174)
-      y = x;
-      return;
-    }
-    interpolateur->step(x, y);
+    y = x;
+    if (ratio == 1) return;                                                   // (ra.cc:162-163)
+    for (auto &d : décimateurs) y = d->step(y);
+    for (auto &s : suréchantilloneurs) y = s->step(y);
+    if (std::abs(facteur_post_interpolation - 1) < 1e-6f) return;             // (ra.cc:172-174)
+    y = interpolateur->step(y);
   }
 };
 template <typename T> sptr<Filtre<T, T, float>> filtre_reechan(float ratio)

@@ -114,6 +114,18 @@ def _declare(L):
     L.orc_ra_schedule.argtypes = [vp, i64, vp, vp, i64]
     L.orc_ra_schedule.restype = i64
     L.orc_reechan_config.argtypes = [fl, vp, vp, vp, vp]
+    L.orc_decimateur_f.argtypes = [i32, vp, vp, i64, vp]
+    L.orc_decimateur_f.restype = i64
+    L.orc_polydecim_f.argtypes = [i32, vp, i32, i32, vp, vp, vp, vp, i64, vp]
+    L.orc_polydecim_f.restype = i64
+    L.orc_polydecim_c.argtypes = [i32, vp, i32, i32, vp, vp, vp, vp, i64, vp]
+    L.orc_polydecim_c.restype = i64
+    L.orc_ups_prepare.argtypes = [vp, i32, i32, vp]
+    L.orc_ups_prepare.restype = i32
+    L.orc_ups_f.argtypes = [vp, i32, i32, vp, vp, vp, i64, vp]
+    L.orc_ups_f.restype = i64
+    L.orc_ups_c.argtypes = [vp, i32, i32, vp, vp, vp, i64, vp]
+    L.orc_ups_c.restype = i64
     L.orc_design_rif_fen_hann.argtypes = [i32, i32, fl, vp]
     L.orc_design_butter_lp.argtypes = [i32, fl, vp, vp, vp, vp]
     L.orc_sinc2.argtypes = [fl, fl]
@@ -327,3 +339,60 @@ class Resampler:
         nout = lib().orc_ra_schedule(C.byref(self.r), n, _p(idx) if want else None,
                                      _p(col) if want else None, cap)
         return nout, idx[:nout], col[:nout]
+
+
+# --------------------------------------------------------------------------- polyphase stages
+class Decimateur:
+    """decimateur<float>(R) (filtre-rt.cc:127-169)."""
+
+    def __init__(self, R):
+        self.R, self.cnt = R, C.c_int(0)
+
+    def step(self, x):
+        x = np.ascontiguousarray(x, dtype=f32)
+        y = np.empty(len(x) // self.R + 2, f32)
+        n = lib().orc_decimateur_f(self.R, C.byref(self.cnt), _p(x), len(x), _p(y))
+        return y[:n].copy()
+
+
+class PolyDecim:
+    """filtre_rif_decim (kind 0) / filtre_rif_demi_bande (kind 1) (polyphase.cc:54-239)."""
+
+    def __init__(self, coefs, R=2, kind=0):
+        self.c = np.ascontiguousarray(coefs, dtype=f32)
+        self.R, self.kind = (2 if kind == 1 else R), kind
+        self.index, self.cnt, self.fen = C.c_int(0), C.c_int(0), None
+
+    def step(self, x):
+        x = np.ascontiguousarray(x)
+        cplx = np.iscomplexobj(x)
+        x = x.astype(c64 if cplx else f32)
+        if self.fen is None:
+            self.fen = np.zeros(len(self.c), x.dtype)
+        y = np.empty(len(x) // self.R + 2, x.dtype)
+        fn = lib().orc_polydecim_c if cplx else lib().orc_polydecim_f
+        n = fn(self.kind, _p(self.c), len(self.c), self.R, _p(self.fen), C.byref(self.index), C.byref(self.cnt),
+               _p(x), len(x), _p(y))
+        return y[:n].copy()
+
+
+class PolyUps:
+    """filtre_rif_ups<float,T>(c, R) (polyphase.cc:246-341)."""
+
+    def __init__(self, coefs, R):
+        c = np.ascontiguousarray(coefs, dtype=f32)
+        pad = np.zeros(len(c) + R, f32)
+        self.K = lib().orc_ups_prepare(_p(c), len(c), R, _p(pad))
+        self.c, self.R = pad[: self.K].copy(), R
+        self.index, self.fen = C.c_int(0), None
+
+    def step(self, x):
+        x = np.ascontiguousarray(x)
+        cplx = np.iscomplexobj(x)
+        x = x.astype(c64 if cplx else f32)
+        if self.fen is None:
+            self.fen = np.zeros(self.K // self.R, x.dtype)
+        y = np.empty(len(x) * self.R, x.dtype)
+        fn = lib().orc_ups_c if cplx else lib().orc_ups_f
+        n = fn(_p(self.c), self.K, self.R, _p(self.fen), C.byref(self.index), _p(x), len(x), _p(y))
+        return y[:n]

@@ -628,6 +628,117 @@ void orc_reechan_config(float ratio, int *nb_decim, int *nb_ups, float *post, fl
 }
 
 /* ======================================================================================
+ * Polyphase stages used by filtre_reechan outside [0.5,2) -- src/reechan/polyphase.cc,
+ * and Decimateur -- src/filtrage/filtre-rt.cc:127-169
+ * ==================================================================================== */
+/* Decimateur::step: y = x[cnt::R]; returns the number of outputs, updates *cnt. */
+int64_t orc_decimateur_f(int R, int *cnt, const float *x, int64_t n, float *y)
+{
+  int64_t ny = (n + R - 1 - *cnt) / R, j = 0, i;
+  for (i = *cnt; i < n; i += R) y[j++] = x[i];
+  i -= R;
+  *cnt = (int) (i - (n - R));
+  return ny < j ? ny : j;
+}
+
+/* kind 0: FiltreRIFDecim (polyphase.cc:156-239)  -- taps forward against oldest->newest window
+ * kind 1: FiltreRIFDemiBande (:54-149)           -- even taps only + 0.5 * centre sample, R = 2
+ * state: fen[K] zero-initialised, *index, *cnt (the reference's cnt / odd).  float data.      */
+int64_t orc_polydecim_f(int kind, const float *coefs, int K, int R, float *fen, int *index, int *cnt,
+                        const float *x, int64_t n, float *y)
+{
+  int64_t no = 0;
+  int idx = *index, c = *cnt;
+  if (kind == 1) R = 2;
+  for (int64_t j = 0; j < n; j++) {
+    fen[idx] = x[j];
+    idx = (idx + 1) % K;
+    if (c < R - 1) { c++; continue; }
+    c = 0;
+    float somme = 0;
+    if (kind == 0) {
+      for (int i = 0; i < K; i++) somme += fen[(idx + i) % K] * coefs[i];
+    } else {
+      for (int i = 0; i < K; i += 2) somme += fen[(idx + i) % K] * coefs[i];
+      somme += 0.5f * fen[(idx + K / 2) % K];
+    }
+    y[no++] = somme;
+  }
+  *index = idx; *cnt = c;
+  return no;
+}
+int64_t orc_polydecim_c(int kind, const float *coefs, int K, int R, orc_cf *fen, int *index, int *cnt,
+                        const orc_cf *x, int64_t n, orc_cf *y)
+{
+  int64_t no = 0;
+  int idx = *index, c = *cnt;
+  if (kind == 1) R = 2;
+  for (int64_t j = 0; j < n; j++) {
+    fen[idx] = x[j];
+    idx = (idx + 1) % K;
+    if (c < R - 1) { c++; continue; }
+    c = 0;
+    orc_cf somme = cf(0, 0);
+    if (kind == 0) {
+      for (int i = 0; i < K; i++) somme = cadd(somme, cscale(fen[(idx + i) % K], coefs[i]));
+    } else {
+      for (int i = 0; i < K; i += 2) somme = cadd(somme, cscale(fen[(idx + i) % K], coefs[i]));
+      somme = cadd(somme, cscale(fen[(idx + K / 2) % K], 0.5f));
+    }
+    y[no++] = somme;
+  }
+  *index = idx; *cnt = c;
+  return no;
+}
+
+/* FiltreRIFUps (polyphase.cc:246-341): coefs_in (Kin taps) are scaled by R and zero-padded to a
+ * multiple of R by this function into coefs_pad (caller provides Kin + R floats); fen has
+ * Kpad/R entries. returns n*R outputs. */
+int orc_ups_prepare(const float *coefs_in, int Kin, int R, float *coefs_pad)
+{
+  int K = Kin;
+  for (int i = 0; i < Kin; i++) coefs_pad[i] = coefs_in[i] * R;
+  if (K % R) { int pad = R - (K % R); for (int i = 0; i < pad; i++) coefs_pad[K + i] = 0; K += pad; }
+  return K;
+}
+int64_t orc_ups_f(const float *coefs, int K, int R, float *fen, int *index, const float *x, int64_t n, float *y)
+{
+  const int W = K / R;
+  int idx = *index;
+  int64_t no = 0;
+  for (int64_t j = 0; j < n; j++) {
+    fen[idx] = x[j];
+    idx = (idx + 1) % W;
+    for (int i = 0; i < R; i++) {
+      float sum = 0;
+      const float *cptr = coefs + (R - 1) - i;
+      for (int t = 0; t < W; t++) { sum += fen[(idx + t) % W] * *cptr; cptr += R; }
+      y[no++] = sum;
+    }
+  }
+  *index = idx;
+  return no;
+}
+int64_t orc_ups_c(const float *coefs, int K, int R, orc_cf *fen, int *index, const orc_cf *x, int64_t n, orc_cf *y)
+{
+  const int W = K / R;
+  int idx = *index;
+  int64_t no = 0;
+  for (int64_t j = 0; j < n; j++) {
+    fen[idx] = x[j];
+    idx = (idx + 1) % W;
+    for (int i = 0; i < R; i++) {
+      orc_cf sum = cf(0, 0);
+      const float *cptr = coefs + (R - 1) - i;
+      for (int t = 0; t < W; t++) { sum = cadd(sum, cscale(fen[(idx + t) % W], *cptr)); cptr += R; }
+      y[no++] = sum;
+    }
+  }
+  *index = idx;
+  return no;
+}
+
+/* ======================================================================================
  * Design helpers
  * ==================================================================================== */
 void orc_design_rif_fen_hann(int n, int type, float fcut, float *h)

@@ -106,6 +106,18 @@ int64_t orc_ra_schedule(orc_ra *r, int64_t n, int64_t *in_idx, int32_t *col, int
 /* AdaptationRythmeArbitraire::configure_impl (ra.cc:104-156): folds ratio into [0.5,2).    */
 void orc_reechan_config(float ratio, int *nb_decim, int *nb_ups, float *post, float *fcut);
 
+/* ---- polyphase stages (src/reechan/polyphase.cc) and Decimateur (filtre-rt.cc:127-169) ---- */
+int64_t orc_decimateur_f(int R, int *cnt, const float *x, int64_t n, float *y);
+/* kind 0 = FiltreRIFDecim (:156-239), 1 = FiltreRIFDemiBande (:54-149, R forced to 2) */
+int64_t orc_polydecim_f(int kind, const float *coefs, int K, int R, float *fen, int *index, int *cnt,
+                        const float *x, int64_t n, float *y);
+int64_t orc_polydecim_c(int kind, const float *coefs, int K, int R, orc_cf *fen, int *index, int *cnt,
+                        const orc_cf *x, int64_t n, orc_cf *y);
+/* FiltreRIFUps (:246-341): prepare scales by R and pads to a multiple of R, returns padded K */
+int orc_ups_prepare(const float *coefs_in, int Kin, int R, float *coefs_pad);
+int64_t orc_ups_f(const float *coefs, int K, int R, float *fen, int *index, const float *x, int64_t n, float *y);
+int64_t orc_ups_c(const float *coefs, int K, int R, orc_cf *fen, int *index, const orc_cf *x, int64_t n, orc_cf *y);
+
 /* ---- design helpers (host-side, run once) ---------------------------------------------- */
 /* design_rif_fen(n,type,fcut,"hn") src/filtrage/rif-fen.cc:31-108 + fenetres.cc:16-60,127-130
  * type: 0 = "lp" (normalised), 1 = "pb" (not normalised), 2 = "hp".                        */

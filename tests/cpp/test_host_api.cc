@@ -260,12 +260,60 @@ static void test_reechan()   // test-ra.cc:55-160 style checks on rééchan / fi
       CHECK(e <= 1e-5f, "ratio=%g err=%g", ratio, e);
     }
   }
-  bool threw = false;
-  try { (void) filtre_reechan<float>(4.0f); } catch (const std::runtime_error &) { threw = true; }
-  CHECK(threw, "ratio outside [0.5,2) must fail loudly until the half-band stages are built");
+  // ratios outside [0.5,2): half-band decimators / x2 upsamplers around the interpolator
+  for (float ratio : {2.0f, 3.14159265f, 0.25f, 0.2f, 4.0f}) {
+    const float fe = 100e3f, f2 = 2e3f;
+    Vecf x = Vecf::int_expr(4000, [&](int i) { return std::sin(2 * π * f2 * i / fe); });
+    Vecf y = rééchan(x, ratio);
+    CHECK(100.0 * std::abs((y.rows() - ratio * x.rows()) / x.rows()) < 1, "ratio=%g rows=%d", ratio, y.rows());
+    const float amp1 = x.valeur_max() - x.valeur_min(), amp2 = y.valeur_max() - y.valeur_min();
+    CHECK(100 * (amp1 - amp2) / amp1 < 10, "ratio=%g amplitude %g -> %g", ratio, amp1, amp2);
+  }
   // dsp::resample spelling
   dsp::Veccf xc = randcn(2000);
   CHECK(dsp::resample(xc, 1.25f).rows() == rééchan(xc, 1.25f).rows(), "dsp::resample");
+}
+
+static void test_polyphase()
+{
+  // test_decimateur (test-filtres.cc:186-200)
+  auto dec = decimateur<float>(3);
+  Vecf y = filtre_par_bloc<float>(dec, linspace(0, 89, 90), 4), xr = linspace(0, 87, 30);
+  CHECK(y.rows() == 30 && maxabs(y - xr) == 0.f, "decimateur");
+  // half-band / decim / ups against the oracle
+  Vecf h = design_rif_fen(15, "lp", 0.25f, "hn");
+  Vecf x = randn(6000);
+  {
+    std::vector<float> fen(15, 0.f), yr(3100);
+    int idx = 0, cnt = 0;
+    const int64_t no = orc_polydecim_f(1, h.data(), 15, 2, fen.data(), &idx, &cnt, x.data(), 6000, yr.data());
+    Vecf yg = filtre_par_bloc<float>(filtre_rif_demi_bande<float, float>(h), x, 501);
+    float e = 0;
+    for (int i = 0; i < std::min<int64_t>(no, yg.rows()); i++) e = std::max(e, std::abs(yg(i) - yr[i]));
+    CHECK(no == yg.rows() && e <= 1e-5f, "demi-bande: %lld vs %d outputs, err %g", (long long) no, yg.rows(), e);
+  }
+  {
+    std::vector<float> pad(17), fen(8, 0.f), yr(12000);
+    const int K = orc_ups_prepare(h.data(), 15, 2, pad.data());
+    int idx = 0;
+    const int64_t no = orc_ups_f(pad.data(), K, 2, fen.data(), &idx, x.data(), 6000, yr.data());
+    Vecf yg = filtre_rif_ups<float, float>(h, 2)->step(x);
+    float e = 0;
+    for (int i = 0; i < std::min<int64_t>(no, yg.rows()); i++) e = std::max(e, std::abs(yg(i) - yr[i]));
+    CHECK(no == yg.rows() && e <= 1e-5f, "ups: %lld vs %d outputs, err %g", (long long) no, yg.rows(), e);
+    CHECK(filtre_rif_ups_délais(15, 2) == 8.0f && rif_delais(15) == 7.0f, "delays");
+  }
+  // forme_polyphase is a pure permutation (identity on memory, zero padded)
+  auto X = forme_polyphase(linspace(0, 9, 10), 4);
+  CHECK(X.lignes == 4 && X.colonnes == 3 && X(1, 2) == 9.f && X(3, 2) == 0.f, "forme_polyphase");
+  CHECK(iforme_polyphase(X).rows() == 12, "iforme_polyphase");
+  // test_filtre_rii (test-filtres.cc:556-606)
+  const float a = 0.1f;
+  auto f = filtre_rii<float, float>(FRat<float>::rii(Vecf::valeurs({a}), Vecf::valeurs({1.0f, -(1 - a)})));
+  Vecf yy = f->step(Vecf::ones(20)), yref(20);
+  yref(0) = a;
+  for (int i = 1; i < 20; i++) yref(i) = yref(i - 1) + a * (1 - yref(i - 1));
+  CHECK(maxabs(yref - yy) <= 1e-6f, "filtre_rii err=%g", maxabs(yref - yy));
 }
 
 int main(int argc, char **argv)
@@ -289,6 +337,7 @@ int main(int argc, char **argv)
   for (int n : {16, 1, 2, 3, 4, 5, 8, 10, 17, 128, 129, 1024}) { test_fft_valide(n, false); test_fft_valide(n, true); }
   test_fft_misc();
   test_reechan();
+  test_polyphase();
   printf(nfail ? "FAILED (%d)\n" : "ALL C++ HOST TESTS OK\n", nfail);
   return nfail ? 1 : 0;
 }

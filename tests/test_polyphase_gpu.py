@@ -1,0 +1,87 @@
+"""GPU parity of the integer-rate polyphase stages, the plain decimator and the generic
+direct-form-I IIR against the CPU oracle (polyphase.cc:54-341, filtre-rt.cc:127-289)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def relerr(y, ref):
+    return float(np.abs(y - ref).max() / max(np.abs(ref).max(), 1e-30))
+
+
+def rand(n, cplx, seed):
+    rng = np.random.default_rng(seed)
+    if cplx:
+        return (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    return rng.standard_normal(n).astype(np.float32)
+
+
+@pytest.fixture(scope="module")
+def tg():
+    import libtsd_amd as t
+    assert t.device_count() >= 1
+    return t
+
+
+def chunks(f, x, bs):
+    return np.concatenate([f.step(x[o:o + bs].copy()) for o in range(0, len(x), bs)])
+
+
+# test_decimateur (test-filtres.cc:186-200): R = 3 on 0..89 in blocks of 4 -> exactly 0,3,...,87
+def test_decimateur_exact(tg, orc):
+    x = np.arange(90, dtype=np.float32)
+    y = chunks(tg.PolyFir(tg.POLY_PICK, tg.F32, None, 3), x, 4)
+    assert len(y) == 30 and np.array_equal(y, np.arange(0, 90, 3, dtype=np.float32))
+    for R in (2, 5, 7):
+        xx = rand(1000, True, R)
+        assert np.array_equal(chunks(tg.PolyFir(tg.POLY_PICK, tg.C64, None, R), xx, 33), xx[::R])
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("R", [2, 3, 4, 5, 8])
+@pytest.mark.parametrize("bs", [100000, 1000, 37])
+def test_rif_decim(tg, orc, cplx, R, bs):        # test_filtre_rif_decim (test-ra.cc:176-191)
+    h = orc.design_rif_fen(15, "lp", 0.5 / R)
+    x = rand(20000, cplx, R)
+    ref = orc.PolyDecim(h, R, 0).step(x)
+    y = chunks(tg.PolyFir(tg.POLY_DECIM, tg.C64 if cplx else tg.F32, h, R), x, bs)
+    assert len(y) == len(ref) and relerr(y, ref) <= TOL
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("K", [15, 17, 31])
+def test_rif_demi_bande(tg, orc, cplx, K):       # test_filtre_rif_demi_bande (test-ra.cc:166-173)
+    h = orc.design_rif_fen(K, "lp", 0.25)
+    x = rand(30001, cplx, K)
+    ref = orc.PolyDecim(h, 2, 1).step(x)
+    y = chunks(tg.PolyFir(tg.POLY_HALFBAND, tg.C64 if cplx else tg.F32, h), x, 777)
+    assert len(y) == len(ref) and relerr(y, ref) <= TOL
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("R", [2, 3, 4])
+def test_rif_ups(tg, orc, cplx, R):              # test_filtre_rif_ups (test-ra.cc:193-199)
+    h = orc.design_rif_fen(15, "lp", 0.5 / R)
+    x = rand(10000, cplx, R + 10)
+    ref = orc.PolyUps(h, R).step(x)
+    y = chunks(tg.PolyFir(tg.POLY_UPS, tg.C64 if cplx else tg.F32, h, R), x, 999)
+    assert len(y) == len(ref) == len(x) * R and relerr(y, ref) <= TOL
+
+
+# test_filtre_rii (test-filtres.cc:556-606): one-pole smoother vs the closed recurrence
+def test_filtre_rii(tg, orc):
+    a = np.float32(0.1)
+    n = 20
+    y = tg.Rii([a], [1.0, -(1 - a)], tg.F32).step(np.ones(n, np.float32))
+    yref = np.empty(n, np.float32)
+    yref[0] = a
+    for i in range(1, n):
+        yref[i] = yref[i - 1] + a * (1 - yref[i - 1])
+    assert np.abs(yref - y).max() <= 1e-6
+    # higher order, chunked, vs the oracle's FiltreRII
+    nu, de = [0.2, 0.3, 0.1, -0.05], [1.0, -0.9, 0.5, -0.1]
+    x = rand(5000, False, 3)
+    ref = orc.Rii(nu, de).step(x)
+    assert relerr(chunks(tg.Rii(nu, de, tg.F32), x, 613), ref) <= TOL
