@@ -11,8 +11,10 @@
 //   n odd              -> Bluestein chirp-z on n2 = next pow2 >= 2n-1 (fourier.cc:237-255,391-400)
 // Twiddles are produced on the host in double precision and rounded once to float.
 #include "common.hpp"
+#include "fft1024_wave.hpp"
 #include <cmath>
 #include <memory>
+#include <cstdlib>
 
 namespace tsdgpu {
 
@@ -112,6 +114,127 @@ __global__ __launch_bounds__(FFT_THREADS) void fft_cols_kernel(const cpx *__rest
   }
 }
 
+// ---- fast paths on the in-wave 1024-point FFT (fft1024_wave.hpp) ---------------------------
+// Inverse transforms use conj(FFT(conj(x))): one forward code path, conjugation at the first
+// load and the last store.
+__device__ __forceinline__ void wave_fence()
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// n = 1024: one wave per transform, 4 transforms per workgroup, contiguous in and out.
+__global__ __launch_bounds__(256) void fft1024_rows_kernel(const cpx *__restrict__ in, cpx *__restrict__ out,
+                                                           const cpx *__restrict__ TW1, const cpx *__restrict__ TW2,
+                                                           int inverse, float scale, int ntr)
+{
+  __shared__ cpx lds[4 * w1024::LDS_ELEMS];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int tr = blockIdx.x * 4 + wv;
+  if (tr >= ntr) return;
+  cpx tw1[16], tw2[16], v[16];
+  const cpx *x = in + (size_t) tr * 1024;
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    v[r] = x[64 * r + lane];
+    if (inverse) v[r].y = -v[r].y;
+    tw1[r] = TW1[r * 64 + lane];
+    tw2[r] = TW2[r * 64 + lane];
+  }
+  w1024::forward<1>(v, lds + wv * w1024::LDS_ELEMS, lane, tw1, tw2, wave_fence);
+  cpx *y = out + (size_t) tr * 1024;
+  const int k0 = (lane >> 2) + 16 * (lane & 3);            // freq_index(lane, r) = k0 + 64*(r>>2) + 256*(r&3)
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    cpx o = cscale(v[r], scale);
+    if (inverse) o.y = -o.y;
+    y[k0 + 64 * (r >> 2) + 256 * (r & 3)] = o;
+  }
+}
+
+// n = 2^20 = 1024 x 1024, four-step.  One workgroup = 8 waves = 8 adjacent columns of the
+// row-major [1024][1024] matrix; the tile [1024 rows][8 cols] is loaded with 16-B accesses
+// (64-B row segments), staged in LDS at pitch 9 (odd -> the column each wave reads, and the
+// exchange image it then reuses in place, stay bank-conflict free), transformed by the wave.
+//   PASS 1: out is the transposed matrix, out[c][k] = FFT_c[k] * W_N^(c*k)  (row c contiguous:
+//           stored straight from registers in 512-B segments)
+//   PASS 2: out[k][c] = FFT_c[k] * scale (natural order; staged back through LDS)
+// Twiddle W_N^(c*k), k = k0(lane) + 64*(r>>2) + 256*(r&3): TA[c][lane] * TD[c][r] (host tables).
+constexpr int C8_ROWS = 1088;
+template <int PASS, int C8>
+__global__ __launch_bounds__(C8 * 64) void fft1m_cols_kernel(const cpx *__restrict__ in, cpx *__restrict__ out,
+                                                         const cpx *__restrict__ TW1, const cpx *__restrict__ TW2,
+                                                         const cpx *__restrict__ TA, const cpx *__restrict__ TD,
+                                                         int inverse, float scale, int zp, int ntiles)
+{
+  (void) ntiles;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int C8_PITCH = C8 + 1;
+  constexpr int TPR = C8 / 2;                 // threads per row (16 B each)
+  constexpr int RPS = C8 * 64 / TPR;          // rows per sweep
+  constexpr int NSW = 1024 / RPS;             // sweeps (= 16-B loads per thread per tile)
+  constexpr int TPB = 1024 / C8;              // column tiles per transform
+  cpx *tile = reinterpret_cast<cpx *>(smem_raw);
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int ipitch = PASS == 1 ? 1024 : zp, opitch = PASS == 1 ? zp : 1024;
+  const int rr = t / TPR, cc = 2 * (t % TPR);
+  const int k0 = (lane >> 2) + 16 * (lane & 3);
+  cpx *col = tile + wv;                                    // this wave's column: slots e*pitch + wv
+
+  // tile `id` = (transform id / TPB, column tile id % TPB).  (A persistent variant with the
+  // next tile prefetched into registers was measured: it does not fit the 128-VGPR budget of a
+  // 1024-thread workgroup and spills; one tile per workgroup is faster.)
+  {
+    const int id = blockIdx.x;      // one tile per workgroup (grid = ntiles)
+    const cpx *x = in + (size_t) (id / TPB) * 1024 * ipitch + (id % TPB) * C8 + cc;
+#pragma unroll
+    for (int i = 0; i < NSW; i++) {
+      const int row = rr + RPS * i;
+      float4 q = *reinterpret_cast<const float4 *>(x + (size_t) row * ipitch);
+      if (PASS == 1 && inverse) { q.y = -q.y; q.w = -q.w; }
+      tile[row * C8_PITCH + cc] = cmk(q.x, q.y);
+      tile[row * C8_PITCH + cc + 1] = cmk(q.z, q.w);
+    }
+    __syncthreads();
+    cpx tw1[16], tw2[16], v[16];
+    const int lo = lane;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      v[r] = col[(64 * r + lane) * C8_PITCH];
+      tw1[r] = TW1[r * 64 + lo];
+      tw2[r] = TW2[r * 64 + lo];
+    }
+    w1024::forward<C8_PITCH>(v, col, lane, tw1, tw2, wave_fence);
+    const int c0 = (id % TPB) * C8, c = c0 + wv;
+    cpx *y = out + (size_t) (id / TPB) * 1024 * opitch;
+    if (PASS == 1) {
+      const cpx a = TA[c * 64 + lane];
+      cpx *z = y + (size_t) c * opitch;
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const cpx w = cmul(a, TD[c * 16 + r]);
+        z[k0 + 64 * (r >> 2) + 256 * (r & 3)] = cmul(v[r], w);
+      }
+    } else {
+      wave_fence();
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        cpx o = cscale(v[r], scale);
+        if (inverse) o.y = -o.y;
+        col[(k0 + 64 * (r >> 2) + 256 * (r & 3)) * C8_PITCH] = o;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NSW; i++) {
+        const int row = rr + RPS * i;
+        const cpx a = tile[row * C8_PITCH + cc], b = tile[row * C8_PITCH + cc + 1];
+        *reinterpret_cast<float4 *>(y + (size_t) row * opitch + c0 + cc) = make_float4(a.x, a.y, b.x, b.y);
+      }
+    }
+  }
+}
+
 // ---- helpers for the non power-of-two paths ------------------------------------------------
 // even split: tmp[b][0..h) = x[b][0::2], tmp[b][h..n) = x[b][1::2]
 __global__ void fft_split_eo_kernel(const cpx *__restrict__ x, cpx *__restrict__ tmp, int n, int64_t total)
@@ -178,13 +301,15 @@ using namespace tsdgpu;
 
 struct tsdgpu_fft {
   int n = 0;
-  enum Kind { ONE, POW2_LDS, POW2_4STEP, EVEN, ODD } kind = ONE;
+  enum Kind { ONE, POW2_LDS, POW2_W1024, POW2_W1M, POW2_4STEP, EVEN, ODD } kind = ONE;
   // pow2
   int logn = 0;
   cpx *d_tw = nullptr;        // W_n^k, k < n/2 (LDS path) ...
   // four-step n = N1 * N2
   int N1 = 0, N2 = 0, logN1 = 0, logN2 = 0;
   cpx *d_tw1 = nullptr, *d_tw2 = nullptr, *d_thi = nullptr, *d_tlo = nullptr;
+  // in-wave 1024-point FFT paths: lane twiddles (2 x 1024) and, for n = 2^20, TA [1024][64] / TD [1024][16]
+  cpx *d_w1 = nullptr, *d_w2 = nullptr, *d_ta = nullptr, *d_td = nullptr;
   // even / odd
   tsdgpu_fft *sub = nullptr;
   cpx *d_rot = nullptr;       // W_n^k, k < n (even split)
@@ -236,7 +361,37 @@ int plan_init(tsdgpu_fft *p, int n)
     p->kind = tsdgpu_fft::ONE;
   } else if ((n & (n - 1)) == 0) {
     p->logn = log2_exact(n);
-    if (n <= LDS_MAX_N) {
+    const bool fast = getenv("TSDGPU_FFT_GENERIC") == nullptr;
+    if (fast && (n == 1024 || n == (1 << 20))) {
+      p->kind = n == 1024 ? tsdgpu_fft::POW2_W1024 : tsdgpu_fft::POW2_W1M;
+      std::vector<cpx> t1(1024), t2(1024);
+      w1024::fill_twiddles(t1.data(), t2.data());
+      if ((rc = upload(&p->d_w1, t1))) return rc;
+      if ((rc = upload(&p->d_w2, t2))) return rc;
+      if (n != 1024) {
+        std::vector<cpx> ta((size_t) 1024 * 64), td((size_t) 1024 * 16);
+        const double PI = 3.14159265358979323846;
+        for (int c = 0; c < 1024; c++) {
+          for (int lane = 0; lane < 64; lane++) {
+            const int64_t m = ((int64_t) c * ((lane >> 2) + 16 * (lane & 3))) % n;
+            const double a = -2.0 * PI * (double) m / (double) n;
+            ta[(size_t) c * 64 + lane] = make_float2((float) std::cos(a), (float) std::sin(a));
+          }
+          for (int r = 0; r < 16; r++) {
+            const int64_t m = ((int64_t) c * (64 * (r >> 2) + 256 * (r & 3))) % n;
+            const double a = -2.0 * PI * (double) m / (double) n;
+            td[(size_t) c * 16 + r] = make_float2((float) std::cos(a), (float) std::sin(a));
+          }
+        }
+        if ((rc = upload(&p->d_ta, ta))) return rc;
+        if ((rc = upload(&p->d_td, td))) return rc;
+        (void) hipFuncSetAttribute((const void *) fft1m_cols_kernel<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void) hipFuncSetAttribute((const void *) fft1m_cols_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void) hipFuncSetAttribute((const void *) fft1m_cols_kernel<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void) hipFuncSetAttribute((const void *) fft1m_cols_kernel<2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void) hipGetLastError();
+      }
+    } else if (n <= LDS_MAX_N) {
       p->kind = tsdgpu_fft::POW2_LDS;
       rc = upload(&p->d_tw, twiddle_table(n, n / 2));
     } else {
@@ -326,7 +481,7 @@ void plan_destroy(tsdgpu_fft *p)
 {
   if (!p) return;
   if (p->sub) plan_destroy(p->sub);
-  for (cpx *q : {p->d_tw, p->d_tw1, p->d_tw2, p->d_thi, p->d_tlo, p->d_rot, p->d_chirp, p->d_xc})
+  for (cpx *q : {p->d_tw, p->d_tw1, p->d_tw2, p->d_thi, p->d_tlo, p->d_rot, p->d_chirp, p->d_xc, p->d_w1, p->d_w2, p->d_ta, p->d_td})
     if (q) (void) hipFree(q);
   p->work.release();
   p->work2.release();
@@ -351,6 +506,45 @@ int step_device(tsdgpu_fft *p, const cpx *x, cpx *y, int batch, int forward, hip
       const float scale = 1.0f / std::sqrt((float) n);
       hipLaunchKernelGGL(fft_rows_kernel, dim3((unsigned) batch), dim3(FFT_THREADS), (size_t) n * sizeof(cpx), st, x,
                          y, p->d_tw, n, p->logn, inverse, scale);
+      TSD_HIP(hipGetLastError());
+      return TSDGPU_OK;
+    }
+    case tsdgpu_fft::POW2_W1024: {
+      const float scale = 1.0f / 32.0f;
+      hipLaunchKernelGGL(fft1024_rows_kernel, dim3((unsigned) cdiv(batch, 4)), dim3(256), 0, st, x, y, p->d_w1, p->d_w2,
+                         inverse, scale, batch);
+      TSD_HIP(hipGetLastError());
+      return TSDGPU_OK;
+    }
+    case tsdgpu_fft::POW2_W1M: {
+      // the transposed intermediate gets a padded row pitch: its columns are read back by
+      // pass 2 with a stride that is no longer a power of two (spreads the HBM channels)
+      static const int ZP = getenv("TSDGPU_FFT_ZP") ? atoi(getenv("TSDGPU_FFT_ZP")) : 1024 + 16;
+      int rc = p->work.reserve((size_t) batch * 1024 * ZP * sizeof(cpx));
+      if (rc) return rc;
+      cpx *z = p->work.as<cpx>();
+      static const int CW = getenv("TSDGPU_FFT_CW") ? atoi(getenv("TSDGPU_FFT_CW")) : 16;
+      const size_t lds = (size_t) C8_ROWS * (CW + 1) * sizeof(cpx);
+      // Transforms are processed in groups small enough for the intermediate (8 MiB per
+      // transform) to still sit in the 256 MiB Infinity Cache when pass 2 reads it back.
+      static const int G = getenv("TSDGPU_FFT_GROUP") ? atoi(getenv("TSDGPU_FFT_GROUP")) : 65535;
+      for (int b0 = 0; b0 < batch; b0 += G) {
+        const int nb = std::min(G, batch - b0);
+        const size_t off = (size_t) b0 << 20, zoff = (size_t) b0 * 1024 * ZP;
+        if (CW == 16) {
+          const int ntiles = 64 * nb, grid = ntiles;
+          hipLaunchKernelGGL((fft1m_cols_kernel<1, 16>), dim3(grid), dim3(1024), lds, st, x + off, z + zoff,
+                             p->d_w1, p->d_w2, p->d_ta, p->d_td, inverse, 1.0f, ZP, ntiles);
+          hipLaunchKernelGGL((fft1m_cols_kernel<2, 16>), dim3(grid), dim3(1024), lds, st, z + zoff, y + off,
+                             p->d_w1, p->d_w2, p->d_ta, p->d_td, inverse, 1.0f / 1024.0f, ZP, ntiles);
+        } else {
+          const int ntiles = 128 * nb, grid = ntiles;
+          hipLaunchKernelGGL((fft1m_cols_kernel<1, 8>), dim3(grid), dim3(512), lds, st, x + off, z + zoff,
+                             p->d_w1, p->d_w2, p->d_ta, p->d_td, inverse, 1.0f, ZP, ntiles);
+          hipLaunchKernelGGL((fft1m_cols_kernel<2, 8>), dim3(grid), dim3(512), lds, st, z + zoff, y + off,
+                             p->d_w1, p->d_w2, p->d_ta, p->d_td, inverse, 1.0f / 1024.0f, ZP, ntiles);
+        }
+      }
       TSD_HIP(hipGetLastError());
       return TSDGPU_OK;
     }

@@ -148,87 +148,90 @@ template <bool INV> TSD_HD void stageC(cpx (&v)[16])
 }
 
 // exchange 1, forward direction: lane n2 / reg k1  ->  lane (k1,m2) / reg m1
-TSD_HD void x1_write_rows(const cpx (&v)[16], cpx *lds, int lane)
+template <int S = 1> TSD_HD void x1_write_rows(const cpx (&v)[16], cpx *lds, int lane)
 {
 #pragma unroll
-  for (int r = 0; r < 16; r++) lds[LDS_ROW * r + lane] = v[r];
+  for (int r = 0; r < 16; r++) lds[(LDS_ROW * r + lane) * S] = v[r];
 }
-TSD_HD void x1_read_rows(cpx (&v)[16], const cpx *lds, int lane)
+template <int S = 1> TSD_HD void x1_read_rows(cpx (&v)[16], const cpx *lds, int lane)
 {
 #pragma unroll
-  for (int r = 0; r < 16; r++) v[r] = lds[LDS_ROW * r + lane];
+  for (int r = 0; r < 16; r++) v[r] = lds[(LDS_ROW * r + lane) * S];
 }
-TSD_HD void x1_write_cols(const cpx (&v)[16], cpx *lds, int lane)
+template <int S = 1> TSD_HD void x1_write_cols(const cpx (&v)[16], cpx *lds, int lane)
 {
   const int base = LDS_ROW * (lane >> 2) + (lane & 3);
 #pragma unroll
-  for (int m1 = 0; m1 < 16; m1++) lds[base + 4 * m1] = v[m1];
+  for (int m1 = 0; m1 < 16; m1++) lds[(base + 4 * m1) * S] = v[m1];
 }
-TSD_HD void x1_read_cols(cpx (&v)[16], const cpx *lds, int lane)
+template <int S = 1> TSD_HD void x1_read_cols(cpx (&v)[16], const cpx *lds, int lane)
 {
   const int base = LDS_ROW * (lane >> 2) + (lane & 3);
 #pragma unroll
-  for (int m1 = 0; m1 < 16; m1++) v[m1] = lds[base + 4 * m1];
+  for (int m1 = 0; m1 < 16; m1++) v[m1] = lds[(base + 4 * m1) * S];
 }
 // exchange 2: image [k1][m2][j1] with plane stride 17
-TSD_HD void x2_write_j1(const cpx (&v)[16], cpx *lds, int lane)     // lane (k1,m2), reg j1
+template <int S = 1> TSD_HD void x2_write_j1(const cpx (&v)[16], cpx *lds, int lane)     // lane (k1,m2), reg j1
 {
   const int base = LDS_ROW * (lane >> 2) + 17 * (lane & 3);
 #pragma unroll
-  for (int j1 = 0; j1 < 16; j1++) lds[base + j1] = v[j1];
+  for (int j1 = 0; j1 < 16; j1++) lds[(base + j1) * S] = v[j1];
 }
-TSD_HD void x2_read_j1(cpx (&v)[16], const cpx *lds, int lane)
+template <int S = 1> TSD_HD void x2_read_j1(cpx (&v)[16], const cpx *lds, int lane)
 {
   const int base = LDS_ROW * (lane >> 2) + 17 * (lane & 3);
 #pragma unroll
-  for (int j1 = 0; j1 < 16; j1++) v[j1] = lds[base + j1];
+  for (int j1 = 0; j1 < 16; j1++) v[j1] = lds[(base + j1) * S];
 }
-TSD_HD void x2_write_m2(const cpx (&v)[16], cpx *lds, int lane)     // lane (k1,j1lo), reg (j1hi,m2)
+template <int S = 1> TSD_HD void x2_write_m2(const cpx (&v)[16], cpx *lds, int lane)     // lane (k1,j1lo), reg (j1hi,m2)
 {
   const int base = LDS_ROW * (lane >> 2) + (lane & 3);
 #pragma unroll
   for (int h = 0; h < 4; h++)
 #pragma unroll
-    for (int m2 = 0; m2 < 4; m2++) lds[base + 17 * m2 + 4 * h] = v[4 * h + m2];
+    for (int m2 = 0; m2 < 4; m2++) lds[(base + 17 * m2 + 4 * h) * S] = v[4 * h + m2];
 }
-TSD_HD void x2_read_m2(cpx (&v)[16], const cpx *lds, int lane)
+template <int S = 1> TSD_HD void x2_read_m2(cpx (&v)[16], const cpx *lds, int lane)
 {
   const int base = LDS_ROW * (lane >> 2) + (lane & 3);
 #pragma unroll
   for (int h = 0; h < 4; h++)
 #pragma unroll
-    for (int m2 = 0; m2 < 4; m2++) v[4 * h + m2] = lds[base + 17 * m2 + 4 * h];
+    for (int m2 = 0; m2 < 4; m2++) v[4 * h + m2] = lds[(base + 17 * m2 + 4 * h) * S];
 }
 
 // Whole transforms for one lane; SYNC is a callable.  Unnormalised (the caller folds 1/N or
 // 1/sqrt(N) into a later multiply).
-template <typename SYNC>
+// S = element stride of the wave's LDS image (1: private contiguous buffer; an ODD stride such
+// as 9 interleaves the images of several waves -- multiplying slot numbers by an odd constant
+// permutes the banks, so the conflict-free property of the maps above is preserved).
+template <int S = 1, typename SYNC>
 TSD_HD void forward(cpx (&v)[16], cpx *lds, int lane, const cpx (&tw1)[16], const cpx (&tw2)[16], SYNC sync)
 {
   stageA<false>(v, tw1);
-  x1_write_rows(v, lds, lane);
+  x1_write_rows<S>(v, lds, lane);
   sync();
-  x1_read_cols(v, lds, lane);
+  x1_read_cols<S>(v, lds, lane);
   stageB<false>(v, tw2);
   sync();
-  x2_write_j1(v, lds, lane);
+  x2_write_j1<S>(v, lds, lane);
   sync();
-  x2_read_m2(v, lds, lane);
+  x2_read_m2<S>(v, lds, lane);
   stageC<false>(v);
 }
-template <typename SYNC>
+template <int S = 1, typename SYNC>
 TSD_HD void inverse(cpx (&v)[16], cpx *lds, int lane, const cpx (&tw1)[16], const cpx (&tw2)[16], SYNC sync)
 {
   stageC<true>(v);
   sync();
-  x2_write_m2(v, lds, lane);
+  x2_write_m2<S>(v, lds, lane);
   sync();
-  x2_read_j1(v, lds, lane);
+  x2_read_j1<S>(v, lds, lane);
   stageB<true>(v, tw2);
   sync();
-  x1_write_cols(v, lds, lane);
+  x1_write_cols<S>(v, lds, lane);
   sync();
-  x1_read_rows(v, lds, lane);
+  x1_read_rows<S>(v, lds, lane);
   stageA<true>(v, tw1);
 }
 
