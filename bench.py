@@ -62,8 +62,8 @@ def cpu_baseline(h, seconds_target=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--log2n", type=int, default=LOG2N, help="samples per GPU = 2^log2n (default: the BASELINE size)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     args = ap.parse_args()

@@ -250,9 +250,12 @@ int tsdgpu_fir_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, void *stre
     TSD_HIP(hipMemcpyAsync(f->in_stage.p, dx, bytes, hipMemcpyDeviceToDevice, st));
     dx = f->in_stage.p;
   }
-  rc = f->method == TSDGPU_FIR_OVERLAP_SAVE ? ols_step(f, dx, dy, n, st) : fir_direct_step(f, dx, dy, n, st);
-  if (rc) return rc;
-  rc = fir_update_history(f, dx, n, st);
+  if (f->method == TSDGPU_FIR_OVERLAP_SAVE) {
+    rc = ols_step(f, dx, dy, n, st);             // history update folded into the launch
+  } else {
+    rc = fir_direct_step(f, dx, dy, n, st);
+    if (!rc) rc = fir_update_history(f, dx, n, st);
+  }
   if (rc) return rc;
   return finish_out(y, bytes, dy, staged, st);
 }

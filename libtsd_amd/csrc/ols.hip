@@ -66,13 +66,12 @@ __device__ __forceinline__ void ols_fetch(cpx (&v)[16], const cpx *__restrict__ 
 // Blocks [b_lo, b_hi) are processed with block b = b_lo + slot + i*G.  The EDGE variant is
 // launched with G = 1 per edge block.
 template <bool EDGE>
-__global__ __launch_bounds__(64, 2) void ols_kernel(const cpx *__restrict__ x, const cpx *__restrict__ hist,
-                                                    cpx *__restrict__ y, const cpx *__restrict__ Hreg,
-                                                    const cpx *__restrict__ TW1, const cpx *__restrict__ TW2,
-                                                    int Km1, int histlen, int L, int64_t n, int64_t b_lo,
-                                                    int64_t b_hi, int64_t b_edge2)
+__device__ __forceinline__ void ols_body(cpx *lds, const cpx *__restrict__ x, const cpx *__restrict__ hist,
+                                         cpx *__restrict__ y, const cpx *__restrict__ Hreg,
+                                         const cpx *__restrict__ TW1, const cpx *__restrict__ TW2, int Km1,
+                                         int histlen, int L, int64_t n, int64_t b_lo, int64_t b_hi, int64_t G,
+                                         int64_t w)
 {
-  __shared__ cpx lds[LDS_ELEMS];
   const int lane = threadIdx.x;
   cpx tw1[16], tw2[16], H[16];
 #pragma unroll
@@ -96,10 +95,7 @@ __global__ __launch_bounds__(64, 2) void ols_kernel(const cpx *__restrict__ x, c
   // over the 8 XCDs, so w % 8 labels its XCD -- takes block (w % 8) * G/8 + w / 8: blocks that
   // share their K-1 overlap samples run on the same XCD at the same time and the second
   // reader hits that XCD's L2.  Placement only affects speed, never results.
-  const int64_t G = gridDim.x;
-  const int64_t w = blockIdx.x;
-  int64_t b = b_lo + ((G % 8 == 0) ? (w % 8) * (G / 8) + w / 8 : w);
-  if (EDGE && w == 1) b = b_edge2;
+  int64_t b = EDGE ? b_lo : b_lo + ((G % 8 == 0) ? (w % 8) * (G / 8) + w / 8 : w);
   if (b >= b_hi) return;
 
   // One block: prefetch the next block into `nxt`, transform `cur` in place, then store it.
@@ -147,6 +143,32 @@ __global__ __launch_bounds__(64, 2) void ols_kernel(const cpx *__restrict__ x, c
     process(B, A, b);
     b += G;
     if (b >= b_hi) break;
+  }
+}
+
+// One launch per step: workgroups [0, G) walk the interior blocks, the next `ne` workgroups
+// take one edge block each (block 0 with the history halo, the ragged last block), and the
+// last workgroup writes the new history (the last `histlen` samples of history ++ x) into
+// the handle's other history buffer.
+__global__ __launch_bounds__(64, 2) void ols_kernel(const cpx *__restrict__ x, const cpx *__restrict__ hist,
+                                                    cpx *__restrict__ hist_next, cpx *__restrict__ y,
+                                                    const cpx *__restrict__ Hreg, const cpx *__restrict__ TW1,
+                                                    const cpx *__restrict__ TW2, int Km1, int histlen, int L,
+                                                    int64_t n, int64_t b_lo, int64_t b_hi, int64_t nblocks, int G,
+                                                    int ne, int64_t e0, int64_t e1)
+{
+  __shared__ cpx lds[LDS_ELEMS];
+  const int w = blockIdx.x;
+  if (w < G) {
+    ols_body<false>(lds, x, hist, y, Hreg, TW1, TW2, Km1, histlen, L, n, b_lo, b_hi, G, w);
+  } else if (w < G + ne) {
+    const int64_t b = (w == G) ? e0 : e1;
+    ols_body<true>(lds, x, hist, y, Hreg, TW1, TW2, Km1, histlen, L, n, b, nblocks, 1, 0);
+  } else {
+    for (int i = threadIdx.x; i < histlen; i += 64) {
+      const int64_t g = n - histlen + i;
+      hist_next[i] = g < 0 ? hist[histlen + g] : x[g];
+    }
   }
 }
 
@@ -204,7 +226,7 @@ int ols_plan_create(tsdgpu_fir *f)
   int dev = 0, cus = 256, per_cu = 8;
   (void) hipGetDevice(&dev);
   (void) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ols_kernel<false>, 64, 0) != hipSuccess || per_cu < 1) {
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ols_kernel, 64, 0) != hipSuccess || per_cu < 1) {
     (void) hipGetLastError();
     per_cu = 8;
   }
@@ -225,33 +247,30 @@ int ols_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, hipStream_t st)
   const int L = f->ols_L;
   const int64_t nblocks = cdiv(n, L);
   const cpx *d = (const cpx *) f->d_H;
-  // interior blocks: inputs [b*L-(K-1), b*L+L) and outputs [b*L, b*L+L) all inside [0, n)
+  // interior blocks: inputs [b*L-overlap, b*L+L) and outputs [b*L, b*L+L) all inside [0, n)
   const int64_t b_lo = f->K > 1 ? 1 : 0;
   const int64_t b_hi = n / L;
+  int64_t grid = 0;
   if (b_hi > b_lo) {
     const int64_t nint = b_hi - b_lo;
     // balance the rounds: every wave gets ceil(nint/grid) or one fewer blocks, no tail round
-    int64_t grid = nint < f->ols_grid ? nint : f->ols_grid;
+    grid = nint < f->ols_grid ? nint : f->ols_grid;
     if (nint > grid) {
       const int64_t rounds = cdiv(nint, grid);
       grid = cdiv(cdiv(nint, rounds), 8) * 8;
     }
-    hipLaunchKernelGGL(ols_kernel<false>, dim3((unsigned) grid), dim3(64), 0, st, (const cpx *) x,
-                       (const cpx *) f->hist[f->cur], (cpx *) y, d, d + OLS_N, d + 2 * OLS_N, OLS_N - L, f->HL,
-                       L, n, b_lo, b_hi, (int64_t) 0);
-    TSD_HIP(hipGetLastError());
   }
   // edge blocks: block 0 (history halo) and the ragged last block, one wave each
-  int64_t e[2];
+  int64_t e[2] = {0, 0};
   int ne = 0;
   if (b_lo == 1 || b_hi == 0) e[ne++] = 0;
   if (b_hi < nblocks && b_hi > 0) e[ne++] = b_hi;
-  if (ne > 0) {
-    hipLaunchKernelGGL(ols_kernel<true>, dim3((unsigned) ne), dim3(64), 0, st, (const cpx *) x,
-                       (const cpx *) f->hist[f->cur], (cpx *) y, d, d + OLS_N, d + 2 * OLS_N, OLS_N - L, f->HL,
-                       L, n, e[0], nblocks, ne > 1 ? e[1] : e[0]);
-    TSD_HIP(hipGetLastError());
-  }
+  const int nxt = f->cur ^ 1;
+  hipLaunchKernelGGL(ols_kernel, dim3((unsigned) (grid + ne + 1)), dim3(64), 0, st, (const cpx *) x,
+                     (const cpx *) f->hist[f->cur], (cpx *) f->hist[nxt], (cpx *) y, d, d + OLS_N, d + 2 * OLS_N,
+                     OLS_N - L, f->HL, L, n, b_lo, b_hi, nblocks, (int) grid, ne, e[0], e[1]);
+  TSD_HIP(hipGetLastError());
+  f->cur = nxt;      // the history update is part of the launch
   return TSDGPU_OK;
 }
 
