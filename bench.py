@@ -27,6 +27,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 LOG2N = 26
 K_TAPS = 127
+# measured offline, per launch of the dominant kernel (see profiles/README.md)
+TRAFFIC_PMC_BYTES = {("overlap-save", 26): (2 * 268927 + 524289) * 1024.0}
 
 
 def design_lowpass(n, fc):
@@ -149,7 +151,10 @@ def main():
                        "method": method_names[fir_auto.method], "samples_per_gpu": n,
                        "sharding": "contiguous chunks, K-1 halo via RCCL send/recv" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         # HBM bytes per launch from rocprofv3 --pmc passes (profiles/r1_pmc_ols.txt):
+                         # FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, in KB
+                         "traffic": TRAFFIC_PMC_BYTES.get((method_names[fir_auto.method], args.log2n)),
                          "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": alg_bytes},
         }
     # secondary line: the direct kernel on the same data (rank-local, N=1 only)
