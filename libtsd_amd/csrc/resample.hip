@@ -13,7 +13,7 @@
 //
 // The recurrence is sequential, so it is cut with checkpoints: the host simulates it once per
 // handle (lazily, only as far as the stream has advanced), records (phase, outputs so far)
-// every 16 inputs and runs Brent's cycle detection on the phase at input boundaries -- the
+// every 8 inputs and runs Brent's cycle detection on the phase at input boundaries -- the
 // state space is finite, so the sequence becomes periodic (ratio 160/147: period 3 853 516
 // inputs <-> 4 194 303 outputs) and from then on any stream position is a table lookup.
 // On the device every lane restarts from the checkpoint at or below its 8-input segment,
@@ -22,13 +22,14 @@
 // LDS) and stores them coalesced.  HBM traffic: 8 B in + 8*ratio B out per complex sample.
 #include "common.hpp"
 #include <cmath>
+#include <cstdlib>
 
 namespace tsdgpu {
 
 constexpr int RS_THREADS = 256;
 constexpr int RS_SEG = 8;                       // inputs per lane
 constexpr int RS_TI = RS_THREADS * RS_SEG;      // inputs per tile (2048)
-constexpr int RS_CK = 16;                       // checkpoint spacing (inputs)
+constexpr int RS_CK = 8;                        // checkpoint spacing (inputs)
 
 struct RsParams {
   int64_t pos;        // absolute index of x[0]
@@ -68,95 +69,164 @@ __device__ __forceinline__ float2 tap_mac(float2 acc, float h, float2 x)
   return make_float2(fmaf(h, x.x, acc.x), fmaf(h, x.y, acc.y));
 }
 
+// KT = 15: the filtre_reechan interpolator -- taps padded to 16 and read as four ds_read_b128
+// from LUT rows of pitch 20 floats (80 B: 16-B aligned, and 5 mod 16 in 16-B units, so the
+// rows selected by 16 lanes whose columns step regularly fall on distinct bank groups).
+// KT = 0: generic K <= 32, scalar tap reads at an odd pitch.
 template <typename T, int KT>
 __global__ __launch_bounds__(RS_THREADS) void resample_kernel(const T *__restrict__ x, const T *__restrict__ hist,
                                                               T *__restrict__ y, const float *__restrict__ lut,
-                                                              const RsCk *__restrict__ ck, RsParams P)
+                                                              const RsCk *__restrict__ ck, RsParams P, int ntiles)
 {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int K = KT > 0 ? KT : P.K;      // KT = 15: the filtre_reechan interpolator, fully unrolled
-  T *tile = reinterpret_cast<T *>(smem_raw);                              // RS_TI + K - 1 samples
-  uint32_t *rec = reinterpret_cast<uint32_t *>(tile + (RS_TI + K - 1 + 1));
-  float *lut_s = reinterpret_cast<float *>(rec + P.rec_cap);
+  const int K = KT > 0 ? KT : P.K;
+  const int lstride = KT == 15 ? 20 : P.lstride;
+  float *lut_s = reinterpret_cast<float *>(smem_raw);                       // (nph+1) x lstride, 16-B aligned
+  T *tile = reinterpret_cast<T *>(lut_s + ((P.nph + 1) * lstride + 3) / 4 * 4);   // RS_TI + K samples
+  uint32_t *rec = reinterpret_cast<uint32_t *>(tile + (RS_TI + K + 1));
   __shared__ long long s_cum_t0;
   __shared__ int s_o_end;
 
   const int tid = threadIdx.x;
-  const int64_t T0 = P.tile0 + (int64_t) blockIdx.x * RS_TI;
-  if (tid == 0) s_o_end = 0;
-
-  // ---- stage the LUT (phase-major, padded to an odd stride) and the input tile
+  // ---- stage the LUT once per (persistent) workgroup
   const int lut_n = (P.nph + 1) * K;
   for (int i = tid; i < lut_n; i += RS_THREADS) {
     const int c = i / K, k = i - c * K;
-    lut_s[c * P.lstride + k] = lut[i];
+    lut_s[c * lstride + k] = lut[i];
   }
-  for (int s = tid; s < RS_TI + K - 1; s += RS_THREADS) {
-    const int64_t rel = T0 - (K - 1) + s - P.pos;
-    T v = zero_of(T{});
-    if (rel < 0) {
-      if (rel >= -(int64_t) (K - 1)) v = hist[(K - 1) + rel];
-    } else if (rel < P.n) {
-      v = x[rel];
-    }
-    tile[s] = v;
-  }
+  if (KT == 15)
+    for (int c = tid; c <= P.nph; c += RS_THREADS) lut_s[c * lstride + 15] = 0.f;   // 16th tap
 
-  // ---- replay the phase recurrence for this lane's 8 inputs
-  const int64_t i_abs = T0 + (int64_t) tid * RS_SEG;
-  int64_t ic = i_abs, q = 0;
-  if (P.lambda > 0 && i_abs >= P.mu + P.lambda) {
-    const int64_t d = i_abs - P.mu;
-    q = d / P.lambda;
-    ic = P.mu + (d - q * P.lambda);
+  // canonical (cycle-folded) index of this workgroup's first tile: ONE 64-bit division per
+  // workgroup; afterwards the index advances by a constant and is folded by subtraction
+  int64_t icT = P.tile0 + (int64_t) blockIdx.x * RS_TI, qT = 0;
+  if (P.lambda > 0 && icT >= P.mu + P.lambda) {
+    const int64_t d = icT - P.mu;
+    qT = d / P.lambda;
+    icT = P.mu + (d - qT * P.lambda);
   }
-  const bool in_call = i_abs < P.pos + P.n;              // lanes past the end of the call do nothing
-  const float inc = P.inc;
-  float phase = 2.f;
-  int64_t cum = 0;
-  if (in_call) {
-    const RsCk c0 = ck[ic / RS_CK];
-    phase = bits2f(c0.phase_bits);
-    cum = (int64_t) c0.cum + q * P.opp;
-    for (int s = (int) (ic % RS_CK); s > 0; s--) {      // catch up from the checkpoint
-      while (phase < 1.f) { phase = phase + inc; cum++; }
-      phase = phase - 1.f;
-    }
-  }
-  if (tid == 0) s_cum_t0 = cum;
-  __syncthreads();
-  const int64_t cum_t0 = s_cum_t0;
-  const float fnph = (float) P.nph;
-  int last = 0;
-  for (int s = 0; s < RS_SEG && in_call; s++) {
-    const int64_t i = i_abs + s;
-    const bool live = i >= P.pos && i < P.pos + P.n;
-    while (phase < 1.f) {
-      if (live) {
-        const int o = (int) (cum - cum_t0);
-        rec[o] = ((uint32_t) (tid * RS_SEG + s) << 9) | (uint32_t) (int) (phase * fnph);   // itrp.cc:19
-        last = o + 1;
-      }
-      phase = phase + inc;                                // ra.cc:71, float32 add
-      cum++;
-    }
-    phase = phase - 1.f;                                  // ra.cc:73
-  }
-  if (last > 0) atomicMax(&s_o_end, last);
-  __syncthreads();
+  const int64_t icStep = (int64_t) gridDim.x * RS_TI;
 
-  // ---- evaluate the tile's outputs in parallel
-  const int o_begin = (int) max((int64_t) 0, P.cum_pos - cum_t0);
-  const int o_end = s_o_end;
-  T *yt = y + (cum_t0 - P.cum_pos);
-  for (int o = o_begin + tid; o < o_end; o += RS_THREADS) {
-    const uint32_t r = rec[o];
-    const T *w = tile + (r >> 9);                         // window: x[i-K+1 .. i], oldest first
-    const float *h = lut_s + (r & 511u) * P.lstride;
-    T acc = zero_of(T{});
+  // Software pipeline over the workgroup's tiles: the NEXT tile's input samples and schedule
+  // checkpoint are loaded into registers while the current tile is replayed and evaluated.
+  // Workgroup barriers fence LDS only (a __syncthreads() would also drain vmcnt and stall on
+  // the prefetch and on the output stores).
+  auto barrier_lds = []() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+  };
+  constexpr int NPF = (RS_TI + 32 + RS_THREADS - 1) / RS_THREADS;   // samples per thread per tile (K <= 32)
+  T pf[NPF];
+  RsCk cpf;
+  auto fetch = [&](int tix_, int64_t icT_) {
+    const int64_t T0_ = P.tile0 + (int64_t) tix_ * RS_TI;
+    const int64_t rel0 = T0_ - (K - 1) - P.pos;                     // x index of tile[0]
+    if (rel0 >= 0 && rel0 + RS_TI + K <= P.n) {                     // interior tile: no guards
+      const T *xs = x + rel0;
 #pragma unroll
-    for (int k = 0; k < K; k++) acc = tap_mac(acc, h[k], w[k]);   // filtrage.hpp:1877-1879 order
-    yt[o] = acc;
+      for (int j = 0; j < NPF; j++) {
+        const int s_ = tid + j * RS_THREADS;
+        pf[j] = s_ < RS_TI + K ? xs[s_] : zero_of(T{});
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NPF; j++) {
+        const int64_t rel = rel0 + tid + j * RS_THREADS;
+        T v = zero_of(T{});
+        if (tid + j * RS_THREADS < RS_TI + K) {
+          if (rel < 0) {
+            if (rel >= -(int64_t) (K - 1)) v = hist[(K - 1) + rel];
+          } else if (rel < P.n) {
+            v = x[rel];
+          }
+        }
+        pf[j] = v;
+      }
+    }
+    int64_t ic_ = icT_ + tid * RS_SEG;
+    if (P.lambda > 0)
+      while (ic_ >= P.mu + P.lambda) ic_ -= P.lambda;
+    cpf.phase_bits = 0x40000000u;                                   // 2.0f: "emit nothing"
+    cpf.cum = 0;
+    if (T0_ + (int64_t) tid * RS_SEG < P.pos + P.n) cpf = ck[ic_ / RS_CK];
+  };
+
+  if ((int) blockIdx.x < ntiles) fetch(blockIdx.x, icT);
+  for (int tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
+    const int64_t T0 = P.tile0 + (int64_t) tix * RS_TI;
+    // ---- consume the prefetched tile: samples to LDS, checkpoint to registers
+#pragma unroll
+    for (int j = 0; j < NPF; j++) {
+      const int s_ = tid + j * RS_THREADS;
+      if (s_ < RS_TI + K) tile[s_] = pf[j];
+    }
+    const int64_t i_abs = T0 + (int64_t) tid * RS_SEG;
+    int64_t ic = icT + tid * RS_SEG, q = qT;
+    if (P.lambda > 0)
+      while (ic >= P.mu + P.lambda) { ic -= P.lambda; q++; }
+    const bool in_call = i_abs < P.pos + P.n;              // lanes past the end of the call do nothing
+    const float inc = P.inc;
+    float phase = bits2f(cpf.phase_bits);
+    int64_t cum = (int64_t) cpf.cum + q * P.opp;
+    // ---- issue the next tile's loads
+    icT += icStep;
+    if (P.lambda > 0)
+      while (icT >= P.mu + P.lambda) { icT -= P.lambda; qT++; }
+    if (tix + (int) gridDim.x < ntiles) fetch(tix + gridDim.x, icT);
+
+    if (in_call) {
+      for (int s = (int) (ic % RS_CK); s > 0; s--) {      // catch up from the checkpoint
+        while (phase < 1.f) { phase = phase + inc; cum++; }
+        phase = phase - 1.f;
+      }
+    }
+    if (tid == 0) { s_cum_t0 = cum; s_o_end = 0; }
+    barrier_lds();
+    const int64_t cum_t0 = s_cum_t0;
+    const float fnph = (float) P.nph;
+    int last = 0;
+    for (int s = 0; s < RS_SEG && in_call; s++) {
+      const int64_t i = i_abs + s;
+      const bool live = i >= P.pos && i < P.pos + P.n;
+      while (phase < 1.f) {
+        if (live) {
+          const int o = (int) (cum - cum_t0);
+          rec[o] = ((uint32_t) (tid * RS_SEG + s) << 9) | (uint32_t) (int) (phase * fnph);   // itrp.cc:19
+          last = o + 1;
+        }
+        phase = phase + inc;                                // ra.cc:71, float32 add
+        cum++;
+      }
+      phase = phase - 1.f;                                  // ra.cc:73
+    }
+    if (last > 0) atomicMax(&s_o_end, last);
+    barrier_lds();
+
+    // ---- evaluate the tile's outputs in parallel
+    const int o_begin = (int) max((int64_t) 0, P.cum_pos - cum_t0);
+    const int o_end = s_o_end;
+    T *yt = y + (cum_t0 - P.cum_pos);
+    for (int o = o_begin + tid; o < o_end; o += RS_THREADS) {
+      const uint32_t r = rec[o];
+      const T *w = tile + (r >> 9);                         // window: x[i-K+1 .. i], oldest first
+      const float *h = lut_s + (r & 511u) * lstride;
+      T acc = zero_of(T{});
+      if (KT == 15) {
+        float hh[16];
+#pragma unroll
+        for (int k4 = 0; k4 < 4; k4++) {
+          const float4 q4 = *reinterpret_cast<const float4 *>(h + 4 * k4);
+          hh[4 * k4] = q4.x; hh[4 * k4 + 1] = q4.y; hh[4 * k4 + 2] = q4.z; hh[4 * k4 + 3] = q4.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 15; k++) acc = tap_mac(acc, hh[k], w[k]);   // filtrage.hpp:1877-1879 order
+      } else {
+        for (int k = 0; k < K; k++) acc = tap_mac(acc, h[k], w[k]);
+      }
+      yt[o] = acc;
+    }
+    barrier_lds();        // tile / rec are rewritten by the next iteration
   }
 }
 
@@ -399,11 +469,16 @@ int tsdgpu_resampler_step(tsdgpu_resampler *r, const void *x, int64_t n, void *y
   P.rec_cap = (int) ((double) RS_TI * (double) r->ratio * 1.0001) + 32;
   const int64_t tiles = cdiv(r->pos + n - P.tile0, RS_TI);
   TSD_CHECK(tiles <= 0x7fffffff, "resampler_step: n too large for one launch");
-  const size_t lds = (size_t) (RS_TI + r->K) * sz + (size_t) P.rec_cap * 4 + (size_t) (r->nph + 1) * r->lstride * 4 + 64;
+  const int lstride = r->K == 15 ? 20 : r->lstride;
+  const size_t lds = (size_t) ((r->nph + 1) * lstride + 4) * 4 + (size_t) (RS_TI + r->K + 2) * sz + (size_t) P.rec_cap * 4 + 64;
   TSD_CHECK(lds <= 158 * 1024, "resampler_step: configuration needs %zu bytes of LDS", lds);
+  // persistent workgroups (the LUT is staged once per workgroup): as many as stay resident
+  static const int PG = getenv("TSDGPU_RS_WG_PER_CU") ? atoi(getenv("TSDGPU_RS_WG_PER_CU")) : 0;
+  int per_cu = PG > 0 ? PG : (int) std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (lds + 1024)));
+  const int64_t pgrid = std::min<int64_t>(tiles, (int64_t) 256 * per_cu);
 #define RS_LAUNCH(T, KT)                                                                                            \
-  hipLaunchKernelGGL((resample_kernel<T, KT>), dim3((unsigned) tiles), dim3(RS_THREADS), lds, st, (const T *) dx, \
-                     (const T *) r->d_hist[r->cur], (T *) dy, r->d_lut, r->d_ck, P)
+  hipLaunchKernelGGL((resample_kernel<T, KT>), dim3((unsigned) pgrid), dim3(RS_THREADS), lds, st, (const T *) dx, \
+                     (const T *) r->d_hist[r->cur], (T *) dy, r->d_lut, r->d_ck, P, (int) tiles)
   if (r->data_type == TSDGPU_C64) {
     if (r->K == 15) RS_LAUNCH(float2, 15); else RS_LAUNCH(float2, 0);
   } else {
