@@ -26,9 +26,10 @@
 
 namespace tsdgpu {
 
-constexpr int RS_THREADS = 256;
+constexpr int RS_WAVES = 8;                     // waves per workgroup; each wave owns its tiles
+constexpr int RS_THREADS = 64 * RS_WAVES;
 constexpr int RS_SEG = 8;                       // inputs per lane
-constexpr int RS_TI = RS_THREADS * RS_SEG;      // inputs per tile (2048)
+constexpr int RS_TI = 64 * RS_SEG;              // inputs per (wave) tile: 512
 constexpr int RS_CK = 8;                        // checkpoint spacing (inputs)
 
 struct RsParams {
@@ -73,6 +74,11 @@ __device__ __forceinline__ float2 tap_mac(float2 acc, float h, float2 x)
 // from LUT rows of pitch 20 floats (80 B: 16-B aligned, and 5 mod 16 in 16-B units, so the
 // rows selected by 16 lanes whose columns step regularly fall on distinct bank groups).
 // KT = 0: generic K <= 32, scalar tap reads at an odd pitch.
+//
+// Work decomposition: the workgroup (8 waves) shares the LUT in LDS; every WAVE owns its own
+// 512-input tiles (64 lanes x 8 inputs) with a private sample window and record list, so the
+// tile loop contains no workgroup barrier at all -- waves drift freely and hide each other's
+// latencies.  The next tile's samples and checkpoint are prefetched into registers.
 template <typename T, int KT>
 __global__ __launch_bounds__(RS_THREADS) void resample_kernel(const T *__restrict__ x, const T *__restrict__ hist,
                                                               T *__restrict__ y, const float *__restrict__ lut,
@@ -81,42 +87,43 @@ __global__ __launch_bounds__(RS_THREADS) void resample_kernel(const T *__restric
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int K = KT > 0 ? KT : P.K;
   const int lstride = KT == 15 ? 20 : P.lstride;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float *lut_s = reinterpret_cast<float *>(smem_raw);                       // (nph+1) x lstride, 16-B aligned
-  T *tile = reinterpret_cast<T *>(lut_s + ((P.nph + 1) * lstride + 3) / 4 * 4);   // RS_TI + K samples
-  uint32_t *rec = reinterpret_cast<uint32_t *>(tile + (RS_TI + K + 1));
-  __shared__ long long s_cum_t0;
-  __shared__ int s_o_end;
+  char *wbase = reinterpret_cast<char *>(lut_s + ((P.nph + 1) * lstride + 3) / 4 * 4);
+  const int tile_elems = RS_TI + 32 + 2;                                    // K <= 32
+  const size_t wbytes = ((size_t) tile_elems * sizeof(T) + (size_t) P.rec_cap * 4 + 15) / 16 * 16;
+  T *tile = reinterpret_cast<T *>(wbase + wv * wbytes);
+  uint32_t *rec = reinterpret_cast<uint32_t *>(tile + tile_elems);
 
-  const int tid = threadIdx.x;
   // ---- stage the LUT once per (persistent) workgroup
   const int lut_n = (P.nph + 1) * K;
-  for (int i = tid; i < lut_n; i += RS_THREADS) {
+  for (int i = threadIdx.x; i < lut_n; i += RS_THREADS) {
     const int c = i / K, k = i - c * K;
     lut_s[c * lstride + k] = lut[i];
   }
   if (KT == 15)
-    for (int c = tid; c <= P.nph; c += RS_THREADS) lut_s[c * lstride + 15] = 0.f;   // 16th tap
+    for (int c = threadIdx.x; c <= P.nph; c += RS_THREADS) lut_s[c * lstride + 15] = 0.f;   // 16th tap
+  __syncthreads();
 
-  // canonical (cycle-folded) index of this workgroup's first tile: ONE 64-bit division per
-  // workgroup; afterwards the index advances by a constant and is folded by subtraction
-  int64_t icT = P.tile0 + (int64_t) blockIdx.x * RS_TI, qT = 0;
+  auto wave_sync = []() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+
+  // canonical (cycle-folded) index of this wave's first tile: ONE 64-bit division per wave;
+  // afterwards the index advances by a constant and is folded by subtraction
+  const int wtile0 = blockIdx.x * RS_WAVES + wv;
+  const int wstep = gridDim.x * RS_WAVES;
+  int64_t icT = P.tile0 + (int64_t) wtile0 * RS_TI, qT = 0;
   if (P.lambda > 0 && icT >= P.mu + P.lambda) {
     const int64_t d = icT - P.mu;
     qT = d / P.lambda;
     icT = P.mu + (d - qT * P.lambda);
   }
-  const int64_t icStep = (int64_t) gridDim.x * RS_TI;
+  const int64_t icStep = (int64_t) wstep * RS_TI;
 
-  // Software pipeline over the workgroup's tiles: the NEXT tile's input samples and schedule
-  // checkpoint are loaded into registers while the current tile is replayed and evaluated.
-  // Workgroup barriers fence LDS only (a __syncthreads() would also drain vmcnt and stall on
-  // the prefetch and on the output stores).
-  auto barrier_lds = []() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-  };
-  constexpr int NPF = (RS_TI + 32 + RS_THREADS - 1) / RS_THREADS;   // samples per thread per tile (K <= 32)
+  constexpr int NPF = (RS_TI + 32 + 63) / 64;      // samples per lane per tile (K <= 32)
   T pf[NPF];
   RsCk cpf;
   auto fetch = [&](int tix_, int64_t icT_) {
@@ -126,15 +133,15 @@ __global__ __launch_bounds__(RS_THREADS) void resample_kernel(const T *__restric
       const T *xs = x + rel0;
 #pragma unroll
       for (int j = 0; j < NPF; j++) {
-        const int s_ = tid + j * RS_THREADS;
+        const int s_ = lane + j * 64;
         pf[j] = s_ < RS_TI + K ? xs[s_] : zero_of(T{});
       }
     } else {
 #pragma unroll
       for (int j = 0; j < NPF; j++) {
-        const int64_t rel = rel0 + tid + j * RS_THREADS;
+        const int64_t rel = rel0 + lane + j * 64;
         T v = zero_of(T{});
-        if (tid + j * RS_THREADS < RS_TI + K) {
+        if (lane + j * 64 < RS_TI + K) {
           if (rel < 0) {
             if (rel >= -(int64_t) (K - 1)) v = hist[(K - 1) + rel];
           } else if (rel < P.n) {
@@ -144,25 +151,25 @@ __global__ __launch_bounds__(RS_THREADS) void resample_kernel(const T *__restric
         pf[j] = v;
       }
     }
-    int64_t ic_ = icT_ + tid * RS_SEG;
+    int64_t ic_ = icT_ + lane * RS_SEG;
     if (P.lambda > 0)
       while (ic_ >= P.mu + P.lambda) ic_ -= P.lambda;
     cpf.phase_bits = 0x40000000u;                                   // 2.0f: "emit nothing"
     cpf.cum = 0;
-    if (T0_ + (int64_t) tid * RS_SEG < P.pos + P.n) cpf = ck[ic_ / RS_CK];
+    if (T0_ + (int64_t) lane * RS_SEG < P.pos + P.n) cpf = ck[ic_ / RS_CK];
   };
 
-  if ((int) blockIdx.x < ntiles) fetch(blockIdx.x, icT);
-  for (int tix = blockIdx.x; tix < ntiles; tix += gridDim.x) {
+  if (wtile0 < ntiles) fetch(wtile0, icT);
+  for (int tix = wtile0; tix < ntiles; tix += wstep) {
     const int64_t T0 = P.tile0 + (int64_t) tix * RS_TI;
     // ---- consume the prefetched tile: samples to LDS, checkpoint to registers
 #pragma unroll
     for (int j = 0; j < NPF; j++) {
-      const int s_ = tid + j * RS_THREADS;
+      const int s_ = lane + j * 64;
       if (s_ < RS_TI + K) tile[s_] = pf[j];
     }
-    const int64_t i_abs = T0 + (int64_t) tid * RS_SEG;
-    int64_t ic = icT + tid * RS_SEG, q = qT;
+    const int64_t i_abs = T0 + (int64_t) lane * RS_SEG;
+    int64_t ic = icT + lane * RS_SEG, q = qT;
     if (P.lambda > 0)
       while (ic >= P.mu + P.lambda) { ic -= P.lambda; q++; }
     const bool in_call = i_abs < P.pos + P.n;              // lanes past the end of the call do nothing
@@ -173,7 +180,7 @@ __global__ __launch_bounds__(RS_THREADS) void resample_kernel(const T *__restric
     icT += icStep;
     if (P.lambda > 0)
       while (icT >= P.mu + P.lambda) { icT -= P.lambda; qT++; }
-    if (tix + (int) gridDim.x < ntiles) fetch(tix + gridDim.x, icT);
+    if (tix + wstep < ntiles) fetch(tix + wstep, icT);
 
     if (in_call) {
       for (int s = (int) (ic % RS_CK); s > 0; s--) {      // catch up from the checkpoint
@@ -181,9 +188,8 @@ __global__ __launch_bounds__(RS_THREADS) void resample_kernel(const T *__restric
         phase = phase - 1.f;
       }
     }
-    if (tid == 0) { s_cum_t0 = cum; s_o_end = 0; }
-    barrier_lds();
-    const int64_t cum_t0 = s_cum_t0;
+    // outputs before the tile = lane 0's count (lane 0 is always inside the call)
+    const int64_t cum_t0 = ((int64_t) __shfl((int) (cum >> 32), 0) << 32) | (uint32_t) __shfl((int) (uint32_t) cum, 0);
     const float fnph = (float) P.nph;
     int last = 0;
     for (int s = 0; s < RS_SEG && in_call; s++) {
@@ -192,7 +198,7 @@ __global__ __launch_bounds__(RS_THREADS) void resample_kernel(const T *__restric
       while (phase < 1.f) {
         if (live) {
           const int o = (int) (cum - cum_t0);
-          rec[o] = ((uint32_t) (tid * RS_SEG + s) << 9) | (uint32_t) (int) (phase * fnph);   // itrp.cc:19
+          rec[o] = ((uint32_t) (lane * RS_SEG + s) << 9) | (uint32_t) (int) (phase * fnph);   // itrp.cc:19
           last = o + 1;
         }
         phase = phase + inc;                                // ra.cc:71, float32 add
@@ -200,14 +206,16 @@ __global__ __launch_bounds__(RS_THREADS) void resample_kernel(const T *__restric
       }
       phase = phase - 1.f;                                  // ra.cc:73
     }
-    if (last > 0) atomicMax(&s_o_end, last);
-    barrier_lds();
+    // wave-wide maximum of `last`
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) last = max(last, __shfl_xor(last, d));
+    wave_sync();
 
     // ---- evaluate the tile's outputs in parallel
     const int o_begin = (int) max((int64_t) 0, P.cum_pos - cum_t0);
-    const int o_end = s_o_end;
+    const int o_end = last;
     T *yt = y + (cum_t0 - P.cum_pos);
-    for (int o = o_begin + tid; o < o_end; o += RS_THREADS) {
+    for (int o = o_begin + lane; o < o_end; o += 64) {
       const uint32_t r = rec[o];
       const T *w = tile + (r >> 9);                         // window: x[i-K+1 .. i], oldest first
       const float *h = lut_s + (r & 511u) * lstride;
@@ -226,7 +234,159 @@ __global__ __launch_bounds__(RS_THREADS) void resample_kernel(const T *__restric
       }
       yt[o] = acc;
     }
-    barrier_lds();        // tile / rec are rewritten by the next iteration
+    wave_sync();          // tile / rec are rewritten by the next iteration
+  }
+}
+
+// ---- K = 15 (the filtre_reechan interpolator): replay and evaluation FUSED per lane --------
+// A lane replays the recurrence for its 8 inputs and evaluates each output on the spot from
+// a 22-sample REGISTER window (samples 8*lane .. 8*lane+21 of the wave's tile, read once from
+// a padded LDS image: lane stride 9 samples, conflict-free ds_read_b64), so an output costs
+// four ds_read_b128 of taps and 30 FMAs instead of 15 sample reads + a schedule record.
+// Outputs are staged in a per-wave LDS buffer and stored coalesced.  The reference's
+// accumulation order (tap 0 .. 14 over the oldest .. newest sample) is kept.
+constexpr int RS15_WAVES = 12;
+constexpr int RS15_TILE_PAD = (RS_TI + 16) + (RS_TI + 16) / 8 + 2;      // padded sample slots per wave
+template <typename T>
+__global__ __launch_bounds__(64 * RS15_WAVES) void resample15_kernel(const T *__restrict__ x, const T *__restrict__ hist,
+                                                                     T *__restrict__ y, const float *__restrict__ lut,
+                                                                     const RsCk *__restrict__ ck, RsParams P, int ntiles)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int K = 15, LS = 20;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float *lut_s = reinterpret_cast<float *>(smem_raw);
+  char *wbase = reinterpret_cast<char *>(lut_s + ((P.nph + 1) * LS + 3) / 4 * 4);
+  const size_t wbytes = ((size_t) (RS15_TILE_PAD + P.rec_cap) * sizeof(T) + 15) / 16 * 16;
+  T *tile = reinterpret_cast<T *>(wbase + wv * wbytes);      // padded: sample s at s + (s >> 3)
+  T *obuf = tile + RS15_TILE_PAD;                            // outputs of the tile, in order
+
+  for (int i = threadIdx.x; i < (P.nph + 1) * K; i += 64 * RS15_WAVES) {
+    const int c = i / K, k = i - c * K;
+    lut_s[c * LS + k] = lut[i];
+  }
+  for (int c = threadIdx.x; c <= P.nph; c += 64 * RS15_WAVES) lut_s[c * LS + 15] = 0.f;
+  __syncthreads();
+
+  auto wave_sync = []() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  const int wtile0 = blockIdx.x * RS15_WAVES + wv;
+  const int wstep = gridDim.x * RS15_WAVES;
+  int64_t icT = P.tile0 + (int64_t) wtile0 * RS_TI, qT = 0;
+  if (P.lambda > 0 && icT >= P.mu + P.lambda) {
+    const int64_t d = icT - P.mu;
+    qT = d / P.lambda;
+    icT = P.mu + (d - qT * P.lambda);
+  }
+  const int64_t icStep = (int64_t) wstep * RS_TI;
+
+  constexpr int NPF = (RS_TI + K + 63) / 64;       // 9 samples per lane per tile
+  T pf[NPF];
+  RsCk cpf;
+  auto fetch = [&](int tix_, int64_t icT_) {
+    const int64_t T0_ = P.tile0 + (int64_t) tix_ * RS_TI;
+    const int64_t rel0 = T0_ - (K - 1) - P.pos;
+    if (rel0 >= 0 && rel0 + RS_TI + K <= P.n) {
+      const T *xs = x + rel0;
+#pragma unroll
+      for (int j = 0; j < NPF; j++) {
+        const int s_ = lane + j * 64;
+        pf[j] = s_ < RS_TI + K ? xs[s_] : zero_of(T{});
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NPF; j++) {
+        const int64_t rel = rel0 + lane + j * 64;
+        T v = zero_of(T{});
+        if (lane + j * 64 < RS_TI + K) {
+          if (rel < 0) {
+            if (rel >= -(int64_t) (K - 1)) v = hist[(K - 1) + rel];
+          } else if (rel < P.n) {
+            v = x[rel];
+          }
+        }
+        pf[j] = v;
+      }
+    }
+    int64_t ic_ = icT_ + lane * RS_SEG;
+    if (P.lambda > 0)
+      while (ic_ >= P.mu + P.lambda) ic_ -= P.lambda;
+    cpf.phase_bits = 0x40000000u;
+    cpf.cum = 0;
+    if (T0_ + (int64_t) lane * RS_SEG < P.pos + P.n) cpf = ck[ic_ / RS_CK];
+  };
+
+  if (wtile0 < ntiles) fetch(wtile0, icT);
+  for (int tix = wtile0; tix < ntiles; tix += wstep) {
+    const int64_t T0 = P.tile0 + (int64_t) tix * RS_TI;
+#pragma unroll
+    for (int j = 0; j < NPF; j++) {
+      const int s_ = lane + j * 64;
+      if (s_ < RS_TI + K) tile[s_ + (s_ >> 3)] = pf[j];
+    }
+    const int64_t i_abs = T0 + (int64_t) lane * RS_SEG;
+    int64_t ic = icT + lane * RS_SEG, q = qT;
+    if (P.lambda > 0)
+      while (ic >= P.mu + P.lambda) { ic -= P.lambda; q++; }
+    const bool in_call = i_abs < P.pos + P.n;
+    const float inc = P.inc;
+    float phase = bits2f(cpf.phase_bits);
+    int64_t cum = (int64_t) cpf.cum + q * P.opp;
+    icT += icStep;
+    if (P.lambda > 0)
+      while (icT >= P.mu + P.lambda) { icT -= P.lambda; qT++; }
+    if (tix + wstep < ntiles) fetch(tix + wstep, icT);
+
+    if (in_call) {
+      for (int s = (int) (ic % RS_CK); s > 0; s--) {
+        while (phase < 1.f) { phase = phase + inc; cum++; }
+        phase = phase - 1.f;
+      }
+    }
+    const int64_t cum_t0 = ((int64_t) __shfl((int) (cum >> 32), 0) << 32) | (uint32_t) __shfl((int) (uint32_t) cum, 0);
+    wave_sync();
+    // register window: W[j] = sample 8*lane + j of the tile (slot 9*lane + j + (j >> 3))
+    T W[22];
+    const T *wl = tile + 9 * lane;
+#pragma unroll
+    for (int j = 0; j < 22; j++) W[j] = wl[j + (j >> 3)];
+    const float fnph = (float) P.nph;
+    int last = 0;
+    int o = (int) (cum - cum_t0);
+#pragma unroll
+    for (int s = 0; s < RS_SEG; s++) {
+      const int64_t i = i_abs + s;
+      const bool live = in_call && i >= P.pos && i < P.pos + P.n;
+      while (in_call && phase < 1.f) {
+        if (live) {
+          const float *h = lut_s + (int) (phase * fnph) * LS;                  // itrp.cc:19
+          float hh[16];
+#pragma unroll
+          for (int k4 = 0; k4 < 4; k4++) {
+            const float4 q4 = *reinterpret_cast<const float4 *>(h + 4 * k4);
+            hh[4 * k4] = q4.x; hh[4 * k4 + 1] = q4.y; hh[4 * k4 + 2] = q4.z; hh[4 * k4 + 3] = q4.w;
+          }
+          T acc = zero_of(T{});
+#pragma unroll
+          for (int k = 0; k < 15; k++) acc = tap_mac(acc, hh[k], W[s + k]);     // filtrage.hpp:1877-1879 order
+          obuf[o] = acc;
+          last = o + 1;
+        }
+        phase = phase + inc;                                                   // ra.cc:71
+        o++;
+      }
+      if (in_call) phase = phase - 1.f;                                        // ra.cc:73
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) last = max(last, __shfl_xor(last, d));
+    wave_sync();
+    const int o_begin = (int) max((int64_t) 0, P.cum_pos - cum_t0);
+    T *yt = y + (cum_t0 - P.cum_pos);
+    for (int oo = o_begin + lane; oo < last; oo += 64) yt[oo] = obuf[oo];
+    wave_sync();
   }
 }
 
@@ -409,8 +569,8 @@ int tsdgpu_resampler_create(tsdgpu_resampler **out, int data_type, float ratio, 
   }
   (void) hipFuncSetAttribute((const void *) resample_kernel<float, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void) hipFuncSetAttribute((const void *) resample_kernel<float2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void) hipFuncSetAttribute((const void *) resample_kernel<float, 15>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void) hipFuncSetAttribute((const void *) resample_kernel<float2, 15>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void) hipFuncSetAttribute((const void *) resample15_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void) hipFuncSetAttribute((const void *) resample15_kernel<float2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void) hipGetLastError();
   *out = r;
   return TSDGPU_OK;
@@ -466,25 +626,34 @@ int tsdgpu_resampler_step(tsdgpu_resampler *r, const void *x, int64_t n, void *y
   P.lstride = r->lstride;
   // at most floor(1/inc)+1 outputs per input
   // outputs are spaced 1/ratio apart in input time (up to float32 rounding of the adds)
-  P.rec_cap = (int) ((double) RS_TI * (double) r->ratio * 1.0001) + 32;
+  P.rec_cap = ((int) ((double) RS_TI * (double) r->ratio * 1.0001) + 32 + 3) / 4 * 4;
   const int64_t tiles = cdiv(r->pos + n - P.tile0, RS_TI);
   TSD_CHECK(tiles <= 0x7fffffff, "resampler_step: n too large for one launch");
   const int lstride = r->K == 15 ? 20 : r->lstride;
-  const size_t lds = (size_t) ((r->nph + 1) * lstride + 4) * 4 + (size_t) (RS_TI + r->K + 2) * sz + (size_t) P.rec_cap * 4 + 64;
+  const size_t wbytes = ((size_t) (RS_TI + 32 + 2) * sz + (size_t) P.rec_cap * 4 + 15) / 16 * 16;
+  const size_t lds = (size_t) ((r->nph + 1) * lstride + 4) * 4 + RS_WAVES * wbytes + 64;
   TSD_CHECK(lds <= 158 * 1024, "resampler_step: configuration needs %zu bytes of LDS", lds);
   // persistent workgroups (the LUT is staged once per workgroup): as many as stay resident
   static const int PG = getenv("TSDGPU_RS_WG_PER_CU") ? atoi(getenv("TSDGPU_RS_WG_PER_CU")) : 0;
   int per_cu = PG > 0 ? PG : (int) std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (lds + 1024)));
-  const int64_t pgrid = std::min<int64_t>(tiles, (int64_t) 256 * per_cu);
+  const int64_t pgrid = std::min<int64_t>(cdiv(tiles, RS_WAVES), (int64_t) 256 * per_cu);
+  const size_t wb15 = ((size_t) (RS15_TILE_PAD + P.rec_cap) * sz + 15) / 16 * 16;
+  const size_t lds15 = (size_t) ((r->nph + 1) * 20 + 4) * 4 + RS15_WAVES * wb15 + 64;
+  if (r->K == 15 && lds15 <= 158 * 1024) {     // fused kernel; larger ratios fall back to the generic one
+    const int64_t g15 = std::min<int64_t>(cdiv(tiles, RS15_WAVES), 256);
+    if (r->data_type == TSDGPU_C64)
+      hipLaunchKernelGGL(resample15_kernel<float2>, dim3((unsigned) g15), dim3(64 * RS15_WAVES), lds15, st, (const float2 *) dx,
+                         (const float2 *) r->d_hist[r->cur], (float2 *) dy, r->d_lut, r->d_ck, P, (int) tiles);
+    else
+      hipLaunchKernelGGL(resample15_kernel<float>, dim3((unsigned) g15), dim3(64 * RS15_WAVES), lds15, st, (const float *) dx,
+                         (const float *) r->d_hist[r->cur], (float *) dy, r->d_lut, r->d_ck, P, (int) tiles);
+  } else {
 #define RS_LAUNCH(T, KT)                                                                                            \
   hipLaunchKernelGGL((resample_kernel<T, KT>), dim3((unsigned) pgrid), dim3(RS_THREADS), lds, st, (const T *) dx, \
                      (const T *) r->d_hist[r->cur], (T *) dy, r->d_lut, r->d_ck, P, (int) tiles)
-  if (r->data_type == TSDGPU_C64) {
-    if (r->K == 15) RS_LAUNCH(float2, 15); else RS_LAUNCH(float2, 0);
-  } else {
-    if (r->K == 15) RS_LAUNCH(float, 15); else RS_LAUNCH(float, 0);
-  }
+  if (r->data_type == TSDGPU_C64) RS_LAUNCH(float2, 0); else RS_LAUNCH(float, 0);
 #undef RS_LAUNCH
+  }
   TSD_HIP(hipGetLastError());
   if (r->K > 1) {
     const int H = r->K - 1, nxt = r->cur ^ 1;
