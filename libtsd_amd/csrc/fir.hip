@@ -17,6 +17,7 @@
 // bound; the overlap-save path (ols.hip) is the HBM-roofline candidate for long filters.
 #include "common.hpp"
 #include "fir_internal.hpp"
+#include <cstdlib>
 
 namespace tsdgpu {
 
@@ -146,7 +147,7 @@ static int launch_direct(const tsdgpu_fir *f, const void *x, void *y, int64_t n,
 int fir_direct_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, hipStream_t st)
 {
   if (f->data_type == TSDGPU_F32) return launch_direct<float, float, 16>(f, x, y, n, st);
-  if (f->tap_type == TSDGPU_F32) return launch_direct<float2, float, 8>(f, x, y, n, st);
+  if (f->tap_type == TSDGPU_F32) return f->R == 16 ? launch_direct<float2, float, 16>(f, x, y, n, st) : launch_direct<float2, float, 8>(f, x, y, n, st);
   return launch_direct<float2, float2, 8>(f, x, y, n, st);
 }
 
@@ -189,7 +190,9 @@ int tsdgpu_fir_create(tsdgpu_fir **out, int data_type, int tap_type, const void 
   f->data_type = data_type;
   f->tap_type = tap_type;
   f->K = ntaps;
-  const int R = data_type == TSDGPU_F32 ? 16 : 8;
+  int R = data_type == TSDGPU_F32 ? 16 : 8;
+  if (data_type == TSDGPU_C64 && tap_type == TSDGPU_F32 && getenv("TSDGPU_FIR_R16")) R = 16;
+  f->R = R;
   f->KP = (int) (cdiv(ntaps, 2 * R) * 2 * R);
   f->HL = (int) (cdiv(f->KP, 64) * 64);
 

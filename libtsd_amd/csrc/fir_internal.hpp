@@ -6,6 +6,7 @@ struct tsdgpu_fir {
   int data_type = 0, tap_type = 0;
   int K = 0;            // taps
   int KP = 0;           // taps padded to a multiple of 2R (direct kernel)
+  int R = 8;            // outputs per lane of the direct kernel
   int HL = 0;           // history length kept in hist[]: >= KP and >= the overlap-save overlap
   int method = TSDGPU_FIR_DIRECT;
   void *d_hrev = nullptr;   // reversed zero-padded taps, KP entries of tap_type
