@@ -131,6 +131,14 @@ def main():
         kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
         return dt, kern_ms
 
+    # GPU clock ramp: the first ~20 ms of kernels after an idle period run at a lower clock
+    # (measured: 0.27 ms vs 0.22 ms per step).  A fixed untimed pre-run brings the device to
+    # its sustained state whatever --warmup the caller picked; the W warm-up steps and the K
+    # timed steps below are unchanged.
+    PRE_WARM = 150
+    for _ in range(PRE_WARM):
+        fir_auto.step(x, y)
+    torch.cuda.synchronize()
     dt, kern_ms = run(fir_auto, args.steps, args.warmup)
     total_samples = float(n) * world * args.steps
     value = total_samples / dt / 1e6
@@ -148,7 +156,7 @@ def main():
             "dtype": "f32 (complex64 data, real f32 taps)", "data": "synthetic",
             "config": {"workload": "configs[1]: 127-tap FIR (design_rif_fen lp 0.02, real taps via filtrer()) "
                                    "on 2^%d-sample Veccf per GPU, inputs resident in HBM" % args.log2n,
-                       "method": method_names[fir_auto.method], "samples_per_gpu": n,
+                       "method": method_names[fir_auto.method], "samples_per_gpu": n, "pre_warm_steps": PRE_WARM,
                        "sharding": "contiguous chunks, K-1 halo via RCCL send/recv" if world > 1 else "single GPU"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
