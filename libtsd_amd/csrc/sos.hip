@@ -36,16 +36,18 @@ constexpr int LDS_LANE_PITCH = 36;    // floats: 32 + 4 pad -> conflict-free b12
 
 struct SosSection {
   float b0, b1, b2, a1, a2;
-  float seed;                 // 1: first-sample seed d1 = d2 = x0 (SOIS), 0: zero start (RIIFoS)
-  float pad0, pad1;
+  float seed;                 // 1: first-sample seed (SOIS), 0: zero start (RIIFoS)
+  float df1;                  // 1: FormeDirecte1 (filtre-rt.cc:384-393), 0: FormeDirecte2 (:369-380)
+  float pad1;
   float A[6][4];              // (M^L)^(2^k), k = 0..5, row-major 2x2, M = [[-a1,-a2],[1,0]]
   float c1[LANE_FLOATS];      // output response to start state d1 (per in-lane sample index)
   float c2[LANE_FLOATS];      // output response to start state d2
 };
 
-// state buffer layout (floats): [0] = seeded flag, then per section per channel (d1, d2)
-__host__ __device__ inline int state_index(int sec, int ch) { return 1 + (sec * 2 + ch) * 2; }
-constexpr int STATE_FLOATS = 1 + SOS_MAX_SEC * 4;
+// state buffer layout (floats): [0] = seeded flag, then per (section, channel) four values:
+// DF2: (d1, d2, -, -);  DF1: (y1, y2, x1, x2)
+__host__ __device__ inline int state_index(int sec, int ch) { return 1 + (sec * 2 + ch) * 4; }
+constexpr int STATE_FLOATS = 1 + SOS_MAX_SEC * 8;
 
 __device__ __forceinline__ void wave_sync()
 {
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(64) void sos_kernel(const float *__restrict__ x, fl
 {
   constexpr int L = LANE_FLOATS / NCH;           // samples per lane
   __shared__ __attribute__((aligned(16))) float lds[64 * LDS_LANE_PITCH];
-  __shared__ float sst[SOS_MAX_SEC * 4];          // running (d1,d2) per section and channel
+  __shared__ float sst[SOS_MAX_SEC * 8];          // running state per (section, channel): 4 floats
   const int lane = threadIdx.x;
   const int64_t chunk = blockIdx.x;
   const int64_t t_first = chunk * spc;                         // first sub-tile whose output we own
@@ -74,10 +76,7 @@ __global__ __launch_bounds__(64) void sos_kernel(const float *__restrict__ x, fl
 
   // running state per section and channel: wave-uniform, kept in LDS (indexed by the
   // runtime section number; a register array would go to scratch)
-  for (int i = lane; i < nsec * 4; i += 64) {
-    const int sc = i >> 1;                                     // (section*2 + channel)
-    sst[i] = first_chunk ? st_in[1 + sc * 2 + (i & 1)] : 0.f;
-  }
+  for (int i = lane; i < nsec * 8; i += 64) sst[i] = first_chunk ? st_in[1 + i] : 0.f;
   wave_sync();
 
   for (; t < t_last; t++) {
@@ -105,22 +104,43 @@ __global__ __launch_bounds__(64) void sos_kernel(const float *__restrict__ x, fl
       const float b0 = k.b0, b1 = k.b1, b2 = k.b2, a1 = k.a1, a2 = k.a2;
 #pragma unroll
       for (int c = 0; c < NCH; c++) {
-        float sin1 = sst[(s * 2 + c) * 2], sin0 = sst[(s * 2 + c) * 2 + 1];
+        float *ss = &sst[(s * 2 + c) * 4];
+        float sin1 = ss[0], sin0 = ss[1];
+        float xin1 = ss[2], xin2 = ss[3];                      // DF1 only: previous two inputs
         if (do_seed && k.seed != 0.f) {
-          // premier_appel: d1 = d2 = the section's own first input sample (filtre-rt.cc:361-365)
+          // premier_appel: every memory of the section = its own first input (filtre-rt.cc:361-365)
           const float x0 = __shfl(v[c], 0);
-          sin1 = x0;
-          sin0 = x0;
+          sin1 = sin0 = xin1 = xin2 = x0;
         }
-        // zero-state run over the lane's L samples
         float d1 = 0.f, d2 = 0.f;
+        if (k.df1 == 0.f) {
+          // DF2 zero-state run over the lane's L samples
 #pragma unroll
-        for (int i = 0; i < L; i++) {
-          const float xin = v[i * NCH + c];
-          const float d = fmaf(-a2, d2, fmaf(-a1, d1, xin));
-          v[i * NCH + c] = fmaf(b2, d2, fmaf(b1, d1, b0 * d));
-          d2 = d1;
-          d1 = d;
+          for (int i = 0; i < L; i++) {
+            const float xin = v[i * NCH + c];
+            const float d = fmaf(-a2, d2, fmaf(-a1, d1, xin));
+            v[i * NCH + c] = fmaf(b2, d2, fmaf(b1, d1, b0 * d));
+            d2 = d1;
+            d1 = d;
+          }
+        } else {
+          // DF1: v = b0 x + b1 x[-1] + b2 x[-2] (previous lane's last two inputs for i < 2),
+          // then the all-pole recursion y = v - a1 y1 - a2 y2 from zero state
+          const float my1 = v[(L - 1) * NCH + c], my2 = v[(L - 2) * NCH + c];
+          float xp1 = __shfl_up(my1, 1), xp2 = __shfl_up(my2, 1);
+          if (lane == 0) { xp1 = xin1; xp2 = xin2; }
+          if (lane == 63) { ss[2] = my1; ss[3] = my2; }
+#pragma unroll
+          for (int i = 0; i < L; i++) {
+            const float xin = v[i * NCH + c];
+            const float fir = fmaf(b2, xp2, fmaf(b1, xp1, b0 * xin));
+            const float yv = fmaf(-a2, d2, fmaf(-a1, d1, fir));
+            v[i * NCH + c] = yv;
+            xp2 = xp1;
+            xp1 = xin;
+            d2 = d1;
+            d1 = yv;
+          }
         }
         // lane 0 absorbs the sub-tile's start state: P = M^L * S_in + Z
         float p1 = d1, p0 = d2;
@@ -146,8 +166,8 @@ __global__ __launch_bounds__(64) void sos_kernel(const float *__restrict__ x, fl
         for (int i = 0; i < L; i++) v[i * NCH + c] = fmaf(k.c1[i], s1, fmaf(k.c2[i], s0, v[i * NCH + c]));
         // state after the sub-tile's last sample, carried to the next sub-tile
         if (lane == 63) {
-          sst[(s * 2 + c) * 2] = p1;
-          sst[(s * 2 + c) * 2 + 1] = p0;
+          ss[0] = p1;
+          ss[1] = p0;
         }
       }
       wave_sync();
@@ -174,7 +194,7 @@ __global__ __launch_bounds__(64) void sos_kernel(const float *__restrict__ x, fl
   // the wave that owns the last sub-tile publishes the stream state
   if (t_last == n_sub && t_last > t_first) {
     if (lane == 0) st_out[0] = 1.f;
-    for (int i = lane; i < nsec * 4; i += 64) st_out[1 + i] = sst[i];
+    for (int i = lane; i < nsec * 8; i += 64) st_out[1 + i] = sst[i];
   }
 }
 
@@ -190,18 +210,29 @@ __global__ void sos_tail_kernel(const float *__restrict__ x, float *__restrict__
   for (int s = 0; s < nsec; s++) {
     const SosSection k = sec[s];
     float d1 = st[state_index(s, c)], d2 = st[state_index(s, c) + 1];
+    float x1 = st[state_index(s, c) + 2], x2 = st[state_index(s, c) + 3];
     for (int64_t i = n0; i < n1; i++) {
       const float xin = (s == 0 ? x : y)[i * NCH + c];
-      if (i == n0 && !seeded && k.seed != 0.f) d1 = d2 = xin;
-      const float d = fmaf(-k.a2, d2, fmaf(-k.a1, d1, xin));
-      float o = fmaf(k.b2, d2, fmaf(k.b1, d1, k.b0 * d));
-      if (s == nsec - 1) o *= gain;
-      y[i * NCH + c] = o;
-      d2 = d1;
-      d1 = d;
+      if (i == n0 && !seeded && k.seed != 0.f) d1 = d2 = x1 = x2 = xin;
+      float o;
+      if (k.df1 == 0.f) {
+        const float d = fmaf(-k.a2, d2, fmaf(-k.a1, d1, xin));
+        o = fmaf(k.b2, d2, fmaf(k.b1, d1, k.b0 * d));
+        d2 = d1;
+        d1 = d;
+      } else {
+        o = fmaf(-k.a2, d2, fmaf(-k.a1, d1, fmaf(k.b2, x2, fmaf(k.b1, x1, k.b0 * xin))));
+        x2 = x1;
+        x1 = xin;
+        d2 = d1;
+        d1 = o;
+      }
+      y[i * NCH + c] = (s == nsec - 1) ? o * gain : o;
     }
     st[state_index(s, c)] = d1;
     st[state_index(s, c) + 1] = d2;
+    st[state_index(s, c) + 2] = x1;
+    st[state_index(s, c) + 3] = x2;
   }
   __syncthreads();
   if (c == 0 && n1 > n0) st[0] = 1.f;
@@ -274,7 +305,9 @@ int64_t compute_halo(const std::vector<SosSection> &sec)
 
 void fill_tables(SosSection &k, int L)
 {
-  const double a1 = k.a1, a2 = k.a2, b0 = k.b0, b1 = k.b1, b2 = k.b2;
+  const double a1 = k.a1, a2 = k.a2;
+  // DF1 carries (y1, y2): the correction is the all-pole zero-input response itself
+  const double b0 = k.df1 != 0.f ? 1.0 : k.b0, b1 = k.df1 != 0.f ? 0.0 : k.b1, b2 = k.df1 != 0.f ? 0.0 : k.b2;
   // zero-input responses from unit start states (d1,d2) = (1,0) and (0,1)
   for (int which = 0; which < 2; which++) {
     double d1 = which == 0 ? 1.0 : 0.0, d2 = which == 0 ? 0.0 : 1.0;
@@ -318,8 +351,7 @@ int tsdgpu_sos_create(tsdgpu_sos **out, int data_type, const float *coefs_host, 
   TSD_CHECK(nsec >= 0 && nsec + (rii1_host ? 1 : 0) <= SOS_MAX_SEC, "sos_create: %d sections unsupported (max %d)",
             nsec, SOS_MAX_SEC);
   TSD_CHECK(nsec == 0 || coefs_host != nullptr, "sos_create: NULL coefficients");
-  if (forme != 2)
-    return set_err(TSDGPU_ERR_UNSUPPORTED, "sos_create: only FormeDirecte2 (the reference default) is built; got %d", forme);
+  TSD_CHECK(forme == 1 || forme == 2, "sos_create: forme must be 1 (FormeDirecte1) or 2 (FormeDirecte2), got %d", forme);
 
   tsdgpu_sos *s = new tsdgpu_sos();
   s->data_type = data_type;
@@ -331,6 +363,7 @@ int tsdgpu_sos_create(tsdgpu_sos **out, int data_type, const float *coefs_host, 
     k.b0 = coefs_host[5 * i]; k.b1 = coefs_host[5 * i + 1]; k.b2 = coefs_host[5 * i + 2];
     k.a1 = coefs_host[5 * i + 3]; k.a2 = coefs_host[5 * i + 4];
     k.seed = 1.f;
+    k.df1 = forme == 1 ? 1.f : 0.f;
     fill_tables(k, L);
     sec.push_back(k);
   }

@@ -106,7 +106,27 @@ def test_sos_device_inplace_reset(tg, orc):
     torch.cuda.synchronize()
     assert relerr(xd.cpu().numpy(), yref) <= TOL
     with pytest.raises(tg.TsdGpuError):
-        tg.Sos(np.zeros((1, 5), np.float32), 1.0, tg.F32, None, forme=1)
+        tg.Sos(np.zeros((1, 5), np.float32), 1.0, tg.F32, None, forme=3)
+
+
+# FormeDirecte1 (filtre-rt.cc:384-393): same transfer function, different arithmetic and a
+# four-value first-call seed x1 = x2 = y1 = y2 = x(0)
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("order,fc", [(12, 0.25), (5, 0.1), (4, 0.02)])
+def test_sos_forme_directe_1(tg, orc, cplx, order, fc):
+    z, p, mn, md = orc.design_butter_lp(order, fc)
+    ref = orc.SosChain(z, p, mn, md, forme=1)
+    co, gain, r1 = ref.coefs()
+    g = tg.Sos(co, gain, tg.C64 if cplx else tg.F32, r1, forme=1)
+    x = rand(150000, cplx, order)
+    yref = ref.step(x)
+    y = np.concatenate([g.step(x[o:o + 40000].copy()) for o in range(0, len(x), 40000)])
+    assert relerr(y, yref) <= TOL
+    # constant input exercises the seed
+    g2 = tg.Sos(co, gain, tg.C64 if cplx else tg.F32, r1, forme=1)
+    ref2 = orc.SosChain(z, p, mn, md, forme=1)
+    xc = np.full(3000, 2.0, np.complex64 if cplx else np.float32)
+    assert relerr(g2.step(xc), ref2.step(xc)) <= TOL
 
 
 # BASELINE configs[3] at full size: 6 sections on 2^26 float samples, whole-vector oracle
