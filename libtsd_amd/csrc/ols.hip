@@ -41,6 +41,26 @@ __device__ __forceinline__ void ntstore(cpx *p, cpx v)
   v2f t = {v.x, v.y};
   __builtin_nontemporal_store(t, reinterpret_cast<v2f *>(p));
 }
+// REAL data: two consecutive real blocks are packed as the real and imaginary part of one
+// complex block (the taps being real, conv(h, a + j b) = conv(h, a) + j conv(h, b)), so block
+// index b then addresses the pair of real blocks (2b, 2b+1).
+template <bool EDGE>
+__device__ __forceinline__ void ols_fetch_real(cpx (&v)[16], const float *__restrict__ x, const float *__restrict__ hist,
+                                               int histlen, int Km1, int L, int64_t n, int64_t b, int lane)
+{
+  const int64_t ga = 2 * b * (int64_t) L - Km1, gb = ga + L;
+  if (!EDGE) {
+    const float *xa = x + ga, *xb = x + gb;
+#pragma unroll
+    for (int r = 0; r < 16; r++) v[r] = mk(xa[64 * r + lane], xb[64 * r + lane]);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const int64_t g1 = ga + 64 * r + lane, g2 = gb + 64 * r + lane;
+      v[r] = mk(g1 < 0 ? hist[histlen + g1] : (g1 < n ? x[g1] : 0.f), g2 < 0 ? hist[histlen + g2] : (g2 < n ? x[g2] : 0.f));
+    }
+  }
+}
 template <bool EDGE>
 __device__ __forceinline__ void ols_fetch(cpx (&v)[16], const cpx *__restrict__ x, const cpx *__restrict__ hist,
                                           int histlen, int Km1, int L, int64_t n, int64_t b, int lane)
@@ -65,14 +85,18 @@ __device__ __forceinline__ void ols_fetch(cpx (&v)[16], const cpx *__restrict__ 
 //
 // Blocks [b_lo, b_hi) are processed with block b = b_lo + slot + i*G.  The EDGE variant is
 // launched with G = 1 per edge block.
-template <bool EDGE>
-__device__ __forceinline__ void ols_body(cpx *lds, const cpx *__restrict__ x, const cpx *__restrict__ hist,
-                                         cpx *__restrict__ y, const cpx *__restrict__ Hreg,
+template <bool EDGE, bool REAL>
+__device__ __forceinline__ void ols_body(cpx *lds, const void *__restrict__ xv, const void *__restrict__ histv,
+                                         void *__restrict__ yv, const cpx *__restrict__ Hreg,
                                          const cpx *__restrict__ TW1, const cpx *__restrict__ TW2, int Km1,
                                          int histlen, int L, int64_t n, int64_t b_lo, int64_t b_hi, int64_t G,
                                          int64_t w)
 {
   const int lane = threadIdx.x;
+  const cpx *x = (const cpx *) xv, *hist = (const cpx *) histv;
+  cpx *y = (cpx *) yv;
+  const float *xr = (const float *) xv, *histr = (const float *) histv;
+  float *yr = (float *) yv;
   cpx tw1[16], tw2[16], H[16];
 #pragma unroll
   for (int r = 0; r < 16; r++) {
@@ -105,7 +129,10 @@ __device__ __forceinline__ void ols_body(cpx *lds, const cpx *__restrict__ x, co
   // nothing waits on the stores: they drain while the next block is being transformed.
   auto process = [&](cpx (&cur)[16], cpx (&nxt)[16], int64_t blk) {
     const bool more = !EDGE && blk + G < b_hi;
-    if (more) ols_fetch<EDGE>(nxt, x, hist, histlen, Km1, L, n, blk + G, lane);
+    if (more) {
+      if (REAL) ols_fetch_real<EDGE>(nxt, xr, histr, histlen, Km1, L, n, blk + G, lane);
+      else ols_fetch<EDGE>(nxt, x, hist, histlen, Km1, L, n, blk + G, lane);
+    }
     forward(cur, lds, lane, tw1, tw2, sync);
 #pragma unroll
     for (int r = 0; r < 16; r++) cur[r] = cmul(cur[r], H[r]);
@@ -116,22 +143,38 @@ __device__ __forceinline__ void ols_body(cpx *lds, const cpx *__restrict__ x, co
       for (int r = 0; r < 16; r++) asm volatile("" ::"v"(nxt[r].x), "v"(nxt[r].y));
     }
     // sample t = 64*r + lane of the circular convolution is output o0 + t - (K-1)
-    const int64_t o0 = blk * (int64_t) L;
-    cpx *yb = y + (o0 - Km1);
     const int r0 = Km1 >> 6;   // Km1 is a multiple of 64: rows below r0 are overlap, the rest whole
+    if (!REAL) {
+      const int64_t o0 = blk * (int64_t) L;
+      cpx *yb = y + (o0 - Km1);
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const int t = 64 * r + lane;
-      if (!EDGE) {
-        if (r >= r0) { if (NT) ntstore(yb + t, cur[r]); else yb[t] = cur[r]; }
-      } else {
-        if (r >= r0 && o0 + t - Km1 < n) yb[t] = cur[r];
+      for (int r = 0; r < 16; r++) {
+        const int t = 64 * r + lane;
+        if (!EDGE) {
+          if (r >= r0) { if (NT) ntstore(yb + t, cur[r]); else yb[t] = cur[r]; }
+        } else {
+          if (r >= r0 && o0 + t - Km1 < n) yb[t] = cur[r];
+        }
+      }
+    } else {
+      const int64_t oa = 2 * blk * (int64_t) L, ob = oa + L;
+      float *ya = yr + (oa - Km1), *yb = yr + (ob - Km1);
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int t = 64 * r + lane;
+        if (!EDGE) {
+          if (r >= r0) { ya[t] = cur[r].x; yb[t] = cur[r].y; }
+        } else {
+          if (r >= r0 && oa + t - Km1 < n) ya[t] = cur[r].x;
+          if (r >= r0 && ob + t - Km1 < n) yb[t] = cur[r].y;
+        }
       }
     }
   };
 
   cpx A[16], B[16];
-  ols_fetch<EDGE>(A, x, hist, histlen, Km1, L, n, b, lane);
+  if (REAL) ols_fetch_real<EDGE>(A, xr, histr, histlen, Km1, L, n, b, lane);
+  else ols_fetch<EDGE>(A, x, hist, histlen, Km1, L, n, b, lane);
   if (EDGE) {
     process(A, B, b);   // edge launches: one block per wave, no prefetch
     return;
@@ -150,8 +193,9 @@ __device__ __forceinline__ void ols_body(cpx *lds, const cpx *__restrict__ x, co
 // take one edge block each (block 0 with the history halo, the ragged last block), and the
 // last workgroup writes the new history (the last `histlen` samples of history ++ x) into
 // the handle's other history buffer.
-__global__ __launch_bounds__(64, 2) void ols_kernel(const cpx *__restrict__ x, const cpx *__restrict__ hist,
-                                                    cpx *__restrict__ hist_next, cpx *__restrict__ y,
+template <bool REAL>
+__global__ __launch_bounds__(64, 2) void ols_kernel(const void *__restrict__ x, const void *__restrict__ hist,
+                                                    void *__restrict__ hist_next, void *__restrict__ y,
                                                     const cpx *__restrict__ Hreg, const cpx *__restrict__ TW1,
                                                     const cpx *__restrict__ TW2, int Km1, int histlen, int L,
                                                     int64_t n, int64_t b_lo, int64_t b_hi, int64_t nblocks, int G,
@@ -160,28 +204,30 @@ __global__ __launch_bounds__(64, 2) void ols_kernel(const cpx *__restrict__ x, c
   __shared__ cpx lds[LDS_ELEMS];
   const int w = blockIdx.x;
   if (w < G) {
-    ols_body<false>(lds, x, hist, y, Hreg, TW1, TW2, Km1, histlen, L, n, b_lo, b_hi, G, w);
+    ols_body<false, REAL>(lds, x, hist, y, Hreg, TW1, TW2, Km1, histlen, L, n, b_lo, b_hi, G, w);
   } else if (w < G + ne) {
     const int64_t b = (w == G) ? e0 : e1;
-    ols_body<true>(lds, x, hist, y, Hreg, TW1, TW2, Km1, histlen, L, n, b, nblocks, 1, 0);
+    ols_body<true, REAL>(lds, x, hist, y, Hreg, TW1, TW2, Km1, histlen, L, n, b, nblocks, 1, 0);
   } else {
     for (int i = threadIdx.x; i < histlen; i += 64) {
       const int64_t g = n - histlen + i;
-      hist_next[i] = g < 0 ? hist[histlen + g] : x[g];
+      if (REAL) ((float *) hist_next)[i] = g < 0 ? ((const float *) hist)[histlen + g] : ((const float *) x)[g];
+      else ((cpx *) hist_next)[i] = g < 0 ? ((const cpx *) hist)[histlen + g] : ((const cpx *) x)[g];
     }
   }
 }
 
 bool ols_preferred(const tsdgpu_fir *f)
 {
-  // complex data only for now; the direct kernel is HBM-bound below ~48 taps and the
-  // 1024-point block needs L = 1025-K >= 512 to stay efficient
-  return f->data_type == TSDGPU_C64 && f->K >= 48 && f->K <= 513;
+  // the direct kernel is HBM-bound below ~48 taps (complex data; ~64 for real data, whose
+  // direct form needs half the flops) and the 1024-point block needs L >= 512 to stay efficient
+  if (f->data_type == TSDGPU_C64) return f->K >= 48 && f->K <= 513;
+  return f->tap_type == TSDGPU_F32 && f->K >= 64 && f->K <= 513;
 }
 
 int ols_plan_create(tsdgpu_fir *f)
 {
-  if (f->data_type != TSDGPU_C64 || f->K > OLS_N / 2 + 1) {
+  if (f->K > OLS_N / 2 + 1) {
     // outside the block-FFT kernel's envelope: serve the request with the direct kernel
     f->method = TSDGPU_FIR_DIRECT;
     return TSDGPU_OK;
@@ -226,7 +272,7 @@ int ols_plan_create(tsdgpu_fir *f)
   int dev = 0, cus = 256, per_cu = 8;
   (void) hipGetDevice(&dev);
   (void) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ols_kernel, 64, 0) != hipSuccess || per_cu < 1) {
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ols_kernel<false>, 64, 0) != hipSuccess || per_cu < 1) {
     (void) hipGetLastError();
     per_cu = 8;
   }
@@ -244,31 +290,38 @@ void ols_plan_destroy(tsdgpu_fir *f)
 
 int ols_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, hipStream_t st)
 {
+  const bool real = f->data_type == TSDGPU_F32;
   const int L = f->ols_L;
-  const int64_t nblocks = cdiv(n, L);
+  const int64_t LB = real ? 2 * (int64_t) L : L;          // outputs per work item (block or block pair)
+  const int64_t nblocks = cdiv(n, LB);
   const cpx *d = (const cpx *) f->d_H;
-  // interior blocks: inputs [b*L-overlap, b*L+L) and outputs [b*L, b*L+L) all inside [0, n)
+  // interior items: inputs [b*LB-overlap, b*LB+LB) and outputs [b*LB, b*LB+LB) all inside [0, n)
   const int64_t b_lo = f->K > 1 ? 1 : 0;
-  const int64_t b_hi = n / L;
+  const int64_t b_hi = n / LB;
   int64_t grid = 0;
   if (b_hi > b_lo) {
     const int64_t nint = b_hi - b_lo;
-    // balance the rounds: every wave gets ceil(nint/grid) or one fewer blocks, no tail round
+    // balance the rounds: every wave gets ceil(nint/grid) or one fewer items, no tail round
     grid = nint < f->ols_grid ? nint : f->ols_grid;
     if (nint > grid) {
       const int64_t rounds = cdiv(nint, grid);
       grid = cdiv(cdiv(nint, rounds), 8) * 8;
     }
   }
-  // edge blocks: block 0 (history halo) and the ragged last block, one wave each
+  // edge items: item 0 (history halo) and the ragged last one, one wave each
   int64_t e[2] = {0, 0};
   int ne = 0;
   if (b_lo == 1 || b_hi == 0) e[ne++] = 0;
   if (b_hi < nblocks && b_hi > 0) e[ne++] = b_hi;
   const int nxt = f->cur ^ 1;
-  hipLaunchKernelGGL(ols_kernel, dim3((unsigned) (grid + ne + 1)), dim3(64), 0, st, (const cpx *) x,
-                     (const cpx *) f->hist[f->cur], (cpx *) f->hist[nxt], (cpx *) y, d, d + OLS_N, d + 2 * OLS_N,
-                     OLS_N - L, f->HL, L, n, b_lo, b_hi, nblocks, (int) grid, ne, e[0], e[1]);
+  if (real)
+    hipLaunchKernelGGL(ols_kernel<true>, dim3((unsigned) (grid + ne + 1)), dim3(64), 0, st, x, (const void *) f->hist[f->cur],
+                       f->hist[nxt], y, d, d + OLS_N, d + 2 * OLS_N, OLS_N - L, f->HL, L, n, b_lo, b_hi, nblocks,
+                       (int) grid, ne, e[0], e[1]);
+  else
+    hipLaunchKernelGGL(ols_kernel<false>, dim3((unsigned) (grid + ne + 1)), dim3(64), 0, st, x, (const void *) f->hist[f->cur],
+                       f->hist[nxt], y, d, d + OLS_N, d + 2 * OLS_N, OLS_N - L, f->HL, L, n, b_lo, b_hi, nblocks,
+                       (int) grid, ne, e[0], e[1]);
   TSD_HIP(hipGetLastError());
   f->cur = nxt;      // the history update is part of the launch
   return TSDGPU_OK;
