@@ -199,14 +199,15 @@ __global__ __launch_bounds__(64, 2) void ols_kernel(const void *__restrict__ x, 
                                                     const cpx *__restrict__ Hreg, const cpx *__restrict__ TW1,
                                                     const cpx *__restrict__ TW2, int Km1, int histlen, int L,
                                                     int64_t n, int64_t b_lo, int64_t b_hi, int64_t nblocks, int G,
-                                                    int ne, int64_t e0, int64_t e1)
+                                                    int ne, int64_t n_lo, int64_t b_tail)
 {
   __shared__ cpx lds[LDS_ELEMS];
   const int w = blockIdx.x;
   if (w < G) {
     ols_body<false, REAL>(lds, x, hist, y, Hreg, TW1, TW2, Km1, histlen, L, n, b_lo, b_hi, G, w);
   } else if (w < G + ne) {
-    const int64_t b = (w == G) ? e0 : e1;
+    // edge items: [0, n_lo) need the history halo, [b_tail, nblocks) are ragged at the end
+    const int64_t b = (w - G) < n_lo ? (int64_t) (w - G) : b_tail + (w - G - n_lo);
     ols_body<true, REAL>(lds, x, hist, y, Hreg, TW1, TW2, Km1, histlen, L, n, b, nblocks, 1, 0);
   } else {
     for (int i = threadIdx.x; i < histlen; i += 64) {
@@ -220,14 +221,17 @@ __global__ __launch_bounds__(64, 2) void ols_kernel(const void *__restrict__ x, 
 bool ols_preferred(const tsdgpu_fir *f)
 {
   // the direct kernel is HBM-bound below ~48 taps (complex data; ~64 for real data, whose
-  // direct form needs half the flops) and the 1024-point block needs L >= 512 to stay efficient
-  if (f->data_type == TSDGPU_C64) return f->K >= 48 && f->K <= 513;
-  return f->tap_type == TSDGPU_F32 && f->K >= 64 && f->K <= 513;
+  // direct form needs half the flops); the 1024-point block loses efficiency as L = 1024 -
+  // roundup(K-1, 64) shrinks but stays ahead of the K-proportional direct kernel
+  // (beyond L = 128, i.e. K > 897, the direct kernel takes over; a partitioned block
+  // convolution for very long filters is future work)
+  if (f->data_type == TSDGPU_C64) return f->K >= 48 && f->K <= 897;
+  return f->tap_type == TSDGPU_F32 && f->K >= 64 && f->K <= 897;
 }
 
 int ols_plan_create(tsdgpu_fir *f)
 {
-  if (f->K > OLS_N / 2 + 1) {
+  if (f->K > OLS_N - 63) {
     // outside the block-FFT kernel's envelope: serve the request with the direct kernel
     f->method = TSDGPU_FIR_DIRECT;
     return TSDGPU_OK;
@@ -296,8 +300,9 @@ int ols_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, hipStream_t st)
   const int64_t nblocks = cdiv(n, LB);
   const cpx *d = (const cpx *) f->d_H;
   // interior items: inputs [b*LB-overlap, b*LB+LB) and outputs [b*LB, b*LB+LB) all inside [0, n)
-  const int64_t b_lo = f->K > 1 ? 1 : 0;
-  const int64_t b_hi = n / LB;
+  const int64_t ovl = OLS_N - L;
+  const int64_t b_lo = std::min<int64_t>(nblocks, f->K > 1 ? cdiv(ovl, LB) : 0);
+  const int64_t b_hi = std::max<int64_t>(b_lo, n / LB);
   int64_t grid = 0;
   if (b_hi > b_lo) {
     const int64_t nint = b_hi - b_lo;
@@ -308,11 +313,10 @@ int ols_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, hipStream_t st)
       grid = cdiv(cdiv(nint, rounds), 8) * 8;
     }
   }
-  // edge items: item 0 (history halo) and the ragged last one, one wave each
-  int64_t e[2] = {0, 0};
-  int ne = 0;
-  if (b_lo == 1 || b_hi == 0) e[ne++] = 0;
-  if (b_hi < nblocks && b_hi > 0) e[ne++] = b_hi;
+  // edge items, one wave each: [0, b_lo) read the history halo, [b_hi, nblocks) are ragged
+  const int64_t n_lo = b_lo, b_tail = b_hi;
+  const int ne = (int) (n_lo + (nblocks - b_tail));
+  int64_t e[2] = {n_lo, b_tail};
   const int nxt = f->cur ^ 1;
   if (real)
     hipLaunchKernelGGL(ols_kernel<true>, dim3((unsigned) (grid + ne + 1)), dim3(64), 0, st, x, (const void *) f->hist[f->cur],

@@ -55,7 +55,7 @@ def test_impulse_response_is_taps(tg, method):
 
 @pytest.mark.parametrize("method", [1, 2])
 @pytest.mark.parametrize("cplx_data,cplx_taps", [(False, False), (True, False), (True, True)])
-@pytest.mark.parametrize("K", [1, 2, 15, 31, 127, 128, 129, 500])
+@pytest.mark.parametrize("K", [1, 2, 15, 31, 127, 128, 129, 500, 897, 961, 1200])
 def test_fir_parity(tg, orc, method, cplx_data, cplx_taps, K):
     n = 20000
     h = rand(K, cplx_taps, K) / np.float32(np.sqrt(K))
