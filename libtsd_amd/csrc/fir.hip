@@ -11,8 +11,9 @@
 //   * each lane owns R consecutive outputs and slides a 2R-sample register window over its
 //     KP+R-1 inputs: every LDS sample read feeds R multiply-adds, taps are wave-uniform
 //     scalar loads (SGPR operands);
-//   * LDS rows are padded by one sample every R so that the lane stride (R+1 samples) is
-//     odd in 4/8-byte bank units: conflict-free ds_read_b32/b64.
+//   * every lane segment (64 B of samples) is followed by 16 B of padding: all LDS traffic is
+//     conflict-free ds_read_b128 / ds_write_b128; interior tiles load and store global memory
+//     with coalesced 16-B accesses (outputs are staged back through LDS).
 // The kernel is fp32-VALU bound (4*K flop per complex sample with real taps), not HBM
 // bound; the overlap-save path (ols.hip) is the HBM-roofline candidate for long filters.
 #include "common.hpp"
@@ -41,51 +42,76 @@ __device__ __forceinline__ float2 mac(float2 acc, float2 x, float2 h)
   return make_float2(re, im);
 }
 
-template <int R> __device__ __forceinline__ unsigned padded(unsigned s) { return s + s / R; }
-
 // ------------------------------------------------------------------ direct kernel
-template <typename T, typename TC, int R, int THREADS>
+// LDS image: the lane's R samples (64 B) form one segment, segments are 80 B apart (16 B of
+// padding): 80 B = 5 x 16 B, so the 16 lanes a ds_read_b128 / ds_write_b128 services together
+// hit 16 distinct 16-B slots -- every LDS access of the kernel is a conflict-free b128.
+// Sample s of the tile (global index tile0 - KP + s) lives at pos(s) = q + (q / R) * P, q = s-1
+// (sample 0 is never needed), which makes every lane window start on a segment boundary.
+template <typename T, typename TC, int R, int THREADS, bool FAST>
 __global__ __launch_bounds__(THREADS) void fir_direct_kernel(
     const T *__restrict__ x, const T *__restrict__ hist, T *__restrict__ y,
     const TC *__restrict__ hrev, int KP, int64_t n)
 {
   constexpr int TILE = THREADS * R;
+  constexpr int VEC = 16 / (int) sizeof(T);          // samples per 16 B
+  constexpr int P = VEC;                             // pad samples per segment
+  constexpr int SP = R + P;                          // segment pitch in samples (80 B)
+  static_assert(R * sizeof(T) == 64, "one lane segment is 64 bytes");
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T *L = reinterpret_cast<T *>(smem_raw);
 
   const int64_t tile0 = (int64_t) blockIdx.x * TILE;
   const int H = KP;
-  const int total = TILE + H;
+  const int total = TILE + H;                        // samples 0 .. total-1 (sample 0 unused)
+  const bool interior = FAST && tile0 - H >= 0 && tile0 + TILE <= n;
 
-  // stage tile + halo: L[padded(s)] = x_ext[tile0 - H + s]
-  for (unsigned s = threadIdx.x; s < (unsigned) total; s += THREADS) {
-    const int64_t g = tile0 - H + (int64_t) s;
-    T v = zero_of(T{});
-    if (g < 0)
-      v = hist[H + g];
-    else if (g < n)
-      v = x[g];
-    L[padded<R>(s)] = v;
+  if (interior) {
+    // 16-B global loads: chunk c = samples [c*VEC, c*VEC + VEC)
+    const float4 *xs = reinterpret_cast<const float4 *>(x + (tile0 - H));
+    for (int c = threadIdx.x; c < total / VEC; c += THREADS) {
+      const float4 q4 = xs[c];
+      const T *e = reinterpret_cast<const T *>(&q4);
+#pragma unroll
+      for (int k = 0; k < VEC; k++) {
+        const int q = c * VEC + k - 1;
+        if (q >= 0) L[q + (q / R) * P] = e[k];
+      }
+    }
+  } else {
+    for (int s = threadIdx.x + 1; s < total; s += THREADS) {
+      const int64_t g = tile0 - H + (int64_t) s;
+      T v = zero_of(T{});
+      if (g < 0)
+        v = hist[H + g];
+      else if (g < n)
+        v = x[g];
+      const int q = s - 1;
+      L[q + (q / R) * P] = v;
+    }
   }
   __syncthreads();
 
-  // lane window: w[i] = L[padded(t*R + 1 + i)], out[r] = sum_j hrev[j] * w[r + j].
-  // With i = c*R + r:  padded(t*R + 1 + i) = t*(R+1) + c*(R+1) + 1 + r + (r == R-1),
-  // i.e. one per-lane base plus compile-time offsets.
-  const T *Lw = L + threadIdx.x * (R + 1);
+  // lane window: w[i] = sample t*R + 1 + i = Lw[(i / R) * SP + i % R], out[r] = sum_j hrev[j] * w[r + j]
+  const T *Lw = L + threadIdx.x * SP;
   T acc[R], A[R], B[R];
+  auto load_seg = [&](T (&dst)[R], const T *seg) {
 #pragma unroll
-  for (int r = 0; r < R; r++) {
-    acc[r] = zero_of(T{});
-    A[r] = Lw[1 + r + (r == R - 1)];
-  }
+    for (int v4 = 0; v4 < R / VEC; v4++) {
+      const float4 q4 = *reinterpret_cast<const float4 *>(seg + v4 * VEC);
+      const T *e = reinterpret_cast<const T *>(&q4);
+#pragma unroll
+      for (int k = 0; k < VEC; k++) dst[v4 * VEC + k] = e[k];
+    }
+  };
+#pragma unroll
+  for (int r = 0; r < R; r++) acc[r] = zero_of(T{});
+  load_seg(A, Lw);
 
   const int nchunk = KP / R;  // even by construction
   for (int c = 0; c < nchunk; c += 2) {
     const TC *h0 = hrev + c * R;
-    const T *Lc = Lw + c * (R + 1);
-#pragma unroll
-    for (int r = 0; r < R; r++) B[r] = Lc[(R + 1) + 1 + r + (r == R - 1)];
+    load_seg(B, Lw + (c + 1) * SP);
 #pragma unroll
     for (int jj = 0; jj < R; jj++) {
       const TC hv = h0[jj];
@@ -96,9 +122,8 @@ __global__ __launch_bounds__(THREADS) void fir_direct_kernel(
       }
     }
     // the last refill reads past the lane's window; the staging area is over-allocated
-    // by 2R samples so the read is in bounds and the values are never used
-#pragma unroll
-    for (int r = 0; r < R; r++) A[r] = Lc[2 * (R + 1) + 1 + r + (r == R - 1)];
+    // by two segments so the read is in bounds and the values are never used
+    load_seg(A, Lw + (c + 2) * SP);
 #pragma unroll
     for (int jj = 0; jj < R; jj++) {
       const TC hv = h0[R + jj];
@@ -110,10 +135,28 @@ __global__ __launch_bounds__(THREADS) void fir_direct_kernel(
     }
   }
 
-  const int64_t o0 = tile0 + (int64_t) threadIdx.x * R;
+  if (interior) {
+    // outputs go back through LDS so that every global store is a coalesced 16-B access
+    __syncthreads();
+    T *Lo = L + threadIdx.x * SP;
 #pragma unroll
-  for (int r = 0; r < R; r++)
-    if (o0 + r < n) y[o0 + r] = acc[r];
+    for (int v4 = 0; v4 < R / VEC; v4++) {
+      float4 q4;
+      T *e = reinterpret_cast<T *>(&q4);
+#pragma unroll
+      for (int k = 0; k < VEC; k++) e[k] = acc[v4 * VEC + k];
+      *reinterpret_cast<float4 *>(Lo + v4 * VEC) = q4;
+    }
+    __syncthreads();
+    float4 *ys = reinterpret_cast<float4 *>(y + tile0);
+    for (int c = threadIdx.x; c < TILE / VEC; c += THREADS)
+      ys[c] = *reinterpret_cast<const float4 *>(L + (c / (R / VEC)) * SP + (c % (R / VEC)) * VEC);
+  } else {
+    const int64_t o0 = tile0 + (int64_t) threadIdx.x * R;
+#pragma unroll
+    for (int r = 0; r < R; r++)
+      if (o0 + r < n) y[o0 + r] = acc[r];
+  }
 }
 
 // new_hist = last H samples of (old_hist ++ x[0..n))
@@ -133,13 +176,19 @@ static int launch_direct(const tsdgpu_fir *f, const void *x, void *y, int64_t n,
   constexpr int THREADS = 256;
   constexpr int TILE = THREADS * R;
   const int KP = f->KP;
-  const int total = TILE + KP + 2 * R;
-  const size_t lds = (size_t) (total + total / R + 2) * sizeof(T);
+  const size_t nseg = (size_t) (TILE + KP) / R + 3;                 // + over-read segments
+  const size_t lds = nseg * 80;
   const int64_t tiles = cdiv(n, TILE);
   if (tiles > 0x7fffffff) return set_err(TSDGPU_ERR_UNSUPPORTED, "fir: n too large for one launch");
-  hipLaunchKernelGGL((fir_direct_kernel<T, TC, R, THREADS>), dim3((unsigned) tiles), dim3(THREADS),
-                     lds, st, (const T *) x, (const T *) f->hist[f->cur] + (f->HL - KP), (T *) y,
-                     (const TC *) f->d_hrev, KP, n);
+  // 16-byte global accesses need 16-byte aligned buffers (tile starts are multiples of 64 B)
+  const bool fast = (((uintptr_t) x | (uintptr_t) y) & 15) == 0;
+  const T *hp = (const T *) f->hist[f->cur] + (f->HL - KP);
+  if (fast)
+    hipLaunchKernelGGL((fir_direct_kernel<T, TC, R, THREADS, true>), dim3((unsigned) tiles), dim3(THREADS), lds, st,
+                       (const T *) x, hp, (T *) y, (const TC *) f->d_hrev, KP, n);
+  else
+    hipLaunchKernelGGL((fir_direct_kernel<T, TC, R, THREADS, false>), dim3((unsigned) tiles), dim3(THREADS), lds, st,
+                       (const T *) x, hp, (T *) y, (const TC *) f->d_hrev, KP, n);
   TSD_HIP(hipGetLastError());
   return TSDGPU_OK;
 }
@@ -147,7 +196,7 @@ static int launch_direct(const tsdgpu_fir *f, const void *x, void *y, int64_t n,
 int fir_direct_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, hipStream_t st)
 {
   if (f->data_type == TSDGPU_F32) return launch_direct<float, float, 16>(f, x, y, n, st);
-  if (f->tap_type == TSDGPU_F32) return f->R == 16 ? launch_direct<float2, float, 16>(f, x, y, n, st) : launch_direct<float2, float, 8>(f, x, y, n, st);
+  if (f->tap_type == TSDGPU_F32) return launch_direct<float2, float, 8>(f, x, y, n, st);
   return launch_direct<float2, float2, 8>(f, x, y, n, st);
 }
 
@@ -190,8 +239,7 @@ int tsdgpu_fir_create(tsdgpu_fir **out, int data_type, int tap_type, const void 
   f->data_type = data_type;
   f->tap_type = tap_type;
   f->K = ntaps;
-  int R = data_type == TSDGPU_F32 ? 16 : 8;
-  if (data_type == TSDGPU_C64 && tap_type == TSDGPU_F32 && getenv("TSDGPU_FIR_R16")) R = 16;
+  const int R = data_type == TSDGPU_F32 ? 16 : 8;
   f->R = R;
   f->KP = (int) (cdiv(ntaps, 2 * R) * 2 * R);
   f->HL = (int) (cdiv(f->KP, 64) * 64);
