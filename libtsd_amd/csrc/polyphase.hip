@@ -57,8 +57,14 @@ struct tsdgpu_polyfir {
   DevBuf z, in_stage, out_stage;
 };
 
+namespace tsdgpu {
+int sos_create_ex(tsdgpu_sos **out, int data_type, const float *coefs_host, int nsec, float gain,
+                  const float *rii1_host, int forme, int seeded);
+}
+
 struct tsdgpu_rii {
   int data_type = 0, Ky = 0;
+  tsdgpu_sos *sos = nullptr;      // Kx <= 3 and Ky <= 2: one zero-seeded DF1 section on the block-parallel kernel
   tsdgpu_fir *fir = nullptr;
   float *d_denom = nullptr, *d_hist = nullptr;
   DevBuf in_stage, out_stage;
@@ -230,6 +236,17 @@ int tsdgpu_rii_create(tsdgpu_rii **out, int data_type, const float *numer_host, 
   tsdgpu_rii *r = new tsdgpu_rii();
   r->data_type = data_type;
   r->Ky = Kd - 1;
+  if (Kx <= 3 && Kd <= 3) {
+    // y = (n0 x + n1 x1 + n2 x2 - d1 y1 - d2 y2) / d0 from zero memory == one FormeDirecte1
+    // section with zero seed; coefficients pre-divided by d0 (the reference divides the sum)
+    const float d0 = denom_host[0];
+    float c[5] = {numer_host[0] / d0, Kx > 1 ? numer_host[1] / d0 : 0.f, Kx > 2 ? numer_host[2] / d0 : 0.f,
+                  Kd > 1 ? denom_host[1] / d0 : 0.f, Kd > 2 ? denom_host[2] / d0 : 0.f};
+    const int rc0 = tsdgpu::sos_create_ex(&r->sos, data_type, c, 1, 1.0f, nullptr, 1, 0);
+    if (rc0) { delete r; return rc0; }
+    *out = r;
+    return TSDGPU_OK;
+  }
   int rc = tsdgpu_fir_create(&r->fir, data_type, TSDGPU_F32, numer_host, Kx, TSDGPU_FIR_AUTO);
   const size_t hb = (size_t) std::max(r->Ky, 1) * 2 * sizeof(float);
   if (!rc && (hipMalloc((void **) &r->d_denom, (size_t) Kd * sizeof(float)) != hipSuccess ||
@@ -252,6 +269,7 @@ int tsdgpu_rii_step(tsdgpu_rii *r, const void *x, void *y, int64_t n, void *stre
   TSD_CHECK(n >= 0, "rii_step: negative length");
   if (n == 0) return TSDGPU_OK;
   TSD_CHECK(x != nullptr && y != nullptr, "rii_step: NULL buffer");
+  if (r->sos) return tsdgpu_sos_step(r->sos, x, y, n, stream);
   hipStream_t st = (hipStream_t) stream;
   const size_t bytes = (size_t) n * dtype_size(r->data_type);
   const void *dx = nullptr;
@@ -272,6 +290,7 @@ int tsdgpu_rii_step(tsdgpu_rii *r, const void *x, void *y, int64_t n, void *stre
 int tsdgpu_rii_destroy(tsdgpu_rii *r)
 {
   if (!r) return TSDGPU_OK;
+  tsdgpu_sos_destroy(r->sos);
   tsdgpu_fir_destroy(r->fir);
   if (r->d_denom) (void) hipFree(r->d_denom);
   if (r->d_hist) (void) hipFree(r->d_hist);

@@ -242,6 +242,11 @@ __global__ void sos_tail_kernel(const float *__restrict__ x, float *__restrict__
 
 using namespace tsdgpu;
 
+namespace tsdgpu {
+int sos_create_ex(tsdgpu_sos **out, int data_type, const float *coefs_host, int nsec, float gain,
+                  const float *rii1_host, int forme, int seeded);
+}
+
 struct tsdgpu_sos {
   int data_type = 0, nsec = 0, nch = 1;
   float gain = 1.f;
@@ -345,6 +350,16 @@ extern "C" {
 int tsdgpu_sos_create(tsdgpu_sos **out, int data_type, const float *coefs_host, int nsec, float gain,
                       const float *rii1_host, int forme)
 {
+  return tsdgpu::sos_create_ex(out, data_type, coefs_host, nsec, gain, rii1_host, forme, 1);
+}
+
+}  // extern "C"
+
+// `seeded` = 0 builds sections that start from zero memory (what FiltreRII does) instead of
+// SOIS' first-sample seed; used by the low-order fast path of tsdgpu_rii.
+int tsdgpu::sos_create_ex(tsdgpu_sos **out, int data_type, const float *coefs_host, int nsec, float gain,
+                          const float *rii1_host, int forme, int seeded)
+{
   TSD_CHECK(out != nullptr, "sos_create: out is NULL");
   *out = nullptr;
   TSD_CHECK(data_type == TSDGPU_F32 || data_type == TSDGPU_C64, "sos_create: bad data_type %d", data_type);
@@ -362,7 +377,7 @@ int tsdgpu_sos_create(tsdgpu_sos **out, int data_type, const float *coefs_host, 
     SosSection k{};
     k.b0 = coefs_host[5 * i]; k.b1 = coefs_host[5 * i + 1]; k.b2 = coefs_host[5 * i + 2];
     k.a1 = coefs_host[5 * i + 3]; k.a2 = coefs_host[5 * i + 4];
-    k.seed = 1.f;
+    k.seed = seeded ? 1.f : 0.f;
     k.df1 = forme == 1 ? 1.f : 0.f;
     fill_tables(k, L);
     sec.push_back(k);
@@ -410,6 +425,8 @@ int tsdgpu_sos_create(tsdgpu_sos **out, int data_type, const float *coefs_host, 
   *out = s;
   return TSDGPU_OK;
 }
+
+extern "C" {
 
 int tsdgpu_sos_step(tsdgpu_sos *s, const void *x, void *y, int64_t n, void *stream)
 {

@@ -80,6 +80,11 @@ def test_filtre_rii(tg, orc):
     for i in range(1, n):
         yref[i] = yref[i - 1] + a * (1 - yref[i - 1])
     assert np.abs(yref - y).max() <= 1e-6
+    # low order (<= 2 poles, <= 3 zeros) runs on the block-parallel SOS kernel: long vector, chunks
+    for nu, de in (([0.1], [1.0, -0.9]), ([0.2, 0.1, 0.05], [2.0, -1.2, 0.5]), ([1.0, -1.0], [1.0, -0.95])):
+        x = rand(200000, False, 4)
+        ref = orc.Rii(nu, de).step(x)
+        assert relerr(chunks(tg.Rii(nu, de, tg.F32), x, 70001), ref) <= TOL
     # higher order, chunked, vs the oracle's FiltreRII
     nu, de = [0.2, 0.3, 0.1, -0.05], [1.0, -0.9, 0.5, -0.1]
     x = rand(5000, False, 3)
