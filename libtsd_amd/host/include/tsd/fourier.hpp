@@ -6,6 +6,7 @@
 // TFRPlanDefaut does (fourier.cc:362,372-376,120).
 #pragma once
 #include "tsd/tsd.hpp"
+#include <tuple>
 
 namespace tsd::fourier {
 
@@ -65,5 +66,13 @@ template <typename T> Vecteur<T> fftshift(const Vecteur<T> &X)
   }
   return res;
 }
+
+// ---- "next" rows of the scope: thin compositions over the FFT plan ----
+// correlations (fourier.cc:489-597): circular, biased and unbiased cross-correlation by FFT
+std::tuple<Vecf, Veccf> ccorr(const Veccf &x0, const Veccf &x1 = Veccf());
+std::tuple<Vecf, Veccf> xcorrb(const Veccf &x, const Veccf &y = Veccf(), entier m = -1);
+std::tuple<Vecf, Veccf> xcorr(const Veccf &x, const Veccf &y = Veccf(), entier m = -1);
+// rééchan_freq (fourier.cc:1391-1419): resampling by zero-padding / truncating the spectrum
+Vecf rééchan_freq(const Vecf &x, float lom);
 
 }  // namespace tsd::fourier

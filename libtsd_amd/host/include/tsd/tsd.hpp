@@ -328,6 +328,21 @@ inline Vecf sigimp(entier n, entier p = 0)
   if (n > 0) x(p) = 1;
   return x;
 }
+// sousech / surech (tsd.hpp:367-401): pure index permutations
+template <typename T> Vecteur<T> sousech(const Vecteur<T> &x, entier R)
+{
+  const entier n = x.dim();
+  Vecteur<T> y(n / R);
+  for (entier i = 0; i < n / R; i++) y(i) = x(i * R);
+  return y;
+}
+template <typename T> Vecteur<T> surech(const Vecteur<T> &x, entier R)
+{
+  const entier n = x.dim();
+  Vecteur<T> y = Vecteur<T>::zeros(n * R);
+  for (entier i = 0; i < n; i++) y(i * R) = x(i);
+  return y;
+}
 // randn / randcn on a default-seeded engine (core/src/tsd.cc:173,410-483)
 std::default_random_engine &generateur_aleatoire();
 Vecf randn(entier n);

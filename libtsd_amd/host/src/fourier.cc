@@ -108,4 +108,75 @@ void csym_forçage_impl(Veccf &X)
   for (entier i = 0; i < m; i++) X(n - m + i) = std::conj(X(1 + (m - 1 - i)));
 }
 
+// ---- correlations (fourier.cc:489-597) --------------------------------------------------------
+static Veccf correlation_freq(const Veccf &X0, const Veccf &X1)
+{
+  const entier n = X0.rows();
+  if (n != X1.rows()) échec("correlation_freq: dimensions {} != {}", n, X1.rows());
+  Veccf Y(n);
+  Y(0) = X0(0) * std::conj(X1(0));
+  // Y.tail(n-1) = X0.tail(n-1).reverse() * X1.tail(n-1).reverse().conjugate()
+  for (entier i = 1; i < n; i++) Y(i) = X0(n - i) * std::conj(X1(n - i));
+  Y *= cfloat(std::sqrt((float) n), 0.f);
+  return Y;
+}
+static Veccf correlateur_bloc(const Veccf &x0, const Veccf &x1)
+{
+  const Veccf &x1p = x1.rows() == 0 ? x0 : x1;
+  if (x0.rows() != x1p.rows()) échec("the two input vectors should have the dimension {} != {}.", x0.rows(), x1p.rows());
+  auto plan = fftplan_defaut();
+  const Veccf X0 = plan->step(x0, true), X1 = plan->step(x1p, true);
+  return plan->step(correlation_freq(X0, X1), false);
+}
+std::tuple<Vecf, Veccf> ccorr(const Veccf &x0, const Veccf &x1)
+{
+  const entier m = x0.rows();
+  Veccf r = correlateur_bloc(x0, x1);
+  r /= cfloat((float) m, 0.f);
+  return {linspace(0, (float) (m - 1), m), r};
+}
+std::tuple<Vecf, Veccf> xcorrb(const Veccf &x, const Veccf &y, entier m)
+{
+  const entier n = x.rows();
+  if (m < 0) m = n;
+  const Veccf &yp = y.rows() == 0 ? x : y;
+  Veccf x2 = Veccf::zeros(m + n + m), y2 = Veccf::zeros(m + n + m);
+  x2.segment(m, n) = x;
+  y2.segment(m, n) = yp;
+  const Veccf r = correlateur_bloc(x2, y2);
+  Veccf res(2 * m - 1);
+  for (entier i = 0; i < m; i++) res(m - 1 + i) = r(i) / (float) n;              // res.tail(m) = r.head(m) / n
+  for (entier i = 0; i < m - 1; i++) res(i) = r(r.rows() - (m - 1) + i) / (float) n;   // res.head(m-1) = r.tail(m-1) / n
+  return {linspace((float) -(m - 1), (float) (m - 1), 2 * m - 1), res};
+}
+std::tuple<Vecf, Veccf> xcorr(const Veccf &x, const Veccf &y, entier m)
+{
+  const entier n = x.rows();
+  if (m < 0) m = n;
+  auto [lags, zb] = xcorrb(x, y, m);
+  if (m > 1) {
+    const Vecf a = linspace((float) (n - (m - 1)), (float) (n - 1), m - 1), b = linspace((float) (n - 1), (float) (n - (m - 1)), m - 1);
+    for (entier i = 0; i < m - 1; i++) {
+      zb(i) /= cfloat(a(i) / n, 0.f);
+      zb(zb.rows() - (m - 1) + i) /= cfloat(b(i) / n, 0.f);
+    }
+  }
+  return {lags, zb};
+}
+
+// ---- rééchan_freq (fourier.cc:1391-1419) -------------------------------------------------------
+Vecf rééchan_freq(const Vecf &x, float lom)
+{
+  if (lom == 1) return x;
+  const entier n = x.rows(), n2 = (entier) std::round(n * lom);
+  const Veccf X = fft(x);
+  Veccf X2 = Veccf::zeros(n2);
+  const entier h = (lom > 1 ? n : n2) / 2;
+  X2.head(h) = X.head(h);
+  X2.tail(h) = X.tail(h);
+  Veccf xi = ifft(X2);
+  xi *= cfloat(std::sqrt(lom), 0.f);
+  return real(xi);
+}
+
 }  // namespace tsd::fourier

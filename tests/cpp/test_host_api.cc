@@ -316,6 +316,44 @@ static void test_polyphase()
   CHECK(maxabs(yref - yy) <= 1e-6f, "filtre_rii err=%g", maxabs(yref - yy));
 }
 
+// test_xcorr (test-fourier.cc:477-560): FFT correlations against the O(n^2) definition
+static void test_xcorr(bool biais)
+{
+  for (int n : {1, 2, 3, 10, 15, 16, 21, 32}) {
+    Veccf a1 = randcn(n), a2 = randcn(n);
+    auto [lags, c] = biais ? xcorrb(a1, a2) : xcorr(a1, a2);
+    CHECK(lags.rows() == 2 * n - 1 && c.rows() == 2 * n - 1, "xcorr dims n=%d", n);
+    const int m = n;
+    Veccf cref(2 * m - 1);
+    for (int i = 0; i < m; i++) {
+      cfloat s = 0; int ns = 0;
+      for (int k = 0; k + i < n; k++) { s += a1(k + i) * std::conj(a2(k)); ns++; }
+      s /= (float) (biais ? n : ns);
+      cref(m - 1 - i) = s;
+    }
+    for (int i = 1; i < m; i++) {
+      cfloat s = 0; int ns = 0;
+      for (int k = 0; k + i < n; k++) { s += a1(k) * std::conj(a2(k + i)); ns++; }
+      s /= (float) (biais ? n : ns);
+      cref(i + m - 1) = s;
+    }
+    for (int i = 0; i < 2 * n - 1; i++) CHECK(lags(i) == (float) (i - (n - 1)), "lags n=%d", n);
+    CHECK(maxabs(c - cref) <= 2e-5f * std::max(1.0f, maxabs(cref)), "xcorr%s n=%d err=%g", biais ? "b" : "", n, maxabs(c - cref));
+  }
+}
+
+// test_reechan (test-fourier.cc:122-159): x2 by spectrum padding then every other sample == x
+static void test_reechan_freq()
+{
+  const int n = 16;
+  Vecf x = linspace(0, 1 - 1.0f / n, n), x1 = rééchan_freq(x, 2);
+  CHECK(x1.rows() == 2 * n, "rééchan_freq rows=%d", x1.rows());
+  Vecf x1b = sousech(x1, 2);
+  CHECK(x1b.rows() == n && maxabs(x1b - x) < 1e-5f, "rééchan_freq err=%g", maxabs(x1b - x));
+  Vecf u = surech(Vecf::valeurs({1, 2, 3}), 2);
+  CHECK(u.rows() == 6 && u(2) == 2 && u(1) == 0, "surech");
+}
+
 int main(int argc, char **argv)
 {
   if (argc > 1 && !std::strcmp(argv[1], "--no-gpu")) {
@@ -338,6 +376,9 @@ int main(int argc, char **argv)
   test_fft_misc();
   test_reechan();
   test_polyphase();
+  test_xcorr(true);
+  test_xcorr(false);
+  test_reechan_freq();
   printf(nfail ? "FAILED (%d)\n" : "ALL C++ HOST TESTS OK\n", nfail);
   return nfail ? 1 : 0;
 }
