@@ -153,86 +153,173 @@ __global__ __launch_bounds__(256) void fft1024_rows_kernel(const cpx *__restrict
   }
 }
 
-// n = 2^20 = 1024 x 1024, four-step.  One workgroup = 8 waves = 8 adjacent columns of the
-// row-major [1024][1024] matrix; the tile [1024 rows][8 cols] is loaded with 16-B accesses
-// (64-B row segments), staged in LDS at pitch 9 (odd -> the column each wave reads, and the
+// n = 2^20 = 1024 x 1024, four-step.  One workgroup = 16 waves = 16 adjacent columns of the
+// row-major [1024][1024] matrix; the tile [1024 rows][16 cols] is loaded with 16-B accesses
+// (128-B row segments), staged in LDS at pitch 17 (odd -> the column each wave reads, and the
 // exchange image it then reuses in place, stay bank-conflict free), transformed by the wave.
-//   PASS 1: out is the transposed matrix, out[c][k] = FFT_c[k] * W_N^(c*k)  (row c contiguous:
-//           stored straight from registers in 512-B segments)
+//   PASS 1: out is the transposed matrix, out[c][k] = FFT_c[k] * W_N^(c*k)  (row c contiguous)
 //   PASS 2: out[k][c] = FFT_c[k] * scale (natural order; staged back through LDS)
 // Twiddle W_N^(c*k), k = k0(lane) + 64*(r>>2) + 256*(r&3): TA[c][lane] * TD[c][r] (host tables).
-constexpr int C8_ROWS = 1088;
-template <int PASS, int C8>
-__global__ __launch_bounds__(C8 * 64) void fft1m_cols_kernel(const cpx *__restrict__ in, cpx *__restrict__ out,
-                                                         const cpx *__restrict__ TW1, const cpx *__restrict__ TW2,
-                                                         const cpx *__restrict__ TA, const cpx *__restrict__ TD,
-                                                         int inverse, float scale, int zp, int ntiles)
-{
-  (void) ntiles;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  constexpr int C8_PITCH = C8 + 1;
-  constexpr int TPR = C8 / 2;                 // threads per row (16 B each)
-  constexpr int RPS = C8 * 64 / TPR;          // rows per sweep
-  constexpr int NSW = 1024 / RPS;             // sweeps (= 16-B loads per thread per tile)
-  constexpr int TPB = 1024 / C8;              // column tiles per transform
-  cpx *tile = reinterpret_cast<cpx *>(smem_raw);
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  const int ipitch = PASS == 1 ? 1024 : zp, opitch = PASS == 1 ? zp : 1024;
-  const int rr = t / TPR, cc = 2 * (t % TPR);
-  const int k0 = (lane >> 2) + 16 * (lane & 3);
-  cpx *col = tile + wv;                                    // this wave's column: slots e*pitch + wv
+//
+// The 148 KiB tile allows one workgroup per CU, so a workgroup is persistent (tiles id, id +
+// grid, ...) and software-pipelined: as soon as the 8 float4 of a tile have been written to
+// LDS the same registers receive the loads of the NEXT tile, which stay in flight through the
+// transform and the store phase of the current one.  That needs (a) barriers that only wait
+// for LDS (a __syncthreads() drains vmcnt and with it the prefetch), and (b) the wave-FFT
+// twiddles out of registers: they sit in the last 8 KiB of LDS (tw1 rows 1..15; tw2 depends on
+// lane & 3 only).  Without the pipeline the load, transform and store phases of a CU ran
+// back to back (measured: pass 1 = 0.65 ms without stores + 0.49 ms without loads = 0.99 ms).
+constexpr int F1M_ROWS = 1088, F1M_PITCH = 17;
+constexpr int F1M_TILE_ELEMS = F1M_ROWS * F1M_PITCH;
+constexpr size_t F1M_LDS = (size_t) (F1M_TILE_ELEMS + 15 * 64 + 16 * 4 + 256) * sizeof(cpx);   // 158,208 B
 
-  // tile `id` = (transform id / TPB, column tile id % TPB).  (A persistent variant with the
-  // next tile prefetched into registers was measured: it does not fit the 128-VGPR budget of a
-  // 1024-thread workgroup and spills; one tile per workgroup is faster.)
-  {
-    const int id = blockIdx.x;      // one tile per workgroup (grid = ntiles)
-    const cpx *x = in + (size_t) (id / TPB) * 1024 * ipitch + (id % TPB) * C8 + cc;
+__device__ __forceinline__ void lds_barrier()
+{
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+struct LdsTw1 {   // [r - 1][lane]
+  const cpx *p;
+  __device__ __forceinline__ cpx operator[](int r) const { return p[(r - 1) * 64]; }
+};
+struct LdsTw2 {   // [r][lane & 3]
+  const cpx *p;
+  __device__ __forceinline__ cpx operator[](int r) const { return p[r * 4]; }
+};
+
+struct F1mCtx {
+  const cpx *in;
+  cpx *out;
+  const cpx *TA, *TD;
+  cpx *tile, *col, *ltd;
+  LdsTw1 tw1;
+  LdsTw2 tw2;
+  int ipitch, opitch, inverse, t, lane, wv, rr, cc, k0, grid;
+  float scale;
+};
+
+// loads of tile `id` into registers: 8 x 16 B of the tile + this tile's share of the TA/TD tables
+// Addresses are formed as (uniform tile base) + (32-bit per-thread byte offset), and the offset
+// is made opaque once per tile: otherwise the 8 row addresses of the loads and of the stores
+// are hoisted out of the tile loop as 64-bit loop invariants (32 VGPRs) and the prefetch spills.
+__device__ __forceinline__ unsigned opaque(unsigned v)
+{
+  asm volatile("" : "+v"(v));
+  return v;
+}
+template <int PASS>
+__device__ __forceinline__ void f1m_issue(const F1mCtx &k, int id, float4 (&q)[8], cpx &ta, cpx &td)
+{
+  const char *x = reinterpret_cast<const char *>(k.in + (size_t) (id >> 6) * 1024 * k.ipitch + (id & 63) * 16);
+  const unsigned o = opaque(((unsigned) k.rr * k.ipitch + k.cc) * 8u), step = 128u * 8u * k.ipitch;
 #pragma unroll
-    for (int i = 0; i < NSW; i++) {
-      const int row = rr + RPS * i;
-      float4 q = *reinterpret_cast<const float4 *>(x + (size_t) row * ipitch);
-      if (PASS == 1 && inverse) { q.y = -q.y; q.w = -q.w; }
-      tile[row * C8_PITCH + cc] = cmk(q.x, q.y);
-      tile[row * C8_PITCH + cc + 1] = cmk(q.z, q.w);
-    }
-    __syncthreads();
-    cpx tw1[16], tw2[16], v[16];
-    const int lo = lane;
+  for (int i = 0; i < 8; i++) q[i] = *reinterpret_cast<const float4 *>(x + (o + step * i));
+  if (PASS == 1) {
+    ta = k.TA[((id & 63) * 16 + k.wv) * 64 + k.lane];
+    td = k.TD[(id & 63) * 256 + (k.t & 255)];              // [column][r] of the 16 columns
+  }
+}
+
+// one tile: registers -> LDS, (prefetch of the next tile), transform, store
+template <int PASS, bool PREFETCH>
+__device__ __forceinline__ void f1m_tile(const F1mCtx &k, int id, float4 (&q)[8], cpx &ta, cpx &td)
+{
+  constexpr int P = F1M_PITCH;
+  cpx *tile = k.tile, *col = k.col;
+  const int lane = k.lane, rr = k.rr, cc = k.cc, k0 = k.k0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const int row = rr + 128 * i;
+    const float sg = (PASS == 1 && k.inverse) ? -1.f : 1.f;
+    tile[row * P + cc] = cmk(q[i].x, sg * q[i].y);
+    tile[row * P + cc + 1] = cmk(q[i].z, sg * q[i].w);
+  }
+  const cpx ta_cur = ta;
+  if (PASS == 1 && k.t < 256) k.ltd[k.t] = td;
+  if (PREFETCH) f1m_issue<PASS>(k, id + k.grid, q, ta, td);   // in flight until the next tile's LDS write
+  lds_barrier();
+  cpx v[16];
+#pragma unroll
+  for (int r = 0; r < 16; r++) v[r] = col[(64 * r + lane) * P];
+  w1024::forward<P>(v, col, lane, k.tw1, k.tw2, wave_fence);
+  const int c0 = (id & 63) * 16, c = c0 + k.wv;
+  cpx *y = k.out + (size_t) (id >> 6) * 1024 * k.opitch;
+  wave_fence();
+  if (PASS == 1) {
+    // row c of the transposed intermediate.  The spectrum leaves the wave through its own LDS
+    // column so that every lane stores 16 B (two adjacent bins): 8-B-per-lane stores from
+    // the register order ran the write phase at 2.8 TB/s.
+    cpx *z = y + (size_t) c * k.opitch;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-      v[r] = col[(64 * r + lane) * C8_PITCH];
-      tw1[r] = TW1[r * 64 + lo];
-      tw2[r] = TW2[r * 64 + lo];
+      const cpx w = cmul(ta_cur, k.ltd[k.wv * 16 + r]);
+      col[(k0 + 64 * (r >> 2) + 256 * (r & 3)) * P] = cmul(v[r], w);
     }
-    w1024::forward<C8_PITCH>(v, col, lane, tw1, tw2, wave_fence);
-    const int c0 = (id % TPB) * C8, c = c0 + wv;
-    cpx *y = out + (size_t) (id / TPB) * 1024 * opitch;
-    if (PASS == 1) {
-      const cpx a = TA[c * 64 + lane];
-      cpx *z = y + (size_t) c * opitch;
+    wave_fence();
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        const cpx w = cmul(a, TD[c * 16 + r]);
-        z[k0 + 64 * (r >> 2) + 256 * (r & 3)] = cmul(v[r], w);
-      }
-    } else {
-      wave_fence();
+    for (int j = 0; j < 8; j++) {
+      const cpx e0 = col[(128 * j + 2 * lane) * P], e1 = col[(128 * j + 2 * lane + 1) * P];
+      *reinterpret_cast<float4 *>(z + 128 * j + 2 * lane) = make_float4(e0.x, e0.y, e1.x, e1.y);
+    }
+  } else {
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
-        cpx o = cscale(v[r], scale);
-        if (inverse) o.y = -o.y;
-        col[(k0 + 64 * (r >> 2) + 256 * (r & 3)) * C8_PITCH] = o;
-      }
-      __syncthreads();
+    for (int r = 0; r < 16; r++) {
+      cpx o = cscale(v[r], k.scale);
+      if (k.inverse) o.y = -o.y;
+      col[(k0 + 64 * (r >> 2) + 256 * (r & 3)) * P] = o;
+    }
+    lds_barrier();
+    char *yb = reinterpret_cast<char *>(y + c0);
+    const unsigned o = opaque(((unsigned) rr * k.opitch + cc) * 8u), step = 128u * 8u * k.opitch;
 #pragma unroll
-      for (int i = 0; i < NSW; i++) {
-        const int row = rr + RPS * i;
-        const cpx a = tile[row * C8_PITCH + cc], b = tile[row * C8_PITCH + cc + 1];
-        *reinterpret_cast<float4 *>(y + (size_t) row * opitch + c0 + cc) = make_float4(a.x, a.y, b.x, b.y);
-      }
+    for (int i = 0; i < 8; i++) {
+      const int row = rr + 128 * i;
+      const cpx a = tile[row * P + cc], b = tile[row * P + cc + 1];
+      *reinterpret_cast<float4 *>(yb + (o + step * i)) = make_float4(a.x, a.y, b.x, b.y);
     }
   }
+  lds_barrier();                                            // the next tile overwrites the LDS image
+}
+
+template <int PASS>
+__global__ __launch_bounds__(1024) void fft1m_cols_kernel(const cpx *__restrict__ in, cpx *__restrict__ out,
+                                                          const cpx *__restrict__ TW1, const cpx *__restrict__ TW2,
+                                                          const cpx *__restrict__ TA, const cpx *__restrict__ TD,
+                                                          int inverse, float scale, int zp, int ntiles)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  cpx *tile = reinterpret_cast<cpx *>(smem_raw);
+  cpx *ltw1 = tile + F1M_TILE_ELEMS, *ltw2 = ltw1 + 15 * 64, *ltd = ltw2 + 16 * 4;
+  const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  if (t < 15 * 64) ltw1[t] = TW1[64 + t];
+  if (t < 64) ltw2[t] = TW2[(t >> 2) * 64 + (t & 3)];
+  F1mCtx k;
+  k.in = in; k.out = out; k.TA = TA; k.TD = TD;
+  k.tile = tile; k.col = tile + wv; k.ltd = ltd;           // this wave's column: slots e*P + wv
+  k.tw1 = LdsTw1{ltw1 + lane}; k.tw2 = LdsTw2{ltw2 + (lane & 3)};
+  k.ipitch = PASS == 1 ? 1024 : zp; k.opitch = PASS == 1 ? zp : 1024;
+  k.inverse = inverse; k.t = t; k.lane = lane; k.wv = wv;
+  k.rr = t >> 3; k.cc = 2 * (t & 7);                       // 8 threads x 16 B per 128-B row segment
+  k.k0 = (lane >> 2) + 16 * (lane & 3);
+  k.grid = gridDim.x; k.scale = scale;
+
+  // tiles id, id + grid, ...: tile = (transform id / 64, column tile id % 64).  The first tile is
+  // peeled so that the loop is entered in the same memory-counter state as its back edge
+  // (prefetch loads followed by 8 stores): the compiler's wait before the LDS write is then
+  // vmcnt(8) -- the stores of the previous tile keep draining -- rather than vmcnt(0).
+  int id = blockIdx.x;
+  if (id >= ntiles) return;
+  float4 q[8];
+  cpx ta = cmk(1.f, 0.f), td = cmk(1.f, 0.f);
+  f1m_issue<PASS>(k, id, q, ta, td);
+  if (id + k.grid < ntiles) {
+    f1m_tile<PASS, true>(k, id, q, ta, td);
+    id += k.grid;
+    while (id + k.grid < ntiles) {
+      f1m_tile<PASS, true>(k, id, q, ta, td);
+      id += k.grid;
+    }
+  }
+  f1m_tile<PASS, false>(k, id, q, ta, td);
 }
 
 // ---- helpers for the non power-of-two paths ------------------------------------------------
@@ -385,10 +472,8 @@ int plan_init(tsdgpu_fft *p, int n)
         }
         if ((rc = upload(&p->d_ta, ta))) return rc;
         if ((rc = upload(&p->d_td, td))) return rc;
-        (void) hipFuncSetAttribute((const void *) fft1m_cols_kernel<1, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void) hipFuncSetAttribute((const void *) fft1m_cols_kernel<2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void) hipFuncSetAttribute((const void *) fft1m_cols_kernel<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void) hipFuncSetAttribute((const void *) fft1m_cols_kernel<2, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void) hipFuncSetAttribute((const void *) fft1m_cols_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void) hipFuncSetAttribute((const void *) fft1m_cols_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void) hipGetLastError();
       }
     } else if (n <= LDS_MAX_N) {
@@ -523,28 +608,19 @@ int step_device(tsdgpu_fft *p, const cpx *x, cpx *y, int batch, int forward, hip
       int rc = p->work.reserve((size_t) batch * 1024 * ZP * sizeof(cpx));
       if (rc) return rc;
       cpx *z = p->work.as<cpx>();
-      static const int CW = getenv("TSDGPU_FFT_CW") ? atoi(getenv("TSDGPU_FFT_CW")) : 16;
-      const size_t lds = (size_t) C8_ROWS * (CW + 1) * sizeof(cpx);
-      // Transforms are processed in groups small enough for the intermediate (8 MiB per
-      // transform) to still sit in the 256 MiB Infinity Cache when pass 2 reads it back.
-      static const int G = getenv("TSDGPU_FFT_GROUP") ? atoi(getenv("TSDGPU_FFT_GROUP")) : 65535;
-      for (int b0 = 0; b0 < batch; b0 += G) {
-        const int nb = std::min(G, batch - b0);
-        const size_t off = (size_t) b0 << 20, zoff = (size_t) b0 * 1024 * ZP;
-        if (CW == 16) {
-          const int ntiles = 64 * nb, grid = ntiles;
-          hipLaunchKernelGGL((fft1m_cols_kernel<1, 16>), dim3(grid), dim3(1024), lds, st, x + off, z + zoff,
-                             p->d_w1, p->d_w2, p->d_ta, p->d_td, inverse, 1.0f, ZP, ntiles);
-          hipLaunchKernelGGL((fft1m_cols_kernel<2, 16>), dim3(grid), dim3(1024), lds, st, z + zoff, y + off,
-                             p->d_w1, p->d_w2, p->d_ta, p->d_td, inverse, 1.0f / 1024.0f, ZP, ntiles);
-        } else {
-          const int ntiles = 128 * nb, grid = ntiles;
-          hipLaunchKernelGGL((fft1m_cols_kernel<1, 8>), dim3(grid), dim3(512), lds, st, x + off, z + zoff,
-                             p->d_w1, p->d_w2, p->d_ta, p->d_td, inverse, 1.0f, ZP, ntiles);
-          hipLaunchKernelGGL((fft1m_cols_kernel<2, 8>), dim3(grid), dim3(512), lds, st, z + zoff, y + off,
-                             p->d_w1, p->d_w2, p->d_ta, p->d_td, inverse, 1.0f / 1024.0f, ZP, ntiles);
-        }
-      }
+      // persistent workgroups, one per CU (148 KiB of LDS each); tiles are dealt round-robin
+      const int ntiles = 64 * batch;
+      static const int NCU = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+      }();
+      static const int GRID = getenv("TSDGPU_FFT_GRID") ? atoi(getenv("TSDGPU_FFT_GRID")) : NCU;
+      const int grid = std::min(ntiles, GRID);
+      hipLaunchKernelGGL((fft1m_cols_kernel<1>), dim3(grid), dim3(1024), F1M_LDS, st, x, z, p->d_w1, p->d_w2, p->d_ta,
+                         p->d_td, inverse, 1.0f, ZP, ntiles);
+      hipLaunchKernelGGL((fft1m_cols_kernel<2>), dim3(grid), dim3(1024), F1M_LDS, st, z, y, p->d_w1, p->d_w2, p->d_ta,
+                         p->d_td, inverse, 1.0f / 1024.0f, ZP, ntiles);
       TSD_HIP(hipGetLastError());
       return TSDGPU_OK;
     }

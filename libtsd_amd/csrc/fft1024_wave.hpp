@@ -117,7 +117,7 @@ TSD_HD int time_index(int lane, int reg) { return 64 * reg + lane; }
 
 // ---- the phases.  SYNC() must order LDS writes before the following LDS reads of the
 // same wave (a __syncthreads() in a 64-lane workgroup; a no-op per-phase loop on the CPU).
-template <bool INV> TSD_HD void stageA(cpx (&v)[16], const cpx (&tw1)[16])
+template <bool INV, typename TW> TSD_HD void stageA(cpx (&v)[16], const TW &tw1)
 {
   if (!INV) {
     dft16<false>(v);
@@ -129,7 +129,7 @@ template <bool INV> TSD_HD void stageA(cpx (&v)[16], const cpx (&tw1)[16])
     dft16<true>(v);
   }
 }
-template <bool INV> TSD_HD void stageB(cpx (&v)[16], const cpx (&tw2)[16])
+template <bool INV, typename TW> TSD_HD void stageB(cpx (&v)[16], const TW &tw2)
 {
   if (!INV) {
     dft16<false>(v);
@@ -205,8 +205,9 @@ template <int S = 1> TSD_HD void x2_read_m2(cpx (&v)[16], const cpx *lds, int la
 // S = element stride of the wave's LDS image (1: private contiguous buffer; an ODD stride such
 // as 9 interleaves the images of several waves -- multiplying slot numbers by an odd constant
 // permutes the banks, so the conflict-free property of the maps above is preserved).
-template <int S = 1, typename SYNC>
-TSD_HD void forward(cpx (&v)[16], cpx *lds, int lane, const cpx (&tw1)[16], const cpx (&tw2)[16], SYNC sync)
+// TW1/TW2: anything indexable with [r], r = 1..15 (register arrays, or an accessor over LDS).
+template <int S = 1, typename TW1, typename TW2, typename SYNC>
+TSD_HD void forward(cpx (&v)[16], cpx *lds, int lane, const TW1 &tw1, const TW2 &tw2, SYNC sync)
 {
   stageA<false>(v, tw1);
   x1_write_rows<S>(v, lds, lane);
@@ -219,8 +220,8 @@ TSD_HD void forward(cpx (&v)[16], cpx *lds, int lane, const cpx (&tw1)[16], cons
   x2_read_m2<S>(v, lds, lane);
   stageC<false>(v);
 }
-template <int S = 1, typename SYNC>
-TSD_HD void inverse(cpx (&v)[16], cpx *lds, int lane, const cpx (&tw1)[16], const cpx (&tw2)[16], SYNC sync)
+template <int S = 1, typename TW1, typename TW2, typename SYNC>
+TSD_HD void inverse(cpx (&v)[16], cpx *lds, int lane, const TW1 &tw1, const TW2 &tw2, SYNC sync)
 {
   stageC<true>(v);
   sync();
