@@ -12,6 +12,10 @@ installs it as the filter history -- the only exchange the path needs.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+`--workload fft|sos|resample` runs BASELINE.json configs[2..4] under the same contract (same
+JSON line, same sharding rules of SURVEY.md 8e); the default `fir` is configs[1], the
+configuration the metric is quoted on.
 """
 import argparse
 import json
@@ -41,24 +45,192 @@ def design_lowpass(n, fc):
     return (h / h.sum()).astype(np.float32)
 
 
-def cpu_baseline(h, seconds_target=12.0):
-    """Times the oracle (CPU restatement of FiltreRIF<cfloat,float>::step, single thread like
-    libtsd) on a bounded sample of the same workload."""
-    from oracle import pyoracle as orc
-    rng = np.random.default_rng(2)
-    n0 = 1 << 20
-    x = (rng.standard_normal(n0) + 1j * rng.standard_normal(n0)).astype(np.complex64)
-    f = orc.Fir(h)
+def _time_cpu(fn, units_per_call, unit, what, seconds_target=12.0):
     t0 = time.perf_counter()
-    f.step(x)
+    fn()
     dt = time.perf_counter() - t0
     reps = max(1, min(64, int(seconds_target / max(dt, 1e-3))))
     t0 = time.perf_counter()
     for _ in range(reps):
-        f.step(x)
+        fn()
     dt = time.perf_counter() - t0
-    return {"value": round(reps * n0 / dt / 1e6, 3), "unit": "Msamples/s", "cores": 1, "kind": "port",
-            "sample": f"{reps} x 2^20 complex samples, 127 real taps, oracle orc_fir_cf, 1 thread of {os.cpu_count()}"}
+    return {"value": round(reps * units_per_call / dt / 1e6, 3), "unit": unit, "cores": 1, "kind": "port",
+            "sample": f"{reps} x {what}, 1 thread of {os.cpu_count()}"}
+
+
+# ---------------------------------------------------------------------------------------
+# Workloads.  Each provides: exchange() (the per-step neighbour exchange, if any), step(),
+# units per step per GPU, algorithmic bytes per step per GPU, and a CPU leg on the oracle.
+# ---------------------------------------------------------------------------------------
+class FirWorkload:
+    """configs[1]: 127-tap FIR on 2^26 cfloat per GPU; halo = K-1 samples from the left rank."""
+    unit = "Msamples/s"
+
+    def __init__(self, t, torch, dev, rank, world, args, method=None):
+        self.t, self.rank, self.world = t, rank, world
+        self.n = 1 << args.log2n
+        self.h = design_lowpass(K_TAPS, 0.02)
+        g = torch.Generator(device=dev).manual_seed(2 + rank)
+        self.x = torch.view_as_complex(torch.randn(self.n, 2, device=dev, generator=g))
+        self.y = torch.empty_like(self.x)
+        self.halo_out = torch.view_as_real(self.x[self.n - (K_TAPS - 1):].clone())
+        self.halo_in_c = torch.zeros(K_TAPS - 1, dtype=self.x.dtype, device=dev)
+        self.halo_in = torch.view_as_real(self.halo_in_c)
+        self.f = t.Fir(self.h, t.C64, t.FIR_AUTO if method is None else method)
+        self.method = {t.FIR_DIRECT: "direct", t.FIR_OVERLAP_SAVE: "overlap-save"}[self.f.method]
+        self.units = float(self.n)
+        self.alg_bytes = 16.0 * self.n            # 8 B read + 8 B written per complex sample (SURVEY 8d)
+        self.metric = "Msamples/s, 127-tap FIR on 2^%d cfloat stream" % args.log2n
+        self.dtype = "f32 (complex64 data, real f32 taps)"
+        self.config = {"workload": "configs[1]: 127-tap FIR (design_rif_fen lp 0.02, real taps via filtrer()) "
+                                   "on 2^%d-sample Veccf per GPU, inputs resident in HBM" % args.log2n,
+                       "method": self.method, "samples_per_gpu": self.n,
+                       "sharding": "contiguous chunks, K-1 halo via RCCL send/recv" if world > 1 else "single GPU"}
+        self.traffic = TRAFFIC_PMC_BYTES.get((self.method, args.log2n))
+
+    def exchange(self):
+        from libtsd_amd import sharding
+        sharding.exchange_left_halo(self.halo_out, self.halo_in, self.rank, self.world)
+        self.f.set_history(self.halo_in_c)
+
+    def step(self):
+        self.f.step(self.x, self.y)   # launched on torch's current stream (passed through the C ABI)
+
+    def cpu_baseline(self):
+        from oracle import pyoracle as orc
+        rng = np.random.default_rng(2)
+        n0 = 1 << 20
+        x = (rng.standard_normal(n0) + 1j * rng.standard_normal(n0)).astype(np.complex64)
+        f = orc.Fir(self.h)
+        return _time_cpu(lambda: f.step(x), n0, "Msamples/s", "2^20 complex samples, 127 real taps, oracle orc_fir_cf")
+
+
+class FftWorkload:
+    """configs[2]: 2^20-point complex FFT, batch 256 per GPU; independent transforms, no exchange."""
+    unit = "Mpoints/s"
+
+    def __init__(self, t, torch, dev, rank, world, args):
+        self.nfft, self.batch = 1 << 20, 256
+        g = torch.Generator(device=dev).manual_seed(3 + rank)
+        self.x = torch.view_as_complex(torch.randn(self.batch * self.nfft, 2, device=dev, generator=g)).reshape(self.batch, self.nfft)
+        self.y = torch.empty_like(self.x)
+        self.p = t.Fft(self.nfft, self.batch)
+        self.units = float(self.nfft) * self.batch
+        self.alg_bytes = 16.0 * self.units
+        self.metric = "Mpoints/s, 2^20-point complex FFT, batch 256"
+        self.dtype = "f32 (complex64)"
+        self.config = {"workload": "configs[2]: fft() of 256 x Veccf[2^20] per GPU, unitary scaling, inputs resident in HBM",
+                       "sharding": "batch index split, no exchange" if world > 1 else "single GPU"}
+        self.traffic = None
+
+    def exchange(self):
+        pass
+
+    def step(self):
+        self.p.step(self.x, True, self.y)
+
+    def cpu_baseline(self):
+        from oracle import pyoracle as orc
+        rng = np.random.default_rng(3)
+        x = (rng.standard_normal(self.nfft) + 1j * rng.standard_normal(self.nfft)).astype(np.complex64)
+        return _time_cpu(lambda: orc.fft(x), self.nfft, "Mpoints/s", "one 2^20-point transform, oracle orc_fft (radix-2)")
+
+
+class SosWorkload:
+    """configs[3]: 6-section SOS (Butterworth 12, fc 0.25) on 2^26 float per GPU.  Sharding: every
+    rank but the first warms its filter on the last `halo` samples of the left neighbour
+    (state transition below 1e-9 after `halo` samples, computed by the library)."""
+    unit = "Msamples/s"
+
+    def __init__(self, t, torch, dev, rank, world, args):
+        from scipy.signal import butter
+        self.rank, self.world = rank, world
+        self.n = 1 << args.log2n
+        sos = butter(12, 0.5, output="sos")          # fcut 0.25 of fs; coefficients = bench input data
+        self.co = np.array([[s[0], s[1], s[2], s[4], s[5]] for s in sos], np.float32)
+        g = torch.Generator(device=dev).manual_seed(4 + rank)
+        self.x = torch.randn(self.n, device=dev, generator=g)
+        self.y = torch.empty_like(self.x)
+        self.f = t.Sos(self.co, 1.0, t.F32)
+        self.halo = int(self.f.halo)
+        self.halo_out = self.x[self.n - self.halo:].clone()
+        self.halo_in = torch.zeros(self.halo, dtype=self.x.dtype, device=dev)
+        self.scratch = torch.empty_like(self.halo_in)
+        self.units = float(self.n)
+        self.alg_bytes = 8.0 * self.n
+        self.metric = "Msamples/s, 6-section SOS IIR on 2^%d float stream" % args.log2n
+        self.dtype = "f32"
+        self.config = {"workload": "configs[3]: 6 DF2 biquads (Butterworth order 12, fc 0.25) on 2^%d-sample Vecf per GPU" % args.log2n,
+                       "halo_samples": self.halo,
+                       "sharding": "contiguous chunks, warm-up halo via RCCL send/recv" if world > 1 else "single GPU"}
+        self.traffic = None
+
+    def exchange(self):
+        from libtsd_amd import sharding
+        if self.world > 1:
+            sharding.exchange_left_halo(self.halo_out, self.halo_in, self.rank, self.world)
+            self.f.reset()
+            if self.rank > 0:
+                self.f.step(self.halo_in, self.scratch)
+
+    def step(self):
+        self.f.step(self.x, self.y)
+
+    def cpu_baseline(self):
+        from oracle import pyoracle as orc
+        z, p, mn, md = orc.design_butter_lp(12, 0.25)     # design_riia(12,"lp","butt",0.25)
+        f = orc.SosChain(z, p, mn, md)
+        rng = np.random.default_rng(4)
+        n0 = 1 << 20
+        x = rng.standard_normal(n0).astype(np.float32)
+        return _time_cpu(lambda: f.step(x), n0, "Msamples/s", "2^20 float samples, 6 sections, oracle orc_sos_step_f")
+
+
+class ResampleWorkload:
+    """configs[4]: 160/147 resampling of a 2^30 cfloat stream, 2^27 inputs per GPU.  Sharding: rank r
+    seeks to stream position r * 2^27 and takes its K-1 = 14-sample window from the left rank."""
+    unit = "Msamples/s"
+
+    def __init__(self, t, torch, dev, rank, world, args):
+        self.rank, self.world = rank, world
+        self.n = 1 << 27
+        self.r = t.Resampler(np.float32(160.0) / np.float32(147.0), t.C64)
+        g = torch.Generator(device=dev).manual_seed(5 + rank)
+        self.x = torch.view_as_complex(torch.randn(self.n, 2, device=dev, generator=g))
+        self.pos = rank * self.n
+        self.r.seek(self.pos)
+        self.nout = int(self.r.out_count(self.n))
+        self.y = torch.empty(self.nout, dtype=self.x.dtype, device=dev)
+        self.halo_out = torch.view_as_real(self.x[self.n - 14:].clone())
+        self.halo_in_c = torch.zeros(14, dtype=self.x.dtype, device=dev)
+        self.halo_in = torch.view_as_real(self.halo_in_c)
+        self.units = float(self.n)
+        self.alg_bytes = 8.0 * self.n + 8.0 * self.nout
+        self.metric = "Msamples/s (input), 160/147 resampling of a cfloat stream, 2^27 inputs per GPU"
+        self.dtype = "f32 (complex64 data, f32 LUT taps)"
+        self.config = {"workload": "configs[4]: filtre_reechan(160/147) interpolator on a 2^27-sample Veccf shard per GPU "
+                                   "(2^30 over 8 GPUs)", "outputs_per_gpu": self.nout,
+                       "sharding": "contiguous input chunks, 14-sample halo via RCCL send/recv + seek" if world > 1 else "single GPU"}
+        self.traffic = None
+
+    def exchange(self):
+        from libtsd_amd import sharding
+        sharding.exchange_left_halo(self.halo_out, self.halo_in, self.rank, self.world)
+        self.r.seek(self.pos, self.halo_in_c if self.rank > 0 else None)
+
+    def step(self):
+        self.r.step(self.x, self.y)
+
+    def cpu_baseline(self):
+        from oracle import pyoracle as orc
+        rng = np.random.default_rng(5)
+        n0 = 1 << 20
+        x = (rng.standard_normal(n0) + 1j * rng.standard_normal(n0)).astype(np.complex64)
+        f = orc.Resampler(np.float32(160.0) / np.float32(147.0))
+        return _time_cpu(lambda: f.step(x), n0, "Msamples/s", "2^20 complex input samples, oracle orc_ra_step")
+
+
+WORKLOADS = {"fir": FirWorkload, "fft": FftWorkload, "sos": SosWorkload, "resample": ResampleWorkload}
 
 
 def main():
@@ -66,13 +238,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--log2n", type=int, default=LOG2N, help="samples per GPU = 2^log2n (default: the BASELINE size)")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="fir")
+    ap.add_argument("--log2n", type=int, default=LOG2N, help="fir/sos: samples per GPU = 2^log2n (default: the BASELINE size)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     import libtsd_amd as t
+    from libtsd_amd import sharding
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -87,42 +261,24 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank)
 
-    n = 1 << args.log2n
-    h = design_lowpass(K_TAPS, 0.02)
-    g = torch.Generator(device=dev).manual_seed(2 + rank)
-    x = torch.view_as_complex(torch.randn(n, 2, device=dev, generator=g))
-    y = torch.empty_like(x)
-    halo_out = x[n - (K_TAPS - 1):].clone()
-    halo_in = torch.zeros(K_TAPS - 1, dtype=x.dtype, device=dev)
-
-    fir_auto = t.Fir(h, t.C64, t.FIR_AUTO)
-    fir_direct = t.Fir(h, t.C64, t.FIR_DIRECT)
-    method_names = {t.FIR_DIRECT: "direct", t.FIR_OVERLAP_SAVE: "overlap-save"}
+    w = WORKLOADS[args.workload](t, torch, dev, rank, world, args)
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    from libtsd_amd import sharding
-    halo_out_r, halo_in_r = torch.view_as_real(halo_out), torch.view_as_real(halo_in)
-
-    def exchange_halo(f):
-        """left-neighbour halo (K-1 samples) over RCCL send/recv; rank 0 starts from zeros."""
-        sharding.exchange_left_halo(halo_out_r, halo_in_r, rank, world)
-        f.set_history(halo_in)
-
-    def run(f, steps, warmup):
+    def run(wl, steps, warmup):
         for _ in range(warmup):
-            exchange_halo(f)
-            f.step(x, y)
+            wl.exchange()
+            wl.step()
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
-            exchange_halo(f)
+            wl.exchange()
             evs[i][0].record()
-            f.step(x, y)              # launched on torch's current stream (passed through the C ABI)
+            wl.step()
             evs[i][1].record()
         torch.cuda.synchronize()
         barrier()
@@ -132,48 +288,46 @@ def main():
         return dt, kern_ms
 
     # GPU clock ramp: the first ~20 ms of kernels after an idle period run at a lower clock
-    # (measured: 0.27 ms vs 0.22 ms per step).  A fixed untimed pre-run brings the device to
+    # (measured: 0.27 ms vs 0.22 ms per FIR step).  A fixed untimed pre-run brings the device to
     # its sustained state whatever --warmup the caller picked; the W warm-up steps and the K
     # timed steps below are unchanged.
-    PRE_WARM = 150
+    PRE_WARM = 150 if args.workload in ("fir", "sos") else 20
     for _ in range(PRE_WARM):
-        fir_auto.step(x, y)
+        w.step()
     torch.cuda.synchronize()
-    dt, kern_ms = run(fir_auto, args.steps, args.warmup)
-    total_samples = float(n) * world * args.steps
-    value = total_samples / dt / 1e6
-    alg_bytes = 16.0 * n                       # 8 B read + 8 B written per complex sample
-    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    dt, kern_ms = run(w, args.steps, args.warmup)
+    value = w.units * world * args.steps / dt / 1e6
+    achieved = w.alg_bytes / (kern_ms * 1e-3) / 1e9
 
     out = None
     if rank == 0:
+        cfg = dict(w.config)
+        cfg["pre_warm_steps"] = PRE_WARM
         out = {
-            "metric": "Msamples/s, 127-tap FIR on 2^%d cfloat stream" % args.log2n,
-            "value": round(value, 1), "unit": "Msamples/s",
+            "metric": w.metric, "value": round(value, 1), "unit": w.unit,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (complex64 data, real f32 taps)", "data": "synthetic",
-            "config": {"workload": "configs[1]: 127-tap FIR (design_rif_fen lp 0.02, real taps via filtrer()) "
-                                   "on 2^%d-sample Veccf per GPU, inputs resident in HBM" % args.log2n,
-                       "method": method_names[fir_auto.method], "samples_per_gpu": n, "pre_warm_steps": PRE_WARM,
-                       "sharding": "contiguous chunks, K-1 halo via RCCL send/recv" if world > 1 else "single GPU"},
+            "dtype": w.dtype, "data": "synthetic", "config": cfg,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
                          # HBM bytes per launch from rocprofv3 --pmc passes (profiles/r1_pmc_ols.txt):
                          # FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, in KB
-                         "traffic": TRAFFIC_PMC_BYTES.get((method_names[fir_auto.method], args.log2n)),
-                         "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": alg_bytes},
+                         "traffic": w.traffic,
+                         "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": w.alg_bytes},
         }
-    # secondary line: the direct kernel on the same data (rank-local, N=1 only)
     if world == 1:
-        dt_d, kern_d = run(fir_direct, max(3, args.steps // 4), 1)
-        out["direct"] = {"value": round(n * max(3, args.steps // 4) / dt_d / 1e6, 1), "unit": "Msamples/s",
-                         "kernel_ms": round(kern_d, 4),
-                         "hbm_frac": round(alg_bytes / (kern_d * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                         "valu_frac_of_157.3TF": round(4.0 * K_TAPS * n / (kern_d * 1e-3) / 157.3e12, 4)}
+        if args.workload == "fir":
+            # secondary line: the direct kernel on the same data (rank-local, N=1 only)
+            wd = FirWorkload(t, torch, dev, rank, world, args, method=t.FIR_DIRECT)
+            sd = max(3, args.steps // 4)
+            dt_d, kern_d = run(wd, sd, 1)
+            out["direct"] = {"value": round(wd.units * sd / dt_d / 1e6, 1), "unit": "Msamples/s",
+                             "kernel_ms": round(kern_d, 4),
+                             "hbm_frac": round(wd.alg_bytes / (kern_d * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             "valu_frac_of_157.3TF": round(4.0 * K_TAPS * wd.n / (kern_d * 1e-3) / 157.3e12, 4)}
         if not args.no_cpu:
-            out["cpu_baseline"] = cpu_baseline(h)
+            out["cpu_baseline"] = w.cpu_baseline()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
