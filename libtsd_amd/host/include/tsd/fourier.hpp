@@ -74,5 +74,12 @@ std::tuple<Vecf, Veccf> xcorrb(const Veccf &x, const Veccf &y = Veccf(), entier 
 std::tuple<Vecf, Veccf> xcorr(const Veccf &x, const Veccf &y = Veccf(), entier m = -1);
 // rééchan_freq (fourier.cc:1391-1419): resampling by zero-padding / truncating the spectrum
 Vecf rééchan_freq(const Vecf &x, float lom);
+// délais (fourier.cc:607-698): integer delays shift (zero fill); fractional ones modulate the
+// spectrum of the vector zero-padded to twice its length
+template <typename T> Vecteur<T> délais(const Vecteur<T> &x, float τ);
+// estimation_délais / aligne_entier (estimation-delais.cc:21-170): peak of the normalised biased
+// cross-correlation with quadratic interpolation -> (delay, score); integer alignment of two vectors
+std::tuple<float, float> estimation_délais(const Veccf &x, const Veccf &y);
+template <typename T> std::tuple<Vecteur<T>, Vecteur<T>, entier, float> aligne_entier(const Vecteur<T> &x, const Vecteur<T> &y);
 
 }  // namespace tsd::fourier

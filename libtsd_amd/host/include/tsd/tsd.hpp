@@ -20,6 +20,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <tuple>
 #include <vector>
 
 namespace tsd {
@@ -349,6 +350,19 @@ Vecf randn(entier n);
 Veccf randcn(entier n);
 // prochaine_puissance_de_2 (core/src/tsd.cc:287-291), float-log based like the reference
 entier prochaine_puissance_de_2(entier i);
+
+// pad_zeros (core/include/tsd/tsd.hpp:514-533): both vectors zero-padded at the end to the
+// larger of the two dimensions (rounded up to a power of two when p2)
+template <typename T> std::tuple<Vecteur<T>, Vecteur<T>> pad_zeros(const Vecteur<T> &x, const Vecteur<T> &y, bouléen p2 = false)
+{
+  const entier n1 = x.dim(), n2 = y.dim();
+  entier n3 = std::max(n1, n2);
+  if (p2) n3 = prochaine_puissance_de_2(n3);
+  Vecteur<T> a = Vecteur<T>::zeros(n3), b = Vecteur<T>::zeros(n3);
+  a.head(n1) = x;
+  b.head(n2) = y;
+  return {a, b};
+}
 
 // ---- operator interfaces (tsd.hpp:544-579,626-668) -------------------------------------------
 template <typename C> struct Configurable {

@@ -179,4 +179,148 @@ Vecf rééchan_freq(const Vecf &x, float lom)
   return real(xi);
 }
 
+// ---- délais (fourier.cc:607-698) ----------------------------------------------------------------
+// Packed real FFT pair used by the real fractional delay (fourier.cc:130-229, "numerical recipes"
+// split): n real samples <-> n/2 complex bins, bin 0 carrying (DC, Nyquist) as (re, im).
+static Veccf rtfr_moitié(const Vecf &x)
+{
+  const entier n = x.rows(), h = n / 2;
+  Veccf z(h);
+  for (entier i = 0; i < h; i++) z(i) = cfloat(x(2 * i), x(2 * i + 1));
+  const Veccf Z = fft(z);
+  Veccf X(h);
+  for (entier i = 0; i <= h; i++) {
+    const cfloat a = Z(i == h ? 0 : i), b = std::conj(Z(i > 0 ? h - i : 0));
+    const cfloat w((float) std::cos(-(2 * π * i) / n), (float) std::sin(-(2 * π * i) / n));
+    const cfloat v = cfloat(0.25f, 0) * (a + b) - cfloat(0, 0.25f) * (a - b) * w;
+    if (i < h)
+      X(i) = v;
+    else
+      X(0).imag(v.real());
+  }
+  return X;
+}
+static Vecf irtfr_moitié(const Veccf &X)
+{
+  const entier h = X.rows(), n = 2 * h;
+  Veccf Z(h);
+  for (entier i = 0; i < h; i++) {
+    const cfloat xi = i == 0 ? cfloat(X(0).real(), 0) : X(i), xp = i == 0 ? cfloat(X(0).imag(), 0) : X(h - i);
+    const cfloat e = xi + std::conj(xp), o = (xi - std::conj(xp)) * std::polar(1.0f, (float) ((2 * π * i) / n));
+    Z(i) = e + cfloat(0, 1) * o;
+  }
+  const Veccf z = ifft(Z);
+  Vecf x(n);
+  for (entier i = 0; i < h; i++) {
+    x(2 * i) = z(i).real();
+    x(2 * i + 1) = z(i).imag();
+  }
+  return x;
+}
+static Veccf délais_frac(const Veccf &x, float τ)
+{
+  const entier n = 2 * x.rows();
+  Veccf x2 = Veccf::zeros(n);
+  x2.segment(n / 4, n / 2) = x;
+  Veccf X = fft(x2);
+  // X *= fftshift(polar(1, -2 pi i tau / n + pi tau))
+  for (entier k = 0; k < n; k++) {
+    const entier i = (k + n / 2) % n;                        // fftshift(rot)(k) = rot((k + n/2) mod n), n even
+    X(k) *= std::polar(1.0f, -2 * π_f * i * τ / n + π_f * τ);
+  }
+  return ifft(X).segment(n / 4, n / 2).clone();
+}
+static Vecf délais_frac(const Vecf &x, float τ)
+{
+  const entier n = 2 * x.rows();
+  Vecf x2 = Vecf::zeros(n);
+  x2.segment(n / 4, n / 2) = x;
+  Veccf X = rtfr_moitié(x2);
+  // the rotation is accumulated by repeated float multiplication, like the reference (:643-660)
+  cfloat rot(1.0f, 0.0f);
+  const cfloat dphi = std::polar(1.0f, (float) (-τ * 2 * π / n));
+  for (entier i = 0; i < n / 2; i++) {
+    if (i == 0)
+      X(i).real((X(i).real() * rot).real());
+    else
+      X(i) *= rot;
+    rot *= dphi;
+  }
+  X(0).imag((X(0).imag() * rot).real());
+  return irtfr_moitié(X).segment(n / 4, n / 2).clone();
+}
+template <typename T> static Vecteur<T> délais_entier(const Vecteur<T> &x, entier τ)
+{
+  if (τ == 0) return x;
+  const entier n = x.rows();
+  Vecteur<T> y = Vecteur<T>::zeros(n);
+  if (τ > 0)
+    y.tail(n - τ) = x.head(n - τ);
+  else
+    y.head(n + τ) = x.tail(n + τ);
+  return y;
+}
+template <typename T> Vecteur<T> délais(const Vecteur<T> &x, float τ)
+{
+  if (std::floor(τ) != τ) return délais_frac(x, τ);
+  return délais_entier<T>(x, (entier) τ);
+}
+template Vecf délais<float>(const Vecf &, float);
+template Veccf délais<cfloat>(const Veccf &, float);
+
+// ---- estimation_délais, aligne_entier (estimation-delais.cc:9-170) ----------------------------
+std::tuple<float, float> estimation_délais(const Veccf &x, const Veccf &y)
+{
+  auto [xp, yp] = pad_zeros(x, y);
+  const entier N = xp.rows();
+  // biased version: the unbiased one amplifies large lags
+  auto [lags, corr] = xcorrb(xp, yp);
+  double s1 = 0, s2 = 0;
+  for (entier i = 0; i < N; i++) {
+    s1 += std::norm(xp(i));
+    s2 += std::norm(yp(i));
+  }
+  const float e1 = std::sqrt((float) (s1 / N)), e2 = std::sqrt((float) (s2 / N));
+  Vecf cn = abs(corr);
+  cn /= (e1 * e2 + 1e-50f);
+  const entier index = cn.index_max();
+  const float score = cn(index);
+  float δ = 0.0f;
+  if (index > 0 && index + 1 < cn.rows()) {
+    // quadratic interpolation of the peak (estimation-delais.cc:9-14)
+    const float ym1 = cn(index - 1), yp1 = cn(index + 1);
+    δ = (yp1 - ym1) / (2 * (2 * score - yp1 - ym1));
+    δ = std::clamp(δ, -0.5f, 0.5f);
+  }
+  return {lags(index) + δ, score};
+}
+template <typename T> std::tuple<Vecteur<T>, Vecteur<T>, entier, float> aligne_entier(const Vecteur<T> &x1, const Vecteur<T> &y1)
+{
+  const Veccf x = x1.as_complex(), y = y1.as_complex();
+  auto [xp, yp] = pad_zeros(x, y, true);
+  auto [df, score] = estimation_délais(xp, yp);
+  const entier d = (entier) std::round(df);
+  Veccf xa, ya;
+  if (d == 0) {
+    xa = x.clone();
+    ya = y.clone();
+  } else if (d < 0) {
+    xa = x.tail(x.rows() + d).clone();
+    ya = y.clone();
+  } else {
+    xa = x.clone();
+    ya = y.tail(y.rows() - d).clone();
+  }
+  if (xa.rows() > ya.rows())
+    xa = xa.head(ya.rows()).clone();
+  else if (xa.rows() < ya.rows())
+    ya = ya.head(xa.rows()).clone();
+  if constexpr (est_complexe<T>())
+    return {xa, ya, d, score};
+  else
+    return {real(xa), real(ya), d, score};
+}
+template std::tuple<Vecf, Vecf, entier, float> aligne_entier<float>(const Vecf &, const Vecf &);
+template std::tuple<Veccf, Veccf, entier, float> aligne_entier<cfloat>(const Veccf &, const Veccf &);
+
 }  // namespace tsd::fourier

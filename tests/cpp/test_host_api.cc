@@ -354,6 +354,93 @@ static void test_reechan_freq()
   CHECK(u.rows() == 6 && u(2) == 2 && u(1) == 0, "surech");
 }
 
+
+// ---- délais / estimation_délais / aligne_entier (ports of core/tests/test-fourier.cc:314-472,
+// 609-635 and test-tsd.cc:189-208) -------------------------------------------------------------
+static Vecf signal_test(int n = 15 * 1024)
+{
+  Vecf x0(n);
+  Vecf fen = fenêtre("hn", n / 2);
+  const float periode = 60e6f / 100e3f;
+  for (int i = 0; i < n; i++) {
+    float w = 0.0f;
+    if (i >= n / 4 && i < n - n / 4) w = fen(i - n / 4);
+    x0(i) = w * (float) std::sin((2.0 * π * i) / periode);
+  }
+  return x0;
+}
+template <typename T> static void test_delais_fractionnaire(float d)
+{
+  Vecteur<T> x0 = signal_test().as<T>();
+  if constexpr (std::is_same<T, cfloat>::value) x0 *= std::polar(1.0f, -π_f / 4);
+  Vecteur<T> x1 = délais(x0, d);
+  const int n = x0.rows();
+  CHECK(x1.rows() == n, "rows");
+  const int di = (int) d;                                         // segment lengths truncate like the reference
+  float em = 0;
+  if (d >= 0)
+    for (int i = 0; i < n - di; i++) em = std::max(em, (float) std::abs(x1(di + i) - x0(i)));
+  else
+    for (int i = 0; i < n + di; i++) em = std::max(em, (float) std::abs(x1(i) - x0(i - di)));
+  CHECK(em < (std::floor(d) == d ? 1e-2f : 1e-1f), "delay %g (%s): err %g", d, est_complexe<T>() ? "cfloat" : "float", em);
+  if (std::floor(d) != d && d > 0) {
+    // sharper than the reference's bound: two half delays compose into the whole one, and the
+    // real and complex code paths (packed real FFT vs full FFT) agree
+    Vecteur<T> h2 = délais(délais(x0, d / 2), d / 2);
+    h2 -= x1;
+    CHECK(maxabs(abs(h2)) < 2e-3f, "delay %g: d/2 twice differs from d by %g", d, maxabs(abs(h2)));
+    if constexpr (!est_complexe<T>()) {
+      Vecf xr = real(délais(x0.as_complex(), d));
+      xr -= x1;
+      CHECK(maxabs(xr) < 2e-3f, "delay %g: real path differs from complex path by %g", d, maxabs(xr));
+    }
+  }
+}
+static void test_delais_unitaire(float vrai, int N)
+{
+  Veccf x0 = signal_test(N).as<cfloat>();
+  Veccf x1 = délais(x0, vrai);
+  x0 *= cfloat(7, 0);                                             // the score must not depend on the norms
+  x1 *= cfloat(4, 0);
+  auto [d, score] = estimation_délais(x0, x1);
+  const float tol_pos = N == 32 ? 0.1f : 0.02f;
+  CHECK(std::abs(d - vrai) < tol_pos, "N=%d delay %g estimated %g", N, vrai, d);
+  CHECK(std::abs(score - 1) < 0.4f, "N=%d delay %g score %g", N, vrai, score);
+}
+static void test_align_entier()
+{
+  for (int dref = -50; dref <= 50; dref += 25) {
+    Vecf x = signal_test();
+    const int n = x.rows();
+    Vecf y = Vecf::zeros(n);
+    if (dref >= 0)
+      y.tail(n - dref) = x.head(n - dref);
+    else
+      y.head(n + dref) = x.tail(n + dref);
+    auto [x2, y2, d, s] = aligne_entier(x, y);
+    CHECK(x2.rows() == y2.rows(), "aligne_entier rows");
+    Vecf e = x2.clone();
+    e -= y2;
+    CHECK(d == dref, "aligne_entier d=%d expected %d", d, dref);
+    CHECK(std::abs(s - 1) < 1e-3f, "aligne_entier score %g", s);
+    CHECK(maxabs(e) < 1e-3f, "aligne_entier err %g", maxabs(e));
+  }
+  // complex instantiation, unequal lengths
+  Veccf xc = signal_test(4096).as<cfloat>();
+  xc *= std::polar(1.0f, 0.3f);
+  Veccf yc = délais(xc, 17.f).head(4000).clone();
+  auto [xa, ya, d, s] = aligne_entier(xc, yc);
+  CHECK(d == 17 && xa.rows() == ya.rows() && xa.rows() == 4000 - 17, "aligne_entier<cfloat> d=%d rows=%d", d, xa.rows());
+}
+static void test_pad_zeros()
+{
+  Vecf x1 = linspace(0, 4, 5), x2 = linspace(0, 3, 4);
+  auto [a, b] = pad_zeros(x1, x2);
+  CHECK(a.rows() == 5 && b.rows() == 5 && b(3) == 3 && b(4) == 0 && a(4) == 4, "pad_zeros");
+  auto [a2, b2] = pad_zeros(x1, x2, true);
+  CHECK(a2.rows() == 8 && b2.rows() == 8 && a2(4) == 4 && a2(5) == 0 && b2(3) == 3 && b2(4) == 0, "pad_zeros p2");
+}
+
 int main(int argc, char **argv)
 {
   if (argc > 1 && !std::strcmp(argv[1], "--no-gpu")) {
@@ -379,6 +466,17 @@ int main(int argc, char **argv)
   test_xcorr(true);
   test_xcorr(false);
   test_reechan_freq();
+  test_pad_zeros();
+  for (float f : {0.f, 250.f, 1.f, 10.f, -10.f, 0.5f, 0.1f, 1.5f}) {
+    test_delais_fractionnaire<cfloat>(f);
+    test_delais_fractionnaire<float>(f);
+  }
+  for (int N : {32, 1024, 15 * 1024})
+    for (float f : {0.f, 1.f, 10.f, 20.f, 30.f, 40.f, -50.f, 11.f, 1.1f}) {
+      if (N == 32) continue;                    // the reference skips (N = 32, test signal) too (test-fourier.cc:724-727)
+      test_delais_unitaire(f, N);
+    }
+  test_align_entier();
   printf(nfail ? "FAILED (%d)\n" : "ALL C++ HOST TESTS OK\n", nfail);
   return nfail ? 1 : 0;
 }

@@ -2,7 +2,8 @@
 with libtsd_amd.sharding (the code bench.py runs over RCCL), and each rank filters its chunk
 with the oracle seeded by the received halo.  The concatenation must equal the one-process
 result (to an ulp: the oracle's two-segment circular sum is split at a different index when
-the delay line is re-seeded, which moves the last bit; the resampler is exactly equal)."""
+the delay line is re-seeded, which moves the last bit; the resampler is exactly equal; the
+SOS chain is warmed on a 256-sample halo, after which its state transition is below 1e-9)."""
 import os
 import sys
 
@@ -47,14 +48,27 @@ def _worker(rank, world, port, n, K, q):
         pre = x[:lo]          # the oracle has no seek: replay the prefix (CPU test only)
         r.step(pre)
     yr = r.step(mine)
+    # --- SOS chain: warm-up halo of W samples (W given: the library computes it per filter)
+    W = 256
+    xr = x.real.copy()
+    mine_r = xr[lo:hi]
+    tailw = torch.from_numpy(mine_r[-W:].copy())
+    halow = torch.zeros(W)
+    sharding.exchange_left_halo(tailw, halow, rank, world)
+    z, p, mn, md = orc.design_butter_lp(12, 0.25)
+    sc = orc.SosChain(z, p, mn, md)
+    if rank > 0:
+        assert np.array_equal(halow.numpy(), xr[lo - W:lo])
+        sc.step(halow.numpy())
+    ys = sc.step(mine_r)
     t = sharding.max_over_ranks(float(rank), torch.device("cpu"), world)
-    q.put((rank, y, yr, t))
+    q.put((rank, y, yr, t, ys))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world", [2, 3])
-def test_sharded_fir_and_resampler_match_single_process(orc, world):
+def test_sharded_fir_resampler_sos_match_single_process(orc, world):
     n, K = 30000, 127
     port = 29600 + world
     ctx = mp.get_context("spawn")
@@ -74,3 +88,6 @@ def test_sharded_fir_and_resampler_match_single_process(orc, world):
     yfull = orc.Resampler(np.float32(160.0) / np.float32(147.0)).step(x)
     assert np.array_equal(np.concatenate([r[2] for r in res]), yfull)
     assert all(r[3] == world - 1 for r in res)
+    z, p, mn, md = orc.design_butter_lp(12, 0.25)
+    ysref = orc.SosChain(z, p, mn, md).step(x.real.copy())
+    assert np.abs(np.concatenate([r[4] for r in res]) - ysref).max() <= 1e-6 * np.abs(ysref).max()

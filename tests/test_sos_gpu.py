@@ -146,3 +146,20 @@ def test_cfg4_full_size(tg, orc):
     y2 = g.step(xd * 0.5)
     torch.cuda.synchronize()
     assert float((y2 - 0.5 * yd).abs().max()) <= 1e-5 * float(yd.abs().max())
+
+
+# Multi-GPU sharding rule of SURVEY 8e as bench.py --workload sos applies it: a shard that does
+# not start the stream is warmed on the last `halo` samples of its left neighbour (output
+# discarded); `halo` is the library's bound for ||Phi^halo|| <= 1e-9, so the shard's output
+# equals the one-pass result.
+@pytest.mark.parametrize("cplx", [False, True])
+def test_sos_shard_warmup_halo(tg, orc, cplx):
+    n, cut = 200000, 77777
+    ref, g = chains(orc, tg, 12, 0.25, cplx)
+    x = rand(n, cplx, 21)
+    yref = ref.step(x)
+    W = int(g.halo)
+    assert 0 < W < cut
+    g.step(x[cut - W:cut])                      # warm-up: state after the halo, output dropped
+    y1 = g.step(x[cut:])
+    assert relerr(y1, yref[cut:]) <= TOL
