@@ -74,6 +74,23 @@ std::tuple<Vecf, Veccf> xcorrb(const Veccf &x, const Veccf &y = Veccf(), entier 
 std::tuple<Vecf, Veccf> xcorr(const Veccf &x, const Veccf &y = Veccf(), entier m = -1);
 // rééchan_freq (fourier.cc:1391-1419): resampling by zero-padding / truncating the spectrum
 Vecf rééchan_freq(const Vecf &x, float lom);
+// filtre_fft (fourier.cc:737-940; include/tsd/fourier.hpp:304-366): frequency-domain block
+// processing by overlap-add with a user callback on every spectrum.  Returns the filter and
+// the FFT size N.  Blocks of Ne = dim_blocs_temporel inputs (512 if <= 0), N = pp2(Ne +
+// nb_zeros_min); with avec_fenetrage the blocks overlap by 1/2 under a Hann window (and the
+// output is then Ne/2 samples late: the first half block is dropped).
+// MI355X mapping: the FFTs of ALL the blocks a step() call completes run as one batched GPU
+// transform each way; the callback (host code) sees the spectra one by one, in order.
+struct FiltreFFTConfig {
+  entier dim_blocs_temporel = 0;
+  entier nb_zeros_min = 0;
+  bouléen avec_fenetrage = false;
+  fonction<void(Veccf &)> traitement_freq;
+};
+std::tuple<sptr<Filtre<cfloat, cfloat, FiltreFFTConfig>>, entier> filtre_fft(const FiltreFFTConfig &config);
+// cost model of the OLA engine (fourier.cc:700-735): flops per input sample, FFT size, zeros
+void ola_complexité(entier M, entier Ne, float &C, entier &Nf, entier &Nz);
+void ola_complexité_optimise(entier M, float &C, entier &Nf, entier &Nz, entier &Ne);
 // délais (fourier.cc:607-698): integer delays shift (zero fill); fractional ones modulate the
 // spectrum of the vector zero-padded to twice its length
 template <typename T> Vecteur<T> délais(const Vecteur<T> &x, float τ);

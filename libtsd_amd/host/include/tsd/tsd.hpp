@@ -404,6 +404,19 @@ template <typename Te, typename Ts = Te, typename Tc = Void> struct Filtre : Con
   virtual ~Filtre() {}
 };
 
+// data sinks (core/include/tsd/tsd.hpp:584-599) and the re-blocking buffer tampon_création
+// (core/src/tsd.cc:307-381): calls `callback` with consecutive blocks of exactly N samples,
+// whatever the sizes of the vectors handed to step()
+template <typename Te> struct SinkGen {
+  virtual ~SinkGen() {}
+  virtual void step(const Vecteur<Te> &x) = 0;
+};
+template <typename Te, typename Tc = Void> struct Sink : Configurable<Tc>, SinkGen<Te> {
+  virtual ~Sink() {}
+};
+template <typename T> sptr<Sink<T, entier>> tampon_création(entier N, fonction<void(const Vecteur<T> &)> callback);
+
+
 namespace filtrage {
 template <typename T> sptr<Filtre<T, T, float>> filtre_reechan(float ratio);
 }

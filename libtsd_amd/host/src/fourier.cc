@@ -1,5 +1,7 @@
 // fourier.cc -- FFTPlan on the MI355X C ABI, the fftplan_defaut hook and the real-FFT plan.
 #include "tsd/fourier.hpp"
+#include "tsd/filtrage.hpp"
+#include <vector>
 #include "../../../include/tsdgpu.h"
 
 namespace tsd::fourier {
@@ -323,4 +325,186 @@ template <typename T> std::tuple<Vecteur<T>, Vecteur<T>, entier, float> aligne_e
 template std::tuple<Vecf, Vecf, entier, float> aligne_entier<float>(const Vecf &, const Vecf &);
 template std::tuple<Veccf, Veccf, entier, float> aligne_entier<cfloat>(const Veccf &, const Veccf &);
 
+// ---- filtre_fft: the OLA engine with a spectral callback (fourier.cc:700-940) ------------------
+void ola_complexité(entier M, entier Ne, float &C, entier &Nf, entier &Nz)
+{
+  Nf = prochaine_puissance_de_2(Ne + M - 1);
+  Nz = Nf - Ne;
+  C = (1.0f / Ne) * 2 * 5 * Nf * std::log(1.0f * Nf) / std::log(2.0f);
+}
+void ola_complexité_optimise(entier M, float &C_, entier &Nf_, entier &Nz_, entier &Ne_)
+{
+  const entier kmin = (entier) std::ceil(std::log(M) / std::log(2));       // Nf must be at least M
+  for (entier k = kmin; k < kmin + 20 && k < 31; k++) {
+    entier Nf, Nz, Ne = (1 << k) - (M - 1);
+    float C;
+    ola_complexité(M, Ne, C, Nf, Nz);
+    if (k == kmin || C < C_) {
+      Nf_ = Nf;
+      Nz_ = Nf - Ne;
+      Ne_ = Ne;
+      C_ = C;
+    }
+  }
+}
+
+namespace {
+
+struct OLAGpu : Filtre<cfloat, cfloat, FiltreFFTConfig> {
+  entier N = 0, Nz = 0, Ne = 0;
+  int64_t cnt_ech = 0;
+  Veccf svg, last, prev_half, reste;     // OLA carry, windowed-mode accumulator, last half block, pending inputs
+  Vecf fen;
+  tsdgpu_fft *plan = nullptr;
+  ~OLAGpu() override { tsdgpu_fft_destroy(plan); }
+
+  void configure_impl(const FiltreFFTConfig &c) override
+  {
+    if (!c.traitement_freq) échec("configuration OLA : traitement fréquentiel non précisé.");
+    Ne = c.dim_blocs_temporel > 0 ? c.dim_blocs_temporel : 512;
+    N = prochaine_puissance_de_2(Ne + c.nb_zeros_min);
+    Nz = N - Ne;
+    if (Nz > Ne) échec("filtre_fft: Nz = {} zeros exceed the block size Ne = {} (the overlap is carried in one block)", Nz, Ne);
+    if (c.avec_fenetrage && (Ne & 1)) échec("filtre_fft: the windowed mode needs an even block size (Ne = {})", Ne);
+    cnt_ech = -(Ne / 2);
+    svg = Veccf::zeros(Ne);
+    last = Veccf::zeros(Ne);
+    prev_half = Veccf::zeros(Ne / 2);
+    reste = Veccf();
+    if (c.avec_fenetrage) fen = tsd::filtrage::fenêtre("hn", Ne, false);
+    tsdgpu_fft_destroy(plan);
+    plan = nullptr;
+    if (tsdgpu_fft_create(&plan, N, 1)) échec("filtre_fft: {}", tsdgpu_last_error());
+  }
+
+  void batch_fft(Veccf &buf, entier count, bool avant)
+  {
+    if (count > 0 && tsdgpu_fft_step(plan, buf.data(), buf.data(), count, avant ? 1 : 0, nullptr))
+      échec("filtre_fft: {}", tsdgpu_last_error());
+  }
+
+  void step(const Veccf &x, Veccf &y) override
+  {
+    const FiltreFFTConfig &c = Configurable<FiltreFFTConfig>::config;
+    if (Ne <= 0) échec("filtre_fft: not configured");
+    // re-blocking (tampon_création semantics): whole blocks of Ne are processed, the rest waits
+    const Veccf all = reste.rows() ? vconcat(reste, x) : x;
+    const entier B = all.rows() / Ne;
+    reste = all.tail(all.rows() - B * Ne).clone();
+    const entier per = c.avec_fenetrage ? 2 : 1;                 // frames per block
+    Veccf frames = Veccf::zeros(B * per * N);
+    for (entier b = 0; b < B; b++) {
+      const Veccf xb = all.segment(b * Ne, Ne);
+      if (!c.avec_fenetrage) {
+        frames.segment(b * N + Nz, Ne) = xb;                      // zeros first, the block last (:850)
+      } else {
+        // frame 1 = window * [second half of the previous block, first half of this one] (:885-886),
+        // frame 2 = window * this block (:910)
+        Veccf f1 = frames.segment((2 * b) * N + Nz, Ne), f2 = frames.segment((2 * b + 1) * N + Nz, Ne);
+        for (entier i = 0; i < Ne / 2; i++) {
+          f1(i) = prev_half(i) * fen(i);
+          f1(Ne / 2 + i) = xb(i) * fen(Ne / 2 + i);
+        }
+        for (entier i = 0; i < Ne; i++) f2(i) = xb(i) * fen(i);
+        prev_half = xb.tail(Ne / 2).clone();
+      }
+    }
+    batch_fft(frames, B * per, true);
+    for (entier f = 0; f < B * per; f++) {
+      Veccf X = frames.segment(f * N, N);                         // a view: the callback edits the batch in place
+      c.traitement_freq(X);
+      if (X.rows() != N || X.data() != frames.data() + (size_t) f * N)
+        échec("filtre_fft: traitement_freq must process the spectrum in place (dimension {})", N);
+    }
+    batch_fft(frames, B * per, false);
+    // sequential overlap-add over the blocks
+    std::vector<Veccf> out;
+    entier nout = 0;
+    for (entier b = 0; b < B; b++) {
+      if (!c.avec_fenetrage) {
+        const Veccf x2 = frames.segment(b * N, N);
+        for (entier i = 0; i < Nz; i++) svg(Ne - Nz + i) += x2(i);
+        out.push_back(svg.clone());
+        svg = x2.tail(Ne).clone();
+        cnt_ech += Ne;
+      } else {
+        const Veccf xa = frames.segment((2 * b) * N, N), xb2 = frames.segment((2 * b + 1) * N, N);
+        const entier h = Ne / 2;
+        for (entier i = 0; i < Nz; i++) svg(Ne - Nz + i) += xa(i);
+        for (entier i = 0; i < h; i++) last(h + i) += svg(i) / 2.0f;
+        out.push_back(cnt_ech >= 0 ? last.clone() : Veccf());
+        for (entier i = 0; i < h; i++) {
+          last(i) = svg(h + i) / 2.0f;
+          last(h + i) = 0;
+        }
+        svg = xa.tail(Ne).clone();
+        cnt_ech += h;
+        for (entier i = 0; i < Nz; i++) svg(Ne - Nz + i) += xb2(i);
+        for (entier i = 0; i < Ne; i++) last(i) += svg(i) / 2.0f;
+        svg = xb2.tail(Ne).clone();
+        cnt_ech += h;
+      }
+      nout += out.back().rows();
+    }
+    y.resize(nout);
+    entier k = 0;
+    for (const Veccf &o : out) {
+      for (entier i = 0; i < o.rows(); i++) y(k + i) = o(i);
+      k += o.rows();
+    }
+  }
+};
+
+}  // namespace
+
+std::tuple<sptr<Filtre<cfloat, cfloat, FiltreFFTConfig>>, entier> filtre_fft(const FiltreFFTConfig &config)
+{
+  auto res = std::make_shared<OLAGpu>();
+  res->configure(config);
+  return {res, res->N};
+}
+
 }  // namespace tsd::fourier
+
+// ---- tampon_création (core/src/tsd.cc:307-381) ----------------------------------------------------
+namespace tsd {
+namespace {
+template <typename T> struct TamponBlocs : Sink<T, entier> {
+  entier N = 0, rempli = 0;
+  fonction<void(const Vecteur<T> &)> callback;
+  Vecteur<T> bloc;
+  TamponBlocs(entier N_, fonction<void(const Vecteur<T> &)> cb) : callback(std::move(cb)) { Configurable<entier>::configure(N_); }
+  void configure_impl(const entier &N_) override
+  {
+    N = N_;
+    rempli = 0;
+  }
+  void step(const Vecteur<T> &x) override
+  {
+    if (rempli == 0 && x.rows() == N) {                     // a ready-made block goes straight through
+      if (callback) callback(x);
+      return;
+    }
+    if (bloc.rows() == 0 && N > 0) bloc.resize(N);
+    entier i = 0;
+    const entier n = x.rows();
+    while (i < n) {
+      const entier k = std::min(N - rempli, n - i);
+      bloc.segment(rempli, k) = x.segment(i, k);
+      i += k;
+      rempli += k;
+      if (rempli == N) {
+        if (callback) callback(bloc);
+        rempli = 0;
+      }
+    }
+  }
+};
+}  // namespace
+template <typename T> sptr<Sink<T, entier>> tampon_création(entier N, fonction<void(const Vecteur<T> &)> callback)
+{
+  return std::make_shared<TamponBlocs<T>>(N, std::move(callback));
+}
+template sptr<Sink<float, entier>> tampon_création<float>(entier, fonction<void(const Vecf &)>);
+template sptr<Sink<cfloat, entier>> tampon_création<cfloat>(entier, fonction<void(const Veccf &)>);
+}  // namespace tsd

@@ -441,6 +441,115 @@ static void test_pad_zeros()
   CHECK(a2.rows() == 8 && b2.rows() == 8 && a2(4) == 4 && a2(5) == 0 && b2(3) == 3 && b2(4) == 0, "pad_zeros p2");
 }
 
+
+// ---- tampon_création (port of core/tests/test-tsd.cc:479-497) and filtre_fft ---------------------
+static void test_tampon()
+{
+  int cnt = 0;
+  const int n = 16 * 512;
+  Vecf X = randn(n);
+  auto t = tampon_création<float>(512, [&](const Vecf &x) {
+    CHECK(x.rows() == 512, "tampon block size %d", x.rows());
+    Vecf e = x.clone();
+    e -= X.segment(cnt, 512);
+    CHECK(maxabs(e) == 0, "tampon block content");
+    cnt += 512;
+  });
+  t->step(X.head(100));
+  t->step(X.segment(100, 1000));
+  t->step(X.tail(n - 100 - 1000));
+  CHECK(cnt == n, "tampon delivered %d of %d", cnt, n);
+}
+// The reference's own test of filtre_fft only plots (core/tests/test-filtre-fft.cc): the checks
+// below are the properties its algorithm implies (fourier.cc:837-932) -- "parity unpinned".
+static void test_filtre_fft()
+{
+  // (1) no window, no zeros, identity processing: the blocks come back unchanged, one block late
+  //     (a block is delivered when the next one has been overlapped onto it, fourier.cc:870-872)
+  {
+    FiltreFFTConfig c;
+    c.dim_blocs_temporel = 512;
+    c.traitement_freq = [](Veccf &) {};
+    auto [ola, N] = filtre_fft(c);
+    CHECK(N == 512, "N=%d", N);
+    Veccf x = randcn(4096 + 100);
+    Veccf y = ola->step(x.head(700));                        // 1 block out, 188 samples wait
+    Veccf y2 = ola->step(x.tail(x.rows() - 700));
+    CHECK(y.rows() == 512 && y2.rows() == 4096 - 512, "rows %d %d", y.rows(), y2.rows());
+    Veccf all = vconcat(y, y2);
+    CHECK(maxabs(abs(all.head(512))) == 0, "the first delivered block is the (zero) initial carry");
+    Veccf e = all.tail(4096 - 512).clone();
+    e -= x.head(4096 - 512);
+    CHECK(maxabs(abs(e)) < 1e-5f, "identity OLA err %g", maxabs(abs(e)));
+  }
+  // (2) FIR by spectral product, H = fft(h placed at the tail) * sqrt(N) as FiltreFFTRIF builds it
+  //     (fourier.cc:946-978): the direct convolution delayed by Ne - M samples
+  {
+    const int M = 127, Ne = 512;
+    Vecf h = design_rif_fen(M, "lp", 0.02f);
+    FiltreFFTConfig c;
+    c.dim_blocs_temporel = Ne;
+    c.nb_zeros_min = M;
+    Veccf H;
+    int calls = 0;
+    c.traitement_freq = [&](Veccf &X) {
+      X *= H;
+      calls++;
+    };
+    auto [ola, N] = filtre_fft(c);
+    CHECK(N == 1024, "N=%d", N);
+    Veccf h2 = Veccf::zeros(N);
+    h2.tail(M) = h.as_complex();
+    H = fft(h2);
+    H *= cfloat(std::sqrt((float) N), 0);
+    const int n = 8 * Ne;
+    Veccf x = randcn(n);
+    Veccf y = ola->step(x);
+    CHECK(y.rows() == n && calls == 8, "rows %d calls %d", y.rows(), calls);
+    float err = 0, ref_max = 0;
+    const int d = Ne - M;
+    for (int i = 0; i < n; i++) {
+      cfloat acc = 0;
+      for (int m = 0; m < M; m++) {
+        const int j = i - d - m;
+        if (j >= 0) acc += h(m) * x(j);
+      }
+      err = std::max(err, (float) std::abs(acc - y(i)));
+      ref_max = std::max(ref_max, (float) std::abs(acc));
+    }
+    CHECK(err <= 1e-5f * std::max(ref_max, 1.0f), "OLA FIR err %g (max %g)", err, ref_max);
+  }
+  // (3) Hann window, 1/2 overlap, identity processing: half the input, Ne/2 late, first block dropped
+  {
+    const int Ne = 256;
+    FiltreFFTConfig c;
+    c.dim_blocs_temporel = Ne;
+    c.avec_fenetrage = true;
+    c.traitement_freq = [](Veccf &) {};
+    auto [ola, N] = filtre_fft(c);
+    const int n = 10 * Ne;
+    Veccf x = randcn(n);
+    Veccf ya = ola->step(x.head(3 * Ne + 17)), yb = ola->step(x.tail(n - 3 * Ne - 17));
+    Veccf y = vconcat(ya, yb);
+    CHECK(N == Ne && y.rows() == n - Ne, "windowed rows %d N %d", y.rows(), N);
+    float err = 0;
+    for (int k = 0; k < y.rows(); k++) {
+      const cfloat ref = k >= Ne / 2 ? x(k - Ne / 2) * 0.5f : cfloat(0);
+      err = std::max(err, (float) std::abs(y(k) - ref));
+    }
+    CHECK(err < 1e-5f, "windowed OLA err %g", err);
+  }
+  // (4) configuration errors and the cost model (test-fourier.cc:737-741 calls it for M = 127... values from the formula)
+  {
+    bool threw = false;
+    try { FiltreFFTConfig c; c.dim_blocs_temporel = 64; filtre_fft(c); } catch (const std::runtime_error &) { threw = true; }
+    CHECK(threw, "filtre_fft without traitement_freq must fail");
+    float C; entier Nf, Nz, Ne;
+    ola_complexité_optimise(127, C, Nf, Nz, Ne);
+    CHECK(Nf == Ne + Nz && Nz == 126 && (Nf & (Nf - 1)) == 0 && C > 0, "ola_complexité_optimise Nf=%d Nz=%d Ne=%d C=%g", Nf, Nz, Ne, C);
+  }
+}
+
 int main(int argc, char **argv)
 {
   if (argc > 1 && !std::strcmp(argv[1], "--no-gpu")) {
@@ -477,6 +586,8 @@ int main(int argc, char **argv)
       test_delais_unitaire(f, N);
     }
   test_align_entier();
+  test_tampon();
+  test_filtre_fft();
   printf(nfail ? "FAILED (%d)\n" : "ALL C++ HOST TESTS OK\n", nfail);
   return nfail ? 1 : 0;
 }
