@@ -91,6 +91,13 @@ std::tuple<sptr<Filtre<cfloat, cfloat, FiltreFFTConfig>>, entier> filtre_fft(con
 // cost model of the OLA engine (fourier.cc:700-735): flops per input sample, FFT size, zeros
 void ola_complexité(entier M, entier Ne, float &C, entier &Nf, entier &Nz);
 void ola_complexité_optimise(entier M, float &C, entier &Nf, entier &Nz, entier &Ne);
+// spectral estimates (include/tsd/fourier.hpp:700-760, freqestim.cc:7-93): Hann-windowed
+// periodogram in dB, and Welch's average over half-overlapping segments of N samples (all the
+// segments of a call are transformed by ONE batched GPU FFT)
+Vecf tfd_freqs(entier n, bouléen avec_shift = true);
+Vecf psd_freqs(entier n, bouléen complexe = true);
+template <typename T> std::tuple<Vecf, Vecf> psd(const Vecteur<T> &x);
+std::tuple<Vecf, Vecf> psd_welch(const Veccf &x, entier N, cstring fen = "hn");
 // délais (fourier.cc:607-698): integer delays shift (zero fill); fractional ones modulate the
 // spectrum of the vector zero-padded to twice its length
 template <typename T> Vecteur<T> délais(const Vecteur<T> &x, float τ);

@@ -301,6 +301,19 @@ template <typename T> Vecteur<float> abs(const Vecteur<T> &x)
   for (entier i = 0; i < x.rows(); i++) y.data()[i] = std::abs(x.data()[i]);
   return y;
 }
+// |x|^2 element-wise and power -> dB (core/include/tsd/tsd.hpp:414-421, tableau.hpp abs2)
+template <typename T> Vecteur<float> abs2(const Vecteur<T> &x)
+{
+  Vecteur<float> y(x.rows());
+  for (entier i = 0; i < x.rows(); i++) y(i) = std::norm(x.data()[i]);
+  return y;
+}
+inline Vecf pow2db(const Vecf &x)
+{
+  Vecf y(x.rows());
+  for (entier i = 0; i < x.rows(); i++) y(i) = 10 * std::log10(x(i));
+  return y;
+}
 inline Vecf real(const Veccf &x) { return Vecf::int_expr(x.rows(), [&](entier i) { return x.data()[i].real(); }); }
 inline Vecf imag(const Veccf &x) { return Vecf::int_expr(x.rows(), [&](entier i) { return x.data()[i].imag(); }); }
 template <typename T> Vecteur<T> vconcat(const Vecteur<T> &a, const Vecteur<T> &b)

@@ -325,6 +325,74 @@ template <typename T> std::tuple<Vecteur<T>, Vecteur<T>, entier, float> aligne_e
 template std::tuple<Vecf, Vecf, entier, float> aligne_entier<float>(const Vecf &, const Vecf &);
 template std::tuple<Veccf, Veccf, entier, float> aligne_entier<cfloat>(const Veccf &, const Veccf &);
 
+// ---- psd, psd_welch and their frequency axes (fourier.hpp:739-757; freqestim.cc:7-93) ----------
+Vecf tfd_freqs(entier n, bouléen avec_shift)
+{
+  const bool pair = (n & 1) == 0;
+  if (avec_shift) return pair ? linspace(-0.5f, 0.5f - 1.0f / n, n) : linspace(-0.5f + 1.0f / n, 0.5f, n);
+  Vecf f(n);
+  if (pair) {
+    f.head(n / 2) = linspace(0, 0.5f - 1.0f / n, n / 2);
+    f.tail(n / 2) = linspace(-0.5f, -1.0f / n, n / 2);
+  } else {
+    f.head(n / 2 + 1) = linspace(0, 0.5f - 0.5f / n, n / 2 + 1);
+    f.tail(n / 2) = linspace(-0.5f, -1.0f / n, n / 2);
+  }
+  return f;
+}
+Vecf psd_freqs(entier n, bouléen complexe)
+{
+  const bool pair = (n & 1) == 0;
+  if (complexe) {
+    double t0 = -0.5, t1 = 0.5;
+    if (pair)
+      t1 -= 1.0 / n;
+    else
+      t0 += 1.0 / n;
+    return linspace((float) t0, (float) t1, n);
+  }
+  double t1 = 0.5;
+  if (!pair) t1 -= 1.0 / n;
+  return linspace(0.0f, (float) t1, n / 2);
+}
+template <typename T> std::tuple<Vecf, Vecf> psd(const Vecteur<T> &x)
+{
+  const Vecf fen = tsd::filtrage::fenêtre("hn", x.rows(), false);
+  Vecteur<T> xf = x.clone();
+  for (entier i = 0; i < x.rows(); i++) xf(i) *= fen(i);
+  if constexpr (est_complexe<T>()) {
+    return {psd_freqs(x.rows(), true), fftshift(pow2db(abs2(fft(xf))))};
+  } else {
+    const Vecf Y = pow2db(abs2(rfft(xf)));
+    return {psd_freqs(x.rows(), false), Y.head(Y.rows() / 2).clone()};
+  }
+}
+template std::tuple<Vecf, Vecf> psd<float>(const Vecf &);
+template std::tuple<Vecf, Vecf> psd<cfloat>(const Veccf &);
+
+std::tuple<Vecf, Vecf> psd_welch(const Veccf &x, entier N, cstring fen)
+{
+  if (N < 1) échec("psd_welch: N = {}", N);
+  const Vecf f = tsd::filtrage::fenêtre(fen, N, false);
+  // segments i = 0, N/2, N, ... while i + N < x.rows()  (freqestim.cc:13)
+  const entier pas = std::max<entier>(N / 2, 1);
+  entier nseg = 0;
+  for (entier i = 0; i + N < x.rows(); i += pas) nseg++;
+  Vecf S = Vecf::zeros(N);
+  if (nseg > 0) {
+    Veccf seg(nseg * N);
+    for (entier k = 0; k < nseg; k++)
+      for (entier j = 0; j < N; j++) seg(k * N + j) = x(k * pas + j) * f(j);
+    tsdgpu_fft *plan = nullptr;
+    if (tsdgpu_fft_create(&plan, N, nseg)) échec("psd_welch: {}", tsdgpu_last_error());
+    const int rc = tsdgpu_fft_step(plan, seg.data(), seg.data(), nseg, 1, nullptr);
+    tsdgpu_fft_destroy(plan);
+    if (rc) échec("psd_welch: {}", tsdgpu_last_error());
+    for (entier k = 0; k < nseg; k++) S += fftshift(abs2(seg.segment(k * N, N)));
+  }
+  return {psd_freqs(N), pow2db(S)};
+}
+
 // ---- filtre_fft: the OLA engine with a spectral callback (fourier.cc:700-940) ------------------
 void ola_complexité(entier M, entier Ne, float &C, entier &Nf, entier &Nz)
 {

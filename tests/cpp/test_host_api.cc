@@ -550,6 +550,46 @@ static void test_filtre_fft()
   }
 }
 
+
+// ---- psd / psd_welch (fourier.hpp:739-757, freqestim.cc:7-93) --------------------------------------
+static void test_psd()
+{
+  // axes: tfd_freqs / psd_freqs known values
+  Vecf f8 = tfd_freqs(8), f7 = tfd_freqs(7), f8n = tfd_freqs(8, false), p7 = psd_freqs(7, false);
+  CHECK(f8(0) == -0.5f && std::abs(f8(7) - 0.375f) < 1e-6f && std::abs(f7(0) + 0.5f - 1.0f / 7) < 1e-6f && f7(6) == 0.5f, "tfd_freqs");
+  CHECK(f8n(0) == 0 && std::abs(f8n(3) - 0.375f) < 1e-6f && f8n(4) == -0.5f && std::abs(f8n(7) + 0.125f) < 1e-6f, "tfd_freqs no shift");
+  CHECK(p7.rows() == 3 && p7(0) == 0 && std::abs(p7(2) - (0.5f - 1.0f / 7)) < 1e-6f, "psd_freqs real odd");
+  // complex exponential at bin 200 of 1024 (f = +0.1953): the periodogram peaks there, Hann main lobe -6 dB at +-1 bin
+  const int n = 1024, k0 = 200;
+  Veccf x(n);
+  for (int i = 0; i < n; i++) x(i) = std::polar(1.0f, (float) (2 * π * k0 * i / n));
+  auto [fr, Y] = psd(x);
+  const int im = Y.index_max();
+  CHECK(im == n / 2 + k0 && std::abs(fr(im) - (float) k0 / n) < 1e-6f, "psd peak at %d (f=%g)", im, fr(im));
+  CHECK(std::abs(Y(im) - Y(im - 1) - 6.02f) < 0.05f && std::abs(Y(im) - Y(im + 1) - 6.02f) < 0.05f, "Hann lobe %g %g", Y(im) - Y(im - 1), Y(im) - Y(im + 1));
+  // unitary FFT of a Hann-weighted unit exponential: |X|^2 = (sum w)^2 / n = n / 4  ->  10 log10(256)
+  CHECK(std::abs(Y(im) - 10 * std::log10(n / 4.0f)) < 0.01f, "psd level %g", Y(im));
+  // real input: half spectrum, peak at the same bin
+  Vecf xr = real(x);
+  auto [frr, Yr] = psd(xr);
+  CHECK(Yr.rows() == n / 2 && Yr.index_max() == k0 && std::abs(frr(k0) - (float) k0 / n) < 1e-3f, "psd real peak %d", Yr.index_max());
+  // Welch: equals the sum of the per-segment periodograms computed one by one through fft()
+  const int N = 256;
+  Veccf z = randcn(5 * N + 77);
+  auto [fw, W] = psd_welch(z, N);
+  Vecf S = Vecf::zeros(N), w = fenêtre("hn", N, false);
+  int nseg = 0;
+  for (int i = 0; i + N < z.rows(); i += N / 2) {
+    Veccf xp = z.segment(i, N).clone();
+    for (int j = 0; j < N; j++) xp(j) *= w(j);
+    S += fftshift(abs2(fft(xp)));
+    nseg++;
+  }
+  Vecf e = pow2db(S);
+  e -= W;
+  CHECK(nseg == 9 && fw.rows() == N && maxabs(e) < 1e-3f, "psd_welch: %d segments, err %g dB", nseg, maxabs(e));
+}
+
 int main(int argc, char **argv)
 {
   if (argc > 1 && !std::strcmp(argv[1], "--no-gpu")) {
@@ -588,6 +628,7 @@ int main(int argc, char **argv)
   test_align_entier();
   test_tampon();
   test_filtre_fft();
+  test_psd();
   printf(nfail ? "FAILED (%d)\n" : "ALL C++ HOST TESTS OK\n", nfail);
   return nfail ? 1 : 0;
 }
