@@ -49,5 +49,26 @@ template <typename T> Veccf ifft(const Vector<T> &X) { return tsd::fourier::ifft
 inline Veccf rfft(const Vecf &x) { return tsd::fourier::rfft(x); }
 template <typename T> Vector<T> fftshift(const Vector<T> &X) { return tsd::fourier::fftshift(X); }
 template <typename T> void force_csym(Vector<T> &X) { tsd::fourier::csym_forçage(X); }
+// "next" rows (dsp/fourier.hpp:140-143,251-355,397-457,488-505,623-672): same objects, English names
+inline Vecf resample_freq(const Vecf &x, float ratio) { return tsd::fourier::rééchan_freq(x, ratio); }
+struct FFTFilterConfig : tsd::fourier::FiltreFFTConfig {
+  int &time_blocks_length = dim_blocs_temporel;
+  int &minimum_zeros_count = nb_zeros_min;
+  bool &enable_windowing = avec_fenetrage;
+  std::function<void(Veccf &)> &freq_domain_processing = traitement_freq;
+};
+inline std::tuple<sptr<Filter<cfloat, cfloat, tsd::fourier::FiltreFFTConfig>>, int> filter_fft(const FFTFilterConfig &config)
+{ return tsd::fourier::filtre_fft(config); }
+inline void ola_complexity(int M, int Ne, float &C, int &Nf, int &Nz) { tsd::fourier::ola_complexité(M, Ne, C, Nf, Nz); }
+inline void ola_complexity_optimize(int M, float &C, int &Nf, int &Nz, int &Ne) { tsd::fourier::ola_complexité_optimise(M, C, Nf, Nz, Ne); }
+inline auto ccorr(const Veccf &x, const Veccf &y = Veccf()) { return tsd::fourier::ccorr(x, y); }
+inline auto xcorr(const Veccf &x, const Veccf &y = Veccf(), int m = -1) { return tsd::fourier::xcorr(x, y, m); }
+inline auto xcorrb(const Veccf &x, const Veccf &y = Veccf(), int m = -1) { return tsd::fourier::xcorrb(x, y, m); }
+template <typename T> Vector<T> delay(const Vector<T> &x, float τ) { return tsd::fourier::délais(x, τ); }
+inline std::tuple<float, float> delay_estimation(const Veccf &x, const Veccf &y) { return tsd::fourier::estimation_délais(x, y); }
+template <typename T> std::tuple<Vector<T>, Vector<T>, int, float> align_int(const Vector<T> &x, const Vector<T> &y) { return tsd::fourier::aligne_entier(x, y); }
+inline Vecf psd_freqs(int n, bool complexe = true) { return tsd::fourier::psd_freqs(n, complexe); }
+template <typename T> std::tuple<Vecf, Vecf> psd(const Vector<T> &x) { return tsd::fourier::psd(x); }
+inline std::tuple<Vecf, Vecf> psd_welch(const Veccf &x, int N, const std::string &fen = "hn") { return tsd::fourier::psd_welch(x, N, fen); }
 }  // namespace fourier
 }  // namespace dsp

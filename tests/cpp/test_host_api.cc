@@ -588,6 +588,22 @@ static void test_psd()
   Vecf e = pow2db(S);
   e -= W;
   CHECK(nseg == 9 && fw.rows() == N && maxabs(e) < 1e-3f, "psd_welch: %d segments, err %g dB", nseg, maxabs(e));
+  // dsp:: spellings of the "next" rows reach the same functions (dsp/fourier.hpp)
+  {
+    dsp::fourier::FFTFilterConfig c;
+    c.time_blocks_length = 64;
+    c.freq_domain_processing = [](dsp::Veccf &) {};
+    auto [flt, Nf] = dsp::fourier::filter_fft(c);
+    dsp::Veccf q = randcn(128);
+    CHECK(Nf == 64 && flt->step(q).rows() == 128, "dsp::fourier::filter_fft");
+    auto [lg, cr] = dsp::fourier::xcorr(q);
+    auto [dl, sc] = dsp::fourier::delay_estimation(q, dsp::fourier::delay(q, 3.f));
+    auto [qa, qb, di, si] = dsp::fourier::align_int(q, dsp::fourier::delay(q, 3.f));
+    auto [pf, pw] = dsp::fourier::psd_welch(q, 32);
+    CHECK(lg.rows() == 255 && std::abs(dl - 3) < 0.05f && di == 3 && qa.rows() == qb.rows() && pf.rows() == 32 && pw.rows() == 32,
+          "dsp::fourier aliases (delay %g/%d)", dl, di);
+    CHECK(dsp::fourier::resample_freq(real(q), 2).rows() == 256 && dsp::fourier::psd_freqs(8).rows() == 8, "dsp::fourier aliases 2");
+  }
 }
 
 int main(int argc, char **argv)
