@@ -27,7 +27,8 @@ __device__ __forceinline__ cpx cconj(cpx a) { return cmk(a.x, -a.y); }
 __device__ __forceinline__ cpx cscale(cpx a, float s) { return cmk(a.x * s, a.y * s); }
 
 constexpr int FFT_THREADS = 256;
-constexpr int LDS_MAX_N = 4096;      // largest transform done in one workgroup's LDS
+constexpr int LDS_MAX_N = 4096;      // largest transform done in one workgroup's LDS (radix-2 fallback kernel)
+constexpr int S16_MAX_N = 16384;     // largest transform of the radix-16 Stockham kernel (139 KiB of LDS)
 constexpr int COL_TILE = 16;         // columns per tile: 16 * 8 B = one 128-B line per row
 
 __device__ __forceinline__ unsigned bitrev(unsigned i, int logn) { return logn == 0 ? 0u : (__brev(i) >> (32 - logn)); }
@@ -150,6 +151,280 @@ __global__ __launch_bounds__(256) void fft1024_rows_kernel(const cpx *__restrict
     cpx o = cscale(v[r], scale);
     if (inverse) o.y = -o.y;
     y[k0 + 64 * (r >> 2) + 256 * (r & 3)] = o;
+  }
+}
+
+// ---- n = 16 .. 16384: Stockham autosort in LDS, radix 16 ---------------------------------------
+// n = R0 * 16^a with R0 in {16, 8, 4, 2}: the first pass has radix R0 and needs no twiddles,
+// every further pass is a 16-point in-register DFT (w1024::dft16).  Thread j of the n/16
+// threads of a transform owns butterfly j of every pass (Stockham indexing: pass with sub-
+// transform length Ns reads x[j + q n/16], multiplies by W_{16 Ns}^{q k}, k = j mod Ns, and writes
+// y[(j - k) 16 + k + q Ns]), so log16(n) passes replace the log2(n) of the radix-2 kernel and
+// the LDS sees each point once per pass.  The twiddle of a butterfly is ONE table value
+// (W_{16 Ns}^k) raised to q = 2..15 by a depth-4 product tree in registers.  LDS index i is
+// stored at i + i/16 (keeps the stride-16 writes of the passes conflict-free).
+// Workgroup = max(256, n/16) threads = 4096/n transforms (n < 4096) or one.  With n < 1024 a
+// wave spans several transforms, so the global accesses are staged through LDS to stay 16-B
+// coalesced; from 1024 up the first pass loads and the last pass stores straight from
+// registers (512 contiguous bytes per wave instruction).
+__device__ __forceinline__ int s16_pad(int i) { return i + (i >> 4); }
+__device__ __forceinline__ void s16_dft2(cpx &a, cpx &b)
+{
+  const cpx t = a;
+  a = cadd(t, b);
+  b = csub(t, b);
+}
+__device__ __forceinline__ void s16_dft8(cpx (&e)[8])
+{
+  constexpr float R2 = 0.70710678118654752f;
+  w1024::dft4<false>(e[0], e[2], e[4], e[6]);               // even samples -> E[0..3] in e[0],e[2],e[4],e[6]
+  w1024::dft4<false>(e[1], e[3], e[5], e[7]);               // odd samples  -> O[0..3] in e[1],e[3],e[5],e[7]
+  const cpx o0 = e[1], o1 = cmul(e[3], cmk(R2, -R2)), o2 = cmk(e[5].y, -e[5].x), o3 = cmul(e[7], cmk(-R2, -R2));
+  const cpx a0 = e[0], a1 = e[2], a2 = e[4], a3 = e[6];
+  e[0] = cadd(a0, o0); e[4] = csub(a0, o0);
+  e[1] = cadd(a1, o1); e[5] = csub(a1, o1);
+  e[2] = cadd(a2, o2); e[6] = csub(a2, o2);
+  e[3] = cadd(a3, o3); e[7] = csub(a3, o3);
+}
+template <int R0>
+__global__ __launch_bounds__(1024) void fft_s16_kernel(const cpx *__restrict__ in, cpx *__restrict__ out,
+                                                       const cpx *__restrict__ TW, int n, int tpt, int inverse,
+                                                       float scale, int ntr)
+{
+  extern __shared__ __attribute__((aligned(16))) char s16_raw[];
+  cpx *lds = reinterpret_cast<cpx *>(s16_raw);
+  const int t = threadIdx.x;
+  const int tl = t / tpt, j = t - tl * tpt;
+  const int T = blockDim.x / tpt;                          // transforms per workgroup
+  const int tr = blockIdx.x * T + tl;
+  const bool live = tr < ntr;
+  const int pn = n + (n >> 4);
+  cpx *s = lds + tl * pn;
+  const bool staged = tpt < 64;
+  const int64_t g0 = (int64_t) blockIdx.x * T * n, gend = (int64_t) ntr * n;   // this workgroup's points
+  cpx v[16];
+  if (staged) {
+    // coalesced 16-B loads of the workgroup's T*n points into the padded per-transform images
+    const int tot2 = (T * n) >> 1;
+    for (int i = t; i < tot2; i += blockDim.x) {
+      const int e = 2 * i;
+      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (g0 + e < gend) q = *reinterpret_cast<const float4 *>(in + g0 + e);
+      const int tq = e / n, eq = e - tq * n;
+      cpx *d = lds + tq * pn + s16_pad(eq);
+      d[0] = cmk(q.x, inverse ? -q.y : q.y);
+      d[1] = cmk(q.z, inverse ? -q.w : q.w);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < 16; m++) v[m] = s[s16_pad(j + m * tpt)];
+    __syncthreads();
+  } else {
+    const cpx *x = in + (size_t) (live ? tr : 0) * n;
+#pragma unroll
+    for (int m = 0; m < 16; m++) {
+      v[m] = x[j + m * tpt];
+      if (inverse) v[m].y = -v[m].y;
+    }
+  }
+  // ---- pass 0: radix R0, no twiddles
+  if (R0 == 16) {
+    w1024::dft16<false>(v);
+  } else if (R0 == 8) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      cpx e[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) e[q] = v[i + 2 * q];
+      s16_dft8(e);
+#pragma unroll
+      for (int q = 0; q < 8; q++) v[i + 2 * q] = e[q];
+    }
+  } else if (R0 == 4) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) w1024::dft4<false>(v[i], v[i + 4], v[i + 8], v[i + 12]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; i++) s16_dft2(v[i], v[i + 8]);
+  }
+  // v[i + q * (16 / R0)] = output q of butterfly jb = j + i * tpt  ->  y[jb * R0 + q]
+  if (n == R0) {                                           // n = 16: a single pass (always staged: tpt = 1)
+#pragma unroll
+    for (int q = 0; q < 16; q++) s[s16_pad(q)] = v[q];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16 / R0; i++)
+#pragma unroll
+      for (int q = 0; q < R0; q++) s[s16_pad((j + i * tpt) * R0 + q)] = v[i + q * (16 / R0)];
+    // ---- radix-16 passes
+    for (int Ns = R0;; Ns <<= 4) {
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 16; q++) v[q] = s[s16_pad(j + q * tpt)];
+      const int k = j & (Ns - 1);
+      {
+        // w^q, q = 1..15, from one table value: products of depth <= 4
+        const cpx w1 = TW[k * (tpt / Ns)];
+        const cpx w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
+        const cpx w5 = cmul(w4, w1), w6 = cmul(w4, w2), w7 = cmul(w4, w3), w8 = cmul(w4, w4);
+        v[1] = cmul(v[1], w1); v[2] = cmul(v[2], w2); v[3] = cmul(v[3], w3); v[4] = cmul(v[4], w4);
+        v[5] = cmul(v[5], w5); v[6] = cmul(v[6], w6); v[7] = cmul(v[7], w7); v[8] = cmul(v[8], w8);
+        v[9] = cmul(v[9], cmul(w8, w1)); v[10] = cmul(v[10], cmul(w8, w2)); v[11] = cmul(v[11], cmul(w8, w3));
+        v[12] = cmul(v[12], cmul(w8, w4)); v[13] = cmul(v[13], cmul(w8, w5)); v[14] = cmul(v[14], cmul(w8, w6));
+        v[15] = cmul(v[15], cmul(w8, w7));
+      }
+      w1024::dft16<false>(v);
+      const int base = (j - k) * 16 + k;
+      const bool last = Ns * 16 == n;
+      if (last && !staged) {
+        if (live) {
+          cpx *y = out + (size_t) tr * n;
+#pragma unroll
+          for (int q = 0; q < 16; q++) {
+            cpx o = cscale(v[q], scale);
+            if (inverse) o.y = -o.y;
+            y[base + q * Ns] = o;
+          }
+        }
+        return;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 16; q++) s[s16_pad(base + q * Ns)] = v[q];
+      if (last) break;
+    }
+  }
+  // staged store: coalesced 16 B per lane
+  __syncthreads();
+  const int tot2 = (T * n) >> 1;
+  for (int i = t; i < tot2; i += blockDim.x) {
+    const int e = 2 * i;
+    if (g0 + e >= gend) break;
+    const int tq = e / n, eq = e - tq * n;
+    const cpx *d = lds + tq * pn + s16_pad(eq);
+    const cpx a = d[0], b = d[1];
+    *reinterpret_cast<float4 *>(out + g0 + e) = make_float4(a.x * scale, inverse ? -a.y * scale : a.y * scale, b.x * scale,
+                                                            inverse ? -b.y * scale : b.y * scale);
+  }
+}
+
+// ---- four-step passes on the radix-16 Stockham engine (n = 2^15 .. 2^24, except 2^20) ---------
+// Column FFTs of a row-major [L][C] matrix (length L along the row index), CT adjacent
+// columns per workgroup (CT * 8 B row segments, 16-B accesses), each column transformed in LDS
+// by L/16 threads exactly like a row of fft_s16_kernel (column c of the tile lives at
+// s[c * pn + pad(i)]).  blockIdx.y = batch.
+//   PASS 1: out is [C][L]: out[c][k] = FFT_c[k] * W_N^(c*k)   (transposed: row c contiguous)
+//   PASS 2: out is [L][C]: out[k][c] = FFT_c[k] * scale       (natural order)
+// W_N^m is looked up as thi[m >> 12] * tlo[m & 4095].  Inverse: conj at the load of pass 1 and
+// at the store of pass 2 (one forward code path).
+template <int PASS, int R0>
+__global__ __launch_bounds__(1024) void fft_cols16_kernel(const cpx *__restrict__ in, cpx *__restrict__ out,
+                                                          const cpx *__restrict__ TW, int L, int tpt, int C, int CT,
+                                                          const cpx *__restrict__ thi, const cpx *__restrict__ tlo,
+                                                          int inverse, float scale)
+{
+  extern __shared__ __attribute__((aligned(16))) char s16_raw[];
+  cpx *lds = reinterpret_cast<cpx *>(s16_raw);
+  const int t = threadIdx.x, nthr = blockDim.x;
+  const int pn = L + (L >> 4) + 1;
+  const size_t boff = (size_t) blockIdx.y * (size_t) L * C;
+  const cpx *x = in + boff;
+  cpx *y = out + boff;
+  const int c0 = blockIdx.x * CT, h = CT >> 1;
+  for (int q = t; q < L * h; q += nthr) {
+    const int r = q / h, c = 2 * (q - r * h);
+    const float4 f = *reinterpret_cast<const float4 *>(x + (size_t) r * C + c0 + c);
+    const float sg = (PASS == 1 && inverse) ? -1.f : 1.f;
+    lds[c * pn + s16_pad(r)] = cmk(f.x, sg * f.y);
+    lds[(c + 1) * pn + s16_pad(r)] = cmk(f.z, sg * f.w);
+  }
+  __syncthreads();
+  const int cl = t / tpt, j = t - cl * tpt;
+  cpx *s = lds + cl * pn;
+  cpx v[16];
+  // pass 1: the four-step twiddle W_N^(c*k) of this thread's 16 outputs k = j + q*tpt is
+  // W_N^(c*j) * (W_N^(c*tpt))^q: two table look-ups and a product tree, applied in registers
+  // before the last write to LDS (a look-up per point in the store loop cost 2x the pass)
+  auto four_step_twiddle = [&](cpx (&u)[16]) {
+    const unsigned c = (unsigned) (c0 + cl);
+    const unsigned mb = c * (unsigned) j, md = c * (unsigned) tpt;            // < N <= 2^24
+    const cpx b = cmul(thi[mb >> 12], tlo[mb & 4095]), d1 = cmul(thi[md >> 12], tlo[md & 4095]);
+    const cpx d2 = cmul(d1, d1), d3 = cmul(d2, d1), d4 = cmul(d2, d2);
+    const cpx d5 = cmul(d4, d1), d6 = cmul(d4, d2), d7 = cmul(d4, d3), d8 = cmul(d4, d4);
+    const cpx b8 = cmul(b, d8);
+    u[0] = cmul(u[0], b);
+    u[1] = cmul(u[1], cmul(b, d1)); u[2] = cmul(u[2], cmul(b, d2)); u[3] = cmul(u[3], cmul(b, d3));
+    u[4] = cmul(u[4], cmul(b, d4)); u[5] = cmul(u[5], cmul(b, d5)); u[6] = cmul(u[6], cmul(b, d6));
+    u[7] = cmul(u[7], cmul(b, d7)); u[8] = cmul(u[8], b8);
+    u[9] = cmul(u[9], cmul(b8, d1)); u[10] = cmul(u[10], cmul(b8, d2)); u[11] = cmul(u[11], cmul(b8, d3));
+    u[12] = cmul(u[12], cmul(b8, d4)); u[13] = cmul(u[13], cmul(b8, d5)); u[14] = cmul(u[14], cmul(b8, d6));
+    u[15] = cmul(u[15], cmul(b8, d7));
+  };
+#pragma unroll
+  for (int m = 0; m < 16; m++) v[m] = s[s16_pad(j + m * tpt)];
+  __syncthreads();
+  if (R0 == 16) {
+    w1024::dft16<false>(v);
+  } else if (R0 == 8) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      cpx e[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) e[q] = v[i + 2 * q];
+      s16_dft8(e);
+#pragma unroll
+      for (int q = 0; q < 8; q++) v[i + 2 * q] = e[q];
+    }
+  } else if (R0 == 4) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) w1024::dft4<false>(v[i], v[i + 4], v[i + 8], v[i + 12]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; i++) s16_dft2(v[i], v[i + 8]);
+  }
+  if (PASS == 1 && R0 == 16 && L == 16) four_step_twiddle(v);
+#pragma unroll
+  for (int i = 0; i < 16 / R0; i++)
+#pragma unroll
+    for (int q = 0; q < R0; q++) s[s16_pad((j + i * tpt) * R0 + q)] = v[i + q * (16 / R0)];
+  for (int Ns = R0; Ns < L; Ns <<= 4) {
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; q++) v[q] = s[s16_pad(j + q * tpt)];
+    const int k = j & (Ns - 1);
+    {
+      const cpx w1 = TW[k * (tpt / Ns)];
+      const cpx w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
+      const cpx w5 = cmul(w4, w1), w6 = cmul(w4, w2), w7 = cmul(w4, w3), w8 = cmul(w4, w4);
+      v[1] = cmul(v[1], w1); v[2] = cmul(v[2], w2); v[3] = cmul(v[3], w3); v[4] = cmul(v[4], w4);
+      v[5] = cmul(v[5], w5); v[6] = cmul(v[6], w6); v[7] = cmul(v[7], w7); v[8] = cmul(v[8], w8);
+      v[9] = cmul(v[9], cmul(w8, w1)); v[10] = cmul(v[10], cmul(w8, w2)); v[11] = cmul(v[11], cmul(w8, w3));
+      v[12] = cmul(v[12], cmul(w8, w4)); v[13] = cmul(v[13], cmul(w8, w5)); v[14] = cmul(v[14], cmul(w8, w6));
+      v[15] = cmul(v[15], cmul(w8, w7));
+    }
+    w1024::dft16<false>(v);
+    const int base = (j - k) * 16 + k;
+    if (PASS == 1 && Ns * 16 == L) four_step_twiddle(v);     // last pass: outputs k = j + q * tpt
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; q++) s[s16_pad(base + q * Ns)] = v[q];
+  }
+  __syncthreads();
+  if (PASS == 1) {
+    const int hl = L >> 1;
+    for (int q = t; q < CT * hl; q += nthr) {
+      const int c = q / hl, k = 2 * (q - c * hl);
+      const cpx *d = lds + c * pn + s16_pad(k);
+      const cpx a = d[0], b = d[1];
+      *reinterpret_cast<float4 *>(y + (size_t) (c0 + c) * L + k) = make_float4(a.x, a.y, b.x, b.y);
+    }
+  } else {
+    for (int q = t; q < L * h; q += nthr) {
+      const int k = q / h, c = 2 * (q - k * h);
+      const cpx a = lds[c * pn + s16_pad(k)], b = lds[(c + 1) * pn + s16_pad(k)];
+      const float si = inverse ? -scale : scale;
+      *reinterpret_cast<float4 *>(y + (size_t) k * C + c0 + c) = make_float4(a.x * scale, a.y * si, b.x * scale, b.y * si);
+    }
   }
 }
 
@@ -388,7 +663,7 @@ using namespace tsdgpu;
 
 struct tsdgpu_fft {
   int n = 0;
-  enum Kind { ONE, POW2_LDS, POW2_W1024, POW2_W1M, POW2_4STEP, EVEN, ODD } kind = ONE;
+  enum Kind { ONE, POW2_LDS, POW2_S16, POW2_W1024, POW2_W1M, POW2_4STEP, EVEN, ODD } kind = ONE;
   // pow2
   int logn = 0;
   cpx *d_tw = nullptr;        // W_n^k, k < n/2 (LDS path) ...
@@ -449,7 +724,8 @@ int plan_init(tsdgpu_fft *p, int n)
   } else if ((n & (n - 1)) == 0) {
     p->logn = log2_exact(n);
     const bool fast = getenv("TSDGPU_FFT_GENERIC") == nullptr;
-    if (fast && (n == 1024 || n == (1 << 20))) {
+    static const bool w1024_rows = getenv("TSDGPU_FFT_W1024") != nullptr;
+    if (fast && ((n == 1024 && w1024_rows) || n == (1 << 20))) {
       p->kind = n == 1024 ? tsdgpu_fft::POW2_W1024 : tsdgpu_fft::POW2_W1M;
       std::vector<cpx> t1(1024), t2(1024);
       w1024::fill_twiddles(t1.data(), t2.data());
@@ -476,6 +752,13 @@ int plan_init(tsdgpu_fft *p, int n)
         (void) hipFuncSetAttribute((const void *) fft1m_cols_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void) hipGetLastError();
       }
+    } else if (fast && n >= 16 && n <= S16_MAX_N) {
+      p->kind = tsdgpu_fft::POW2_S16;
+      rc = upload(&p->d_tw, twiddle_table(n, n / 16));       // W_n^i, i < n/16: the base twiddles of every pass
+#define S16_ATTR(R) (void) hipFuncSetAttribute((const void *) fft_s16_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+      S16_ATTR(16); S16_ATTR(8); S16_ATTR(4); S16_ATTR(2);
+#undef S16_ATTR
+      (void) hipGetLastError();
     } else if (n <= LDS_MAX_N) {
       p->kind = tsdgpu_fft::POW2_LDS;
       rc = upload(&p->d_tw, twiddle_table(n, n / 2));
@@ -502,6 +785,9 @@ int plan_init(tsdgpu_fft *p, int n)
       if ((rc = upload(&p->d_thi, hi))) return rc;
       if ((rc = upload(&p->d_tlo, lo))) return rc;
       // the column tiles use up to ~150 KiB of the CU's 160 KiB LDS
+#define C16_ATTR(P, R) (void) hipFuncSetAttribute((const void *) fft_cols16_kernel<P, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+      C16_ATTR(1, 16); C16_ATTR(1, 8); C16_ATTR(1, 4); C16_ATTR(1, 2); C16_ATTR(2, 16); C16_ATTR(2, 8); C16_ATTR(2, 4); C16_ATTR(2, 2);
+#undef C16_ATTR
       (void) hipFuncSetAttribute((const void *) fft_cols_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       (void) hipFuncSetAttribute((const void *) fft_cols_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       (void) hipGetLastError();
@@ -594,6 +880,18 @@ int step_device(tsdgpu_fft *p, const cpx *x, cpx *y, int batch, int forward, hip
       TSD_HIP(hipGetLastError());
       return TSDGPU_OK;
     }
+    case tsdgpu_fft::POW2_S16: {
+      const float scale = 1.0f / std::sqrt((float) n);
+      const int tpt = n / 16, threads = std::max(256, tpt), T = threads / tpt;
+      const size_t lds = (size_t) T * (n + n / 16) * sizeof(cpx);
+      const unsigned grid = (unsigned) cdiv(batch, T);
+      const int r0 = 1 << ((p->logn & 3) == 0 ? 4 : (p->logn & 3));
+#define S16_LAUNCH(R) hipLaunchKernelGGL((fft_s16_kernel<R>), dim3(grid), dim3(threads), lds, st, x, y, p->d_tw, n, tpt, inverse, scale, batch)
+      if (r0 == 16) S16_LAUNCH(16); else if (r0 == 8) S16_LAUNCH(8); else if (r0 == 4) S16_LAUNCH(4); else S16_LAUNCH(2);
+#undef S16_LAUNCH
+      TSD_HIP(hipGetLastError());
+      return TSDGPU_OK;
+    }
     case tsdgpu_fft::POW2_W1024: {
       const float scale = 1.0f / 32.0f;
       hipLaunchKernelGGL(fft1024_rows_kernel, dim3((unsigned) cdiv(batch, 4)), dim3(256), 0, st, x, y, p->d_w1, p->d_w2,
@@ -630,6 +928,34 @@ int step_device(tsdgpu_fft *p, const cpx *x, cpx *y, int batch, int forward, hip
       if (rc) return rc;
       cpx *z = p->work.as<cpx>();
       const float scale = 1.0f / std::sqrt((float) n);
+      // x viewed [N1][N2]: pass 1 = column FFTs (length N1) + twiddle, stored transposed [N2][N1];
+      // z viewed [N2][N1]: pass 2 = column FFTs (length N2), natural store y[k2 * N1 + k1]
+      static const bool generic = getenv("TSDGPU_FFT_GENERIC") != nullptr;
+      if (!generic) {
+        auto launch = [&](int pass, const cpx *src, cpx *dst, const cpx *tw, int L, int logL, int C, float sc) {
+          const int tpt = L / 16;
+          static const int CTMIN = getenv("TSDGPU_FFT_CT") ? atoi(getenv("TSDGPU_FFT_CT")) : 16;
+          int CT = std::max(CTMIN, 256 / tpt);
+          CT = std::min(CT, C);
+          while ((size_t) CT * (L + L / 16 + 1) * sizeof(cpx) > 150 * 1024) CT >>= 1;
+          while (CT * tpt > 1024) CT >>= 1;                                    // L = 2048 -> 8 columns, 4096 -> 4
+          const size_t lds = (size_t) CT * (L + L / 16 + 1) * sizeof(cpx);
+          const dim3 grid((unsigned) (C / CT), (unsigned) batch), blk((unsigned) (CT * tpt));
+          const int r0 = 1 << ((logL & 3) == 0 ? 4 : (logL & 3));
+#define C16_LAUNCH(P, R) hipLaunchKernelGGL((fft_cols16_kernel<P, R>), grid, blk, lds, st, src, dst, tw, L, tpt, C, CT, p->d_thi, p->d_tlo, inverse, sc)
+          if (pass == 1) {
+            if (r0 == 16) C16_LAUNCH(1, 16); else if (r0 == 8) C16_LAUNCH(1, 8); else if (r0 == 4) C16_LAUNCH(1, 4); else C16_LAUNCH(1, 2);
+          } else {
+            if (r0 == 16) C16_LAUNCH(2, 16); else if (r0 == 8) C16_LAUNCH(2, 8); else if (r0 == 4) C16_LAUNCH(2, 4); else C16_LAUNCH(2, 2);
+          }
+#undef C16_LAUNCH
+        };
+        launch(1, x, z, p->d_tw1, p->N1, p->logN1, p->N2, 1.0f);
+        TSD_HIP(hipGetLastError());
+        launch(2, z, y, p->d_tw2, p->N2, p->logN2, p->N1, scale);
+        TSD_HIP(hipGetLastError());
+        return TSDGPU_OK;
+      }
       // x viewed [N1][N2]: pass 1 = column FFTs (length N1) + twiddle, stored transposed [N2][N1]
       int tile1 = COL_TILE, tile2 = COL_TILE;
       while ((size_t) tile1 * (p->N1 + 1) * sizeof(cpx) > 150 * 1024) tile1 >>= 1;

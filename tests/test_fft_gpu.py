@@ -25,8 +25,8 @@ def tg():
 
 # sizes of the reference's own FFT tests (test-fourier.cc:23,263,698) + the LDS / four-step
 # boundaries of this implementation
-SIZES = [1, 2, 3, 4, 5, 8, 10, 16, 17, 18, 19, 101, 128, 129, 1000, 1001, 1024, 2048, 4096, 8192, 15360,
-         1 << 14, 1 << 15, 1 << 17]
+SIZES = [1, 2, 3, 4, 5, 8, 10, 16, 17, 18, 19, 32, 64, 101, 128, 129, 256, 512, 1000, 1001, 1024, 2048, 4096, 8192,
+         15360, 1 << 14, 1 << 15, 1 << 16, 1 << 17, 1 << 18, 1 << 19, 1 << 21, 1 << 22]
 
 
 @pytest.mark.parametrize("n", SIZES)
@@ -76,6 +76,27 @@ def test_fft_batched_device(tg, orc):
     p.step(xd, True, xd)                    # in place
     torch.cuda.synchronize()
     assert np.array_equal(xd.cpu().numpy(), y)
+
+
+# every power-of-two plan, batched (several transforms per workgroup below 4096, ragged last
+# workgroup), forward + inverse, out of place and in place, on device buffers
+@pytest.mark.parametrize("logn", list(range(1, 17)))
+def test_fft_pow2_batched(tg, orc, logn):
+    import torch
+    n = 1 << logn
+    batch = 37 if n <= 4096 else 3
+    x = crand((batch, n), 100 + logn)
+    xd = torch.from_numpy(x).cuda()
+    p = tg.Fft(n, batch)
+    yd = p.step(xd)
+    torch.cuda.synchronize()
+    y = yd.cpu().numpy()
+    for b in (0, batch // 2, batch - 1):
+        assert relerr(y[b], orc.fft(x[b])) <= TOL
+    assert np.allclose(np.sum(np.abs(y) ** 2, axis=1), np.sum(np.abs(x) ** 2, axis=1), rtol=1e-4)
+    zd = p.step(yd, False, yd)             # inverse, in place
+    torch.cuda.synchronize()
+    assert relerr(zd.cpu().numpy(), x) <= TOL
 
 
 # BASELINE configs[2]: 2^20-point complex FFT, batch (bounded here; the bench runs 256)
