@@ -31,8 +31,14 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 LOG2N = 26
 K_TAPS = 127
-# measured offline, per launch of the dominant kernel (see profiles/README.md)
-TRAFFIC_PMC_BYTES = {("overlap-save", 26): (2 * 268927 + 524289) * 1024.0}
+# HBM bytes per step from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs; FETCH x2 is
+# the gfx950 correction of MI355X_MICROARCH.md), measured offline: profiles/r1_pmc_traffic.txt
+TRAFFIC_PMC_BYTES = {
+    ("fir", "overlap-save", 26): (2 * 269147 + 524289) * 1024.0,
+    ("fft", 20, 256): (2 * 1061970 + 2100220 + 2 * 1048730 + 2097150) * 1024.0,     # both four-step passes
+    ("sos", 26): (2 * 147515 + 262144) * 1024.0,
+    ("resample", 27): (2 * 603416 + 1146770) * 1024.0,
+}
 
 
 def design_lowpass(n, fc):
@@ -86,7 +92,7 @@ class FirWorkload:
                                    "on 2^%d-sample Veccf per GPU, inputs resident in HBM" % args.log2n,
                        "method": self.method, "samples_per_gpu": self.n,
                        "sharding": "contiguous chunks, K-1 halo via RCCL send/recv" if world > 1 else "single GPU"}
-        self.traffic = TRAFFIC_PMC_BYTES.get((self.method, args.log2n))
+        self.traffic = TRAFFIC_PMC_BYTES.get(("fir", self.method, args.log2n))
 
     def exchange(self):
         from libtsd_amd import sharding
@@ -121,7 +127,7 @@ class FftWorkload:
         self.dtype = "f32 (complex64)"
         self.config = {"workload": "configs[2]: fft() of 256 x Veccf[2^20] per GPU, unitary scaling, inputs resident in HBM",
                        "sharding": "batch index split, no exchange" if world > 1 else "single GPU"}
-        self.traffic = None
+        self.traffic = TRAFFIC_PMC_BYTES.get(("fft", 20, self.batch))
 
     def exchange(self):
         pass
@@ -163,7 +169,7 @@ class SosWorkload:
         self.config = {"workload": "configs[3]: 6 DF2 biquads (Butterworth order 12, fc 0.25) on 2^%d-sample Vecf per GPU" % args.log2n,
                        "halo_samples": self.halo,
                        "sharding": "contiguous chunks, warm-up halo via RCCL send/recv" if world > 1 else "single GPU"}
-        self.traffic = None
+        self.traffic = TRAFFIC_PMC_BYTES.get(("sos", args.log2n))
 
     def exchange(self):
         from libtsd_amd import sharding
@@ -211,7 +217,7 @@ class ResampleWorkload:
         self.config = {"workload": "configs[4]: filtre_reechan(160/147) interpolator on a 2^27-sample Veccf shard per GPU "
                                    "(2^30 over 8 GPUs)", "outputs_per_gpu": self.nout,
                        "sharding": "contiguous input chunks, 14-sample halo via RCCL send/recv + seek" if world > 1 else "single GPU"}
-        self.traffic = None
+        self.traffic = TRAFFIC_PMC_BYTES.get(("resample", 27))
 
     def exchange(self):
         from libtsd_amd import sharding
@@ -311,8 +317,7 @@ def main():
             "dtype": w.dtype, "data": "synthetic", "config": cfg,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         # HBM bytes per launch from rocprofv3 --pmc passes (profiles/r1_pmc_ols.txt):
-                         # FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md HBM section) + WRITE_SIZE, in KB
+                         # HBM bytes per step from rocprofv3 --pmc passes (profiles/r1_pmc_traffic.txt)
                          "traffic": w.traffic,
                          "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": w.alg_bytes},
         }
