@@ -321,7 +321,7 @@ template <int PASS, int R0>
 __global__ __launch_bounds__(1024) void fft_cols16_kernel(const cpx *__restrict__ in, cpx *__restrict__ out,
                                                           const cpx *__restrict__ TW, int L, int tpt, int C, int CT,
                                                           const cpx *__restrict__ thi, const cpx *__restrict__ tlo,
-                                                          int inverse, float scale)
+                                                          int inverse, float scale, int ragged)
 {
   extern __shared__ __attribute__((aligned(16))) char s16_raw[];
   cpx *lds = reinterpret_cast<cpx *>(s16_raw);
@@ -331,6 +331,16 @@ __global__ __launch_bounds__(1024) void fft_cols16_kernel(const cpx *__restrict_
   const cpx *x = in + boff;
   cpx *y = out + boff;
   const int c0 = blockIdx.x * CT, h = CT >> 1;
+  if (ragged) {
+    // C is not a multiple of CT (or odd): 8-B accesses, columns beyond C read as zero
+    for (int q = t; q < L * CT; q += nthr) {
+      const int r = q / CT, c = q - r * CT;
+      cpx f = cmk(0.f, 0.f);
+      if (c0 + c < C) f = x[(size_t) r * C + c0 + c];
+      if (PASS == 1 && inverse) f.y = -f.y;
+      lds[c * pn + s16_pad(r)] = f;
+    }
+  } else
   for (int q = t; q < L * h; q += nthr) {
     const int r = q / h, c = 2 * (q - r * h);
     const float4 f = *reinterpret_cast<const float4 *>(x + (size_t) r * C + c0 + c);
@@ -418,6 +428,14 @@ __global__ __launch_bounds__(1024) void fft_cols16_kernel(const cpx *__restrict_
       const cpx a = d[0], b = d[1];
       *reinterpret_cast<float4 *>(y + (size_t) (c0 + c) * L + k) = make_float4(a.x, a.y, b.x, b.y);
     }
+  } else if (ragged) {
+    for (int q = t; q < L * CT; q += nthr) {
+      const int k = q / CT, c = q - k * CT;
+      if (c0 + c < C) {
+        const cpx a = lds[c * pn + s16_pad(k)];
+        y[(size_t) k * C + c0 + c] = cmk(a.x * scale, inverse ? -a.y * scale : a.y * scale);
+      }
+    }
   } else {
     for (int q = t; q < L * h; q += nthr) {
       const int k = q / h, c = 2 * (q - k * h);
@@ -426,6 +444,63 @@ __global__ __launch_bounds__(1024) void fft_cols16_kernel(const cpx *__restrict_
       *reinterpret_cast<float4 *>(y + (size_t) k * C + c0 + c) = make_float4(a.x * scale, a.y * si, b.x * scale, b.y * si);
     }
   }
+}
+
+// ---- n = m * P, m odd <= 31, P = 2^p in 16 .. 4096 (e.g. 15360 = 15 * 1024) --------------------
+// The reference reaches such sizes by p levels of even/odd split down to m-point Bluestein
+// transforms (fourier.cc:438-464), i.e. a radix-2 decimation in time over the 2^p factor.  The
+// same transform as two passes: (1) for every residue r = index mod P, the m-point DFT of the
+// decimated sequence x[r + P i] -- evaluated directly, one thread per r with the m samples
+// in registers -- times the four-step twiddle W_n^(r k1), stored as Z[r][k1]; (2) P-point
+// column FFTs of Z over r (fft_cols16_kernel<2>, ragged columns), which leave
+// X[k1 + m k2] at [k2][k1] = natural order.  For m <= 31 the direct m-point DFT differs from
+// the reference's float32-chirp Bluestein by < 5e-6 (larger odd parts keep the recursion).
+template <int MMAX>
+__global__ __launch_bounds__(256) void fft_odd_dft_kernel(const cpx *__restrict__ in, cpx *__restrict__ z,
+                                                          const cpx *__restrict__ Wm, const cpx *__restrict__ Wn, int m,
+                                                          int P, int inverse, float scale, int64_t total)
+{
+  extern __shared__ __attribute__((aligned(16))) char odd_raw[];
+  cpx *wm = reinterpret_cast<cpx *>(odd_raw);                // W_m^j, j < m
+  cpx *stage = wm + 32;                                      // 256 x m outputs of the workgroup
+  const int t = threadIdx.x;
+  if (t < m) wm[t] = Wm[t];
+  __syncthreads();
+  const int64_t g0 = (int64_t) blockIdx.x * 256, g = g0 + t;
+  if (g < total) {
+    const int64_t b = g / P;
+    const int r = (int) (g - b * P);
+    const cpx *x = in + (size_t) b * m * P + r;
+    cpx u[MMAX];
+#pragma unroll
+    for (int i = 0; i < MMAX; i++) {
+      u[i] = cmk(0.f, 0.f);
+      if (i < m) {
+        u[i] = x[(size_t) P * i];
+        if (inverse) u[i].y = -u[i].y;
+      }
+    }
+    for (int k1 = 0; k1 < m; k1++) {
+      cpx acc = u[0];
+      int idx = 0;
+#pragma unroll
+      for (int i = 1; i < MMAX; i++) {
+        idx += k1;
+        if (idx >= m) idx -= m;
+        if (i < m) {
+          const cpx w = wm[idx];
+          acc.x = fmaf(u[i].x, w.x, fmaf(-u[i].y, w.y, acc.x));
+          acc.y = fmaf(u[i].x, w.y, fmaf(u[i].y, w.x, acc.y));
+        }
+      }
+      stage[t * m + k1] = cscale(cmul(acc, Wn[r * k1]), scale);   // odd m: the lane stride 2m dwords is conflict-free
+    }
+  }
+  __syncthreads();
+  // Z[(b P + r) m + k1]: the workgroup's 256 residues are one contiguous run of 256 m values
+  const int64_t zbase = g0 * m, zend = total * m;
+  for (int i = t; i < 256 * m; i += 256)
+    if (zbase + i < zend) z[zbase + i] = stage[i];
 }
 
 // n = 2^20 = 1024 x 1024, four-step.  One workgroup = 16 waves = 16 adjacent columns of the
@@ -663,7 +738,7 @@ using namespace tsdgpu;
 
 struct tsdgpu_fft {
   int n = 0;
-  enum Kind { ONE, POW2_LDS, POW2_S16, POW2_W1024, POW2_W1M, POW2_4STEP, EVEN, ODD } kind = ONE;
+  enum Kind { ONE, POW2_LDS, POW2_S16, POW2_W1024, POW2_W1M, POW2_4STEP, MIXED, EVEN, ODD } kind = ONE;
   // pow2
   int logn = 0;
   cpx *d_tw = nullptr;        // W_n^k, k < n/2 (LDS path) ...
@@ -676,6 +751,8 @@ struct tsdgpu_fft {
   tsdgpu_fft *sub = nullptr;
   cpx *d_rot = nullptr;       // W_n^k, k < n (even split)
   int n2 = 0;
+  int mix_m = 0, mix_P = 0;   // MIXED: n = mix_m * mix_P
+  cpx *d_wm = nullptr;        // W_m^j, j < m
   cpx *d_chirp = nullptr, *d_xc = nullptr;   // Bluestein chirp (2n-1) and FFT of its conjugate (n2)
   DevBuf work, work2, in_stage, out_stage;
 };
@@ -714,6 +791,17 @@ int ref_next_pow2(int i)
 
 int plan_create(tsdgpu_fft **out, int n);
 void plan_destroy(tsdgpu_fft *p);
+
+// n = m * P with m odd in 3..31 and P = 2^p in 16..4096: the two-pass mixed-radix plan
+bool mixed_split(int n, int *m, int *P)
+{
+  int q = n, pw = 1;
+  while ((q & 1) == 0) { q >>= 1; pw <<= 1; }
+  if (q < 3 || q > 31 || pw < 16 || pw > 4096) return false;
+  *m = q;
+  *P = pw;
+  return true;
+}
 
 int plan_init(tsdgpu_fft *p, int n)
 {
@@ -792,6 +880,20 @@ int plan_init(tsdgpu_fft *p, int n)
       (void) hipFuncSetAttribute((const void *) fft_cols_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       (void) hipGetLastError();
     }
+  } else if ((n & 1) == 0 && mixed_split(n, &p->mix_m, &p->mix_P) && getenv("TSDGPU_FFT_GENERIC") == nullptr) {
+    p->kind = tsdgpu_fft::MIXED;
+    const int m = p->mix_m, P = p->mix_P;
+    p->logn = log2_exact(P);
+    if ((rc = upload(&p->d_wm, twiddle_table(m, m)))) return rc;
+    if ((rc = upload(&p->d_rot, twiddle_table(n, n)))) return rc;            // W_n^j: the four-step twiddles
+    if ((rc = upload(&p->d_tw, twiddle_table(P, std::max(1, P / 16))))) return rc;
+#define C16_ATTR(R) (void) hipFuncSetAttribute((const void *) fft_cols16_kernel<2, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+    C16_ATTR(16); C16_ATTR(8); C16_ATTR(4); C16_ATTR(2);
+#undef C16_ATTR
+    (void) hipFuncSetAttribute((const void *) fft_odd_dft_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void) hipFuncSetAttribute((const void *) fft_odd_dft_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void) hipFuncSetAttribute((const void *) fft_odd_dft_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void) hipGetLastError();
   } else if ((n & 1) == 0) {
     p->kind = tsdgpu_fft::EVEN;
     if ((rc = plan_create(&p->sub, n / 2))) return rc;
@@ -852,7 +954,7 @@ void plan_destroy(tsdgpu_fft *p)
 {
   if (!p) return;
   if (p->sub) plan_destroy(p->sub);
-  for (cpx *q : {p->d_tw, p->d_tw1, p->d_tw2, p->d_thi, p->d_tlo, p->d_rot, p->d_chirp, p->d_xc, p->d_w1, p->d_w2, p->d_ta, p->d_td})
+  for (cpx *q : {p->d_tw, p->d_tw1, p->d_tw2, p->d_thi, p->d_tlo, p->d_rot, p->d_chirp, p->d_xc, p->d_w1, p->d_w2, p->d_ta, p->d_td, p->d_wm})
     if (q) (void) hipFree(q);
   p->work.release();
   p->work2.release();
@@ -942,7 +1044,7 @@ int step_device(tsdgpu_fft *p, const cpx *x, cpx *y, int batch, int forward, hip
           const size_t lds = (size_t) CT * (L + L / 16 + 1) * sizeof(cpx);
           const dim3 grid((unsigned) (C / CT), (unsigned) batch), blk((unsigned) (CT * tpt));
           const int r0 = 1 << ((logL & 3) == 0 ? 4 : (logL & 3));
-#define C16_LAUNCH(P, R) hipLaunchKernelGGL((fft_cols16_kernel<P, R>), grid, blk, lds, st, src, dst, tw, L, tpt, C, CT, p->d_thi, p->d_tlo, inverse, sc)
+#define C16_LAUNCH(P, R) hipLaunchKernelGGL((fft_cols16_kernel<P, R>), grid, blk, lds, st, src, dst, tw, L, tpt, C, CT, p->d_thi, p->d_tlo, inverse, sc, 0)
           if (pass == 1) {
             if (r0 == 16) C16_LAUNCH(1, 16); else if (r0 == 8) C16_LAUNCH(1, 8); else if (r0 == 4) C16_LAUNCH(1, 4); else C16_LAUNCH(1, 2);
           } else {
@@ -968,6 +1070,32 @@ int step_device(tsdgpu_fft *p, const cpx *x, cpx *y, int batch, int forward, hip
       hipLaunchKernelGGL(fft_cols_kernel<false>, dim3((unsigned) cdiv(p->N1, tile2), (unsigned) batch), dim3(FFT_THREADS),
                          (size_t) tile2 * (p->N2 + 1) * sizeof(cpx), st, z, y, p->d_tw2, p->N2, p->logN2, p->N1,
                          p->d_thi, p->d_tlo, inverse, scale, tile2);
+      TSD_HIP(hipGetLastError());
+      return TSDGPU_OK;
+    }
+    case tsdgpu_fft::MIXED: {
+      const int m = p->mix_m, P = p->mix_P;
+      TSD_CHECK(batch <= 65535, "fft_step: batch %d too large for the mixed-radix path (max 65535 per call)", batch);
+      int rc = p->work.reserve((size_t) total * sizeof(cpx));
+      if (rc) return rc;
+      cpx *z = p->work.as<cpx>();
+      const int64_t tot1 = (int64_t) batch * P;
+      const unsigned g1 = (unsigned) cdiv(tot1, 256);
+      const float s1 = 1.0f / std::sqrt((float) m), s2 = 1.0f / std::sqrt((float) P);
+#define ODD_LAUNCH(M) hipLaunchKernelGGL((fft_odd_dft_kernel<M>), dim3(g1), dim3(256), (size_t) (32 + 256 * m) * sizeof(cpx), st, x, z, p->d_wm, p->d_rot, m, P, inverse, s1, tot1)
+      if (m <= 8) ODD_LAUNCH(8); else if (m <= 16) ODD_LAUNCH(16); else ODD_LAUNCH(32);
+#undef ODD_LAUNCH
+      TSD_HIP(hipGetLastError());
+      const int tpt = P / 16;
+      // ragged tiles: any column count works; no wider than the m live columns
+      int CT = std::min(std::min(16, m), 1024 / tpt);
+      while ((size_t) CT * (P + P / 16 + 1) * sizeof(cpx) > 150 * 1024) CT--;
+      const size_t lds = (size_t) CT * (P + P / 16 + 1) * sizeof(cpx);
+      const dim3 grid((unsigned) cdiv(m, CT), (unsigned) batch), blk((unsigned) (CT * tpt));
+      const int r0 = 1 << ((p->logn & 3) == 0 ? 4 : (p->logn & 3));
+#define C16_LAUNCH(R) hipLaunchKernelGGL((fft_cols16_kernel<2, R>), grid, blk, lds, st, z, y, p->d_tw, P, tpt, m, CT, nullptr, nullptr, inverse, s2, 1)
+      if (r0 == 16) C16_LAUNCH(16); else if (r0 == 8) C16_LAUNCH(8); else if (r0 == 4) C16_LAUNCH(4); else C16_LAUNCH(2);
+#undef C16_LAUNCH
       TSD_HIP(hipGetLastError());
       return TSDGPU_OK;
     }

@@ -78,6 +78,26 @@ def test_fft_batched_device(tg, orc):
     assert np.array_equal(xd.cpu().numpy(), y)
 
 
+# n = m * 2^p (m odd <= 31, 16 <= 2^p <= 4096): the two-pass mixed-radix plan, alone and
+# underneath one level of even/odd split (24576 = 2 * 12288); forward, inverse, batched
+@pytest.mark.parametrize("n", [48, 80, 112, 240, 496, 1536, 3072, 7168, 12288, 24576, 31 * 4096])
+def test_fft_mixed_radix(tg, orc, n):
+    import torch
+    batch = 5 if n <= 4096 else 2
+    x = crand((batch, n), n)
+    p = tg.Fft(n, batch)
+    xd = torch.from_numpy(x).cuda()
+    yd = p.step(xd)
+    torch.cuda.synchronize()
+    y = yd.cpu().numpy()
+    for b in range(batch):
+        assert relerr(y[b], orc.fft(x[b])) <= TOL
+    zd = p.step(yd, False, yd)
+    torch.cuda.synchronize()
+    assert relerr(zd.cpu().numpy(), x) <= 2 * TOL
+    assert relerr(tg.fft(x[0], False), orc.fft(x[0], False)) <= TOL
+
+
 # every power-of-two plan, batched (several transforms per workgroup below 4096, ragged last
 # workgroup), forward + inverse, out of place and in place, on device buffers
 @pytest.mark.parametrize("logn", list(range(1, 17)))
