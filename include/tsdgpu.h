@@ -84,6 +84,15 @@ int tsdgpu_fft_create(tsdgpu_fft **out, int n, int batch_hint);
 int tsdgpu_fft_step(tsdgpu_fft *p, const void *x, void *y, int batch, int forward, void *stream);
 int tsdgpu_fft_size(const tsdgpu_fft *p);
 int tsdgpu_fft_destroy(tsdgpu_fft *p);
+/* Real FFT: RTFRPlan::step / rfft() / fft(Vecf) (src/fourier/fourier.cc:280-355,
+ * include/tsd/fourier.hpp:99,116-122): n real samples -> the full n-bin complex spectrum.
+ * Even n: n/2-point complex FFT of the packed pairs + untangling + forced conjugate symmetry,
+ * all on the device; odd n: the complex FFT of x.as_complex(), like the reference.          */
+typedef struct tsdgpu_rfft tsdgpu_rfft;
+int tsdgpu_rfft_create(tsdgpu_rfft **out, int n);
+int tsdgpu_rfft_step(tsdgpu_rfft *p, const void *x /* float[batch][n] */, void *y /* cfloat[batch][n] */, int batch,
+                     void *stream);
+int tsdgpu_rfft_destroy(tsdgpu_rfft *p);
 /* fftshift (include/tsd/fourier.hpp:232-248): pure index permutation, bit-exact */
 int tsdgpu_fftshift(const void *x, void *y, int n, int data_type, void *stream);
 

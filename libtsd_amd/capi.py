@@ -80,6 +80,9 @@ def _declare(L):
     L.tsdgpu_fft_step.argtypes = [vp, vp, vp, i32, i32, vp]
     L.tsdgpu_fft_size.argtypes = [vp]
     L.tsdgpu_fft_destroy.argtypes = [vp]
+    L.tsdgpu_rfft_create.argtypes = [C.POINTER(vp), i32]
+    L.tsdgpu_rfft_step.argtypes = [vp, vp, vp, i32, vp]
+    L.tsdgpu_rfft_destroy.argtypes = [vp]
     L.tsdgpu_fftshift.argtypes = [vp, vp, i32, i32, vp]
 
 
@@ -195,6 +198,44 @@ def fft(x, forward=True):
     p = Fft(x.shape[-1])
     try:
         return p.step(x, forward)
+    finally:
+        p.close()
+
+
+class Rfft:
+    """RTFRPlan (fourier.cc:280-355): step(x) on [batch, n] float32 data -> [batch, n] complex64."""
+
+    def __init__(self, n):
+        self.n = int(n)
+        self._h = C.c_void_p()
+        _check(lib().tsdgpu_rfft_create(C.byref(self._h), self.n))
+
+    def step(self, x, y=None, stream=None):
+        assert _dtype_code(x) == F32
+        total = int(np.prod(x.shape))
+        assert total % self.n == 0
+        if y is None:
+            y = np.empty(x.shape, np.complex64) if isinstance(x, np.ndarray) else x.new_empty(x.shape, dtype=__import__("torch").complex64)
+        _check(lib().tsdgpu_rfft_step(self._h, _ptr(x), _ptr(y), total // self.n, _stream_of(x, stream)))
+        return y
+
+    def close(self):
+        if self._h:
+            lib().tsdgpu_rfft_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def rfft(x):
+    """One-shot rfft() (fourier.hpp:116-122)."""
+    p = Rfft(x.shape[-1])
+    try:
+        return p.step(x)
     finally:
         p.close()
 

@@ -722,6 +722,37 @@ __global__ void czt_post_kernel(const cpx *__restrict__ y2, cpx *__restrict__ y,
   const int kk = inverse ? (n - k) % n : k;
   y[i] = cscale(cmul(y2[b * n2 + n - 1 + kk], chirp[n - 1 + kk]), g);
 }
+// ---- real FFT (RTFRPlan::step, fourier.cc:311-354), even n ---------------------------------------
+// The n real samples ARE the n/2 packed complex samples; after their FFT Xt the spectrum is
+//   y(i) = r2 (Xt(i) + conj Xt(h-i)) - j2 (Xt(i) - conj Xt(h-i)) rot(i),  i = 0..h,  h = n/2
+// (Xt(h) := Xt(0)), with r2 = j2/i = 0.5/sqrt(2) on top of the unitary half-size FFT, and the upper
+// half is the forced conjugate symmetry csym_forçage(): y(0), y(h) real, y(n-i) = conj y(i).
+__global__ void rfft_untangle_kernel(const cpx *__restrict__ Xt, cpx *__restrict__ y, const cpx *__restrict__ rot, int n,
+                                     int64_t total)
+{
+  const int h = n >> 1;
+  const int64_t g = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;     // one thread per (transform, i in 0..h)
+  if (g >= total) return;
+  const int64_t b = g / (h + 1);
+  const int i = (int) (g - b * (h + 1));
+  const cpx *X = Xt + (size_t) b * h;
+  cpx *Y = y + (size_t) b * n;
+  const cpx X1 = X[i == h ? 0 : i], X2c = cconj(X[i > 0 ? h - i : 0]);
+  const float c = 0.35355339059327373f;                                  // (float) (0.5 / sqrt(2.0))
+  const cpx a = cscale(cadd(X1, X2c), c);
+  const cpx d = csub(X1, X2c);
+  const cpx jd = cmk(-d.y * c, d.x * c);                                 // j2 * d
+  cpx v = csub(a, cmul(jd, rot[i]));
+  if (i == 0 || i == h) v.y = 0.f;
+  Y[i] = v;
+  if (i > 0 && i < h) Y[n - i] = cconj(v);
+}
+__global__ void real_to_complex_kernel(const float *__restrict__ x, cpx *__restrict__ y, int64_t total)
+{
+  const int64_t g = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < total) y[g] = cmk(x[g], 0.f);
+}
+
 template <typename T>
 __global__ void fftshift_kernel(const T *__restrict__ x, T *__restrict__ y, int n)
 {
@@ -1210,6 +1241,98 @@ int tsdgpu_fftshift(const void *x, void *y, int n, int data_type, void *stream)
   a.release();
   b.release();
   return rc;
+}
+
+/* ---- real FFT ---------------------------------------------------------------------------- */
+struct tsdgpu_rfft {
+  int n = 0;
+  tsdgpu_fft *sub = nullptr;      // n/2-point complex plan (even n) or n-point plan (odd n)
+  cpx *d_rot = nullptr;           // tfr_rotation(n): W_n^i, double recurrence rounded to float
+  DevBuf work, in_stage, out_stage;
+};
+
+int tsdgpu_rfft_create(tsdgpu_rfft **out, int n)
+{
+  TSD_CHECK(out != nullptr, "rfft_create: out is NULL");
+  *out = nullptr;
+  TSD_CHECK(n >= 1, "rfft_create: n must be >= 1 (got %d)", n);
+  tsdgpu_rfft *p = new tsdgpu_rfft();
+  p->n = n;
+  int rc = TSDGPU_OK;
+  if ((n & 1) == 0) {
+    rc = plan_create(&p->sub, n / 2);
+    if (!rc) {
+      std::vector<cpx> rot((size_t) n);
+      const double PI = 3.14159265358979323846;
+      double rr = 1.0, ri = 0.0;
+      const double wr = std::cos(-2 * PI / n), wi = std::sin(-2 * PI / n);
+      for (int i = 0; i < n; i++) {
+        rot[i] = make_float2((float) rr, (float) ri);
+        const double tr = rr * wr - ri * wi, ti = rr * wi + ri * wr;
+        rr = tr; ri = ti;
+      }
+      rc = upload(&p->d_rot, rot);
+    }
+  } else {
+    rc = plan_create(&p->sub, n);
+  }
+  if (rc) {
+    tsdgpu_rfft_destroy(p);
+    return rc;
+  }
+  *out = p;
+  return TSDGPU_OK;
+}
+
+int tsdgpu_rfft_step(tsdgpu_rfft *p, const void *x, void *y, int batch, void *stream)
+{
+  TSD_CHECK(p != nullptr, "rfft_step: NULL plan");
+  TSD_CHECK(batch >= 0, "rfft_step: negative batch");
+  if (batch == 0) return TSDGPU_OK;
+  TSD_CHECK(x != nullptr && y != nullptr && x != y, "rfft_step: needs distinct non-NULL buffers");
+  hipStream_t st = (hipStream_t) stream;
+  const int n = p->n;
+  const size_t in_bytes = (size_t) n * batch * sizeof(float), out_bytes = (size_t) n * batch * sizeof(cpx);
+  const void *dx = nullptr;
+  void *dy = nullptr;
+  bool staged = false;
+  int rc = stage_in(x, in_bytes, p->in_stage, st, &dx);
+  if (rc) return rc;
+  rc = stage_out(y, out_bytes, p->out_stage, &dy, &staged);
+  if (rc) return rc;
+  if ((n & 1) == 0) {
+    const int h = n / 2;
+    rc = p->work.reserve((size_t) h * batch * sizeof(cpx));
+    if (rc) return rc;
+    cpx *xt = p->work.as<cpx>();
+    rc = step_device(p->sub, (const cpx *) dx, xt, batch, 1, st);     // the real pairs, read as complex
+    if (rc) return rc;
+    const int64_t total = (int64_t) batch * (h + 1);
+    hipLaunchKernelGGL(rfft_untangle_kernel, dim3((unsigned) cdiv(total, 256)), dim3(256), 0, st, xt, (cpx *) dy, p->d_rot, n,
+                       total);
+    TSD_HIP(hipGetLastError());
+  } else {
+    // odd n: the reference simply transforms x.as_complex() (fourier.cc:348-352)
+    const int64_t total = (int64_t) batch * n;
+    hipLaunchKernelGGL(real_to_complex_kernel, dim3((unsigned) cdiv(total, 256)), dim3(256), 0, st, (const float *) dx,
+                       (cpx *) dy, total);
+    TSD_HIP(hipGetLastError());
+    rc = step_device(p->sub, (const cpx *) dy, (cpx *) dy, batch, 1, st);
+    if (rc) return rc;
+  }
+  return finish_out(y, out_bytes, dy, staged, st);
+}
+
+int tsdgpu_rfft_destroy(tsdgpu_rfft *p)
+{
+  if (!p) return TSDGPU_OK;
+  if (p->sub) plan_destroy(p->sub);
+  if (p->d_rot) (void) hipFree(p->d_rot);
+  p->work.release();
+  p->in_stage.release();
+  p->out_stage.release();
+  delete p;
+  return TSDGPU_OK;
 }
 
 }  // extern "C"

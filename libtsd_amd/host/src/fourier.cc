@@ -34,29 +34,20 @@ struct FFTPlanGpu : FFTPlan {
   }
 };
 
-// RTFRPlan (fourier.cc:280-355): even n -> n/2-point complex FFT of the packed pairs, then the
-// untangling pass with the 0.5/sqrt(2) factors, then forced conjugate symmetry.
+// RTFRPlan (fourier.cc:280-355) on tsdgpu_rfft: packed n/2-point complex FFT, untangling with
+// the 0.5/sqrt(2) factors and the forced conjugate symmetry all run on the device.
 struct RTFRPlanGpu : FiltreGen<float, cfloat> {
   entier n = -1;
-  sptr<FFTPlan> cplan;
-  Veccf rotations;
+  tsdgpu_rfft *h = nullptr;
   explicit RTFRPlanGpu(entier n_) { configure(n_); }
+  ~RTFRPlanGpu() override { tsdgpu_rfft_destroy(h); }
   void configure(entier n_)
   {
+    if (n_ == n) return;
+    tsdgpu_rfft_destroy(h);
+    h = nullptr;
     n = n_;
-    if (n <= 0) return;
-    if ((n & 1) == 0) {
-      cplan = tfrplan_création(n / 2);
-      // tfr_rotation_rapide (fourier.cc:32-46): double recurrence rounded to float
-      rotations.resize(n);
-      cdouble r = 1, w0 = std::polar<double>(1.0, (-2 * π) / n);
-      for (entier i = 0; i < n; i++) {
-        rotations(i) = cfloat(r);
-        r *= w0;
-      }
-    } else {
-      cplan = tfrplan_création(n);
-    }
+    if (n > 0 && tsdgpu_rfft_create(&h, n)) échec("rtfrplan_création({}): {}", n, tsdgpu_last_error());
   }
   void step(const Vecf &x, Veccf &y) override
   {
@@ -65,22 +56,8 @@ struct RTFRPlanGpu : FiltreGen<float, cfloat> {
       y.resize(0);
       return;
     }
-    if ((n & 1) == 0) {
-      y.resize(n);
-      Veccf x2(n / 2);
-      for (entier i = 0; i < n / 2; i++) x2(i) = cfloat(x(2 * i), x(2 * i + 1));
-      const Veccf Xt = n / 2 > 0 ? cplan->step(x2) : Veccf();
-      const cfloat j2(0, (float) (0.5 / std::sqrt(2.0))), r2((float) (0.5 / std::sqrt(2.0)), 0);
-      for (entier i = 0; i <= n / 2; i++) {
-        const cfloat X1 = (i == n / 2) ? Xt(0) : Xt(i);
-        const cfloat X2 = (i > 0) ? Xt(n / 2 - i) : Xt(0);
-        y(i) = r2 * (X1 + std::conj(X2)) - j2 * (X1 - std::conj(X2)) * rotations(i);
-      }
-      csym_forçage(y);
-    } else {
-      const Veccf y1 = x.as_complex();
-      cplan->step(y1, y);
-    }
+    y.resize(n);
+    if (tsdgpu_rfft_step(h, x.data(), y.data(), 1, nullptr)) échec("rfft: {}", tsdgpu_last_error());
   }
 };
 

@@ -148,3 +148,31 @@ def test_fftshift_exact(tg, orc, n):
     m = n // 2
     ref = np.concatenate([xf[n - m:], xf[:n - m]])
     assert np.array_equal(tg.fftshift(xf), ref)
+
+
+# rfft / fft(Vecf): RTFRPlan on the device (even n: packed half-size FFT + untangling + forced
+# conjugate symmetry; odd n: complex FFT of the real samples), sizes of test_fft_valide
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 8, 10, 16, 17, 18, 19, 101, 128, 129, 1000, 1001, 1024, 4096, 15360, 1 << 16])
+def test_rfft_matches_oracle(tg, orc, n):
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal(n).astype(np.float32)
+    ref = orc.rfft(x)
+    y = tg.rfft(x)
+    assert relerr(y, ref) <= TOL
+    if n % 2 == 0 and n > 2:
+        # csym_forçage is exact: y(0), y(n/2) real, y(n-i) == conj(y(i)) bit for bit
+        assert y[0].imag == 0 and y[n // 2].imag == 0
+        assert np.array_equal(y[n // 2 + 1:], np.conj(y[1:n // 2][::-1]))
+
+
+def test_rfft_batched_device(tg, orc):
+    import torch
+    n, batch = 2048, 9
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((batch, n)).astype(np.float32)
+    p = tg.Rfft(n)
+    yd = p.step(torch.from_numpy(x).cuda())
+    torch.cuda.synchronize()
+    y = yd.cpu().numpy()
+    for b in range(batch):
+        assert relerr(y[b], orc.rfft(x[b])) <= TOL
