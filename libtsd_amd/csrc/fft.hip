@@ -12,6 +12,7 @@
 // Twiddles are produced on the host in double precision and rounded once to float.
 #include "common.hpp"
 #include "fft1024_wave.hpp"
+#include "stockham16.hpp"
 #include <cmath>
 #include <memory>
 #include <cstdlib>
@@ -167,25 +168,6 @@ __global__ __launch_bounds__(256) void fft1024_rows_kernel(const cpx *__restrict
 // wave spans several transforms, so the global accesses are staged through LDS to stay 16-B
 // coalesced; from 1024 up the first pass loads and the last pass stores straight from
 // registers (512 contiguous bytes per wave instruction).
-__device__ __forceinline__ int s16_pad(int i) { return i + (i >> 4); }
-__device__ __forceinline__ void s16_dft2(cpx &a, cpx &b)
-{
-  const cpx t = a;
-  a = cadd(t, b);
-  b = csub(t, b);
-}
-__device__ __forceinline__ void s16_dft8(cpx (&e)[8])
-{
-  constexpr float R2 = 0.70710678118654752f;
-  w1024::dft4<false>(e[0], e[2], e[4], e[6]);               // even samples -> E[0..3] in e[0],e[2],e[4],e[6]
-  w1024::dft4<false>(e[1], e[3], e[5], e[7]);               // odd samples  -> O[0..3] in e[1],e[3],e[5],e[7]
-  const cpx o0 = e[1], o1 = cmul(e[3], cmk(R2, -R2)), o2 = cmk(e[5].y, -e[5].x), o3 = cmul(e[7], cmk(-R2, -R2));
-  const cpx a0 = e[0], a1 = e[2], a2 = e[4], a3 = e[6];
-  e[0] = cadd(a0, o0); e[4] = csub(a0, o0);
-  e[1] = cadd(a1, o1); e[5] = csub(a1, o1);
-  e[2] = cadd(a2, o2); e[6] = csub(a2, o2);
-  e[3] = cadd(a3, o3); e[7] = csub(a3, o3);
-}
 template <int R0>
 __global__ __launch_bounds__(1024) void fft_s16_kernel(const cpx *__restrict__ in, cpx *__restrict__ out,
                                                        const cpx *__restrict__ TW, int n, int tpt, int inverse,
@@ -211,13 +193,13 @@ __global__ __launch_bounds__(1024) void fft_s16_kernel(const cpx *__restrict__ i
       float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
       if (g0 + e < gend) q = *reinterpret_cast<const float4 *>(in + g0 + e);
       const int tq = e / n, eq = e - tq * n;
-      cpx *d = lds + tq * pn + s16_pad(eq);
+      cpx *d = lds + tq * pn + s16::pad(eq);
       d[0] = cmk(q.x, inverse ? -q.y : q.y);
       d[1] = cmk(q.z, inverse ? -q.w : q.w);
     }
     __syncthreads();
 #pragma unroll
-    for (int m = 0; m < 16; m++) v[m] = s[s16_pad(j + m * tpt)];
+    for (int m = 0; m < 16; m++) v[m] = s[s16::pad(j + m * tpt)];
     __syncthreads();
   } else {
     const cpx *x = in + (size_t) (live ? tr : 0) * n;
@@ -228,51 +210,20 @@ __global__ __launch_bounds__(1024) void fft_s16_kernel(const cpx *__restrict__ i
     }
   }
   // ---- pass 0: radix R0, no twiddles
-  if (R0 == 16) {
-    w1024::dft16<false>(v);
-  } else if (R0 == 8) {
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-      cpx e[8];
-#pragma unroll
-      for (int q = 0; q < 8; q++) e[q] = v[i + 2 * q];
-      s16_dft8(e);
-#pragma unroll
-      for (int q = 0; q < 8; q++) v[i + 2 * q] = e[q];
-    }
-  } else if (R0 == 4) {
-#pragma unroll
-    for (int i = 0; i < 4; i++) w1024::dft4<false>(v[i], v[i + 4], v[i + 8], v[i + 12]);
-  } else {
-#pragma unroll
-    for (int i = 0; i < 8; i++) s16_dft2(v[i], v[i + 8]);
-  }
+  s16::pass0<R0>(v);
   // v[i + q * (16 / R0)] = output q of butterfly jb = j + i * tpt  ->  y[jb * R0 + q]
   if (n == R0) {                                           // n = 16: a single pass (always staged: tpt = 1)
 #pragma unroll
-    for (int q = 0; q < 16; q++) s[s16_pad(q)] = v[q];
+    for (int q = 0; q < 16; q++) s[s16::pad(q)] = v[q];
   } else {
-#pragma unroll
-    for (int i = 0; i < 16 / R0; i++)
-#pragma unroll
-      for (int q = 0; q < R0; q++) s[s16_pad((j + i * tpt) * R0 + q)] = v[i + q * (16 / R0)];
+    s16::pass0_store<R0>(s, v, j, tpt);
     // ---- radix-16 passes
     for (int Ns = R0;; Ns <<= 4) {
       __syncthreads();
 #pragma unroll
-      for (int q = 0; q < 16; q++) v[q] = s[s16_pad(j + q * tpt)];
+      for (int q = 0; q < 16; q++) v[q] = s[s16::pad(j + q * tpt)];
       const int k = j & (Ns - 1);
-      {
-        // w^q, q = 1..15, from one table value: products of depth <= 4
-        const cpx w1 = TW[k * (tpt / Ns)];
-        const cpx w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
-        const cpx w5 = cmul(w4, w1), w6 = cmul(w4, w2), w7 = cmul(w4, w3), w8 = cmul(w4, w4);
-        v[1] = cmul(v[1], w1); v[2] = cmul(v[2], w2); v[3] = cmul(v[3], w3); v[4] = cmul(v[4], w4);
-        v[5] = cmul(v[5], w5); v[6] = cmul(v[6], w6); v[7] = cmul(v[7], w7); v[8] = cmul(v[8], w8);
-        v[9] = cmul(v[9], cmul(w8, w1)); v[10] = cmul(v[10], cmul(w8, w2)); v[11] = cmul(v[11], cmul(w8, w3));
-        v[12] = cmul(v[12], cmul(w8, w4)); v[13] = cmul(v[13], cmul(w8, w5)); v[14] = cmul(v[14], cmul(w8, w6));
-        v[15] = cmul(v[15], cmul(w8, w7));
-      }
+      s16::twiddle_powers(v, TW[k * (tpt / Ns)]);
       w1024::dft16<false>(v);
       const int base = (j - k) * 16 + k;
       const bool last = Ns * 16 == n;
@@ -290,7 +241,7 @@ __global__ __launch_bounds__(1024) void fft_s16_kernel(const cpx *__restrict__ i
       }
       __syncthreads();
 #pragma unroll
-      for (int q = 0; q < 16; q++) s[s16_pad(base + q * Ns)] = v[q];
+      for (int q = 0; q < 16; q++) s[s16::pad(base + q * Ns)] = v[q];
       if (last) break;
     }
   }
@@ -301,7 +252,7 @@ __global__ __launch_bounds__(1024) void fft_s16_kernel(const cpx *__restrict__ i
     const int e = 2 * i;
     if (g0 + e >= gend) break;
     const int tq = e / n, eq = e - tq * n;
-    const cpx *d = lds + tq * pn + s16_pad(eq);
+    const cpx *d = lds + tq * pn + s16::pad(eq);
     const cpx a = d[0], b = d[1];
     *reinterpret_cast<float4 *>(out + g0 + e) = make_float4(a.x * scale, inverse ? -a.y * scale : a.y * scale, b.x * scale,
                                                             inverse ? -b.y * scale : b.y * scale);
@@ -338,15 +289,15 @@ __global__ __launch_bounds__(1024) void fft_cols16_kernel(const cpx *__restrict_
       cpx f = cmk(0.f, 0.f);
       if (c0 + c < C) f = x[(size_t) r * C + c0 + c];
       if (PASS == 1 && inverse) f.y = -f.y;
-      lds[c * pn + s16_pad(r)] = f;
+      lds[c * pn + s16::pad(r)] = f;
     }
   } else
   for (int q = t; q < L * h; q += nthr) {
     const int r = q / h, c = 2 * (q - r * h);
     const float4 f = *reinterpret_cast<const float4 *>(x + (size_t) r * C + c0 + c);
     const float sg = (PASS == 1 && inverse) ? -1.f : 1.f;
-    lds[c * pn + s16_pad(r)] = cmk(f.x, sg * f.y);
-    lds[(c + 1) * pn + s16_pad(r)] = cmk(f.z, sg * f.w);
+    lds[c * pn + s16::pad(r)] = cmk(f.x, sg * f.y);
+    lds[(c + 1) * pn + s16::pad(r)] = cmk(f.z, sg * f.w);
   }
   __syncthreads();
   const int cl = t / tpt, j = t - cl * tpt;
@@ -371,60 +322,30 @@ __global__ __launch_bounds__(1024) void fft_cols16_kernel(const cpx *__restrict_
     u[15] = cmul(u[15], cmul(b8, d7));
   };
 #pragma unroll
-  for (int m = 0; m < 16; m++) v[m] = s[s16_pad(j + m * tpt)];
+  for (int m = 0; m < 16; m++) v[m] = s[s16::pad(j + m * tpt)];
   __syncthreads();
-  if (R0 == 16) {
-    w1024::dft16<false>(v);
-  } else if (R0 == 8) {
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-      cpx e[8];
-#pragma unroll
-      for (int q = 0; q < 8; q++) e[q] = v[i + 2 * q];
-      s16_dft8(e);
-#pragma unroll
-      for (int q = 0; q < 8; q++) v[i + 2 * q] = e[q];
-    }
-  } else if (R0 == 4) {
-#pragma unroll
-    for (int i = 0; i < 4; i++) w1024::dft4<false>(v[i], v[i + 4], v[i + 8], v[i + 12]);
-  } else {
-#pragma unroll
-    for (int i = 0; i < 8; i++) s16_dft2(v[i], v[i + 8]);
-  }
+  s16::pass0<R0>(v);
   if (PASS == 1 && R0 == 16 && L == 16) four_step_twiddle(v);
-#pragma unroll
-  for (int i = 0; i < 16 / R0; i++)
-#pragma unroll
-    for (int q = 0; q < R0; q++) s[s16_pad((j + i * tpt) * R0 + q)] = v[i + q * (16 / R0)];
+  s16::pass0_store<R0>(s, v, j, tpt);
   for (int Ns = R0; Ns < L; Ns <<= 4) {
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 16; q++) v[q] = s[s16_pad(j + q * tpt)];
+    for (int q = 0; q < 16; q++) v[q] = s[s16::pad(j + q * tpt)];
     const int k = j & (Ns - 1);
-    {
-      const cpx w1 = TW[k * (tpt / Ns)];
-      const cpx w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
-      const cpx w5 = cmul(w4, w1), w6 = cmul(w4, w2), w7 = cmul(w4, w3), w8 = cmul(w4, w4);
-      v[1] = cmul(v[1], w1); v[2] = cmul(v[2], w2); v[3] = cmul(v[3], w3); v[4] = cmul(v[4], w4);
-      v[5] = cmul(v[5], w5); v[6] = cmul(v[6], w6); v[7] = cmul(v[7], w7); v[8] = cmul(v[8], w8);
-      v[9] = cmul(v[9], cmul(w8, w1)); v[10] = cmul(v[10], cmul(w8, w2)); v[11] = cmul(v[11], cmul(w8, w3));
-      v[12] = cmul(v[12], cmul(w8, w4)); v[13] = cmul(v[13], cmul(w8, w5)); v[14] = cmul(v[14], cmul(w8, w6));
-      v[15] = cmul(v[15], cmul(w8, w7));
-    }
+    s16::twiddle_powers(v, TW[k * (tpt / Ns)]);
     w1024::dft16<false>(v);
     const int base = (j - k) * 16 + k;
     if (PASS == 1 && Ns * 16 == L) four_step_twiddle(v);     // last pass: outputs k = j + q * tpt
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < 16; q++) s[s16_pad(base + q * Ns)] = v[q];
+    for (int q = 0; q < 16; q++) s[s16::pad(base + q * Ns)] = v[q];
   }
   __syncthreads();
   if (PASS == 1) {
     const int hl = L >> 1;
     for (int q = t; q < CT * hl; q += nthr) {
       const int c = q / hl, k = 2 * (q - c * hl);
-      const cpx *d = lds + c * pn + s16_pad(k);
+      const cpx *d = lds + c * pn + s16::pad(k);
       const cpx a = d[0], b = d[1];
       *reinterpret_cast<float4 *>(y + (size_t) (c0 + c) * L + k) = make_float4(a.x, a.y, b.x, b.y);
     }
@@ -432,14 +353,14 @@ __global__ __launch_bounds__(1024) void fft_cols16_kernel(const cpx *__restrict_
     for (int q = t; q < L * CT; q += nthr) {
       const int k = q / CT, c = q - k * CT;
       if (c0 + c < C) {
-        const cpx a = lds[c * pn + s16_pad(k)];
+        const cpx a = lds[c * pn + s16::pad(k)];
         y[(size_t) k * C + c0 + c] = cmk(a.x * scale, inverse ? -a.y * scale : a.y * scale);
       }
     }
   } else {
     for (int q = t; q < L * h; q += nthr) {
       const int k = q / h, c = 2 * (q - k * h);
-      const cpx a = lds[c * pn + s16_pad(k)], b = lds[(c + 1) * pn + s16_pad(k)];
+      const cpx a = lds[c * pn + s16::pad(k)], b = lds[(c + 1) * pn + s16::pad(k)];
       const float si = inverse ? -scale : scale;
       *reinterpret_cast<float4 *>(y + (size_t) k * C + c0 + c) = make_float4(a.x * scale, a.y * si, b.x * scale, b.y * si);
     }

@@ -301,7 +301,9 @@ int tsdgpu_fir_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, void *stre
     TSD_HIP(hipMemcpyAsync(f->in_stage.p, dx, bytes, hipMemcpyDeviceToDevice, st));
     dx = f->in_stage.p;
   }
-  if (f->method == TSDGPU_FIR_OVERLAP_SAVE) {
+  if (f->method == TSDGPU_FIR_OVERLAP_SAVE && f->ols_long) {
+    rc = ols_long_step(f, dx, dy, n, st);
+  } else if (f->method == TSDGPU_FIR_OVERLAP_SAVE) {
     rc = ols_step(f, dx, dy, n, st);             // history update folded into the launch
   } else {
     rc = fir_direct_step(f, dx, dy, n, st);

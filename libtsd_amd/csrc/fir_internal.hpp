@@ -1,6 +1,7 @@
 // fir_internal.hpp -- FIR handle shared by the direct (fir.hip) and overlap-save (ols.hip) paths.
 #pragma once
 #include "common.hpp"
+#include <vector>
 
 struct tsdgpu_fir {
   int data_type = 0, tap_type = 0;
@@ -19,6 +20,7 @@ struct tsdgpu_fir {
   int ols_N = 0;            // FFT block size
   int ols_L = 0;            // valid outputs per block = N - (K-1)
   int ols_grid = 0;         // persistent grid size (waves)
+  bool ols_long = false;    // long-filter plan (ols_long.hip): N = 4096..16384, H in natural order + W_N table
 };
 
 namespace tsdgpu {
@@ -29,4 +31,8 @@ bool ols_preferred(const tsdgpu_fir *f);
 int ols_plan_create(tsdgpu_fir *f);
 void ols_plan_destroy(tsdgpu_fir *f);
 int ols_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, hipStream_t st);
+// overlap-save for long filters (514..12289 taps), radix-16 Stockham blocks
+bool ols_long_supported(const tsdgpu_fir *f);
+int ols_long_plan_create(tsdgpu_fir *f);
+int ols_long_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, hipStream_t st);
 }  // namespace tsdgpu
