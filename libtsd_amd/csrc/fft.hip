@@ -30,6 +30,12 @@ __device__ __forceinline__ cpx cscale(cpx a, float s) { return cmk(a.x * s, a.y 
 constexpr int FFT_THREADS = 256;
 constexpr int LDS_MAX_N = 4096;      // largest transform done in one workgroup's LDS (radix-2 fallback kernel)
 constexpr int S16_MAX_N = 16384;     // largest transform of the radix-16 Stockham kernel (139 KiB of LDS)
+// threads per transform from which fft_s16_kernel loads / stores straight from registers (measured:
+// even 32-B runs per transform beat the LDS staging: n = 64: 0.193 vs 0.236 ms per 2^26 points;
+// n = 32 and 16 are better staged)
+#ifndef S16_DIRECT_TPT
+#define S16_DIRECT_TPT 4
+#endif
 constexpr int COL_TILE = 16;         // columns per tile: 16 * 8 B = one 128-B line per row
 
 __device__ __forceinline__ unsigned bitrev(unsigned i, int logn) { return logn == 0 ? 0u : (__brev(i) >> (32 - logn)); }
@@ -164,10 +170,10 @@ __global__ __launch_bounds__(256) void fft1024_rows_kernel(const cpx *__restrict
 // the LDS sees each point once per pass.  The twiddle of a butterfly is ONE table value
 // (W_{16 Ns}^k) raised to q = 2..15 by a depth-4 product tree in registers.  LDS index i is
 // stored at i + i/16 (keeps the stride-16 writes of the passes conflict-free).
-// Workgroup = max(256, n/16) threads = 4096/n transforms (n < 4096) or one.  With n < 1024 a
-// wave spans several transforms, so the global accesses are staged through LDS to stay 16-B
-// coalesced; from 1024 up the first pass loads and the last pass stores straight from
-// registers (512 contiguous bytes per wave instruction).
+// Workgroup = max(256, n/16) threads = 4096/n transforms (n < 4096) or one.  From n = 64 the
+// first pass loads and the last pass stores straight from registers (runs of n/2 contiguous
+// bytes per transform, 512 B per wave instruction from n = 1024); n = 16 and 32 stage their
+// global accesses through LDS to keep them 16-B coalesced.
 template <int R0>
 __global__ __launch_bounds__(1024) void fft_s16_kernel(const cpx *__restrict__ in, cpx *__restrict__ out,
                                                        const cpx *__restrict__ TW, int n, int tpt, int inverse,
@@ -182,7 +188,7 @@ __global__ __launch_bounds__(1024) void fft_s16_kernel(const cpx *__restrict__ i
   const bool live = tr < ntr;
   const int pn = n + (n >> 4);
   cpx *s = lds + tl * pn;
-  const bool staged = tpt < 64;
+  const bool staged = tpt < S16_DIRECT_TPT;
   const int64_t g0 = (int64_t) blockIdx.x * T * n, gend = (int64_t) ntr * n;   // this workgroup's points
   cpx v[16];
   if (staged) {
