@@ -4,11 +4,14 @@
 //   FiltreRIFDemiBande        (polyphase.cc:54-149)                             half-band, R = 2
 //   FiltreRIFUps              (polyphase.cc:246-341)                            polyphase x R
 //   FiltreRII                 (filtre-rt.cc:177-289)                            direct form I
-// They are compositions of the FIR kernels of fir.hip / ols.hip with small permutation
-// kernels, all on device scratch (correctness-first: the decimators compute every
-// full-rate output and keep one in R).
+// The FIR stages run one fused kernel (polyfir_fused_kernel: only the kept outputs of a decimator
+// are computed, all R branches of the upsampler come from one pass over the input); very high
+// rates or tap counts that do not fit its LDS tile fall back to compositions of the FIR
+// kernels of fir.hip / ols.hip with small permutation kernels on device scratch.
 #include "common.hpp"
 #include <cmath>
+#include <cstdlib>
+#include <vector>
 
 namespace tsdgpu {
 
@@ -25,6 +28,82 @@ __global__ void interleave_kernel(const T *__restrict__ z, T *__restrict__ y, in
 {
   const int64_t a = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
   if (a < n) y[a * R + i] = z[a];
+}
+
+// Fused integer-rate FIR: output o belongs to group grp = o / NPH and phase ph = o % NPH and is
+//     y[o] = sum_{k < W} g[ph][k] * x[grp * stride + start - k]          (x[i < 0] = history)
+// Decimators: NPH = 1, stride = R (only the kept outputs are ever computed).  Upsampler: NPH = R,
+// stride = 1, one W = ceil(K/R)-tap branch per output phase.  A workgroup stages the input
+// span of its PF_TO outputs in LDS with coalesced loads; every thread then evaluates
+// PF_TO/256 outputs from LDS (taps in LDS too).  Algorithmic bytes per input sample:
+// 8 + 8/R (decimate) or 8 + 8 R (upsample) for complex data.
+#ifndef PF_SPAN_TARGET
+#define PF_SPAN_TARGET 2048
+#endif
+constexpr int PF_TO = 2048;          // outputs per workgroup (fewer when the decimation rate makes their input span too long)
+constexpr int PF_MAX_SPAN = 16000;   // staged input samples per workgroup (129 KiB of complex data with the padding)
+__device__ __forceinline__ float pf_mac(float acc, float g, float x) { return fmaf(g, x, acc); }
+__device__ __forceinline__ float2 pf_mac(float2 acc, float g, float2 x) { return make_float2(fmaf(g, x.x, acc.x), fmaf(g, x.y, acc.y)); }
+__device__ __forceinline__ float pf_zero(float) { return 0.f; }
+__device__ __forceinline__ float2 pf_zero(float2) { return make_float2(0.f, 0.f); }
+template <typename T>
+__global__ __launch_bounds__(256) void polyfir_fused_kernel(const T *__restrict__ x, const T *__restrict__ hist, T *__restrict__ y,
+                                                            const float *__restrict__ g, int NPH, int W, int stride,
+                                                            int64_t start, int HW, int64_t n, int64_t nout, int TO)
+{
+  extern __shared__ __attribute__((aligned(16))) char pf_raw[];
+  float *gs = reinterpret_cast<float *>(pf_raw);                         // NPH * W taps
+  T *xs = reinterpret_cast<T *>(gs + ((NPH * W + 3) & ~3));              // staged inputs
+  const int t = threadIdx.x;
+  for (int i = t; i < NPH * W; i += 256) gs[i] = g[i];
+  const int64_t o0 = (int64_t) blockIdx.x * TO;
+  const int64_t o1 = min(o0 + TO, nout);                              // exclusive
+  const int64_t grp0 = o0 / NPH, grp1 = (o1 - 1) / NPH;
+  const int64_t i_lo = grp0 * stride + start - (W - 1), i_hi = grp1 * stride + start;   // inclusive input span
+  const int span = (int) (i_hi - i_lo + 1);
+  // 8 loads in flight per thread (a one-load-per-iteration loop exposed the HBM latency 16-32 times
+  // per workgroup and ran the decimators at 0.30 ms per 2^26 samples)
+  for (int i0 = t; i0 < span; i0 += 256 * 8) {
+    T v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int i = i0 + 256 * u;
+      const int64_t idx = i_lo + i;
+      v[u] = pf_zero(T{});
+      if (i < span) {
+        if (idx < 0) {
+          if (idx >= -(int64_t) HW) v[u] = hist[HW + idx];
+        } else if (idx < n) {
+          v[u] = x[idx];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int i = i0 + 256 * u;
+      if (i < span) xs[i] = v[u];
+    }
+  }
+  __syncthreads();
+  for (int64_t o = o0 + t; o < o1; o += 256) {
+    const int64_t grp = o / NPH;
+    const int ph = (int) (o - grp * NPH);
+    const int b = (int) (grp * stride + start - i_lo);                   // staged index of the newest sample
+    const float *gp = gs + ph * W;
+    T acc = pf_zero(T{});
+    for (int k = W - 1; k >= 0; k--) acc = pf_mac(acc, gp[k], xs[b - k]);   // oldest sample first, like the reference
+    y[o] = acc;
+  }
+}
+// new_hist = last HW samples of (old_hist ++ x[0..n))
+template <typename T>
+__global__ void pf_hist_update_kernel(const T *__restrict__ x, const T *__restrict__ old_hist, T *__restrict__ new_hist, int HW,
+                                      int64_t n)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= HW) return;
+  const int64_t src = n - HW + i;
+  new_hist[i] = src >= 0 ? x[src] : old_hist[HW + src];
 }
 
 // Recursive half of FiltreRII (filtre-rt.cc:251-279), literally sequential: one lane per
@@ -54,6 +133,11 @@ struct tsdgpu_polyfir {
   int kind = 0, data_type = 0, R = 1, K = 0;
   std::vector<tsdgpu_fir *> fir;    // 1 (decimators) or R (upsampler phases)
   int cnt = 0;                      // inputs seen since the last kept output (decimators / pick)
+  // fused path (polyfir_fused_kernel): taps [NPH][W] in FIR convention, history of the last HW inputs
+  bool fused = false;
+  int NPH = 1, W = 0, HW = 0, cur = 0, TO = 0;
+  float *d_g = nullptr;
+  void *d_hist[2] = {nullptr, nullptr};
   DevBuf z, in_stage, out_stage;
 };
 
@@ -78,6 +162,49 @@ int launch_pick(const void *x, void *y, int64_t start, int R, int64_t nout, hipS
   if (nout <= 0) return TSDGPU_OK;
   hipLaunchKernelGGL(pick_kernel<T>, dim3((unsigned) cdiv(nout, 256)), dim3(256), 0, st, (const T *) x, (T *) y, start, R, nout);
   TSD_HIP(hipGetLastError());
+  return TSDGPU_OK;
+}
+
+// the fused kernel serves a stage when its taps and the input span of PF_TO outputs fit in LDS
+int fused_setup(tsdgpu_polyfir *p, const std::vector<float> &g, int NPH, int W, int stride)
+{
+  // outputs per workgroup: as many as keep the staged input span within PF_MAX_SPAN samples
+  // ... and preferably within ~PF_SPAN_TARGET samples (17 KiB: several workgroups per CU overlap their load and compute phases)
+  int64_t to = std::min<int64_t>(PF_TO, ((int64_t) (PF_MAX_SPAN - W) / stride - 1) * NPH);
+  to = std::min<int64_t>(to, std::max<int64_t>(256, (int64_t) (PF_SPAN_TARGET / stride) * NPH));
+  if (getenv("TSDGPU_POLY_COMPOSED") || to < 256 || (size_t) NPH * W > 4096 || W < 1) return TSDGPU_OK;
+  p->TO = (int) (to / 256 * 256);
+  p->NPH = NPH;
+  p->W = W;
+  p->HW = std::max(W - 1, 1);
+  const size_t hb = (size_t) p->HW * dtype_size(p->data_type);
+  if (hipMalloc((void **) &p->d_g, g.size() * sizeof(float)) != hipSuccess || hipMalloc(&p->d_hist[0], hb) != hipSuccess ||
+      hipMalloc(&p->d_hist[1], hb) != hipSuccess)
+    return set_err(TSDGPU_ERR_HIP, "polyfir_create: hipMalloc failed: %s", hipGetErrorString(hipGetLastError()));
+  if (hipMemcpy(p->d_g, g.data(), g.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemset(p->d_hist[0], 0, hb) != hipSuccess || hipMemset(p->d_hist[1], 0, hb) != hipSuccess)
+    return set_err(TSDGPU_ERR_HIP, "polyfir_create: upload failed: %s", hipGetErrorString(hipGetLastError()));
+  (void) hipFuncSetAttribute((const void *) polyfir_fused_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void) hipFuncSetAttribute((const void *) polyfir_fused_kernel<float2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void) hipGetLastError();
+  p->fused = true;
+  return TSDGPU_OK;
+}
+
+template <typename T>
+int fused_step(tsdgpu_polyfir *p, const void *dx, void *dy, int stride, int64_t start, int64_t n, int64_t nout, hipStream_t st)
+{
+  if (nout > 0) {
+    const int64_t span = (int64_t) (p->TO / p->NPH + 1) * stride + p->W;
+    const size_t lds = (size_t) ((p->NPH * p->W + 3) & ~3) * sizeof(float) + (size_t) span * sizeof(T);
+    hipLaunchKernelGGL(polyfir_fused_kernel<T>, dim3((unsigned) cdiv(nout, p->TO)), dim3(256), lds, st, (const T *) dx,
+                       (const T *) p->d_hist[p->cur], (T *) dy, p->d_g, p->NPH, p->W, stride, start, p->HW, n, nout, p->TO);
+    TSD_HIP(hipGetLastError());
+  }
+  hipLaunchKernelGGL(pf_hist_update_kernel<T>, dim3((unsigned) cdiv(p->HW, 64)), dim3(64), 0, st, (const T *) dx,
+                     (const T *) p->d_hist[p->cur], (T *) p->d_hist[p->cur ^ 1], p->HW, n);
+  TSD_HIP(hipGetLastError());
+  p->cur ^= 1;
   return TSDGPU_OK;
 }
 
@@ -123,6 +250,7 @@ int tsdgpu_polyfir_create(tsdgpu_polyfir **out, int kind, int data_type, const f
     tsdgpu_fir *f = nullptr;
     rc = tsdgpu_fir_create(&f, data_type, TSDGPU_F32, h.data(), ntaps, TSDGPU_FIR_AUTO);
     if (!rc) p->fir.push_back(f);
+    if (!rc) rc = fused_setup(p, h, 1, ntaps, R);
   } else if (kind == TSDGPU_POLY_UPS) {
     // coefs = c * R, zero-padded to a multiple of R (polyphase.cc:259-270); phase i correlates
     // the K/R-sample window with coefs[(R-1-i) + j*R]
@@ -130,13 +258,16 @@ int tsdgpu_polyfir_create(tsdgpu_polyfir **out, int kind, int data_type, const f
     for (int i = 0; i < ntaps; i++) c[i] = taps_host[i] * (float) R;
     while (c.size() % (size_t) R) c.push_back(0.f);
     const int W = (int) c.size() / R;
+    std::vector<float> gall;
     for (int i = 0; i < R && !rc; i++) {
       std::vector<float> g((size_t) W);
       for (int k = 0; k < W; k++) g[k] = c[(size_t) (R - 1 - i) + (size_t) (W - 1 - k) * R];
       tsdgpu_fir *f = nullptr;
       rc = tsdgpu_fir_create(&f, data_type, TSDGPU_F32, g.data(), W, TSDGPU_FIR_AUTO);
       if (!rc) p->fir.push_back(f);
+      gall.insert(gall.end(), g.begin(), g.end());
     }
+    if (!rc) rc = fused_setup(p, gall, R, W, 1);
   }
   if (rc) {
     tsdgpu_polyfir_destroy(p);
@@ -174,6 +305,16 @@ int tsdgpu_polyfir_step(tsdgpu_polyfir *p, const void *x, int64_t n, void *y, in
     rc = cplx ? launch_pick<float2>(dx, dy, p->cnt, p->R, nout, st) : launch_pick<float>(dx, dy, p->cnt, p->R, nout, st);
     if (rc) return rc;
     p->cnt = (int) (p->cnt + nout * p->R - n);
+  } else if (p->fused && p->kind == TSDGPU_POLY_UPS) {
+    // output n*R + i = phase i of input n: group = input index, newest sample = that input
+    rc = cplx ? fused_step<float2>(p, dx, dy, 1, 0, n, nout, st) : fused_step<float>(p, dx, dy, 1, 0, n, nout, st);
+    if (rc) return rc;
+  } else if (p->fused) {
+    // kept outputs sit at local inputs R-1-cnt, then every R
+    const int64_t start = p->R - 1 - p->cnt;
+    rc = cplx ? fused_step<float2>(p, dx, dy, p->R, start, n, nout, st) : fused_step<float>(p, dx, dy, p->R, start, n, nout, st);
+    if (rc) return rc;
+    p->cnt = (int) ((p->cnt + n) % p->R);
   } else if (p->kind == TSDGPU_POLY_UPS) {
     rc = p->z.reserve((size_t) n * sz);
     if (rc) return rc;
@@ -207,6 +348,7 @@ int tsdgpu_polyfir_reset(tsdgpu_polyfir *p)
 {
   TSD_CHECK(p != nullptr, "polyfir_reset: NULL handle");
   p->cnt = 0;
+  if (p->fused) TSD_HIP(hipMemset(p->d_hist[p->cur], 0, (size_t) p->HW * dtype_size(p->data_type)));
   for (auto *f : p->fir) {
     const int rc = tsdgpu_fir_reset(f);
     if (rc) return rc;
@@ -218,6 +360,9 @@ int tsdgpu_polyfir_destroy(tsdgpu_polyfir *p)
 {
   if (!p) return TSDGPU_OK;
   for (auto *f : p->fir) tsdgpu_fir_destroy(f);
+  if (p->d_g) (void) hipFree(p->d_g);
+  for (void *h : p->d_hist)
+    if (h) (void) hipFree(h);
   p->z.release();
   p->in_stage.release();
   p->out_stage.release();

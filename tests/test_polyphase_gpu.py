@@ -70,6 +70,28 @@ def test_rif_ups(tg, orc, cplx, R):              # test_filtre_rif_ups (test-ra.
     assert len(y) == len(ref) == len(x) * R and relerr(y, ref) <= TOL
 
 
+# rates / tap counts beyond the reference's tests: long decimation (fewer outputs per workgroup),
+# a rate the fused kernel hands back to the composed path (R = 100), many-tap branches, tiny chunks
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("R,K", [(16, 63), (60, 15), (100, 31), (7, 200)])
+def test_rif_decim_wide(tg, orc, cplx, R, K):
+    h = orc.design_rif_fen(K, "lp", 0.5 / R)
+    x = rand(50000, cplx, R + K)
+    ref = orc.PolyDecim(h, R, 0).step(x)
+    y = chunks(tg.PolyFir(tg.POLY_DECIM, tg.C64 if cplx else tg.F32, h, R), x, 12345)
+    assert len(y) == len(ref) and relerr(y, ref) <= TOL
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("R,K,bs", [(8, 127, 5000), (2, 15, 1), (5, 33, 7)])
+def test_rif_ups_wide(tg, orc, cplx, R, K, bs):
+    h = orc.design_rif_fen(K, "lp", 0.5 / R)
+    x = rand(4000 if bs > 1 else 100, cplx, R + K)
+    ref = orc.PolyUps(h, R).step(x)
+    y = chunks(tg.PolyFir(tg.POLY_UPS, tg.C64 if cplx else tg.F32, h, R), x, bs)
+    assert len(y) == len(ref) == len(x) * R and relerr(y, ref) <= TOL
+
+
 # test_filtre_rii (test-filtres.cc:556-606): one-pole smoother vs the closed recurrence
 def test_filtre_rii(tg, orc):
     a = np.float32(0.1)
