@@ -194,14 +194,24 @@ __global__ __launch_bounds__(1024) void fft_s16_kernel(const cpx *__restrict__ i
   if (staged) {
     // coalesced 16-B loads of the workgroup's T*n points into the padded per-transform images
     const int tot2 = (T * n) >> 1;
-    for (int i = t; i < tot2; i += blockDim.x) {
-      const int e = 2 * i;
-      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (g0 + e < gend) q = *reinterpret_cast<const float4 *>(in + g0 + e);
-      const int tq = e / n, eq = e - tq * n;
-      cpx *d = lds + tq * pn + s16::pad(eq);
-      d[0] = cmk(q.x, inverse ? -q.y : q.y);
-      d[1] = cmk(q.z, inverse ? -q.w : q.w);
+    for (int i0 = t; i0 < tot2; i0 += 8 * blockDim.x) {      // 8 loads in flight per thread
+      float4 q[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int e = 2 * (i0 + u * (int) blockDim.x);
+        q[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e < 2 * tot2 && g0 + e < gend) q[u] = *reinterpret_cast<const float4 *>(in + g0 + e);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int e = 2 * (i0 + u * (int) blockDim.x);
+        if (e < 2 * tot2) {
+          const int tq = e / n, eq = e - tq * n;
+          cpx *d = lds + tq * pn + s16::pad(eq);
+          d[0] = cmk(q[u].x, inverse ? -q[u].y : q[u].y);
+          d[1] = cmk(q[u].z, inverse ? -q[u].w : q[u].w);
+        }
+      }
     }
     __syncthreads();
 #pragma unroll
@@ -298,12 +308,21 @@ __global__ __launch_bounds__(1024) void fft_cols16_kernel(const cpx *__restrict_
       lds[c * pn + s16::pad(r)] = f;
     }
   } else
-  for (int q = t; q < L * h; q += nthr) {
-    const int r = q / h, c = 2 * (q - r * h);
-    const float4 f = *reinterpret_cast<const float4 *>(x + (size_t) r * C + c0 + c);
+  {
+    // L*CT/2 float4 over CT*L/16 threads = exactly 8 per thread: all 8 loads in flight at once
+    float4 f[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int q = t + i * nthr, r = q / h, c = 2 * (q - r * h);
+      f[i] = *reinterpret_cast<const float4 *>(x + (size_t) r * C + c0 + c);
+    }
     const float sg = (PASS == 1 && inverse) ? -1.f : 1.f;
-    lds[c * pn + s16::pad(r)] = cmk(f.x, sg * f.y);
-    lds[(c + 1) * pn + s16::pad(r)] = cmk(f.z, sg * f.w);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int q = t + i * nthr, r = q / h, c = 2 * (q - r * h);
+      lds[c * pn + s16::pad(r)] = cmk(f[i].x, sg * f[i].y);
+      lds[(c + 1) * pn + s16::pad(r)] = cmk(f[i].z, sg * f[i].w);
+    }
   }
   __syncthreads();
   const int cl = t / tpt, j = t - cl * tpt;

@@ -69,13 +69,27 @@ __global__ __launch_bounds__(THREADS) void fir_direct_kernel(
   if (interior) {
     // 16-B global loads: chunk c = samples [c*VEC, c*VEC + VEC)
     const float4 *xs = reinterpret_cast<const float4 *>(x + (tile0 - H));
-    for (int c = threadIdx.x; c < total / VEC; c += THREADS) {
-      const float4 q4 = xs[c];
-      const T *e = reinterpret_cast<const T *>(&q4);
+    // four loads in flight per thread (the tile is 4..5 chunks per thread: one load per
+    // iteration exposed the HBM latency that many times per workgroup)
+    const int nchunks = total / VEC;
+    for (int c0 = threadIdx.x; c0 < nchunks; c0 += 4 * THREADS) {
+      float4 q4[4];
 #pragma unroll
-      for (int k = 0; k < VEC; k++) {
-        const int q = c * VEC + k - 1;
-        if (q >= 0) L[q + (q / R) * P] = e[k];
+      for (int u = 0; u < 4; u++) {
+        const int c = c0 + u * THREADS;
+        if (c < nchunks) q4[u] = xs[c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int c = c0 + u * THREADS;
+        if (c < nchunks) {
+          const T *e = reinterpret_cast<const T *>(&q4[u]);
+#pragma unroll
+          for (int k = 0; k < VEC; k++) {
+            const int q = c * VEC + k - 1;
+            if (q >= 0) L[q + (q / R) * P] = e[k];
+          }
+        }
       }
     }
   } else {

@@ -220,14 +220,14 @@ __global__ __launch_bounds__(64, 2) void ols_kernel(const void *__restrict__ x, 
 
 bool ols_preferred(const tsdgpu_fir *f)
 {
-  // the direct kernel is HBM-bound below ~48 taps (complex data; ~64 for real data, whose
-  // direct form needs half the flops); the 1024-point wave block loses efficiency as
+  // the direct kernel is HBM-bound below ~48 taps (complex data; measured crossover for real data,
+  // whose blocks are packed two per complex FFT: ~40 taps); the 1024-point wave block loses efficiency as
   // L = 1024 - roundup(K-1, 64) shrinks, so from L = 512 on larger blocks take over:
   // K = 514 .. 12289: the long-filter plan (ols_long.hip, blocks of 4096..16384 on the Stockham engine;
   // measured crossover with the 1024-point wave blocks: K = 513 -> 0.313 ms here, 0.294 ms there)
   if (ols_long_supported(f)) return true;
   if (f->data_type == TSDGPU_C64) return f->K >= 48 && f->K <= 513;
-  return f->tap_type == TSDGPU_F32 && f->K >= 64 && f->K <= 513;
+  return f->tap_type == TSDGPU_F32 && f->K >= 40 && f->K <= 513;
 }
 
 int ols_plan_create(tsdgpu_fir *f)
