@@ -34,6 +34,22 @@ template <typename T> sptr<FilterGen<T>> filter_fir_fft(const Vecf &h) { return 
 template <typename T> sptr<FilterGen<T>> filter_sois(const FRat<cfloat> &h, RIIStructure s = FormeDirecte2) { return tsd::filtrage::filtre_sois<T>(h, s); }
 template <typename T> sptr<FilterGen<T>> filter_sois(const FRat<float> &h, RIIStructure s = FormeDirecte2) { return tsd::filtrage::filtre_sois<T>(h, s); }
 template <typename T> sptr<Filter<T, T, float>> filter_resample(float ratio) { return tsd::filtrage::filtre_reechan<T>(ratio); }
+// dsp/filter.hpp:1128-1164,1288-1292,1354-1358,1407-1411,1578-1631,1827-1883,1910
+using Frequency = tsd::filtrage::Fréquence;
+inline float ema_coef(Frequency fc) { return tsd::filtrage::lexp_coef(fc); }
+inline float ema_tc2coef(float tc) { return tsd::filtrage::lexp_tc_vers_coef(tc); }
+inline float ema_coef2tc(float γ) { return tsd::filtrage::lexp_coef_vers_tc(γ); }
+inline Frequency ema_fcut(float γ) { return tsd::filtrage::lexp_fcoupure(γ); }
+template <typename T> sptr<FilterGen<T>> delay_line(unsigned int n) { return tsd::filtrage::ligne_a_retard<T>((int) n); }
+template <typename T> sptr<FilterGen<T>> decimator(int R) { return tsd::filtrage::decimateur<T>(R); }
+template <typename Tc, typename T = Tc> sptr<FilterGen<T>> filter_iir(const FRat<Tc> &h) { return tsd::filtrage::filtre_rii<Tc, T>(h); }
+template <typename T> sptr<FilterGen<T>> filter_ema(float γ) { return tsd::filtrage::filtre_lexp<T>(γ); }
+template <typename T> sptr<FilterGen<T>> filter_dc(float fc) { return tsd::filtrage::filtre_dc<T>(fc); }
+template <typename T, typename Tacc> sptr<FilterGen<T>> filter_ma(unsigned int K) { return tsd::filtrage::filtre_mg<T, Tacc>((int) K); }
+template <typename Tc, typename T = Tc> sptr<FilterGen<T>> filter_fir_decim(const Vector<Tc> &h, unsigned int R) { return tsd::filtrage::filtre_rif_decim<Tc, T>(h, (int) R); }
+template <typename Tc, typename T = Tc> sptr<FilterGen<T>> filter_fir_half_band(const Vector<Tc> &c) { return tsd::filtrage::filtre_rif_demi_bande<Tc, T>(c); }
+template <typename Tc, typename T = Tc> sptr<FilterGen<T>> filter_fir_ups(const Vector<Tc> &h, unsigned int R) { return tsd::filtrage::filtre_rif_ups<Tc, T>(h, (int) R); }
+inline float filter_fir_ups_delay(int nc, int R) { return tsd::filtrage::filtre_rif_ups_délais(nc, R); }
 template <typename T> Vector<T> filter(const Design &d, const Vector<T> &x) { return tsd::filtrage::filtrer<T>(d, x); }
 template <typename T> Vector<T> filtfilt(const Design &d, const Vector<T> &x) { return tsd::filtrage::filtfilt<T>(d, x); }
 template <typename T, typename Tc> Vector<T> convol(const Vector<Tc> &h, const Vector<T> &x) { return tsd::filtrage::convol<T, Tc>(h, x); }

@@ -78,6 +78,26 @@ template <typename T> sptr<FiltreGen<T>> filtre_sois(const FRat<float> &h, RIISt
 
 template <typename Tc, typename T = Tc> sptr<FiltreGen<T>> filtre_rii(const FRat<Tc> &h);   // filtrage.hpp:1428-1429
 
+// ---- small first-order / running operators (filtrage.hpp:1127-1134,1192-1222,1324,1610-1652;
+// src/filtrage/filtre-rt.cc:14-51,603-786; src/filtrage/filtrage.cc:121-139), all on the C ABI:
+//   filtre_lexp(γ)  y_n = y_{n-1} + γ (x_n - y_{n-1}), y_{-1} = x_0   -> one seeded DF1 section (block-parallel SOS kernel)
+//   filtre_dc(fc)   y_n = α ((x_n - x_{n-1}) + y_{n-1}), α = 1 - lexp_coef(fc)  -> tsdgpu_rii (zero-seeded DF1 section)
+//   filtre_mg(K)    y_n = (1/K) sum_{k<K} x_{n-k}                       -> FIR with K equal taps (direct / overlap-save)
+//   ligne_a_retard(n)  y_i = x_{i-n}                                    -> index shift (host: pure data movement)
+struct Fréquence {
+  float value;
+  Fréquence(float v) : value(v) {}
+  operator float() const { return value; }
+};
+float lexp_coef(Fréquence fc);
+float lexp_tc_vers_coef(float τ);
+float lexp_coef_vers_tc(float γ);
+Fréquence lexp_fcoupure(float γ);
+template <typename T> sptr<FiltreGen<T>> ligne_a_retard(entier n);
+template <typename T> sptr<FiltreGen<T>> filtre_lexp(float γ);
+template <typename T> sptr<FiltreGen<T>> filtre_dc(float fc);
+template <typename T, typename Tacc> sptr<FiltreGen<T>> filtre_mg(entier K);
+
 // ---- integer-rate stages (filtrage.hpp:1968-1998; src/reechan/polyphase.cc; filtre-rt.cc:127-169)
 template <typename T> sptr<FiltreGen<T>> decimateur(entier R);
 template <typename Tc, typename T = Tc> sptr<FiltreGen<T>> filtre_rif_decim(const Vecteur<Tc> &h, entier R);

@@ -401,6 +401,80 @@ template <typename Tc, typename T> sptr<FiltreGen<T>> filtre_rii(const FRat<Tc> 
 template sptr<FiltreGen<float>> filtre_rii<float, float>(const FRat<float> &);
 template sptr<FiltreGen<cfloat>> filtre_rii<float, cfloat>(const FRat<float> &);
 
+// ---- filtre_lexp / filtre_dc / filtre_mg / ligne_a_retard (filtre-rt.cc:14-51,603-786) ----------
+float lexp_coef(Fréquence fc) { return (float) (1.0 - std::exp(-fc.value * 2 * π)); }
+float lexp_tc_vers_coef(float τ) { return lexp_coef((float) (1.0 / (2 * π * τ))); }
+Fréquence lexp_fcoupure(float γ) { return (float) (-std::log(1.0 - γ) / (2 * π)); }
+float lexp_coef_vers_tc(float γ) { return (float) (1.0 / (2 * π * lexp_fcoupure(γ).value)); }
+
+// FiltreLExp: acc <- x(0) on the first sample, then acc += γ (x - acc).  As a transfer function
+// that is the FormeDirecte1 section (γ, 0, 0 ; 1, -(1-γ), 0) whose memories all start at x(0) --
+// exactly SOIS' first-call seed -- so it runs on the block-parallel SOS kernel.
+template <typename T> struct FiltreLExpGpu : FiltreGen<T> {
+  tsdgpu_sos *h = nullptr;
+  explicit FiltreLExpGpu(float γ)
+  {
+    const float coefs[5] = {γ, 0.f, 0.f, -(1.0f - γ), 0.f};
+    if (tsdgpu_sos_create(&h, dtype_of<T>(), coefs, 1, 1.0f, nullptr, 1)) gpu_fail("filtre_lexp");
+  }
+  ~FiltreLExpGpu() override { tsdgpu_sos_destroy(h); }
+  void step(const Vecteur<T> &x, Vecteur<T> &y) override
+  {
+    const entier n = x.rows();
+    if (n == 0) return;
+    if (x.data() != y.data()) y.resize(n);
+    if (tsdgpu_sos_step(h, x.data(), y.data(), n, nullptr)) gpu_fail("filtre_lexp::step");
+  }
+};
+template <typename T> sptr<FiltreGen<T>> filtre_lexp(float γ) { return std::make_shared<FiltreLExpGpu<T>>(γ); }
+template sptr<FiltreGen<float>> filtre_lexp<float>(float);
+template sptr<FiltreGen<cfloat>> filtre_lexp<cfloat>(float);
+
+// FiltreDC: y = α ((x - xp) + yp) from zero memory = H(z^-1) = (α - α z^-1) / (1 - α z^-1)
+template <typename T> sptr<FiltreGen<T>> filtre_dc(float fc)
+{
+  const float α = 1 - lexp_coef(Fréquence(fc));
+  return std::make_shared<FiltreRIIGpu<T>>(FRat<float>::rii(Vecf::valeurs({α, -α}), Vecf::valeurs({1.0f, -α})));
+}
+template sptr<FiltreGen<float>> filtre_dc<float>(float);
+template sptr<FiltreGen<cfloat>> filtre_dc<cfloat>(float);
+
+// MoyenneGlissante: running sum in Tacc times (T)(1/K) = a K-tap FIR with equal taps (the GPU sums
+// the K products in float: relative difference ~ 1e-7 sqrt(K) to the reference's double accumulator)
+template <typename T, typename Tacc> sptr<FiltreGen<T>> filtre_mg(entier K)
+{
+  if (K <= 0) échec("filtre_mg: K = {}", K);
+  Vecf h(K);
+  h.setConstant((float) (1.0 / (double) K));
+  return std::make_shared<FiltreRIFGpu<T, float>>(h, TSDGPU_FIR_AUTO);
+}
+template sptr<FiltreGen<float>> filtre_mg<float, double>(entier);
+template sptr<FiltreGen<cfloat>> filtre_mg<cfloat, cdouble>(entier);
+template sptr<FiltreGen<float>> filtre_mg<float, float>(entier);
+
+// LigneARetard: y_i = x_{i-n} with n zeros first, streaming.  Pure index work on the caller's
+// (host) vectors: no arithmetic, so no kernel.
+template <typename T> struct LigneARetardHote : FiltreGen<T> {
+  Vecteur<T> mem;          // the last n inputs, oldest first
+  explicit LigneARetardHote(entier n) : mem(Vecteur<T>::zeros(n < 0 ? 0 : n)) {}
+  void step(const Vecteur<T> &x, Vecteur<T> &y) override
+  {
+    const entier d = mem.rows(), n = x.rows();
+    if (d == 0) {
+      y = x;
+      return;
+    }
+    const Vecteur<T> all = vconcat(mem, x);
+    Vecteur<T> out(n);
+    for (entier i = 0; i < n; i++) out(i) = all(i);
+    for (entier i = 0; i < d; i++) mem(i) = all(n + i);
+    y = out;
+  }
+};
+template <typename T> sptr<FiltreGen<T>> ligne_a_retard(entier n) { return std::make_shared<LigneARetardHote<T>>(n); }
+template sptr<FiltreGen<float>> ligne_a_retard<float>(entier);
+template sptr<FiltreGen<cfloat>> ligne_a_retard<cfloat>(entier);
+
 // ---- resampling: itrp_sinc / filtre_itrp / filtre_reechan -----------------------------------
 template <typename T> InterpolateurSinc<T>::InterpolateurSinc(const InterpolateurSincConfig &c) : config(c)
 {

@@ -606,6 +606,86 @@ static void test_psd()
   }
 }
 
+
+// ---- filtre_lexp / filtre_dc / filtre_mg / ligne_a_retard (filtre-rt.cc:14-51,603-786) -----------
+// No reference test pins their samples (test-filtres.cc only plots them): checked against the
+// literal recurrences, in float (the reference's arithmetic) and in double (the yardstick for
+// how far float arithmetic may drift on a slow first-order recursion).
+template <typename T> static void test_petits_filtres()
+{
+  const int n = 20000;
+  Vecteur<T> x(n);
+  {
+    Veccf r = randcn(n);
+    for (int i = 0; i < n; i++) {
+      if constexpr (est_complexe<T>()) x(i) = r(i) + cfloat(0.5f, -0.25f);
+      else x(i) = r(i).real() + 0.5f;
+    }
+  }
+  using Td = std::conditional_t<est_complexe<T>(), cdouble, double>;
+  auto chunks = [&](sptr<FiltreGen<T>> f) {
+    Vecteur<T> y = f->step(x.head(777));
+    y = vconcat(y, f->step(x.segment(777, 9001)));
+    return vconcat(y, f->step(x.tail(n - 777 - 9001)));
+  };
+  for (float γ : {0.5f, 0.05f, 0.002f}) {
+    // FiltreLExp: acc = x(0); acc += γ (x - acc)
+    Vecteur<T> y = chunks(filtre_lexp<T>(γ));
+    T acc = x(0);
+    Td accd = (Td) x(0);
+    float e_ref = 0, e_gpu = 0, ymax = 0;
+    for (int i = 0; i < n; i++) {
+      acc += γ * (x(i) - acc);
+      accd += (double) γ * ((Td) x(i) - accd);
+      e_ref = std::max(e_ref, (float) std::abs((Td) acc - accd));
+      e_gpu = std::max(e_gpu, (float) std::abs((Td) y(i) - accd));
+      ymax = std::max(ymax, (float) std::abs(accd));
+    }
+    // the parity bar (1e-5 of the maximum); the reference's incremental form acc += γ (x - acc) is better
+    // conditioned than any transfer-function form for small γ (here: 7e-7 vs 7e-6 at γ = 0.002)
+    CHECK(y.rows() == n && e_gpu <= std::max(4 * e_ref, 1e-5f * ymax), "filtre_lexp(%g): err %g (float recurrence: %g, max %g)", γ, e_gpu, e_ref, ymax);
+    CHECK(std::abs(y(0) - x(0)) <= 1e-6f * std::abs(x(0)), "filtre_lexp first output is the first input");
+  }
+  for (float fc : {0.1f, 0.001f}) {
+    // FiltreDC: y = α ((x - xp) + yp), zero memory
+    Vecteur<T> y = chunks(filtre_dc<T>(fc));
+    const float α = 1 - lexp_coef(fc);
+    T xp = 0, yp = 0;
+    Td xpd = 0, ypd = 0;
+    float e_ref = 0, e_gpu = 0, ymax = 0;
+    for (int i = 0; i < n; i++) {
+      const T o = (T) (α * ((x(i) - xp) + yp));
+      xp = x(i); yp = o;
+      const Td od = (double) α * (((Td) x(i) - xpd) + ypd);
+      xpd = (Td) x(i); ypd = od;
+      e_ref = std::max(e_ref, (float) std::abs((Td) o - od));
+      e_gpu = std::max(e_gpu, (float) std::abs((Td) y(i) - od));
+      ymax = std::max(ymax, (float) std::abs(od));
+    }
+    CHECK(e_gpu <= std::max(4 * e_ref, 2e-6f * ymax), "filtre_dc(%g): err %g (float recurrence: %g, max %g)", fc, e_gpu, e_ref, ymax);
+  }
+  for (int K : {1, 7, 100, 1000}) {
+    // MoyenneGlissante<T, double>
+    Vecteur<T> y = chunks(filtre_mg<T, Td>(K));
+    Td accu = 0;
+    float e = 0, ymax = 0;
+    for (int i = 0; i < n; i++) {
+      accu += (Td) x(i);
+      if (i >= K) accu -= (Td) x(i - K);
+      const Td o = accu * (double) (float) (1.0 / K);
+      e = std::max(e, (float) std::abs((Td) y(i) - o));
+      ymax = std::max(ymax, (float) std::abs(o));
+    }
+    CHECK(e <= 1e-5f * ymax, "filtre_mg(%d): err %g (max %g)", K, e, ymax);
+  }
+  for (int d : {0, 1, 100, 5000}) {
+    Vecteur<T> y = chunks(ligne_a_retard<T>(d));
+    bool ok = y.rows() == n;
+    for (int i = 0; ok && i < n; i++) ok = y(i) == (i >= d ? x(i - d) : T(0));
+    CHECK(ok, "ligne_a_retard(%d)", d);
+  }
+}
+
 int main(int argc, char **argv)
 {
   if (argc > 1 && !std::strcmp(argv[1], "--no-gpu")) {
@@ -645,6 +725,17 @@ int main(int argc, char **argv)
   test_tampon();
   test_filtre_fft();
   test_psd();
+  test_petits_filtres<float>();
+  test_petits_filtres<cfloat>();
+  {
+    // dsp:: spellings (dsp/filter.hpp:1128-1164,1288-1292,1578-1631,1827-1883)
+    dsp::Vecf q = real(randcn(300));
+    auto ma = dsp::filter::filter_ma<float, double>(8);
+    CHECK(dsp::filter::delay_line<float>(3)->step(q).rows() == 300 && dsp::filter::filter_ema<float>(0.1f)->step(q).rows() == 300 &&
+          dsp::filter::filter_dc<float>(0.01f)->step(q).rows() == 300 && ma->step(q).rows() == 300 &&
+          dsp::filter::decimator<float>(3)->step(q).rows() == 100 && std::abs(dsp::filter::ema_coef(0.1f) - lexp_coef(0.1f)) == 0,
+          "dsp::filter small-filter aliases");
+  }
   printf(nfail ? "FAILED (%d)\n" : "ALL C++ HOST TESTS OK\n", nfail);
   return nfail ? 1 : 0;
 }
