@@ -41,9 +41,13 @@ struct RsParams {
   int64_t cum_pos;    // outputs emitted before `pos`
   float inc;          // 1/ratio as float (ra.cc:29)
   int K, nph, lstride, rec_cap;
+  int lut_in_lds;     // generic kernel: LUT staged in LDS (1) or read from global memory (0: large K)
 };
 
-struct RsCk { uint32_t phase_bits; uint32_t cum; };   // cum = outputs before this input (canonical index space)
+struct RsCk { uint32_t phase_bits; uint32_t cum; };
+constexpr int RS_KMAX = 256;                   // longest interpolator (taps); LUTs beyond RS_LUT_LDS_BYTES stay in global memory
+constexpr int RS_LUT_LDS_BYTES = 48 * 1024;
+__host__ __device__ inline int rs_tile_elems(int K) { return RS_TI + (K <= 32 ? 32 : (K + 31) / 32 * 32) + 2; }   // cum = outputs before this input (canonical index space)
 
 __host__ __device__ inline float bits2f(uint32_t b)
 {
@@ -89,18 +93,20 @@ __global__ __launch_bounds__(RS_THREADS) void resample_kernel(const T *__restric
   const int lstride = KT == 15 ? 20 : P.lstride;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float *lut_s = reinterpret_cast<float *>(smem_raw);                       // (nph+1) x lstride, 16-B aligned
-  char *wbase = reinterpret_cast<char *>(lut_s + ((P.nph + 1) * lstride + 3) / 4 * 4);
-  const int tile_elems = RS_TI + 32 + 2;                                    // K <= 32
+  char *wbase = reinterpret_cast<char *>(lut_s + (P.lut_in_lds ? ((P.nph + 1) * lstride + 3) / 4 * 4 : 4));
+  const int tile_elems = rs_tile_elems(K);
   const size_t wbytes = ((size_t) tile_elems * sizeof(T) + (size_t) P.rec_cap * 4 + 15) / 16 * 16;
   T *tile = reinterpret_cast<T *>(wbase + wv * wbytes);
   uint32_t *rec = reinterpret_cast<uint32_t *>(tile + tile_elems);
 
-  // ---- stage the LUT once per (persistent) workgroup
-  const int lut_n = (P.nph + 1) * K;
+  // ---- stage the LUT once per (persistent) workgroup (a LUT too large for LDS is read in place)
+  const int lut_n = P.lut_in_lds ? (P.nph + 1) * K : 0;
   for (int i = threadIdx.x; i < lut_n; i += RS_THREADS) {
     const int c = i / K, k = i - c * K;
     lut_s[c * lstride + k] = lut[i];
   }
+  const float *lutp = P.lut_in_lds ? lut_s : lut;
+  const int lrow = P.lut_in_lds ? lstride : K;
   if (KT == 15)
     for (int c = threadIdx.x; c <= P.nph; c += RS_THREADS) lut_s[c * lstride + 15] = 0.f;   // 16th tap
   __syncthreads();
@@ -123,7 +129,7 @@ __global__ __launch_bounds__(RS_THREADS) void resample_kernel(const T *__restric
   }
   const int64_t icStep = (int64_t) wstep * RS_TI;
 
-  constexpr int NPF = (RS_TI + 32 + 63) / 64;      // samples per lane per tile (K <= 32)
+  constexpr int NPF = (RS_TI + RS_KMAX + 63) / 64;   // samples per lane per tile (K <= RS_KMAX)
   T pf[NPF];
   RsCk cpf;
   auto fetch = [&](int tix_, int64_t icT_) {
@@ -218,7 +224,7 @@ __global__ __launch_bounds__(RS_THREADS) void resample_kernel(const T *__restric
     for (int o = o_begin + lane; o < o_end; o += 64) {
       const uint32_t r = rec[o];
       const T *w = tile + (r >> 9);                         // window: x[i-K+1 .. i], oldest first
-      const float *h = lut_s + (r & 511u) * lstride;
+      const float *h = lutp + (r & 511u) * lrow;
       T acc = zero_of(T{});
       if (KT == 15) {
         float hh[16];
@@ -545,8 +551,8 @@ int tsdgpu_resampler_create(tsdgpu_resampler **out, int data_type, float ratio, 
   if (ratio > 8.f || ratio < 1.f / 64.f)
     return set_err(TSDGPU_ERR_UNSUPPORTED, "resampler_create: ratio %g outside [1/64, 8] (filtre_reechan folds "
                    "ratios into [0.5,2) with half-band stages first)", (double) ratio);
-  if (K < 1 || K > 32 || nphases < 1 || nphases > 511)
-    return set_err(TSDGPU_ERR_UNSUPPORTED, "resampler_create: K=%d nphases=%d unsupported (K <= 32, nphases <= 511)", K, nphases);
+  if (K < 1 || K > RS_KMAX || nphases < 1 || nphases > 511)
+    return set_err(TSDGPU_ERR_UNSUPPORTED, "resampler_create: K=%d nphases=%d unsupported (K <= %d, nphases <= 511)", K, nphases, RS_KMAX);
   tsdgpu_resampler *r = new tsdgpu_resampler();
   r->data_type = data_type;
   r->K = K;
@@ -630,8 +636,9 @@ int tsdgpu_resampler_step(tsdgpu_resampler *r, const void *x, int64_t n, void *y
   const int64_t tiles = cdiv(r->pos + n - P.tile0, RS_TI);
   TSD_CHECK(tiles <= 0x7fffffff, "resampler_step: n too large for one launch");
   const int lstride = r->K == 15 ? 20 : r->lstride;
-  const size_t wbytes = ((size_t) (RS_TI + 32 + 2) * sz + (size_t) P.rec_cap * 4 + 15) / 16 * 16;
-  const size_t lds = (size_t) ((r->nph + 1) * lstride + 4) * 4 + RS_WAVES * wbytes + 64;
+  const size_t wbytes = ((size_t) rs_tile_elems(r->K) * sz + (size_t) P.rec_cap * 4 + 15) / 16 * 16;
+  P.lut_in_lds = (size_t) (r->nph + 1) * lstride * 4 <= (size_t) RS_LUT_LDS_BYTES ? 1 : 0;
+  const size_t lds = (size_t) (P.lut_in_lds ? (r->nph + 1) * lstride + 4 : 8) * 4 + RS_WAVES * wbytes + 64;
   TSD_CHECK(lds <= 158 * 1024, "resampler_step: configuration needs %zu bytes of LDS", lds);
   // persistent workgroups (the LUT is staged once per workgroup): as many as stay resident
   static const int PG = getenv("TSDGPU_RS_WG_PER_CU") ? atoi(getenv("TSDGPU_RS_WG_PER_CU")) : 0;
@@ -658,10 +665,10 @@ int tsdgpu_resampler_step(tsdgpu_resampler *r, const void *x, int64_t n, void *y
   if (r->K > 1) {
     const int H = r->K - 1, nxt = r->cur ^ 1;
     if (r->data_type == TSDGPU_C64)
-      hipLaunchKernelGGL(rs_hist_update_kernel<float2>, dim3(1), dim3(64), 0, st, (const float2 *) dx,
+      hipLaunchKernelGGL(rs_hist_update_kernel<float2>, dim3((unsigned) cdiv(H, 64)), dim3(64), 0, st, (const float2 *) dx,
                          (const float2 *) r->d_hist[r->cur], (float2 *) r->d_hist[nxt], H, n);
     else
-      hipLaunchKernelGGL(rs_hist_update_kernel<float>, dim3(1), dim3(64), 0, st, (const float *) dx,
+      hipLaunchKernelGGL(rs_hist_update_kernel<float>, dim3((unsigned) cdiv(H, 64)), dim3(64), 0, st, (const float *) dx,
                          (const float *) r->d_hist[r->cur], (float *) r->d_hist[nxt], H, n);
     TSD_HIP(hipGetLastError());
     r->cur = nxt;

@@ -149,13 +149,23 @@ struct InterpolateurSincConfig {
   float fcut = 0.5;
   std::string fenetre = "hn";
 };
-// LUT-sinc interpolator; exposes its table so the GPU resampler can take it as is
-template <typename T> struct InterpolateurSinc : InterpolateurRIF<T> {
-  InterpolateurSincConfig config;
+// Interpolators whose coefficients come from a table indexed by (int)(τ * nphases) -- the sinc
+// (itrp.cc:10-55) and the cubic spline (itrp.cc:56-79,293-320) -- expose it so that the GPU
+// resampler takes it as is.  itrp_lineaire / itrp_lagrange evaluate their coefficients from the
+// float phase itself (itrp.cc:81-135): they are not built.
+template <typename T> struct InterpolateurLut : InterpolateurRIF<T> {
+  entier nphases = 0;
   std::vector<float> lut;   // phase-major [(nphases+1) x K]
-  explicit InterpolateurSinc(const InterpolateurSincConfig &c);
   Vecf coefs(float τ) override;
 };
+template <typename T> struct InterpolateurSinc : InterpolateurLut<T> {
+  InterpolateurSincConfig config;
+  explicit InterpolateurSinc(const InterpolateurSincConfig &c);
+};
+template <typename T> struct InterpolateurCSpline : InterpolateurLut<T> {
+  explicit InterpolateurCSpline(entier n = 256, float c = 0);
+};
+template <typename T> sptr<Interpolateur<T>> itrp_cspline();
 template <typename T> sptr<Interpolateur<T>> itrp_sinc(const InterpolateurSincConfig &config);
 template <typename T> sptr<FiltreGen<T>> filtre_itrp(float ratio, sptr<Interpolateur<T>> itrp);
 template <typename T> sptr<Filtre<T, T, float>> filtre_reechan(float ratio);

@@ -484,6 +484,8 @@ template <typename T> InterpolateurSinc<T>::InterpolateurSinc(const Interpolateu
   this->K = nc;
   this->delais = 0.5f * nc;
   this->nom = detail::fmt("sinc - ncoefs={}, nphases={}, fcut={}, fen={}", nc, c.nphases, c.fcut, c.fenetre);
+  this->nphases = c.nphases;
+  auto &lut = this->lut;
   lut.resize((size_t) (c.nphases + 1) * nc);
   const Vecf ls = linspace((float) (-nc / 2), (float) ((nc - 1) / 2), nc);
   for (entier j = 0; j <= c.nphases; j++) {
@@ -495,14 +497,41 @@ template <typename T> InterpolateurSinc<T>::InterpolateurSinc(const Interpolateu
     }
   }
 }
-template <typename T> Vecf InterpolateurSinc<T>::coefs(float τ)
+template <typename T> Vecf InterpolateurLut<T>::coefs(float τ)
 {
-  if (!(τ >= 0 && τ <= 1)) échec("InterpolateurSinc::coefs(τ={}) : délais invalide.", τ);
-  const entier idx = (entier) (τ * config.nphases);
+  if (!(τ >= 0 && τ <= 1)) échec("Interpolateur::coefs(τ={}) : délais invalide.", τ);
+  const entier idx = (entier) (τ * nphases);
   return Vecf::int_expr(this->K, [&](entier i) { return lut[(size_t) idx * this->K + i]; });
 }
+template struct InterpolateurLut<float>;
+template struct InterpolateurLut<cfloat>;
 template struct InterpolateurSinc<float>;
 template struct InterpolateurSinc<cfloat>;
+
+// cubic (cardinal) spline, tension c: coefficients on (p-1, p0, p1, p2) from the Hermite basis
+// (itrp.cc:293-320), tabulated at τ = i/n
+template <typename T> InterpolateurCSpline<T>::InterpolateurCSpline(entier n, float c)
+{
+  this->nom = "cspline";
+  this->K = 4;
+  this->delais = 1.5f;
+  this->nphases = n;
+  this->lut.resize((size_t) (n + 1) * 4);
+  for (entier i = 0; i <= n; i++) {
+    const float t = ((float) i) / n;
+    const float h0 = (1 + 2 * t) * (t - 1) * (t - 1), h1 = t * (t - 1) * (t - 1), h2 = t * t * (3 - 2 * t), h3 = t * t * (t - 1);
+    float *o = &this->lut[(size_t) i * 4];
+    o[0] = -(1 - c) * h1 / 2;
+    o[1] = h0 - (1 - c) * h3 / 2;
+    o[2] = h2 + (1 - c) * h1 / 2;
+    o[3] = (1 - c) * h3 / 2;
+  }
+}
+template struct InterpolateurCSpline<float>;
+template struct InterpolateurCSpline<cfloat>;
+template <typename T> sptr<Interpolateur<T>> itrp_cspline() { return std::make_shared<InterpolateurCSpline<T>>(); }
+template sptr<Interpolateur<float>> itrp_cspline<float>();
+template sptr<Interpolateur<cfloat>> itrp_cspline<cfloat>();
 
 template <typename T> sptr<Interpolateur<T>> itrp_sinc(const InterpolateurSincConfig &config)
 {
@@ -511,14 +540,14 @@ template <typename T> sptr<Interpolateur<T>> itrp_sinc(const InterpolateurSincCo
 template sptr<Interpolateur<float>> itrp_sinc<float>(const InterpolateurSincConfig &);
 template sptr<Interpolateur<cfloat>> itrp_sinc<cfloat>(const InterpolateurSincConfig &);
 
-// AdaptationRythmeSimple (ra.cc:13-79) on the GPU resampler; needs a LUT-sinc interpolator
+// AdaptationRythmeSimple (ra.cc:13-79) on the GPU resampler; needs a table-driven interpolator
 template <typename T> struct AdaptationRythmeSimpleGpu : FiltreGen<T> {
   tsdgpu_resampler *h = nullptr;
   AdaptationRythmeSimpleGpu(float ratio, sptr<Interpolateur<T>> itrp)
   {
-    auto s = std::dynamic_pointer_cast<InterpolateurSinc<T>>(itrp);
-    if (!s) échec("filtre_itrp: only the LUT-sinc interpolator (itrp_sinc) runs on the GPU path");
-    if (tsdgpu_resampler_create(&h, dtype_of<T>(), ratio, s->lut.data(), s->K, s->config.nphases)) gpu_fail("filtre_itrp");
+    auto s = std::dynamic_pointer_cast<InterpolateurLut<T>>(itrp);
+    if (!s) échec("filtre_itrp: only table-driven interpolators (itrp_sinc, itrp_cspline) run on the GPU path");
+    if (tsdgpu_resampler_create(&h, dtype_of<T>(), ratio, s->lut.data(), s->K, s->nphases)) gpu_fail("filtre_itrp");
   }
   ~AdaptationRythmeSimpleGpu() override { tsdgpu_resampler_destroy(h); }
   void step(const Vecteur<T> &x, Vecteur<T> &y) override

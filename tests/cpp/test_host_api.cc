@@ -686,6 +686,57 @@ template <typename T> static void test_petits_filtres()
   }
 }
 
+
+// ---- test_ra_unit (core/tests/test-ra.cc:11-160): a 2 kHz sine at fe = 100 kHz through each
+// resampler; the output must be a pure sine at f2 / (ratio fe): >= 80 % of the energy in the 3 bins
+// around it, spurious lines <= -50 dB, sample count within 1 %, amplitude within 10 %.
+struct Purete { float freq_spurius, max_spurius_db; };
+static Purete verifie_sinus(const char *nom, const Vecf &x, float f)
+{
+  const int n = x.rows();
+  Vecf fen = fenêtre("hn", n, false), xf = x.clone();
+  for (int i = 0; i < n; i++) xf(i) *= fen(i);
+  Vecf X = abs2(fft(xf).head(n / 2));
+  const float etotal = X.somme();
+  const int idx = (int) (f * n);
+  float ef = X(idx);
+  if (idx > 0) ef += X(idx - 1);
+  if (idx + 1 < n / 2) ef += X(idx + 1);
+  const float score = ef / etotal;
+  if (idx >= 10)
+    for (int i = idx - 10; i < idx + 10; i++) X(i) = 0;
+  const int is = X.index_max();
+  Purete res{(float) is / n, 10 * std::log10(X(is) / ef)};
+  CHECK(!(std::isnan(score) || score < 0.8f), "%s: a pure sine is expected (energy ratio %g)", nom, score);
+  return res;
+}
+static void test_ra_unit(const char *nom, float ratio, sptr<FiltreGen<float>> ra, float max_spurius_dB = -50)
+{
+  const float fe = 100e3f, f2 = 2e3f;
+  Vecf x = Vecf::int_expr(1000, [&](int i) { return (float) std::sin((double) i / fe * 2 * π * f2); });
+  Vecf y = ra->step(x);
+  verifie_sinus(nom, x, f2 / fe);
+  const Purete spy = verifie_sinus(nom, y, f2 / (ratio * fe));
+  CHECK(100.0 * std::abs((y.rows() - ratio * x.rows()) / x.rows()) < 1, "%s ratio %g: %d samples", nom, ratio, y.rows());
+  const float amp1 = x.valeur_max() - x.valeur_min(), amp2 = y.valeur_max() - y.valeur_min();
+  CHECK(100 * (amp1 - amp2) / amp1 < 10, "%s ratio %g: amplitude %g -> %g", nom, ratio, amp1, amp2);
+  CHECK(spy.max_spurius_db <= max_spurius_dB, "%s ratio %g: spurious line %.1f dB at f = %g", nom, ratio, spy.max_spurius_db, spy.freq_spurius);
+}
+static void test_ra()
+{
+  for (float ratio : {1.f, 1.5f, 0.5f, 2.f, 1.2f, π_f}) {
+    test_ra_unit("filtre_itrp/cspline", ratio, filtre_itrp<float>(ratio, itrp_cspline<float>()));
+    test_ra_unit("filtre_itrp/sinc", ratio, filtre_itrp<float>(ratio, itrp_sinc<float>({127, 256, 0.5f, "hn"})));
+    test_ra_unit("filtre_reechan", ratio, filtre_reechan<float>(ratio));
+  }
+  {
+    Vecf h = design_rif_fen(15, "lp", 0.25f, "hn");
+    test_ra_unit("rif demi-bande", 0.5f, filtre_rif_demi_bande<float, float>(h));
+    test_ra_unit("rif ups", 2.0f, filtre_rif_ups<float, float>(h, 2));
+  }
+  for (int R : {2, 3, 4, 5, 8}) test_ra_unit("rif decim", 1.0f / R, filtre_rif_decim<float, float>(design_rif_fen(15, "lp", 0.5f / R, "hn"), R));
+}
+
 int main(int argc, char **argv)
 {
   if (argc > 1 && !std::strcmp(argv[1], "--no-gpu")) {
@@ -725,6 +776,7 @@ int main(int argc, char **argv)
   test_tampon();
   test_filtre_fft();
   test_psd();
+  test_ra();
   test_petits_filtres<float>();
   test_petits_filtres<cfloat>();
   {

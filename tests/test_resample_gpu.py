@@ -44,6 +44,23 @@ def test_resample_values(tg, orc, ratio, cplx):
     assert relerr(y, yref) <= TOL
 
 
+# other interpolator lengths through the generic kernel: the 4-tap cspline shape, K = 31/32 (LUT in
+# LDS), the 127-tap sinc of the reference's test_ra_unit (test-ra.cc:154-156: LUT read from global
+# memory) and the 256-tap limit; chunked so that the window history is exercised
+@pytest.mark.parametrize("K,nph", [(4, 256), (2, 64), (31, 256), (32, 511), (127, 256), (256, 128)])
+@pytest.mark.parametrize("ratio", [R160, 0.5, 1.999])
+@pytest.mark.parametrize("cplx", [True, False])
+def test_resample_other_lengths(tg, orc, K, nph, ratio, cplx):
+    n = 30000
+    x = rand(n, cplx, K)
+    ref = orc.Resampler(ratio, K=K, nphases=nph, fcut=0.4)
+    yref = ref.step(x)
+    g = tg.Resampler(ratio, tg.C64 if cplx else tg.F32, K=K, nphases=nph, lut=ref.lut)
+    y = np.concatenate([g.step(x[:12345].copy()), g.step(x[12345:].copy())])
+    assert len(y) == len(yref)
+    assert relerr(y, yref) <= TOL
+
+
 # Bit-exact schedule: with a LUT that is 1 on the newest tap the output IS the input sample
 # selected (x = ramp -> input index); with LUT[col][newest] = col and x = 1 the output IS the column.
 @pytest.mark.parametrize("ratio", RATIOS)
@@ -120,6 +137,8 @@ def test_resample_device_large(tg, orc):
 
 def test_resample_bad_arguments(tg):
     with pytest.raises(tg.TsdGpuError):
+        tg.Resampler(1.1, tg.F32, K=257, nphases=16, lut=np.zeros((17, 257), np.float32))
+    with pytest.raises(tg.TsdGpuError):
         tg.Resampler(0.0, tg.F32)
     with pytest.raises(tg.TsdGpuError):
-        tg.Resampler(1.5, tg.F32, K=127, nphases=256, fcut=0.5)       # documented gap: K <= 32
+        tg.Resampler(1.5, tg.F32, K=15, nphases=512, lut=np.zeros((513, 15), np.float32))   # nphases <= 511
