@@ -414,7 +414,11 @@ template <typename T> struct FiltreLExpGpu : FiltreGen<T> {
   tsdgpu_sos *h = nullptr;
   explicit FiltreLExpGpu(float γ)
   {
-    const float coefs[5] = {γ, 0.f, 0.f, -(1.0f - γ), 0.f};
+    // pole a = fl(1 - γ), gain 1 - a (exact in float): the DC gain stays exactly 1, as it is for the
+    // reference's incremental form -- with b0 = γ the float rounding of 1 - γ alone would move the
+    // DC gain by 3e-8 / γ (1.5e-5 at γ = 0.002)
+    const float a = 1.0f - γ;
+    const float coefs[5] = {1.0f - a, 0.f, 0.f, -a, 0.f};
     if (tsdgpu_sos_create(&h, dtype_of<T>(), coefs, 1, 1.0f, nullptr, 1)) gpu_fail("filtre_lexp");
   }
   ~FiltreLExpGpu() override { tsdgpu_sos_destroy(h); }
