@@ -204,7 +204,7 @@ __global__ __launch_bounds__(RS_THREADS) void resample_kernel(const T *__restric
       while (phase < 1.f) {
         if (live) {
           const int o = (int) (cum - cum_t0);
-          rec[o] = ((uint32_t) (lane * RS_SEG + s) << 9) | (uint32_t) (int) (phase * fnph);   // itrp.cc:19
+          rec[o] = ((uint32_t) (lane * RS_SEG + s) << 13) | (uint32_t) (int) (phase * fnph);   // itrp.cc:19
           last = o + 1;
         }
         phase = phase + inc;                                // ra.cc:71, float32 add
@@ -223,8 +223,8 @@ __global__ __launch_bounds__(RS_THREADS) void resample_kernel(const T *__restric
     T *yt = y + (cum_t0 - P.cum_pos);
     for (int o = o_begin + lane; o < o_end; o += 64) {
       const uint32_t r = rec[o];
-      const T *w = tile + (r >> 9);                         // window: x[i-K+1 .. i], oldest first
-      const float *h = lutp + (r & 511u) * lrow;
+      const T *w = tile + (r >> 13);                         // window: x[i-K+1 .. i], oldest first
+      const float *h = lutp + (r & 8191u) * lrow;
       T acc = zero_of(T{});
       if (KT == 15) {
         float hh[16];
@@ -551,8 +551,8 @@ int tsdgpu_resampler_create(tsdgpu_resampler **out, int data_type, float ratio, 
   if (ratio > 8.f || ratio < 1.f / 64.f)
     return set_err(TSDGPU_ERR_UNSUPPORTED, "resampler_create: ratio %g outside [1/64, 8] (filtre_reechan folds "
                    "ratios into [0.5,2) with half-band stages first)", (double) ratio);
-  if (K < 1 || K > RS_KMAX || nphases < 1 || nphases > 511)
-    return set_err(TSDGPU_ERR_UNSUPPORTED, "resampler_create: K=%d nphases=%d unsupported (K <= %d, nphases <= 511)", K, nphases, RS_KMAX);
+  if (K < 1 || K > RS_KMAX || nphases < 1 || nphases > 8191)
+    return set_err(TSDGPU_ERR_UNSUPPORTED, "resampler_create: K=%d nphases=%d unsupported (K <= %d, nphases <= 8191)", K, nphases, RS_KMAX);
   tsdgpu_resampler *r = new tsdgpu_resampler();
   r->data_type = data_type;
   r->K = K;

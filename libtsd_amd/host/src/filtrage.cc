@@ -483,7 +483,6 @@ template sptr<FiltreGen<cfloat>> ligne_a_retard<cfloat>(entier);
 template <typename T> InterpolateurSinc<T>::InterpolateurSinc(const InterpolateurSincConfig &c) : config(c)
 {
   // itrp.cc:24-54: lut.col(j) = coefs_calcule(j / nphases), Hann window shifted by -tau
-  if (c.fenetre != "hn") échec("itrp_sinc: only the \"hn\" window is built");
   const entier nc = c.ncoefs;
   this->K = nc;
   this->delais = 0.5f * nc;
@@ -497,7 +496,8 @@ template <typename T> InterpolateurSinc<T>::InterpolateurSinc(const Interpolateu
     for (entier i = 0; i < nc; i++) {
       const float hv = sinc(2 * c.fcut, (float) (i - nc / 2) - τ);
       const float t = (ls(i) - τ) * (float) (2 * π / nc);
-      lut[(size_t) j * nc + i] = hv * (0.5f + 2 * 0.25f * std::cos(t));
+      // Hann window shifted by the fractional delay; any other window name = no window (itrp.cc:29-37)
+      lut[(size_t) j * nc + i] = c.fenetre == "hn" ? hv * (0.5f + 2 * 0.25f * std::cos(t)) : hv;
     }
   }
 }

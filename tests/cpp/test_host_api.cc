@@ -735,6 +735,30 @@ static void test_ra()
     test_ra_unit("rif demi-bande", 0.5f, filtre_rif_demi_bande<float, float>(h));
     test_ra_unit("rif ups", 2.0f, filtre_rif_ups<float, float>(h, 2));
   }
+  // the table-driven interpolators of test_itrp (test-itrp.cc:62-87) all build and run; the sinc table
+  // equals the oracle's for the Hann window, and any other window name means no window (itrp.cc:29-37)
+  {
+    Veccf xs = randcn(3000);
+    for (auto cfg : std::vector<InterpolateurSincConfig>{{15, 256, 0.5f, "re"}, {15, 256, 0.25f, "re"}, {15, 256, 0.5f, "hn"}, {15, 256, 0.25f, "hn"},
+                                                          {15, 256, 0.4f, "hn"}, {15, 512, 0.5f, "hn"}, {31, 256, 0.5f, "hn"}, {63, 256, 0.5f, "hn"},
+                                                          {127, 256, 0.5f, "hn"}, {31, 256, 0.48f, "hn"}, {63, 256, 0.48f, "hn"}, {15, 1024, 0.5f, "hn"}}) {
+      auto it = itrp_sinc<cfloat>(cfg);
+      Veccf ys = filtre_itrp<cfloat>(1.3f, it)->step(xs);
+      CHECK(it->K == cfg.ncoefs && std::abs(ys.rows() - 3900) <= 2, "itrp_sinc{%d,%d,%g,%s}: %d outputs", cfg.ncoefs, cfg.nphases, cfg.fcut, cfg.fenetre.c_str(), ys.rows());
+      if (cfg.fenetre == "hn") {
+        std::vector<float> lut((size_t) (cfg.nphases + 1) * cfg.ncoefs);
+        orc_itrp_sinc_lut(cfg.ncoefs, cfg.nphases, cfg.fcut, lut.data());
+        float e = 0;
+        for (float τ : {0.f, 0.1f, 0.5f, 0.999f}) {
+          const Vecf hc = std::dynamic_pointer_cast<InterpolateurRIF<cfloat>>(it)->coefs(τ);
+          const int row = (int) (τ * cfg.nphases);
+          for (int k = 0; k < cfg.ncoefs; k++) e = std::max(e, std::abs(hc(k) - lut[(size_t) row * cfg.ncoefs + k]));
+        }
+        CHECK(e <= 2e-7f, "itrp_sinc{%d,%d,%g} table differs from the oracle's by %g", cfg.ncoefs, cfg.nphases, cfg.fcut, e);
+      }
+    }
+    CHECK(std::abs(filtre_itrp<cfloat>(0.77f, itrp_cspline<cfloat>())->step(xs).rows() - 2310) <= 2, "cspline rows");
+  }
   for (int R : {2, 3, 4, 5, 8}) test_ra_unit("rif decim", 1.0f / R, filtre_rif_decim<float, float>(design_rif_fen(15, "lp", 0.5f / R, "hn"), R));
 }
 

@@ -47,7 +47,7 @@ def test_resample_values(tg, orc, ratio, cplx):
 # other interpolator lengths through the generic kernel: the 4-tap cspline shape, K = 31/32 (LUT in
 # LDS), the 127-tap sinc of the reference's test_ra_unit (test-ra.cc:154-156: LUT read from global
 # memory) and the 256-tap limit; chunked so that the window history is exercised
-@pytest.mark.parametrize("K,nph", [(4, 256), (2, 64), (31, 256), (32, 511), (127, 256), (256, 128)])
+@pytest.mark.parametrize("K,nph", [(4, 256), (2, 64), (31, 256), (32, 511), (127, 256), (256, 128), (15, 512), (15, 1024), (63, 8191)])
 @pytest.mark.parametrize("ratio", [R160, 0.5, 1.999])
 @pytest.mark.parametrize("cplx", [True, False])
 def test_resample_other_lengths(tg, orc, K, nph, ratio, cplx):
@@ -141,4 +141,4 @@ def test_resample_bad_arguments(tg):
     with pytest.raises(tg.TsdGpuError):
         tg.Resampler(0.0, tg.F32)
     with pytest.raises(tg.TsdGpuError):
-        tg.Resampler(1.5, tg.F32, K=15, nphases=512, lut=np.zeros((513, 15), np.float32))   # nphases <= 511
+        tg.Resampler(1.5, tg.F32, K=15, nphases=8192, lut=np.zeros((8193, 15), np.float32))   # nphases <= 8191
