@@ -251,7 +251,10 @@ __global__ __launch_bounds__(RS_THREADS) void resample_kernel(const T *__restric
 // four ds_read_b128 of taps and 30 FMAs instead of 15 sample reads + a schedule record.
 // Outputs are staged in a per-wave LDS buffer and stored coalesced.  The reference's
 // accumulation order (tap 0 .. 14 over the oldest .. newest sample) is kept.
-constexpr int RS15_WAVES = 12;
+#ifndef RS15_NW
+#define RS15_NW 12
+#endif
+constexpr int RS15_WAVES = RS15_NW;
 constexpr int RS15_TILE_PAD = (RS_TI + 16) + (RS_TI + 16) / 8 + 2;      // padded sample slots per wave
 template <typename T>
 __global__ __launch_bounds__(64 * RS15_WAVES) void resample15_kernel(const T *__restrict__ x, const T *__restrict__ hist,
@@ -263,9 +266,14 @@ __global__ __launch_bounds__(64 * RS15_WAVES) void resample15_kernel(const T *__
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float *lut_s = reinterpret_cast<float *>(smem_raw);
   char *wbase = reinterpret_cast<char *>(lut_s + ((P.nph + 1) * LS + 3) / 4 * 4);
-  const size_t wbytes = ((size_t) (RS15_TILE_PAD + P.rec_cap) * sizeof(T) + 15) / 16 * 16;
+  // The output staging buffer ALIASES the sample image: every lane has its 22-sample window in
+  // registers before the first output of the wave is written (one wave: program order is LDS
+  // order), and the image is only rewritten after the outputs have been flushed.  (It halves the
+  // per-wave LDS; 16 waves per CU then fit but need 128 VGPRs -- 60 B of spills -- and measured
+  // 0.531 ms against 0.538 ms for 12 waves: not worth it.)
+  const size_t wbytes = ((size_t) max(RS15_TILE_PAD, P.rec_cap) * sizeof(T) + 15) / 16 * 16;
   T *tile = reinterpret_cast<T *>(wbase + wv * wbytes);      // padded: sample s at s + (s >> 3)
-  T *obuf = tile + RS15_TILE_PAD;                            // outputs of the tile, in order
+  T *obuf = tile;                                            // outputs of the tile, in order
 
   for (int i = threadIdx.x; i < (P.nph + 1) * K; i += 64 * RS15_WAVES) {
     const int c = i / K, k = i - c * K;
@@ -644,7 +652,7 @@ int tsdgpu_resampler_step(tsdgpu_resampler *r, const void *x, int64_t n, void *y
   static const int PG = getenv("TSDGPU_RS_WG_PER_CU") ? atoi(getenv("TSDGPU_RS_WG_PER_CU")) : 0;
   int per_cu = PG > 0 ? PG : (int) std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (lds + 1024)));
   const int64_t pgrid = std::min<int64_t>(cdiv(tiles, RS_WAVES), (int64_t) 256 * per_cu);
-  const size_t wb15 = ((size_t) (RS15_TILE_PAD + P.rec_cap) * sz + 15) / 16 * 16;
+  const size_t wb15 = ((size_t) std::max(RS15_TILE_PAD, P.rec_cap) * sz + 15) / 16 * 16;
   const size_t lds15 = (size_t) ((r->nph + 1) * 20 + 4) * 4 + RS15_WAVES * wb15 + 64;
   if (r->K == 15 && lds15 <= 158 * 1024) {     // fused kernel; larger ratios fall back to the generic one
     const int64_t g15 = std::min<int64_t>(cdiv(tiles, RS15_WAVES), 256);
