@@ -95,6 +95,8 @@ class FirWorkload:
         self.traffic = TRAFFIC_PMC_BYTES.get(("fir", self.method, args.log2n))
 
     def exchange(self):
+        if self.world == 1:
+            return                    # one GPU: no neighbour; the handle streams on from its own history
         from libtsd_amd import sharding
         sharding.exchange_left_halo(self.halo_out, self.halo_in, self.rank, self.world)
         self.f.set_history(self.halo_in_c)
@@ -222,6 +224,7 @@ class ResampleWorkload:
     def exchange(self):
         from libtsd_amd import sharding
         sharding.exchange_left_halo(self.halo_out, self.halo_in, self.rank, self.world)
+        # (also at N = 1: every step resamples the same 2^27-sample shard from stream position `pos`)
         self.r.seek(self.pos, self.halo_in_c if self.rank > 0 else None)
 
     def step(self):
