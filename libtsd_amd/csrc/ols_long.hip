@@ -7,7 +7,8 @@
 // transforms them in LDS (stockham16.hpp), multiplies by the frequency response H (natural
 // order, pre-divided by N), transforms back with conj(FFT(conj .)) -- the spectrum is already
 // in the register layout the first pass reads, so the two transforms need no exchange in
-// between -- and stores the N-(K-1) valid outputs.  HBM traffic per output sample:
+// between -- and stores the N-(K-1) valid outputs.  Real data: two blocks per transform (re / im).
+// HBM traffic per output sample:
 // 8 B * N/L read + 8 B written (the direct kernel's cost grows with K instead: 4K flop/sample).
 #include "fir_internal.hpp"
 #include "stockham16.hpp"
@@ -28,15 +29,22 @@ __global__ __launch_bounds__(1024) void ols_long_kernel(const void *__restrict__
   cpx *lds = reinterpret_cast<cpx *>(olsl_raw);
   const int j = threadIdx.x;
   const int64_t b = blockIdx.x;
-  const int64_t in0 = b * L - (K - 1);                      // stream index of block position 0
+  // REAL data: two consecutive real blocks ride as the real and imaginary part of one complex
+  // block (the taps being real, conv(h, a + j b) = conv(h, a) + j conv(h, b)): block index b then
+  // addresses the real blocks 2b and 2b+1
+  const int64_t in0 = (REAL ? 2 * b : b) * L - (K - 1);    // stream index of block position 0 (first block of the pair)
   cpx v[16];
 #pragma unroll
   for (int m = 0; m < 16; m++) {
     const int64_t idx = in0 + j + m * tpt;
     cpx s = s16::c_mk(0.f, 0.f);
     if (REAL) {
-      if (idx < 0) s.x = reinterpret_cast<const float *>(hist)[HL + idx];        // idx >= -(K-1) >= -HL
-      else if (idx < n) s.x = reinterpret_cast<const float *>(xin)[idx];
+      const float *xr = reinterpret_cast<const float *>(xin), *hr = reinterpret_cast<const float *>(hist);
+      if (idx < 0) s.x = hr[HL + idx];                       // idx >= -(K-1) >= -HL
+      else if (idx < n) s.x = xr[idx];
+      const int64_t idx2 = idx + L;                          // same position in the second block of the pair
+      if (idx2 < 0) s.y = hr[HL + idx2];
+      else if (idx2 < n) s.y = xr[idx2];
     } else {
       if (idx < 0) s = reinterpret_cast<const cpx *>(hist)[HL + idx];
       else if (idx < n) s = reinterpret_cast<const cpx *>(xin)[idx];
@@ -55,10 +63,15 @@ __global__ __launch_bounds__(1024) void ols_long_kernel(const void *__restrict__
 #pragma unroll
   for (int q = 0; q < 16; q++) {
     const int pos = j + q * tpt;
-    const int64_t o = b * L + pos - (K - 1);
-    if (pos >= K - 1 && o < n) {
-      if (REAL) reinterpret_cast<float *>(yout)[o] = v[q].x;
-      else reinterpret_cast<cpx *>(yout)[o] = s16::c_mk(v[q].x, -v[q].y);
+    if (pos < K - 1) continue;
+    if (REAL) {
+      const int64_t o = 2 * b * L + pos - (K - 1);
+      float *yr = reinterpret_cast<float *>(yout);
+      if (o < n) yr[o] = v[q].x;
+      if (o + L < n) yr[o + L] = -v[q].y;                    // imaginary part of conj(...) restored
+    } else {
+      const int64_t o = b * L + pos - (K - 1);
+      if (o < n) reinterpret_cast<cpx *>(yout)[o] = s16::c_mk(v[q].x, -v[q].y);
     }
   }
 }
@@ -135,11 +148,11 @@ int ols_long_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, hipStream_t 
   int logn = 0;
   while ((1 << logn) < N) logn++;
   const int r0 = 1 << ((logn & 3) == 0 ? 4 : (logn & 3));
-  const int64_t nblocks = cdiv(n, L);
+  const bool real = f->data_type == TSDGPU_F32;
+  const int64_t nblocks = cdiv(n, real ? 2 * (int64_t) L : L);      // real data: one workgroup per pair of blocks
   TSD_CHECK(nblocks <= 0x7fffffff, "fir_step: too many blocks");
   const size_t lds = (size_t) (N + N / 16) * sizeof(cpx);
   const cpx *H = (const cpx *) f->d_H, *TW = H + N;
-  const bool real = f->data_type == TSDGPU_F32;
 #define OLSL_LAUNCH(R, B)                                                                                         \
   hipLaunchKernelGGL((ols_long_kernel<R, B>), dim3((unsigned) nblocks), dim3(tpt), lds, st, x, (const void *) f->hist[f->cur], \
                      y, H, TW, N, tpt, f->K, f->HL, L, n)
