@@ -668,6 +668,94 @@ __global__ void czt_post_kernel(const cpx *__restrict__ y2, cpx *__restrict__ y,
   const int kk = inverse ? (n - k) % n : k;
   y[i] = cscale(cmul(y2[b * n2 + n - 1 + kk], chirp[n - 1 + kk]), g);
 }
+// ---- odd n = 5 .. 8191: Bluestein in ONE kernel ------------------------------------------------------
+// Same arithmetic as the five-kernel path above (pre-multiply by the reference's float32 chirp,
+// zero-pad to n2 = pp2(2n-1) <= 16384, FFT, times the transformed conjugate chirp, inverse FFT,
+// post-multiply), but n2/16 threads keep a whole transform in registers + LDS (stockham16.hpp):
+// 16 B of HBM traffic per point instead of ~150.  The spectrum leaves the forward transform in
+// the register layout the next one reads, as in ols_long.hip.  max(256, n2/16) threads per
+// workgroup = several transforms when n2 < 4096.
+// The same kernel is pass 1 of the mixed-radix plan for n = m * P with a large odd part m:
+// transform tr = (b, r) then reads the decimated sequence x[b][r + P i] (in_stride = P) and
+// writes Z[b][r][k1] * W_n^(r k1) (Wn != nullptr).  For the inverse of that plan the odd part is
+// inverted like the reference does it (forward transform + index reversal, so the float32-chirp
+// rounding enters identically) and conjugated (conj_out): pass 2 then runs forward and conjugates
+// at its store, i.e. the power-of-two part uses conj(FFT(conj .)).
+template <int R0>
+__global__ __launch_bounds__(1024) void fft_bluestein_kernel(const cpx *__restrict__ in, cpx *__restrict__ out,
+                                                             const cpx *__restrict__ chirp, const cpx *__restrict__ xc,
+                                                             const cpx *__restrict__ TW, int n, int n2, int tpt, int reverse,
+                                                             float g, int P, const cpx *__restrict__ Wn, int conj_out,
+                                                             int64_t ntr)
+{
+  extern __shared__ __attribute__((aligned(16))) char blu_raw[];
+  const int t = threadIdx.x;
+  const int tl = t / tpt, j = t - tl * tpt, T = blockDim.x / tpt;
+  const int64_t tr = (int64_t) blockIdx.x * T + tl;
+  const bool live = tr < ntr;
+  cpx *lds = reinterpret_cast<cpx *>(blu_raw) + (size_t) tl * (n2 + (n2 >> 4));
+  const int64_t bb = tr / P;
+  const int r = (int) (tr - bb * P);
+  const cpx *x = in + (size_t) bb * n * P + r;
+  cpx *y = out + (size_t) tr * n;
+  cpx v[16];
+#pragma unroll
+  for (int m = 0; m < 16; m++) {
+    const int pos = j + m * tpt;
+    v[m] = cmk(0.f, 0.f);
+    if (live && pos < n) {
+      v[m] = cmul(x[(size_t) pos * P], chirp[n - 1 + pos]);
+    }
+  }
+  auto sync = []() { __syncthreads(); };
+  s16::transform<R0>(v, lds, TW, n2, j, tpt, sync);          // sqrt(n2) * unitary FFT
+#pragma unroll
+  for (int q = 0; q < 16; q++) {
+    const cpx p2 = cmul(v[q], xc[j + q * tpt]);
+    v[q] = cmk(p2.x, -p2.y);
+  }
+  sync();
+  s16::transform<R0>(v, lds, TW, n2, j, tpt, sync);          // conj of n2 * (unitary inverse of the product)
+  if (!live) return;
+#pragma unroll
+  for (int q = 0; q < 16; q++) {
+    const int pos = j + q * tpt, kk = pos - (n - 1);
+    if (kk >= 0 && kk < n) {
+      const int k = reverse ? (kk == 0 ? 0 : n - kk) : kk;    // tfr2itfr: X^-1[k] = X[(n - k) % n]
+      cpx o = cscale(cmul(cmk(v[q].x, -v[q].y), chirp[pos]), g);
+      if (conj_out) o.y = -o.y;
+      if (Wn) o = cmul(o, Wn[(size_t) r * k]);
+      y[k] = o;
+    }
+  }
+}
+
+// Pass 2 of the mixed-radix plan when the power-of-two factor is only 2, 4 or 8: one thread per
+// column k1 combines the PP residues, X[k1 + m k2] at [k2][k1] (natural order).
+template <int PP>
+__global__ __launch_bounds__(256) void fft_smallcols_kernel(const cpx *__restrict__ z, cpx *__restrict__ out, int m,
+                                                            int inverse, float scale, int64_t total)
+{
+  const int64_t gidx = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (gidx >= total) return;
+  const int64_t b = gidx / m;
+  const int k1 = (int) (gidx - b * m);
+  const cpx *zb = z + (size_t) b * m * PP + k1;
+  cpx *yb = out + (size_t) b * m * PP + k1;
+  cpx e[8];
+#pragma unroll
+  for (int r = 0; r < PP; r++) e[r] = zb[(size_t) r * m];
+  if (PP == 2) {
+    s16::dft2(e[0], e[1]);
+  } else if (PP == 4) {
+    w1024::dft4<false>(e[0], e[1], e[2], e[3]);
+  } else {
+    s16::dft8(e);
+  }
+#pragma unroll
+  for (int k2 = 0; k2 < PP; k2++) yb[(size_t) k2 * m] = cmk(e[k2].x * scale, inverse ? -e[k2].y * scale : e[k2].y * scale);
+}
+
 // ---- real FFT (RTFRPlan::step, fourier.cc:311-354), even n ---------------------------------------
 // The n real samples ARE the n/2 packed complex samples; after their FFT Xt the spectrum is
 //   y(i) = r2 (Xt(i) + conj Xt(h-i)) - j2 (Xt(i) - conj Xt(h-i)) rot(i),  i = 0..h,  h = n/2
@@ -729,6 +817,7 @@ struct tsdgpu_fft {
   cpx *d_rot = nullptr;       // W_n^k, k < n (even split)
   int n2 = 0;
   int mix_m = 0, mix_P = 0;   // MIXED: n = mix_m * mix_P
+  bool blu_fused = false;     // ODD: the one-kernel Bluestein (n2 = 1024 .. 16384)
   cpx *d_wm = nullptr;        // W_m^j, j < m
   cpx *d_chirp = nullptr, *d_xc = nullptr;   // Bluestein chirp (2n-1) and FFT of its conjugate (n2)
   DevBuf work, work2, in_stage, out_stage;
@@ -769,12 +858,12 @@ int ref_next_pow2(int i)
 int plan_create(tsdgpu_fft **out, int n);
 void plan_destroy(tsdgpu_fft *p);
 
-// n = m * P with m odd in 3..31 and P = 2^p in 16..4096: the two-pass mixed-radix plan
+// n = m * P with m odd in 3..8191 and P = 2^p in 2..4096: the two-pass mixed-radix plan
 bool mixed_split(int n, int *m, int *P)
 {
   int q = n, pw = 1;
   while ((q & 1) == 0) { q >>= 1; pw <<= 1; }
-  if (q < 3 || q > 31 || pw < 16 || pw > 4096) return false;
+  if (q < 3 || q > 8191 || pw < 2 || pw > 4096 || n > (1 << 22)) return false;   // (W_n table: 8 n bytes)
   *m = q;
   *P = pw;
   return true;
@@ -861,7 +950,12 @@ int plan_init(tsdgpu_fft *p, int n)
     p->kind = tsdgpu_fft::MIXED;
     const int m = p->mix_m, P = p->mix_P;
     p->logn = log2_exact(P);
-    if ((rc = upload(&p->d_wm, twiddle_table(m, m)))) return rc;
+    if (m <= 31) {
+      if ((rc = upload(&p->d_wm, twiddle_table(m, m)))) return rc;           // pass 1 = direct m-point DFT
+    } else {
+      if ((rc = plan_create(&p->sub, m))) return rc;                           // pass 1 = one-kernel Bluestein
+      TSD_CHECK(p->sub->kind == tsdgpu_fft::ODD && p->sub->blu_fused, "fft: no fused Bluestein plan for m = %d", m);
+    }
     if ((rc = upload(&p->d_rot, twiddle_table(n, n)))) return rc;            // W_n^j: the four-step twiddles
     if ((rc = upload(&p->d_tw, twiddle_table(P, std::max(1, P / 16))))) return rc;
 #define C16_ATTR(R) (void) hipFuncSetAttribute((const void *) fft_cols16_kernel<2, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
@@ -911,6 +1005,15 @@ int plan_init(tsdgpu_fft *p, int n)
     rc = tsdgpu_fft_step(p->sub, d_icp, p->d_xc, 1, 1, nullptr);
     (void) hipDeviceSynchronize();
     (void) hipFree(d_icp);
+    if (!rc && p->n2 >= 16 && p->n2 <= S16_MAX_N && getenv("TSDGPU_FFT_GENERIC") == nullptr) {
+      p->blu_fused = true;
+      rc = upload(&p->d_tw, twiddle_table(p->n2, p->n2 / 16));
+      (void) hipFuncSetAttribute((const void *) fft_bluestein_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void) hipFuncSetAttribute((const void *) fft_bluestein_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void) hipFuncSetAttribute((const void *) fft_bluestein_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void) hipFuncSetAttribute((const void *) fft_bluestein_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void) hipGetLastError();
+    }
   }
   return rc;
 }
@@ -942,12 +1045,43 @@ void plan_destroy(tsdgpu_fft *p)
 
 inline unsigned blocks_for(int64_t total) { return (unsigned) cdiv(total, 256); }
 
+// One-kernel Bluestein of `p` (an ODD plan with blu_fused) over ntr = batch * P transforms;
+// P > 1 / Wn: pass 1 of the mixed-radix plan (see fft_bluestein_kernel)
+int launch_bluestein(const tsdgpu_fft *p, const cpx *x, cpx *y, int64_t ntr, int reverse, int conj_out, int P, const cpx *Wn,
+                     hipStream_t st)
+{
+  const int n = p->n, n2 = p->n2;
+  // unitary FFT, product with the unitary xc, unitary inverse, times sqrt(n2)/sqrt(n): the two
+  // unnormalised transforms carry n2, so the output factor is sqrt(n2)/sqrt(n) / n2
+  const float gf = std::sqrt((float) n2) / std::sqrt((float) n) / (float) n2;
+  int l2 = 0;
+  while ((1 << l2) < n2) l2++;
+  const int r0 = 1 << ((l2 & 3) == 0 ? 4 : (l2 & 3)), tpt = n2 / 16;
+  const int threads = std::max(256, tpt), T = threads / tpt;
+  const size_t lds = (size_t) T * (n2 + n2 / 16) * sizeof(cpx);
+  const int64_t grid = cdiv(ntr, T);
+  TSD_CHECK(grid <= 0x7fffffff, "fft_step: too many transforms");
+#define BLU_LAUNCH(R) hipLaunchKernelGGL((fft_bluestein_kernel<R>), dim3((unsigned) grid), dim3(threads), lds, st, x, y, p->d_chirp, p->d_xc, p->d_tw, n, n2, tpt, reverse, gf, P, Wn, conj_out, ntr)
+  if (r0 == 16) BLU_LAUNCH(16); else if (r0 == 8) BLU_LAUNCH(8); else if (r0 == 4) BLU_LAUNCH(4); else BLU_LAUNCH(2);
+#undef BLU_LAUNCH
+  TSD_HIP(hipGetLastError());
+  return TSDGPU_OK;
+}
+
 // device pointers in, device pointers out; x == y allowed
 int step_device(tsdgpu_fft *p, const cpx *x, cpx *y, int batch, int forward, hipStream_t st)
 {
   const int n = p->n;
   const int inverse = forward ? 0 : 1;
   const int64_t total = (int64_t) n * batch;
+  if (batch > 65535 && (p->kind == tsdgpu_fft::MIXED || p->kind == tsdgpu_fft::POW2_4STEP)) {
+    // these plans put the batch index in gridDim.y: larger batches go in slices
+    for (int b0 = 0; b0 < batch; b0 += 65535) {
+      const int rc = step_device(p, x + (size_t) b0 * n, y + (size_t) b0 * n, std::min(65535, batch - b0), forward, st);
+      if (rc) return rc;
+    }
+    return TSDGPU_OK;
+  }
   switch (p->kind) {
     case tsdgpu_fft::ONE:
       if (x != y) TSD_HIP(hipMemcpyAsync(y, x, (size_t) total * sizeof(cpx), hipMemcpyDeviceToDevice, st));
@@ -1057,12 +1191,29 @@ int step_device(tsdgpu_fft *p, const cpx *x, cpx *y, int batch, int forward, hip
       if (rc) return rc;
       cpx *z = p->work.as<cpx>();
       const int64_t tot1 = (int64_t) batch * P;
-      const unsigned g1 = (unsigned) cdiv(tot1, 256);
-      const float s1 = 1.0f / std::sqrt((float) m), s2 = 1.0f / std::sqrt((float) P);
+      const float s2 = 1.0f / std::sqrt((float) P);
+      // pass 1: Z[b][r][k1] = W_n^(r k1) * (unitary m-point DFT of x[b][r + P i])
+      if (m <= 31) {
+        const unsigned g1 = (unsigned) cdiv(tot1, 256);
+        const float s1 = 1.0f / std::sqrt((float) m);
 #define ODD_LAUNCH(M) hipLaunchKernelGGL((fft_odd_dft_kernel<M>), dim3(g1), dim3(256), (size_t) (32 + 256 * m) * sizeof(cpx), st, x, z, p->d_wm, p->d_rot, m, P, inverse, s1, tot1)
-      if (m <= 8) ODD_LAUNCH(8); else if (m <= 16) ODD_LAUNCH(16); else ODD_LAUNCH(32);
+        if (m <= 8) ODD_LAUNCH(8); else if (m <= 16) ODD_LAUNCH(16); else ODD_LAUNCH(32);
 #undef ODD_LAUNCH
-      TSD_HIP(hipGetLastError());
+        TSD_HIP(hipGetLastError());
+      } else {
+        rc = launch_bluestein(p->sub, x, z, tot1, inverse, inverse, P, p->d_rot, st);
+        if (rc) return rc;
+      }
+      // pass 2: P-point column FFTs over r, natural-order store
+      if (P < 16) {
+        const int64_t tot2 = (int64_t) batch * m;
+        const unsigned g2 = (unsigned) cdiv(tot2, 256);
+        if (P == 2) hipLaunchKernelGGL((fft_smallcols_kernel<2>), dim3(g2), dim3(256), 0, st, z, y, m, inverse, s2, tot2);
+        else if (P == 4) hipLaunchKernelGGL((fft_smallcols_kernel<4>), dim3(g2), dim3(256), 0, st, z, y, m, inverse, s2, tot2);
+        else hipLaunchKernelGGL((fft_smallcols_kernel<8>), dim3(g2), dim3(256), 0, st, z, y, m, inverse, s2, tot2);
+        TSD_HIP(hipGetLastError());
+        return TSDGPU_OK;
+      }
       const int tpt = P / 16;
       // ragged tiles: any column count works; no wider than the m live columns
       int CT = std::min(std::min(16, m), 1024 / tpt);
@@ -1093,6 +1244,10 @@ int step_device(tsdgpu_fft *p, const cpx *x, cpx *y, int batch, int forward, hip
     }
     case tsdgpu_fft::ODD: {
       const int n2 = p->n2;
+      if (p->blu_fused) {                                       // (in place is fine: a workgroup loads its whole transforms before it stores)
+        const int rc2 = launch_bluestein(p, x, y, batch, inverse, 0, 1, nullptr, st);
+        return rc2;
+      }
       const int64_t tot2 = (int64_t) n2 * batch;
       int rc = p->work.reserve((size_t) tot2 * sizeof(cpx));
       if (rc) return rc;
