@@ -1,0 +1,38 @@
+"""CPU-side guards of the driver contract: bench.py parses its flags without a GPU, and the bench
+lines committed under profiles/ carry every key the contract names (metric, value, ..., roofline,
+cpu_baseline)."""
+import glob
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+        "dtype", "data", "config", "roofline", "cpu_baseline"]
+
+
+def test_bench_help_lists_the_contract_flags():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0
+    for flag in ("--gpus", "--steps", "--warmup", "--workload"):
+        assert flag in r.stdout
+
+
+def test_committed_bench_lines_follow_the_contract():
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_*.json")))
+    assert files, "no bench line committed under profiles/"
+    for f in files:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        for k in KEYS:
+            assert k in d, (f, k)
+        assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+        assert "workload" in d["config"] and "model" not in d["config"]
+        rf = d["roofline"]
+        for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+            assert k in rf, (f, k)
+        assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+        cb = d["cpu_baseline"]
+        for k in ("value", "unit", "cores", "kind", "sample"):
+            assert k in cb, (f, k)
+        assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1
