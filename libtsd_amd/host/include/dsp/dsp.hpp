@@ -86,5 +86,17 @@ template <typename T> std::tuple<Vector<T>, Vector<T>, int, float> align_int(con
 inline Vecf psd_freqs(int n, bool complexe = true) { return tsd::fourier::psd_freqs(n, complexe); }
 template <typename T> std::tuple<Vecf, Vecf> psd(const Vector<T> &x) { return tsd::fourier::psd(x); }
 inline std::tuple<Vecf, Vecf> psd_welch(const Veccf &x, int N, const std::string &fen = "hn") { return tsd::fourier::psd_welch(x, N, fen); }
+// pattern detector (dsp/fourier.hpp:505-583)
+using tsd::fourier::Detection;
+using tsd::fourier::Detecteur;
+struct DetectorConfig : tsd::fourier::DetecteurConfig {
+  uint32_t &Ns = Ne;
+  tsd::Veccf &pattern = motif;
+  float &threshold = seuil;
+  bool &debug_active = debug_actif;
+  std::function<void(const Detection &det)> &on_detection = gere_detection;
+  bool &compute_correlation_signal = calculer_signal_correlation;
+};
+inline sptr<Detecteur> detector_new(const DetectorConfig &config) { return tsd::fourier::détecteur_création(config); }
 }  // namespace fourier
 }  // namespace dsp

@@ -6,6 +6,7 @@
 // TFRPlanDefaut does (fourier.cc:362,372-376,120).
 #pragma once
 #include "tsd/tsd.hpp"
+#include <cstdint>
 #include <tuple>
 
 namespace tsd::fourier {
@@ -105,5 +106,28 @@ template <typename T> Vecteur<T> délais(const Vecteur<T> &x, float τ);
 // cross-correlation with quadratic interpolation -> (delay, score); integer alignment of two vectors
 std::tuple<float, float> estimation_délais(const Veccf &x, const Veccf &y);
 template <typename T> std::tuple<Vecteur<T>, Vecteur<T>, entier, float> aligne_entier(const Vecteur<T> &x, const Vecteur<T> &y);
+
+// ---- pattern detector (include/tsd/fourier.hpp:545-660; src/fourier/detection.cc) ----------------
+// Normalised correlation of the stream with a fixed pattern: the correlation runs on the GPU (the
+// OLA engine above with X *= conj(FFT(pattern)) as spectral processing, or an FIR with the reversed
+// conjugated pattern), the energy normalisation on the GPU moving average, the peak logic on the
+// host like the reference.  position = first sample of the pattern relative to the start of the
+// current block (negative: in an earlier block); position_prec adds the quadratic sub-sample
+// interpolation; gain / θ = complex amplitude of the received pattern; SNR from the residual.
+struct Detection {
+  entier position = 0;
+  float position_prec = 0, score = 0, gain = 0, θ = 0, SNR_dB = 0, σ_noise = 0;
+};
+struct DetecteurConfig {
+  uint32_t Ne = 0;                 // block length (0: chosen by ola_complexité_optimise)
+  Veccf motif;
+  float seuil = 0.5f;
+  bouléen debug_actif = false;
+  enum Mode { MODE_OLA = 0, MODE_RIF = 1 } mode = MODE_OLA;
+  fonction<void(const Detection &det)> gere_detection;
+  bouléen calculer_signal_correlation = false;
+};
+struct Detecteur : Filtre<cfloat, float, DetecteurConfig> {};
+sptr<Detecteur> détecteur_création(const DetecteurConfig &config);
 
 }  // namespace tsd::fourier

@@ -825,6 +825,75 @@ static void test_filtrage_ola_ref()
   CHECK(num / den < 0.02, "OLA low-pass: relative residual %g", num / den);
 }
 
+
+// ---- test_detecteur_unit (core/tests/test-detecteur.cc:153-328): a 400-sample Gaussian-windowed
+// quadratic chirp, seven occurrences (gains 2 .. 0.02, one at a fractional position, one straddling
+// a block boundary, one ending exactly on one) in noise of σ = 0.01, blocks of 4096; every
+// occurrence must be reported once, with the reference's error bounds.
+static void test_detecteur_unit(float σ, int BS, DetecteurConfig::Mode mode)
+{
+  const int N = 8 * BS, M = 400;
+  Veccf motif(M);
+  {
+    double phase = 0;
+    for (int i = 0; i < M; i++) {
+      const double u = (double) i / (M - 1), freq = 0.001 + (0.2 - 0.001) * u * u;   // sigchirp(0.001, 0.2, M, 'q')
+      phase += 2 * π * freq;                                                          // cumsum
+      const double t = (i - M / 2.0) / (M / 2.0);                                     // siggauss(M, 10)
+      motif(i) = (float) (std::exp(-10 * t * t) * std::cos(phase));
+    }
+    double en = 0;
+    for (int i = 0; i < M; i++) en += std::norm(motif(i));
+    motif *= cfloat((float) (std::sqrt(400.0) / std::sqrt(en)), 0);
+  }
+  struct Occurence { float gain, position, phase; };
+  const std::vector<Occurence> occ = {{2.0f, 900.0f, π_f / 4}, {4.0f, 2000.4f, -π_f / 4}, {1.0f, BS - 1.0f, 0}, {1.0f, 2.0f * BS, 0},
+                                      {0.1f, 2.2f * BS, 0},   {0.05f, 2.5f * BS, 0},     {0.02f, 2.7f * BS, 0}};
+  Veccf x = Veccf::zeros(N);
+  for (const auto &o : occ) {
+    Veccf m2 = motif.clone();
+    const float p = o.position - std::floor(o.position);
+    if (p > 0.01f) m2 = délais(motif, p);
+    m2 *= std::polar(o.gain, o.phase);
+    x.segment((int) std::floor(o.position), M) = m2;
+  }
+  Veccf bruit = randcn(N);
+  bruit *= cfloat(σ / std::sqrt(2.0f), 0);
+  x += bruit;
+  double pm = 0;
+  for (int i = 0; i < M; i++) pm += std::norm(motif(i));
+  pm /= M;
+  int cnt_ech = 0, ndet = 0, err = 0;
+  DetecteurConfig config;
+  config.mode = mode;
+  config.gere_detection = [&](const Detection &det) {
+    const float pos_abs = det.position_prec + cnt_ech;
+    const int k = ndet++;
+    if (k >= (int) occ.size()) return;
+    const float SNR_v = 10 * std::log10((float) (pm * occ[k].gain * occ[k].gain) / (σ * σ));
+    const float err_phase = (det.θ - occ[k].phase) * 180 / π_f, err_gain = det.gain - occ[k].gain, err_pos = pos_abs - occ[k].position;
+    const float err_σ = det.σ_noise - σ, err_SNR = det.SNR_dB - SNR_v;
+    bool bad = false;
+    if (SNR_v > 15) bad = bad || std::abs(err_phase) > 1 || std::abs(err_gain / occ[k].gain) > 1e-2f;
+    bad = bad || std::abs(err_pos) > 0.1f || std::abs(err_σ / σ) > 0.25f || std::abs(err_SNR) > 1;
+    if (bad) {
+      err = 1;
+      printf("  detection %d (mode %d): pos %.3f (expected %.1f) gain %.4f (%.2f) phase %.2f deg err, sigma %.4g, SNR %.1f (%.1f)\n", k, (int) mode,
+             pos_abs, occ[k].position, det.gain, occ[k].gain, err_phase, det.σ_noise, det.SNR_dB, SNR_v);
+    }
+  };
+  config.Ne = BS;
+  config.motif = motif;
+  config.seuil = 0.8f;
+  auto det = détecteur_création(config);
+  for (int i = 0; i < N / BS; i++) {
+    det->step(x.segment(i * BS, BS));
+    cnt_ech += BS;
+  }
+  CHECK(ndet == (int) occ.size(), "détecteur mode %d: %d detections, expected %d", (int) mode, ndet, (int) occ.size());
+  CHECK(!err, "détecteur mode %d: error bounds of the reference's test exceeded", (int) mode);
+}
+
 int main(int argc, char **argv)
 {
   if (argc > 1 && !std::strcmp(argv[1], "--no-gpu")) {
@@ -869,6 +938,22 @@ int main(int argc, char **argv)
   test_ligne_a_retard_ref(70);
   for (int K : {4, 11, 20}) test_filtre_mg_ref(K);
   test_filtrage_ola_ref();
+  test_detecteur_unit(0.01f, 4 * 1024, DetecteurConfig::MODE_OLA);
+  test_detecteur_unit(0.01f, 4 * 1024, DetecteurConfig::MODE_RIF);
+  {
+    // dsp:: spelling (dsp/fourier.hpp:528-583): the same object
+    dsp::fourier::DetectorConfig dc;
+    dc.pattern = randcn(64);
+    dc.Ns = 256;
+    dc.threshold = 0.9f;
+    int hits = 0;
+    dc.on_detection = [&](const dsp::fourier::Detection &) { hits++; };
+    auto d = dsp::fourier::detector_new(dc);
+    Veccf sig = Veccf::zeros(1024);
+    sig.segment(300, 64) = dc.pattern;
+    for (int i = 0; i < 4; i++) d->step(sig.segment(256 * i, 256));
+    CHECK(hits == 1, "dsp::fourier::detector_new: %d detections of a clean pattern", hits);
+  }
   test_petits_filtres<float>();
   test_petits_filtres<cfloat>();
   {
