@@ -86,6 +86,9 @@ template <typename T> std::tuple<Vector<T>, Vector<T>, int, float> align_int(con
 inline Vecf psd_freqs(int n, bool complexe = true) { return tsd::fourier::psd_freqs(n, complexe); }
 template <typename T> std::tuple<Vecf, Vecf> psd(const Vector<T> &x) { return tsd::fourier::psd(x); }
 inline std::tuple<Vecf, Vecf> psd_welch(const Veccf &x, int N, const std::string &fen = "hn") { return tsd::fourier::psd_welch(x, N, fen); }
+// real-time spectrum (dsp/fourier.hpp:815-828)
+using tsd::fourier::SpectrumConfig;
+inline sptr<Filter<cfloat, float, SpectrumConfig>> rt_spectrum(const SpectrumConfig &config) { return tsd::fourier::rt_spectrum(config); }
 // pattern detector (dsp/fourier.hpp:505-583)
 using tsd::fourier::Detection;
 using tsd::fourier::Detecteur;

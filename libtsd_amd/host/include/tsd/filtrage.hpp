@@ -64,7 +64,10 @@ struct Design {
 typedef enum { FormeDirecte1, FormeDirecte2 } RIIStructure;
 
 // ---- design helpers (run once on the host) ---------------------------------------------------
-Vecf fenêtre(cstring type, entier n, bouléen symetrique = true);                       // "hn","hm","re","tr"
+Vecf fenêtre(cstring type, entier n, bouléen symetrique = true);
+// enum spelling (filtrage.hpp:119-134); BLACKMAN and CHEBYCHEV are design-time windows that are not built
+enum class Fenetre { AUCUNE = 0, HANN, TRIANGLE, HAMMING, BLACKMAN, CHEBYCHEV };
+Vecf fenêtre(Fenetre type, entier n, bouléen symetrique = true);                       // "hn","hm","re","tr"
 Vecf design_rif_fen(entier n, cstring type, float fc, cstring fen = "hn", float fc2 = 0);
 Vecf design_rif_prod(const Vecf &h1, const Vecf &h2);
 FRat<cfloat> design_riia(entier n, cstring type, cstring prototype, float fc, float δ_bp = 0.1f, float δ_bc = 60);

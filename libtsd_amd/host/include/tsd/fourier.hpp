@@ -6,6 +6,7 @@
 // TFRPlanDefaut does (fourier.cc:362,372-376,120).
 #pragma once
 #include "tsd/tsd.hpp"
+#include "tsd/filtrage.hpp"
 #include <cstdint>
 #include <tuple>
 
@@ -106,6 +107,25 @@ template <typename T> Vecteur<T> délais(const Vecteur<T> &x, float τ);
 // cross-correlation with quadratic interpolation -> (delay, score); integer alignment of two vectors
 std::tuple<float, float> estimation_délais(const Veccf &x, const Veccf &y);
 template <typename T> std::tuple<Vecteur<T>, Vecteur<T>, entier, float> aligne_entier(const Vecteur<T> &x, const Vecteur<T> &y);
+
+// ---- real-time spectrum (include/tsd/fourier.hpp:909-952; src/fourier/fourier.cc:1148-1342) ------
+// Blocks of BS samples are cut in nsubs sub-blocks of Nf = BS / nsubs, windowed (window normalised
+// to energy Nf), transformed -- ONE batched GPU FFT per block -- and |X|^2 (fftshift-ed) is averaged
+// over nmeans blocks; the spectrum in dB comes out with every nmeans-th block (an empty vector
+// otherwise).  sweep: the sub-blocks are successive tunings `step` bins apart, accumulated side by
+// side into a Ns-bin spectrum with optional masks on the band edges / centre.
+struct SpectrumConfig {
+  entier BS = 1024, nmeans = 10, nsubs = 1;
+  struct {
+    bouléen active = false;
+    entier step = 1024, masque_bf = 0, masque_hf = 0;
+  } sweep;
+  entier Nf() const { return BS / nsubs; }
+  entier Ns() const { return sweep.active ? Nf() + (nsubs - 1) * sweep.step : Nf(); }
+  tsd::filtrage::Fenetre fenetre = tsd::filtrage::Fenetre::HANN;
+  sptr<FFTPlan> plan;              // accepted for compatibility; the batched GPU plan is always used
+};
+sptr<Filtre<cfloat, float, SpectrumConfig>> rt_spectrum(const SpectrumConfig &config);
 
 // ---- pattern detector (include/tsd/fourier.hpp:545-660; src/fourier/detection.cc) ----------------
 // Normalised correlation of the stream with a fixed pattern: the correlation runs on the GPU (the

@@ -91,6 +91,17 @@ Vecf fenêtre(cstring type, entier n, bouléen symetrique)
   échec("fenêtre: window type '{}' is not built in this hot-path mirror (have hn, hm, re, tr)", type);
 }
 
+Vecf fenêtre(Fenetre type, entier n, bouléen symetrique)
+{
+  switch (type) {
+    case Fenetre::AUCUNE: return fenêtre("re", n, symetrique);
+    case Fenetre::HANN: return fenêtre("hn", n, symetrique);
+    case Fenetre::TRIANGLE: return fenêtre("tr", n, symetrique);
+    case Fenetre::HAMMING: return fenêtre("hm", n, symetrique);
+    default: échec("fenêtre: this window is not built in the hot-path mirror (have AUCUNE, HANN, TRIANGLE, HAMMING)");
+  }
+}
+
 static Vecf coefs_filtre_sinc(entier n, float fc)
 {
   if (n & 1) return Vecf::int_expr(n, [&](entier i) { return sinc(2 * fc, (float) (i - n / 2)); });

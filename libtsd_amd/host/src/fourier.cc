@@ -1,6 +1,7 @@
 // fourier.cc -- FFTPlan on the MI355X C ABI, the fftplan_defaut hook and the real-FFT plan.
 #include "tsd/fourier.hpp"
 #include "tsd/filtrage.hpp"
+#include <limits>
 #include <vector>
 #include "../../../include/tsdgpu.h"
 
@@ -368,6 +369,80 @@ std::tuple<Vecf, Vecf> psd_welch(const Veccf &x, entier N, cstring fen)
     for (entier k = 0; k < nseg; k++) S += fftshift(abs2(seg.segment(k * N, N)));
   }
   return {psd_freqs(N), pow2db(S)};
+}
+
+// ---- rt_spectrum (fourier.cc:1148-1342) ---------------------------------------------------------------
+namespace {
+struct SpectreGpu : Filtre<cfloat, float, SpectrumConfig> {
+  Vecf f, mag_moy, mag_cnt, masque;
+  entier cntmag = 0, Nf = 0, Ns = 0;
+  tsdgpu_fft *plan = nullptr;
+  ~SpectreGpu() override { tsdgpu_fft_destroy(plan); }
+  void configure_impl(const SpectrumConfig &c) override
+  {
+    if (c.nsubs < 1 || c.BS < c.nsubs || c.nmeans < 1) échec("rt_spectrum: BS = {}, nsubs = {}, nmeans = {}", c.BS, c.nsubs, c.nmeans);
+    cntmag = 0;
+    Nf = c.BS / c.nsubs;
+    Ns = Nf;
+    masque = Vecf::ones(Nf);
+    if (c.sweep.masque_hf > 0) {
+      masque.head(c.sweep.masque_hf).setZero();
+      masque.tail(c.sweep.masque_hf).setZero();
+    }
+    if (c.sweep.masque_bf > 0) masque.segment(Nf / 2 - c.sweep.masque_bf, 2 * c.sweep.masque_bf).setZero();
+    if (c.sweep.active) {
+      Ns = Nf + (c.nsubs - 1) * c.sweep.step;
+      mag_cnt = Vecf::zeros(Ns);
+      for (entier i = 0; i < c.nsubs; i++)
+        for (entier k = 0; k < Nf; k++) mag_cnt(i * c.sweep.step + k) += masque(k);
+      for (entier k = 0; k < Ns; k++) mag_cnt(k) = std::max(mag_cnt(k), 1.0f);   // a sweep step wider than the unmasked band
+    }
+    mag_moy = Vecf::zeros(Ns);
+    f = tsd::filtrage::fenêtre(c.fenetre, Nf, false);
+    // window energy normalised to Nf: the total energy of an uncorrelated signal is preserved
+    double e = 0;
+    for (entier k = 0; k < Nf; k++) e += (double) f(k) * f(k);
+    f *= (float) std::sqrt(Nf / e);
+    tsdgpu_fft_destroy(plan);
+    plan = nullptr;
+    if (tsdgpu_fft_create(&plan, Nf, c.nsubs)) échec("rt_spectrum: {}", tsdgpu_last_error());
+  }
+  void step(const Veccf &x, Vecf &y) override
+  {
+    const SpectrumConfig &c = Configurable<SpectrumConfig>::config;
+    if (x.rows() != c.BS) échec("Spectrum : dimension invalide ({} au lieu de {}).", x.rows(), c.BS);
+    Veccf w(c.nsubs * Nf);
+    for (entier i = 0; i < c.nsubs; i++)
+      for (entier k = 0; k < Nf; k++) w(i * Nf + k) = x(i * Nf + k) * f(k);
+    if (tsdgpu_fft_step(plan, w.data(), w.data(), c.nsubs, 1, nullptr)) échec("rt_spectrum: {}", tsdgpu_last_error());
+    for (entier i = 0; i < c.nsubs; i++) {
+      const Vecf p = fftshift(abs2(w.segment(i * Nf, Nf)));
+      if (c.sweep.active) {
+        for (entier k = 0; k < Nf; k++) mag_moy(i * c.sweep.step + k) += p(k) * masque(k);
+      } else {
+        mag_moy += p;
+      }
+    }
+    cntmag++;
+    if (cntmag == c.nmeans) {
+      mag_moy /= (float) (c.nmeans * c.nsubs * Nf);
+      if (c.sweep.active)
+        for (entier k = 0; k < Ns; k++) mag_moy(k) /= mag_cnt(k);
+      y.resize(Ns);
+      for (entier k = 0; k < Ns; k++) y(k) = 10 * std::log10(mag_moy(k) + std::numeric_limits<float>::min());
+      mag_moy.setZero();
+      cntmag = 0;
+    } else {
+      y.resize(0);
+    }
+  }
+};
+}  // namespace
+sptr<Filtre<cfloat, float, SpectrumConfig>> rt_spectrum(const SpectrumConfig &config)
+{
+  auto res = std::make_shared<SpectreGpu>();
+  res->configure(config);
+  return res;
 }
 
 // ---- filtre_fft: the OLA engine with a spectral callback (fourier.cc:700-940) ------------------

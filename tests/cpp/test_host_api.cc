@@ -894,6 +894,61 @@ static void test_detecteur_unit(float σ, int BS, DetecteurConfig::Mode mode)
   CHECK(!err, "détecteur mode %d: error bounds of the reference's test exceeded", (int) mode);
 }
 
+
+// ---- rt_spectrum (fourier.cc:1148-1342): no reference test exists; checked on its definition
+static void test_rt_spectrum()
+{
+  // white noise of unit variance: every bin averages to 1/Nf (unitary FFT, window energy Nf, extra 1/Nf)
+  {
+    SpectrumConfig c;
+    c.BS = 1024; c.nsubs = 4; c.nmeans = 10;
+    auto sp = rt_spectrum(c);
+    Vecf y;
+    int nonvide = 0;
+    for (int b = 0; b < 20; b++) {
+      Vecf o = sp->step(randcn(c.BS));
+      if (o.rows()) { y = o; nonvide++; CHECK((b + 1) % c.nmeans == 0, "spectrum delivered at block %d", b); }
+    }
+    CHECK(nonvide == 2 && y.rows() == 256, "rt_spectrum cadence %d rows %d", nonvide, y.rows());
+    double m = 0;
+    for (int k = 0; k < y.rows(); k++) m += std::pow(10.0, y(k) / 10);
+    m /= y.rows();
+    // randcn: unit variance per component, E|x|^2 = 2
+    CHECK(std::abs(10 * std::log10(m) - 10 * std::log10(2.0 / 256)) < 0.3, "noise floor %g dB (expected %g)", 10 * std::log10(m), 10 * std::log10(2.0 / 256));
+  }
+  // a complex exponential on bin +40 of 256: the peak sits at the fftshift-ed position, Hann main lobe
+  {
+    SpectrumConfig c;
+    c.BS = 256; c.nsubs = 1; c.nmeans = 3;
+    auto sp = rt_spectrum(c);
+    Veccf x = Veccf::int_expr(256, [&](int i) { return std::polar(1.0f, (float) (2 * π * 40 * i / 256)); });
+    sp->step(x); sp->step(x);
+    Vecf y = sp->step(x);
+    CHECK(y.rows() == 256 && y.index_max() == 128 + 40, "rt_spectrum peak at %d", y.index_max());
+    // |X|^2 = (sum f)^2 / Nf with f = sqrt(8/3) * hann  ->  Nf * 2/3; divided by Nf: 2/3
+    CHECK(std::abs(y(168) - 10 * std::log10(2.0 / 3)) < 0.05 && std::abs(y(168) - y(167) - 6.02) < 0.1, "rt_spectrum level %g dB", y(168));
+  }
+  // sweep: 4 tunings 64 bins apart, edges masked: Ns = 256 + 3*64 bins, flat for white noise
+  {
+    SpectrumConfig c;
+    c.BS = 1024; c.nsubs = 4; c.nmeans = 20;
+    c.sweep.active = true; c.sweep.step = 64; c.sweep.masque_hf = 16;
+    c.fenetre = tsd::filtrage::Fenetre::AUCUNE;
+    auto sp = rt_spectrum(c);
+    Vecf y;
+    for (int b = 0; b < 20; b++) y = sp->step(randcn(c.BS));
+    CHECK(c.Ns() == 448 && y.rows() == 448, "sweep rows %d", y.rows());
+    double lo = 1e9, hi = -1e9;
+    for (int k = 16; k < 448 - 16; k++) { lo = std::min<double>(lo, y(k)); hi = std::max<double>(hi, y(k)); }
+    // (the reference divides by nsubs in sweep mode too, although a bin only collects mag_cnt(k) <= nsubs
+    // sub-blocks: the floor sits 10 log10(nsubs) lower; 20 averages per contribution: +-3 dB extremes)
+    CHECK(hi - lo < 7.0 && std::abs(0.5 * (hi + lo) - 10 * std::log10(2.0 / 256 / 4)) < 2.0, "sweep flatness %g .. %g dB", lo, hi);
+  }
+  bool threw = false;
+  try { SpectrumConfig c; auto sp = rt_spectrum(c); sp->step(randcn(100)); } catch (const std::runtime_error &) { threw = true; }
+  CHECK(threw, "rt_spectrum must reject a block of the wrong size");
+}
+
 int main(int argc, char **argv)
 {
   if (argc > 1 && !std::strcmp(argv[1], "--no-gpu")) {
@@ -933,6 +988,7 @@ int main(int argc, char **argv)
   test_tampon();
   test_filtre_fft();
   test_psd();
+  test_rt_spectrum();
   test_ra();
   test_ligne_a_retard_ref(0);
   test_ligne_a_retard_ref(70);
