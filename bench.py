@@ -110,7 +110,26 @@ class FirWorkload:
         n0 = 1 << 20
         x = (rng.standard_normal(n0) + 1j * rng.standard_normal(n0)).astype(np.complex64)
         f = orc.Fir(self.h)
-        return _time_cpu(lambda: f.step(x), n0, "Msamples/s", "2^20 complex samples, 127 real taps, oracle orc_fir_cf")
+        res = _time_cpu(lambda: f.step(x), n0, "Msamples/s", "2^20 complex samples, 127 real taps, oracle orc_fir_cf")
+        # the same port chunk-parallel over the host cores this process may use (libtsd itself is
+        # single-threaded: one stateful filter per chunk) -- informative extra, not the baseline
+        try:
+            from concurrent.futures import ThreadPoolExecutor
+            nthr = max(1, min(16, len(os.sched_getaffinity(0))))
+            firs = [orc.Fir(self.h) for _ in range(nthr)]
+            xs = [x.copy() for _ in range(nthr)]
+            with ThreadPoolExecutor(nthr) as ex:
+                list(ex.map(lambda i: firs[i].step(xs[i]), range(nthr)))
+                t0 = time.perf_counter()
+                reps = 8
+                for _ in range(reps):
+                    list(ex.map(lambda i: firs[i].step(xs[i]), range(nthr)))
+                dt = time.perf_counter() - t0
+            res["parallel"] = {"value": round(reps * nthr * n0 / dt / 1e6, 3), "unit": "Msamples/s", "cores": nthr,
+                               "sample": f"{reps} x {nthr} chunks of 2^20 samples, one oracle filter per thread"}
+        except Exception as e:      # never let the informative leg break the bench line
+            res["parallel"] = {"error": str(e)}
+        return res
 
 
 class FftWorkload:
