@@ -58,6 +58,28 @@ void DevBuf::release()
   cap = 0;
 }
 
+int StepOrder::enter(hipStream_t st)
+{
+  if (used && st != last) TSD_HIP(hipStreamWaitEvent(st, ev, 0));
+  return TSDGPU_OK;
+}
+
+int StepOrder::leave(hipStream_t st)
+{
+  if (!ev) TSD_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  TSD_HIP(hipEventRecord(ev, st));
+  last = st;
+  used = true;
+  return TSDGPU_OK;
+}
+
+void StepOrder::release()
+{
+  if (ev) (void) hipEventDestroy(ev);
+  ev = nullptr;
+  used = false;
+}
+
 int stage_in(const void *src, size_t bytes, DevBuf &buf, hipStream_t st, const void **dev)
 {
   if (bytes == 0 || is_device_ptr(src)) {

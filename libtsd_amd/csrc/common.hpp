@@ -2,6 +2,7 @@
 // pointer staging).  Product code: never includes or links anything under oracle/.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -49,6 +50,19 @@ int stage_in(const void *src, size_t bytes, DevBuf &buf, hipStream_t st, const v
 // else `buf`.  finish_out() copies back to the host buffer and synchronises when staged.
 int stage_out(void *dst, size_t bytes, DevBuf &buf, void **dev, bool *staged);
 int finish_out(void *dst, size_t bytes, const void *dev, bool staged, hipStream_t st);
+
+// Serialises use of a handle's scratch buffers: host threads through the mutex, streams through
+// an event (a step on another stream waits for the previous step's work).  libtsd's Spectrum calls
+// plan->step from OpenMP threads on one plan (fourier.cc:1244-1252), so plans must tolerate it.
+struct StepOrder {
+  std::mutex mu;
+  hipEvent_t ev = nullptr;
+  hipStream_t last = nullptr;
+  bool used = false;
+  int enter(hipStream_t st);   // call with mu held, before enqueueing
+  int leave(hipStream_t st);   // call with mu held, after enqueueing
+  void release();
+};
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -821,6 +821,7 @@ struct tsdgpu_fft {
   cpx *d_wm = nullptr;        // W_m^j, j < m
   cpx *d_chirp = nullptr, *d_xc = nullptr;   // Bluestein chirp (2n-1) and FFT of its conjugate (n2)
   DevBuf work, work2, in_stage, out_stage;
+  StepOrder order;            // top-level plans only (sub-plans run under their owner's)
 };
 
 namespace {
@@ -1040,6 +1041,7 @@ void plan_destroy(tsdgpu_fft *p)
   p->work2.release();
   p->in_stage.release();
   p->out_stage.release();
+  p->order.release();
   delete p;
 }
 
@@ -1297,13 +1299,18 @@ int tsdgpu_fft_step(tsdgpu_fft *p, const void *x, void *y, int batch, int forwar
   const void *dx = nullptr;
   void *dy = nullptr;
   bool staged = false;
-  int rc = stage_in(x, bytes, p->in_stage, st, &dx);
+  std::lock_guard<std::mutex> lock(p->order.mu);
+  int rc = p->order.enter(st);
+  if (rc) return rc;
+  rc = stage_in(x, bytes, p->in_stage, st, &dx);
   if (rc) return rc;
   rc = stage_out(y, bytes, p->out_stage, &dy, &staged);
   if (rc) return rc;
   rc = step_device(p, (const cpx *) dx, (cpx *) dy, batch, forward, st);
   if (rc) return rc;
-  return finish_out(y, bytes, dy, staged, st);
+  rc = finish_out(y, bytes, dy, staged, st);
+  if (rc) return rc;
+  return p->order.leave(st);
 }
 
 int tsdgpu_fft_size(const tsdgpu_fft *p) { return p ? p->n : -1; }
@@ -1350,6 +1357,7 @@ struct tsdgpu_rfft {
   tsdgpu_fft *sub = nullptr;      // n/2-point complex plan (even n) or n-point plan (odd n)
   cpx *d_rot = nullptr;           // tfr_rotation(n): W_n^i, double recurrence rounded to float
   DevBuf work, in_stage, out_stage;
+  StepOrder order;
 };
 
 int tsdgpu_rfft_create(tsdgpu_rfft **out, int n)
@@ -1397,7 +1405,10 @@ int tsdgpu_rfft_step(tsdgpu_rfft *p, const void *x, void *y, int batch, void *st
   const void *dx = nullptr;
   void *dy = nullptr;
   bool staged = false;
-  int rc = stage_in(x, in_bytes, p->in_stage, st, &dx);
+  std::lock_guard<std::mutex> lock(p->order.mu);
+  int rc = p->order.enter(st);
+  if (rc) return rc;
+  rc = stage_in(x, in_bytes, p->in_stage, st, &dx);
   if (rc) return rc;
   rc = stage_out(y, out_bytes, p->out_stage, &dy, &staged);
   if (rc) return rc;
@@ -1421,7 +1432,9 @@ int tsdgpu_rfft_step(tsdgpu_rfft *p, const void *x, void *y, int batch, void *st
     rc = step_device(p->sub, (const cpx *) dy, (cpx *) dy, batch, 1, st);
     if (rc) return rc;
   }
-  return finish_out(y, out_bytes, dy, staged, st);
+  rc = finish_out(y, out_bytes, dy, staged, st);
+  if (rc) return rc;
+  return p->order.leave(st);
 }
 
 int tsdgpu_rfft_destroy(tsdgpu_rfft *p)
@@ -1432,6 +1445,7 @@ int tsdgpu_rfft_destroy(tsdgpu_rfft *p)
   p->work.release();
   p->in_stage.release();
   p->out_stage.release();
+  p->order.release();
   delete p;
   return TSDGPU_OK;
 }

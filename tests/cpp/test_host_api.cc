@@ -5,6 +5,7 @@
 //          test_host_api --no-gpu   -> checks that the factories fail loudly without a GPU
 #include <cstdio>
 #include <cstring>
+#include <thread>
 #include "dsp/dsp.hpp"
 #include "../../oracle/tsd_oracle.h"
 
@@ -949,6 +950,27 @@ static void test_rt_spectrum()
   CHECK(threw, "rt_spectrum must reject a block of the wrong size");
 }
 
+// Spectrum's OpenMP loop calls plan->step on ONE plan from several threads (fourier.cc:1244-1252):
+// a plan must give every caller its own transform although the scratch buffers are shared.
+static void test_plan_concurrent(int n)
+{
+  auto plan = tfrplan_création(n);
+  const int NT = 4, REP = 6;
+  std::vector<Veccf> x(NT), ref(NT);
+  for (int t = 0; t < NT; t++) { x[t] = randcn(n); ref[t] = plan->step(x[t]); }
+  std::vector<float> err(NT, 0.0f);
+  std::vector<std::thread> th;
+  for (int t = 0; t < NT; t++)
+    th.emplace_back([&, t]() {
+      for (int r = 0; r < REP; r++) {
+        Veccf y = plan->step(x[t]);
+        for (int i = 0; i < n; i++) err[t] = std::max(err[t], std::abs(y(i) - ref[t](i)));
+      }
+    });
+  for (auto &q : th) q.join();
+  for (int t = 0; t < NT; t++) CHECK(err[t] == 0.0f, "concurrent plan->step n=%d thread %d: err %g", n, t, err[t]);
+}
+
 int main(int argc, char **argv)
 {
   if (argc > 1 && !std::strcmp(argv[1], "--no-gpu")) {
@@ -989,6 +1011,7 @@ int main(int argc, char **argv)
   test_filtre_fft();
   test_psd();
   test_rt_spectrum();
+  for (int n : {4096, 1 << 18, 3000, 1001}) test_plan_concurrent(n);
   test_ra();
   test_ligne_a_retard_ref(0);
   test_ligne_a_retard_ref(70);
