@@ -16,7 +16,8 @@ class TsdGpuError(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(_HERE, "lib", "libtsdgpu.so")
+    # TSDGPU_LIB: developer switch -- load an experimental build of the same C ABI (scripts/build_variant.sh)
+    return os.environ.get("TSDGPU_LIB") or os.path.join(_HERE, "lib", "libtsdgpu.so")
 
 
 def lib():

@@ -42,22 +42,80 @@ TSD_HD cpx cadd(cpx a, cpx b) { return mk(a.x + b.x, a.y + b.y); }
 TSD_HD cpx csub(cpx a, cpx b) { return mk(a.x - b.x, a.y - b.y); }
 TSD_HD cpx cmul(cpx a, cpx b) { return mk(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
 TSD_HD cpx cmulc(cpx a, cpx b) { return mk(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a*conj(b)
-template <bool INV> TSD_HD cpx ctw(cpx a, cpx w) { return INV ? cmulc(a, w) : cmul(a, w); }
 // multiply by -i (forward) / +i (inverse)
 template <bool INV> TSD_HD cpx rot90(cpx a) { return INV ? mk(-a.y, a.x) : mk(a.y, -a.x); }
+// a +- rot90(t) (one instruction each in the packed flavour below)
+template <bool INV> TSD_HD cpx caddrot(cpx a, cpx t) { return cadd(a, rot90<INV>(t)); }
+template <bool INV> TSD_HD cpx csubrot(cpx a, cpx t) { return csub(a, rot90<INV>(t)); }
+template <typename C> struct Make;
+template <> struct Make<cpx> { static TSD_HD cpx of(float a, float b) { return mk(a, b); } };
+
+#if defined(__HIPCC__)
+// Packed flavour: a complex number is a 64-bit VGPR pair and every primitive is ONE or TWO
+// VOP3P instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: two fp32 lanes per issue
+// slot -- the only way to the full fp32 VALU rate of gfx950).  The swaps and sign flips of
+// complex arithmetic ride on the op_sel / neg modifiers (op_sel[i]: half of source i read by
+// the LOW result lane, op_sel_hi[i]: by the HIGH lane), which hipcc does not form by itself
+// (it builds (-w.y, w.y) with two extra moves), hence the inline assembly.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f cadd(v2f a, v2f b) { return a + b; }
+__device__ __forceinline__ v2f csub(v2f a, v2f b) { return a - b; }
+__device__ __forceinline__ v2f cmul(v2f a, v2f w)
+{
+  v2f t, r;   // t = (a.x w.x, a.y w.x);  r = (t.x - a.y w.y, t.y + a.x w.y)
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+  return r;
+}
+__device__ __forceinline__ v2f cmulc(v2f a, v2f w)   // a * conj(w)
+{
+  v2f t, r;   // r = (t.x + a.y w.y, t.y - a.x w.y)
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+  return r;
+}
+template <bool INV> __device__ __forceinline__ v2f caddrot(v2f a, v2f t)
+{
+  v2f r;      // forward: (a.x + t.y, a.y - t.x);  inverse: (a.x - t.y, a.y + t.x)
+  if (!INV) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(t));
+  else asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(t));
+  return r;
+}
+template <bool INV> __device__ __forceinline__ v2f csubrot(v2f a, v2f t) { return caddrot<!INV>(a, t); }
+template <bool INV> __device__ __forceinline__ v2f rot90(v2f a)
+{
+  v2f r;
+  const v2f z = {0.f, 0.f};
+  if (!INV) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(z), "v"(a));
+  else asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(z), "v"(a));
+  return r;
+}
+template <> struct Make<v2f> { static __device__ __forceinline__ v2f of(float a, float b) { return (v2f){a, b}; } };
+#endif
+
+template <bool INV, typename C> TSD_HD C ctw(C a, C w) { return INV ? cmulc(a, w) : cmul(a, w); }
 
 // 4-point DFT, natural order in and out. forward: W4 = -i.
-template <bool INV> TSD_HD void dft4(cpx &a, cpx &b, cpx &c, cpx &d)
+template <bool INV, typename C> TSD_HD void dft4(C &a, C &b, C &c, C &d)
 {
-  const cpx t0 = cadd(a, c), t1 = csub(a, c), t2 = cadd(b, d), t3 = rot90<INV>(csub(b, d));
+  const C t0 = cadd(a, c), t1 = csub(a, c), t2 = cadd(b, d), t3 = csub(b, d);
   a = cadd(t0, t2);
-  b = cadd(t1, t3);
+  b = caddrot<INV>(t1, t3);
   c = csub(t0, t2);
-  d = csub(t1, t3);
+  d = csubrot<INV>(t1, t3);
+}
+// the same with input c still owing a factor W4 (-i forward, +i inverse)
+template <bool INV, typename C> TSD_HD void dft4_crot(C &a, C &b, C &c, C &d)
+{
+  const C t0 = caddrot<INV>(a, c), t1 = csubrot<INV>(a, c), t2 = cadd(b, d), t3 = csub(b, d);
+  a = cadd(t0, t2);
+  b = caddrot<INV>(t1, t3);
+  c = csub(t0, t2);
+  d = csubrot<INV>(t1, t3);
 }
 
 // 16-point DFT in registers, natural order in and out.
-template <bool INV> TSD_HD void dft16(cpx (&v)[16])
+template <bool INV, typename C> TSD_HD void dft16(C (&v)[16])
 {
   constexpr float C1 = 0.92387953251128674f;   // cos(pi/8)
   constexpr float S1 = 0.38268343236508977f;   // sin(pi/8)
@@ -66,24 +124,26 @@ template <bool INV> TSD_HD void dft16(cpx (&v)[16])
 #pragma unroll
   for (int n2 = 0; n2 < 4; n2++) dft4<INV>(v[n2], v[4 + n2], v[8 + n2], v[12 + n2]);
   // twiddles W16^(n2*k1), forward value (conjugated by ctw<INV> for the inverse)
-  v[5] = ctw<INV>(v[5], mk(C1, -S1));      // k1=1,n2=1: W16^1
-  v[6] = ctw<INV>(v[6], mk(R2, -R2));      // k1=1,n2=2: W16^2
-  v[7] = ctw<INV>(v[7], mk(S1, -C1));      // k1=1,n2=3: W16^3
-  v[9] = ctw<INV>(v[9], mk(R2, -R2));      // k1=2,n2=1: W16^2
-  v[10] = rot90<INV>(v[10]);               // k1=2,n2=2: W16^4 = -i
-  v[11] = ctw<INV>(v[11], mk(-R2, -R2));   // k1=2,n2=3: W16^6
-  v[13] = ctw<INV>(v[13], mk(S1, -C1));    // k1=3,n2=1: W16^3
-  v[14] = ctw<INV>(v[14], mk(-R2, -R2));   // k1=3,n2=2: W16^6
-  v[15] = ctw<INV>(v[15], mk(-C1, S1));    // k1=3,n2=3: W16^9
+  v[5] = ctw<INV>(v[5], Make<C>::of(C1, -S1));      // k1=1,n2=1: W16^1
+  v[6] = ctw<INV>(v[6], Make<C>::of(R2, -R2));      // k1=1,n2=2: W16^2
+  v[7] = ctw<INV>(v[7], Make<C>::of(S1, -C1));      // k1=1,n2=3: W16^3
+  v[9] = ctw<INV>(v[9], Make<C>::of(R2, -R2));      // k1=2,n2=1: W16^2
+  //  v[10]: k1=2,n2=2: W16^4 = -i, applied inside dft4_crot below
+  v[11] = ctw<INV>(v[11], Make<C>::of(-R2, -R2));   // k1=2,n2=3: W16^6
+  v[13] = ctw<INV>(v[13], Make<C>::of(S1, -C1));    // k1=3,n2=1: W16^3
+  v[14] = ctw<INV>(v[14], Make<C>::of(-R2, -R2));   // k1=3,n2=2: W16^6
+  v[15] = ctw<INV>(v[15], Make<C>::of(-C1, S1));    // k1=3,n2=3: W16^9
   // stage 2: over n2 for each k1: v[4*k1 + k2] <- X[k1 + 4*k2]
-#pragma unroll
-  for (int k1 = 0; k1 < 4; k1++) dft4<INV>(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
+  dft4<INV>(v[0], v[1], v[2], v[3]);
+  dft4<INV>(v[4], v[5], v[6], v[7]);
+  dft4_crot<INV>(v[8], v[9], v[10], v[11]);
+  dft4<INV>(v[12], v[13], v[14], v[15]);
   // transpose to natural order: out[k1 + 4*k2] = v[4*k1 + k2]
 #pragma unroll
   for (int a = 0; a < 4; a++)
 #pragma unroll
     for (int b = a + 1; b < 4; b++) {
-      const cpx t = v[4 * a + b];
+      const C t = v[4 * a + b];
       v[4 * a + b] = v[4 * b + a];
       v[4 * b + a] = t;
     }
@@ -117,7 +177,7 @@ TSD_HD int time_index(int lane, int reg) { return 64 * reg + lane; }
 
 // ---- the phases.  SYNC() must order LDS writes before the following LDS reads of the
 // same wave (a __syncthreads() in a 64-lane workgroup; a no-op per-phase loop on the CPU).
-template <bool INV, typename TW> TSD_HD void stageA(cpx (&v)[16], const TW &tw1)
+template <bool INV, typename C, typename TW> TSD_HD void stageA(C (&v)[16], const TW &tw1)
 {
   if (!INV) {
     dft16<false>(v);
@@ -129,7 +189,7 @@ template <bool INV, typename TW> TSD_HD void stageA(cpx (&v)[16], const TW &tw1)
     dft16<true>(v);
   }
 }
-template <bool INV, typename TW> TSD_HD void stageB(cpx (&v)[16], const TW &tw2)
+template <bool INV, typename C, typename TW> TSD_HD void stageB(C (&v)[16], const TW &tw2)
 {
   if (!INV) {
     dft16<false>(v);
@@ -141,49 +201,49 @@ template <bool INV, typename TW> TSD_HD void stageB(cpx (&v)[16], const TW &tw2)
     dft16<true>(v);
   }
 }
-template <bool INV> TSD_HD void stageC(cpx (&v)[16])
+template <bool INV, typename C> TSD_HD void stageC(C (&v)[16])
 {
 #pragma unroll
   for (int h = 0; h < 4; h++) dft4<INV>(v[4 * h], v[4 * h + 1], v[4 * h + 2], v[4 * h + 3]);
 }
 
 // exchange 1, forward direction: lane n2 / reg k1  ->  lane (k1,m2) / reg m1
-template <int S = 1> TSD_HD void x1_write_rows(const cpx (&v)[16], cpx *lds, int lane)
+template <int S = 1, typename C> TSD_HD void x1_write_rows(const C (&v)[16], C *lds, int lane)
 {
 #pragma unroll
   for (int r = 0; r < 16; r++) lds[(LDS_ROW * r + lane) * S] = v[r];
 }
-template <int S = 1> TSD_HD void x1_read_rows(cpx (&v)[16], const cpx *lds, int lane)
+template <int S = 1, typename C> TSD_HD void x1_read_rows(C (&v)[16], const C *lds, int lane)
 {
 #pragma unroll
   for (int r = 0; r < 16; r++) v[r] = lds[(LDS_ROW * r + lane) * S];
 }
-template <int S = 1> TSD_HD void x1_write_cols(const cpx (&v)[16], cpx *lds, int lane)
+template <int S = 1, typename C> TSD_HD void x1_write_cols(const C (&v)[16], C *lds, int lane)
 {
   const int base = LDS_ROW * (lane >> 2) + (lane & 3);
 #pragma unroll
   for (int m1 = 0; m1 < 16; m1++) lds[(base + 4 * m1) * S] = v[m1];
 }
-template <int S = 1> TSD_HD void x1_read_cols(cpx (&v)[16], const cpx *lds, int lane)
+template <int S = 1, typename C> TSD_HD void x1_read_cols(C (&v)[16], const C *lds, int lane)
 {
   const int base = LDS_ROW * (lane >> 2) + (lane & 3);
 #pragma unroll
   for (int m1 = 0; m1 < 16; m1++) v[m1] = lds[(base + 4 * m1) * S];
 }
 // exchange 2: image [k1][m2][j1] with plane stride 17
-template <int S = 1> TSD_HD void x2_write_j1(const cpx (&v)[16], cpx *lds, int lane)     // lane (k1,m2), reg j1
+template <int S = 1, typename C> TSD_HD void x2_write_j1(const C (&v)[16], C *lds, int lane)     // lane (k1,m2), reg j1
 {
   const int base = LDS_ROW * (lane >> 2) + 17 * (lane & 3);
 #pragma unroll
   for (int j1 = 0; j1 < 16; j1++) lds[(base + j1) * S] = v[j1];
 }
-template <int S = 1> TSD_HD void x2_read_j1(cpx (&v)[16], const cpx *lds, int lane)
+template <int S = 1, typename C> TSD_HD void x2_read_j1(C (&v)[16], const C *lds, int lane)
 {
   const int base = LDS_ROW * (lane >> 2) + 17 * (lane & 3);
 #pragma unroll
   for (int j1 = 0; j1 < 16; j1++) v[j1] = lds[(base + j1) * S];
 }
-template <int S = 1> TSD_HD void x2_write_m2(const cpx (&v)[16], cpx *lds, int lane)     // lane (k1,j1lo), reg (j1hi,m2)
+template <int S = 1, typename C> TSD_HD void x2_write_m2(const C (&v)[16], C *lds, int lane)     // lane (k1,j1lo), reg (j1hi,m2)
 {
   const int base = LDS_ROW * (lane >> 2) + (lane & 3);
 #pragma unroll
@@ -191,7 +251,7 @@ template <int S = 1> TSD_HD void x2_write_m2(const cpx (&v)[16], cpx *lds, int l
 #pragma unroll
     for (int m2 = 0; m2 < 4; m2++) lds[(base + 17 * m2 + 4 * h) * S] = v[4 * h + m2];
 }
-template <int S = 1> TSD_HD void x2_read_m2(cpx (&v)[16], const cpx *lds, int lane)
+template <int S = 1, typename C> TSD_HD void x2_read_m2(C (&v)[16], const C *lds, int lane)
 {
   const int base = LDS_ROW * (lane >> 2) + (lane & 3);
 #pragma unroll
@@ -206,8 +266,8 @@ template <int S = 1> TSD_HD void x2_read_m2(cpx (&v)[16], const cpx *lds, int la
 // as 9 interleaves the images of several waves -- multiplying slot numbers by an odd constant
 // permutes the banks, so the conflict-free property of the maps above is preserved).
 // TW1/TW2: anything indexable with [r], r = 1..15 (register arrays, or an accessor over LDS).
-template <int S = 1, typename TW1, typename TW2, typename SYNC>
-TSD_HD void forward(cpx (&v)[16], cpx *lds, int lane, const TW1 &tw1, const TW2 &tw2, SYNC sync)
+template <int S = 1, typename C, typename TW1, typename TW2, typename SYNC>
+TSD_HD void forward(C (&v)[16], C *lds, int lane, const TW1 &tw1, const TW2 &tw2, SYNC sync)
 {
   stageA<false>(v, tw1);
   x1_write_rows<S>(v, lds, lane);
@@ -220,8 +280,8 @@ TSD_HD void forward(cpx (&v)[16], cpx *lds, int lane, const TW1 &tw1, const TW2 
   x2_read_m2<S>(v, lds, lane);
   stageC<false>(v);
 }
-template <int S = 1, typename TW1, typename TW2, typename SYNC>
-TSD_HD void inverse(cpx (&v)[16], cpx *lds, int lane, const TW1 &tw1, const TW2 &tw2, SYNC sync)
+template <int S = 1, typename C, typename TW1, typename TW2, typename SYNC>
+TSD_HD void inverse(C (&v)[16], C *lds, int lane, const TW1 &tw1, const TW2 &tw2, SYNC sync)
 {
   stageC<true>(v);
   sync();

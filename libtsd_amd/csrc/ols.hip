@@ -21,6 +21,19 @@ namespace tsdgpu {
 
 using namespace w1024;
 constexpr int OLS_N = 1024;
+// complex values of the kernel: packed VGPR pairs (fft1024_wave.hpp), -DOLS_SCALAR=1 = the float2 flavour
+#ifndef OLS_SCALAR
+#define OLS_SCALAR 0
+#endif
+#ifndef OLS_WIDE   // experiment: 16-B global accesses (layout NOT the FFT's: ablation only)
+#define OLS_WIDE 0
+#endif
+#if OLS_SCALAR
+using cv = cpx;
+#else
+using cv = v2f;
+#endif
+__device__ __forceinline__ cv mkv(float a, float b) { return Make<cv>::of(a, b); }
 
 // EDGE = false: block fully inside [0, n) on both the input and the output side -- no guards,
 // straight-line code (lets hipcc use counted vmcnt waits so the prefetch and the previous
@@ -29,15 +42,13 @@ constexpr int OLS_N = 1024;
 #define OLS_NT 0
 #endif
 constexpr bool NT = OLS_NT != 0;
-__device__ __forceinline__ cpx ntload(const cpx *p)
+__device__ __forceinline__ cv ntload(const cv *p)
 {
-  typedef float v2f __attribute__((ext_vector_type(2)));
   v2f t = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(p));
-  return mk(t.x, t.y);
+  return mkv(t.x, t.y);
 }
-__device__ __forceinline__ void ntstore(cpx *p, cpx v)
+__device__ __forceinline__ void ntstore(cv *p, cv v)
 {
-  typedef float v2f __attribute__((ext_vector_type(2)));
   v2f t = {v.x, v.y};
   __builtin_nontemporal_store(t, reinterpret_cast<v2f *>(p));
 }
@@ -45,36 +56,44 @@ __device__ __forceinline__ void ntstore(cpx *p, cpx v)
 // complex block (the taps being real, conv(h, a + j b) = conv(h, a) + j conv(h, b)), so block
 // index b then addresses the pair of real blocks (2b, 2b+1).
 template <bool EDGE>
-__device__ __forceinline__ void ols_fetch_real(cpx (&v)[16], const float *__restrict__ x, const float *__restrict__ hist,
+__device__ __forceinline__ void ols_fetch_real(cv (&v)[16], const float *__restrict__ x, const float *__restrict__ hist,
                                                int histlen, int Km1, int L, int64_t n, int64_t b, int lane)
 {
   const int64_t ga = 2 * b * (int64_t) L - Km1, gb = ga + L;
   if (!EDGE) {
     const float *xa = x + ga, *xb = x + gb;
 #pragma unroll
-    for (int r = 0; r < 16; r++) v[r] = mk(xa[64 * r + lane], xb[64 * r + lane]);
+    for (int r = 0; r < 16; r++) v[r] = mkv(xa[64 * r + lane], xb[64 * r + lane]);
   } else {
 #pragma unroll
     for (int r = 0; r < 16; r++) {
       const int64_t g1 = ga + 64 * r + lane, g2 = gb + 64 * r + lane;
-      v[r] = mk(g1 < 0 ? hist[histlen + g1] : (g1 < n ? x[g1] : 0.f), g2 < 0 ? hist[histlen + g2] : (g2 < n ? x[g2] : 0.f));
+      v[r] = mkv(g1 < 0 ? hist[histlen + g1] : (g1 < n ? x[g1] : 0.f), g2 < 0 ? hist[histlen + g2] : (g2 < n ? x[g2] : 0.f));
     }
   }
 }
 template <bool EDGE>
-__device__ __forceinline__ void ols_fetch(cpx (&v)[16], const cpx *__restrict__ x, const cpx *__restrict__ hist,
+__device__ __forceinline__ void ols_fetch(cv (&v)[16], const cv *__restrict__ x, const cv *__restrict__ hist,
                                           int histlen, int Km1, int L, int64_t n, int64_t b, int lane)
 {
   const int64_t g0 = b * (int64_t) L - Km1;   // first input of block b
   if (!EDGE) {
-    const cpx *xb = x + g0;
+    const cv *xb = x + g0;
+#if OLS_WIDE
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      const float4 q = *reinterpret_cast<const float4 *>(xb + 128 * r + 2 * lane);
+      v[2 * r] = mkv(q.x, q.y); v[2 * r + 1] = mkv(q.z, q.w);
+    }
+#else
 #pragma unroll
     for (int r = 0; r < 16; r++) v[r] = NT ? ntload(xb + 64 * r + lane) : xb[64 * r + lane];
+#endif
   } else {
 #pragma unroll
     for (int r = 0; r < 16; r++) {
       const int64_t g = g0 + 64 * r + lane;
-      v[r] = g < 0 ? hist[histlen + g] : (g < n ? x[g] : mk(0.f, 0.f));
+      v[r] = g < 0 ? hist[histlen + g] : (g < n ? x[g] : mkv(0.f, 0.f));
     }
   }
 }
@@ -86,18 +105,18 @@ __device__ __forceinline__ void ols_fetch(cpx (&v)[16], const cpx *__restrict__ 
 // Blocks [b_lo, b_hi) are processed with block b = b_lo + slot + i*G.  The EDGE variant is
 // launched with G = 1 per edge block.
 template <bool EDGE, bool REAL>
-__device__ __forceinline__ void ols_body(cpx *lds, const void *__restrict__ xv, const void *__restrict__ histv,
-                                         void *__restrict__ yv, const cpx *__restrict__ Hreg,
-                                         const cpx *__restrict__ TW1, const cpx *__restrict__ TW2, int Km1,
+__device__ __forceinline__ void ols_body(cv *lds, const void *__restrict__ xv, const void *__restrict__ histv,
+                                         void *__restrict__ yv, const cv *__restrict__ Hreg,
+                                         const cv *__restrict__ TW1, const cv *__restrict__ TW2, int Km1,
                                          int histlen, int L, int64_t n, int64_t b_lo, int64_t b_hi, int64_t G,
                                          int64_t w)
 {
   const int lane = threadIdx.x;
-  const cpx *x = (const cpx *) xv, *hist = (const cpx *) histv;
-  cpx *y = (cpx *) yv;
+  const cv *x = (const cv *) xv, *hist = (const cv *) histv;
+  cv *y = (cv *) yv;
   const float *xr = (const float *) xv, *histr = (const float *) histv;
   float *yr = (float *) yv;
-  cpx tw1[16], tw2[16], H[16];
+  cv tw1[16], tw2[16], H[16];
 #pragma unroll
   for (int r = 0; r < 16; r++) {
     tw1[r] = TW1[r * 64 + lane];
@@ -127,26 +146,38 @@ __device__ __forceinline__ void ols_body(cpx *lds, const void *__restrict__ xv, 
   // predicated stores): the wait for the prefetch is forced BEFORE this block's stores are
   // issued -- the loads are a whole block old by then, so it costs nothing -- and afterwards
   // nothing waits on the stores: they drain while the next block is being transformed.
-  auto process = [&](cpx (&cur)[16], cpx (&nxt)[16], int64_t blk) {
+  auto process = [&](cv (&cur)[16], cv (&nxt)[16], int64_t blk) {
     const bool more = !EDGE && blk + G < b_hi;
     if (more) {
       if (REAL) ols_fetch_real<EDGE>(nxt, xr, histr, histlen, Km1, L, n, blk + G, lane);
       else ols_fetch<EDGE>(nxt, x, hist, histlen, Km1, L, n, blk + G, lane);
     }
-    forward(cur, lds, lane, tw1, tw2, sync);
+#ifndef OLS_ABLATE   // measurement only: bit 0 drops the forward FFT, bit 1 the product, bit 2 the inverse
+#define OLS_ABLATE 0
+#endif
+    if (!(OLS_ABLATE & 1)) forward(cur, lds, lane, tw1, tw2, sync);
+    if (!(OLS_ABLATE & 2)) {
 #pragma unroll
-    for (int r = 0; r < 16; r++) cur[r] = cmul(cur[r], H[r]);
-    inverse(cur, lds, lane, tw1, tw2, sync);
+      for (int r = 0; r < 16; r++) cur[r] = cmul(cur[r], H[r]);
+    }
+    if (!(OLS_ABLATE & 4)) inverse(cur, lds, lane, tw1, tw2, sync);
     sync();   // LDS is reused by the next block
     if (more) {
 #pragma unroll
-      for (int r = 0; r < 16; r++) asm volatile("" ::"v"(nxt[r].x), "v"(nxt[r].y));
+      for (int r = 0; r < 16; r++) asm volatile("" ::"v"(nxt[r]));
     }
     // sample t = 64*r + lane of the circular convolution is output o0 + t - (K-1)
     const int r0 = Km1 >> 6;   // Km1 is a multiple of 64: rows below r0 are overlap, the rest whole
     if (!REAL) {
       const int64_t o0 = blk * (int64_t) L;
-      cpx *yb = y + (o0 - Km1);
+      cv *yb = y + (o0 - Km1);
+#if OLS_WIDE
+      if (!EDGE) {
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+          if (2 * r >= r0) *reinterpret_cast<float4 *>(yb + 128 * r + 2 * lane) = make_float4(cur[2 * r].x, cur[2 * r].y, cur[2 * r + 1].x, cur[2 * r + 1].y);
+      } else
+#endif
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int t = 64 * r + lane;
@@ -172,7 +203,7 @@ __device__ __forceinline__ void ols_body(cpx *lds, const void *__restrict__ xv, 
     }
   };
 
-  cpx A[16], B[16];
+  cv A[16], B[16];
   if (REAL) ols_fetch_real<EDGE>(A, xr, histr, histlen, Km1, L, n, b, lane);
   else ols_fetch<EDGE>(A, x, hist, histlen, Km1, L, n, b, lane);
   if (EDGE) {
@@ -201,14 +232,14 @@ __global__ __launch_bounds__(64, 2) void ols_kernel(const void *__restrict__ x, 
                                                     int64_t n, int64_t b_lo, int64_t b_hi, int64_t nblocks, int G,
                                                     int ne, int64_t n_lo, int64_t b_tail)
 {
-  __shared__ cpx lds[LDS_ELEMS];
+  __shared__ cv lds[LDS_ELEMS];
   const int w = blockIdx.x;
   if (w < G) {
-    ols_body<false, REAL>(lds, x, hist, y, Hreg, TW1, TW2, Km1, histlen, L, n, b_lo, b_hi, G, w);
+    ols_body<false, REAL>(lds, x, hist, y, (const cv *) Hreg, (const cv *) TW1, (const cv *) TW2, Km1, histlen, L, n, b_lo, b_hi, G, w);
   } else if (w < G + ne) {
     // edge items: [0, n_lo) need the history halo, [b_tail, nblocks) are ragged at the end
     const int64_t b = (w - G) < n_lo ? (int64_t) (w - G) : b_tail + (w - G - n_lo);
-    ols_body<true, REAL>(lds, x, hist, y, Hreg, TW1, TW2, Km1, histlen, L, n, b, nblocks, 1, 0);
+    ols_body<true, REAL>(lds, x, hist, y, (const cv *) Hreg, (const cv *) TW1, (const cv *) TW2, Km1, histlen, L, n, b, nblocks, 1, 0);
   } else {
     for (int i = threadIdx.x; i < histlen; i += 64) {
       const int64_t g = n - histlen + i;
@@ -320,14 +351,13 @@ int ols_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, hipStream_t st)
   const int ne = (int) (n_lo + (nblocks - b_tail));
   int64_t e[2] = {n_lo, b_tail};
   const int nxt = f->cur ^ 1;
-  if (real)
-    hipLaunchKernelGGL(ols_kernel<true>, dim3((unsigned) (grid + ne + 1)), dim3(64), 0, st, x, (const void *) f->hist[f->cur],
-                       f->hist[nxt], y, d, d + OLS_N, d + 2 * OLS_N, OLS_N - L, f->HL, L, n, b_lo, b_hi, nblocks,
-                       (int) grid, ne, e[0], e[1]);
-  else
-    hipLaunchKernelGGL(ols_kernel<false>, dim3((unsigned) (grid + ne + 1)), dim3(64), 0, st, x, (const void *) f->hist[f->cur],
-                       f->hist[nxt], y, d, d + OLS_N, d + 2 * OLS_N, OLS_N - L, f->HL, L, n, b_lo, b_hi, nblocks,
-                       (int) grid, ne, e[0], e[1]);
+#define OLS_LAUNCH(REAL)                                                                                                       \
+  hipLaunchKernelGGL((ols_kernel<REAL>), dim3((unsigned) (grid + ne + 1)), dim3(64), 0, st, x, (const void *) f->hist[f->cur], \
+                     f->hist[nxt], y, d, d + OLS_N, d + 2 * OLS_N, OLS_N - L, f->HL, L, n, b_lo, b_hi, nblocks, (int) grid, ne,   \
+                     e[0], e[1])
+  if (real) OLS_LAUNCH(true);
+  else OLS_LAUNCH(false);
+#undef OLS_LAUNCH
   TSD_HIP(hipGetLastError());
   f->cur = nxt;      // the history update is part of the launch
   return TSDGPU_OK;

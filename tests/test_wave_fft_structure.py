@@ -1,0 +1,17 @@
+"""CPU structural test of the in-wave 1024-point FFT (libtsd_amd/csrc/fft1024_wave.hpp): the
+header's scalar flavour is plain C++, so g++ emulates the 64 lanes phase by phase and checks
+forward() against a double-precision DFT and inverse(forward(x)) == N x
+(tests/cpu/test_fft1024_wave.cc).  The packed (VOP3P) flavour is covered on the GPU by the
+overlap-save parity tests."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_wave_fft_header_on_cpu(tmp_path):
+    exe = str(tmp_path / "t_w1024")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "cpu", "test_fft1024_wave.cc")],
+                   check=True, capture_output=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
