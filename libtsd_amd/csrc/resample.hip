@@ -384,8 +384,14 @@ __global__ __launch_bounds__(64 * RS15_WAVES) void resample15_kernel(const T *__
             hh[4 * k4] = q4.x; hh[4 * k4 + 1] = q4.y; hh[4 * k4 + 2] = q4.z; hh[4 * k4 + 3] = q4.w;
           }
           T acc = zero_of(T{});
+#ifndef RS15_ABLATE   // measurement only: 1 = no taps, no MACs (the replay, the loads and the stores remain)
+#define RS15_ABLATE 0
+#endif
+          if (RS15_ABLATE & 1) acc = W[s + 7];
+          else {
 #pragma unroll
-          for (int k = 0; k < 15; k++) acc = tap_mac(acc, hh[k], W[s + k]);     // filtrage.hpp:1877-1879 order
+            for (int k = 0; k < 15; k++) acc = tap_mac(acc, hh[k], W[s + k]);     // filtrage.hpp:1877-1879 order
+          }
           obuf[o] = acc;
           last = o + 1;
         }
