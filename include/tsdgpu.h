@@ -93,6 +93,39 @@ int tsdgpu_rfft_create(tsdgpu_rfft **out, int n);
 int tsdgpu_rfft_step(tsdgpu_rfft *p, const void *x /* float[batch][n] */, void *y /* cfloat[batch][n] */, int batch,
                      void *stream);
 int tsdgpu_rfft_destroy(tsdgpu_rfft *p);
+/* --------------------------------------------------------------------------------------
+ * OLA frequency-domain engine: OLA<cfloat>::step / step_interne behind filtre_fft()
+ * (src/fourier/fourier.cc:737-940; include/tsd/fourier.hpp:305-370).  Blocks of Ne input
+ * samples, N = nextpow2(Ne + min_zeros), frames = [Nz zeros | block]; per frame FFT ->
+ * spectral processing -> inverse FFT -> overlap-add of the first Nz output samples onto the
+ * previous tail.  window = NULL: simple OLA (one frame per block, Ne outputs per block);
+ * window = Ne floats (the reference uses fenêtre("hn", Ne, false)): two half-overlapping
+ * windowed frames per block, averaged; the very first block then yields no output
+ * (cnt_ech < 0, fourier.cc:895-898).  Any call length: whole blocks are processed, the rest
+ * waits in the handle (tampon_création semantics, fourier.cc:806-812).
+ * The reference's user callback traitement_freq(X) has two device-side forms here:
+ *  - built-in product X *= H (tsdgpu_ola_set_response) inside tsdgpu_ola_step -- nothing
+ *    leaves the device (this is FiltreFFTRIF's own callback, fourier.cc:958);
+ *  - tsdgpu_ola_analyse leaves the spectra of the new frames in a device buffer owned by the
+ *    handle ([frames][N] complex); the caller edits them in place (own kernel, or copy out /
+ *    copy back around a host callback) and tsdgpu_ola_synthese completes the step.
+ * ------------------------------------------------------------------------------------ */
+typedef struct tsdgpu_ola tsdgpu_ola;
+int tsdgpu_ola_create(tsdgpu_ola **out, int block_len /* Ne; <= 0 -> 512 */, int min_zeros, const float *window);
+int tsdgpu_ola_fft_size(const tsdgpu_ola *h);      /* N */
+int tsdgpu_ola_block_len(const tsdgpu_ola *h);     /* Ne */
+int tsdgpu_ola_set_response(tsdgpu_ola *h, const void *H /* N complex, host or device; NULL: none */);
+int64_t tsdgpu_ola_max_out(const tsdgpu_ola *h, int64_t n);   /* bound on the outputs of a step of n inputs */
+int tsdgpu_ola_step(tsdgpu_ola *h, const void *x, int64_t n, void *y, int64_t *n_out, void *stream);
+int tsdgpu_ola_analyse(tsdgpu_ola *h, const void *x, int64_t n, void **spectra, int *frames, void *stream);
+int tsdgpu_ola_synthese(tsdgpu_ola *h, void *y, int64_t *n_out, void *stream);
+/* host-callback bridge: copy the pending spectra out of / back into the handle's device buffer
+ * ([frames][N] complex, frames as returned by tsdgpu_ola_analyse); synchronous */
+int tsdgpu_ola_apply_response(tsdgpu_ola *h, void *stream);   /* pending spectra *= H (no-op without a response) */
+int tsdgpu_ola_read_spectra(tsdgpu_ola *h, void *host_dst, void *stream);
+int tsdgpu_ola_write_spectra(tsdgpu_ola *h, const void *host_src, void *stream);
+int tsdgpu_ola_destroy(tsdgpu_ola *h);
+
 /* fftshift (include/tsd/fourier.hpp:232-248): pure index permutation, bit-exact */
 int tsdgpu_fftshift(const void *x, void *y, int n, int data_type, void *stream);
 

@@ -85,6 +85,19 @@ def _declare(L):
     L.tsdgpu_rfft_step.argtypes = [vp, vp, vp, i32, vp]
     L.tsdgpu_rfft_destroy.argtypes = [vp]
     L.tsdgpu_fftshift.argtypes = [vp, vp, i32, i32, vp]
+    L.tsdgpu_ola_create.argtypes = [C.POINTER(vp), i32, i32, vp]
+    L.tsdgpu_ola_fft_size.argtypes = [vp]
+    L.tsdgpu_ola_block_len.argtypes = [vp]
+    L.tsdgpu_ola_set_response.argtypes = [vp, vp]
+    L.tsdgpu_ola_max_out.argtypes = [vp, C.c_int64]
+    L.tsdgpu_ola_max_out.restype = C.c_int64
+    L.tsdgpu_ola_step.argtypes = [vp, vp, C.c_int64, vp, C.POINTER(C.c_int64), vp]
+    L.tsdgpu_ola_analyse.argtypes = [vp, vp, C.c_int64, C.POINTER(vp), C.POINTER(i32), vp]
+    L.tsdgpu_ola_synthese.argtypes = [vp, vp, C.POINTER(C.c_int64), vp]
+    L.tsdgpu_ola_apply_response.argtypes = [vp, vp]
+    L.tsdgpu_ola_read_spectra.argtypes = [vp, vp, vp]
+    L.tsdgpu_ola_write_spectra.argtypes = [vp, vp, vp]
+    L.tsdgpu_ola_destroy.argtypes = [vp]
 
 
 def device_count():
@@ -223,6 +236,70 @@ class Rfft:
     def close(self):
         if self._h:
             lib().tsdgpu_rfft_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Ola:
+    """OLA<cfloat> engine behind filtre_fft() (fourier.cc:737-940).  step(x) uses the built-in
+    product with `response` (set_response); analyse()/synthese() bracket a caller-side edit of
+    the spectra, which stay on the device (a torch view when the input is a device tensor)."""
+
+    def __init__(self, block_len=0, min_zeros=0, window=None):
+        self._h = C.c_void_p()
+        w = None if window is None else np.ascontiguousarray(window, np.float32)
+        _check(lib().tsdgpu_ola_create(C.byref(self._h), int(block_len), int(min_zeros), None if w is None else w.ctypes.data))
+        self.N = lib().tsdgpu_ola_fft_size(self._h)
+        self.Ne = lib().tsdgpu_ola_block_len(self._h)
+
+    def set_response(self, H):
+        if H is None:
+            _check(lib().tsdgpu_ola_set_response(self._h, None))
+            return
+        if isinstance(H, np.ndarray):
+            H = np.ascontiguousarray(H, np.complex64)
+        assert int(np.prod(H.shape)) == self.N
+        _check(lib().tsdgpu_ola_set_response(self._h, _ptr(H)))
+
+    def _out(self, x, n):
+        return np.empty(n, np.complex64) if isinstance(x, np.ndarray) else x.new_empty(n)
+
+    def step(self, x, stream=None):
+        assert _dtype_code(x) == C64
+        n = int(x.shape[0])
+        y = self._out(x, max(1, lib().tsdgpu_ola_max_out(self._h, n)))
+        nout = C.c_int64(0)
+        _check(lib().tsdgpu_ola_step(self._h, _ptr(x) if n else None, n, _ptr(y), C.byref(nout), _stream_of(x, stream)))
+        return y[:nout.value]
+
+    def analyse(self, x, stream=None):
+        """-> (device address of the spectra [frames][N] complex64, frames)."""
+        assert _dtype_code(x) == C64
+        sp, nf = C.c_void_p(), C.c_int(0)
+        n = int(x.shape[0])
+        self._last = x
+        _check(lib().tsdgpu_ola_analyse(self._h, _ptr(x) if n else None, n, C.byref(sp), C.byref(nf), _stream_of(x, stream)))
+        return sp.value, nf.value
+
+    def synthese(self, stream=None):
+        x = self._last
+        # the pending block count is not visible here: size the output for the worst case
+        y = self._out(x, max(1, self._pending_out(x)))
+        nout = C.c_int64(0)
+        _check(lib().tsdgpu_ola_synthese(self._h, _ptr(y), C.byref(nout), _stream_of(x, stream)))
+        return y[:nout.value]
+
+    def _pending_out(self, x):
+        return (int(x.shape[0]) // self.Ne + 1) * self.Ne
+
+    def close(self):
+        if self._h:
+            lib().tsdgpu_ola_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

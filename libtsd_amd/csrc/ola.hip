@@ -1,0 +1,372 @@
+// ola.hip -- the OLA frequency-domain engine behind filtre_fft() (libtsd
+// core/src/fourier/fourier.cc:737-940): framing, batched FFTs, spectral processing and
+// overlap-add all on the device.  The reference handles one block at a time (two FFTs of N
+// per block, full-vector copies in between); here all the whole blocks of a call are framed by
+// one kernel, transformed by ONE batched FFT each way, and overlap-added by one kernel.
+#include "common.hpp"
+#include <algorithm>
+
+namespace tsdgpu { using cpx = float2; }
+
+struct tsdgpu_ola {
+  int Ne = 0, N = 0, Nz = 0;
+  bool windowed = false;
+  tsdgpu_fft *plan = nullptr;
+  float *d_fen = nullptr;                  // Ne
+  tsdgpu::cpx *d_H = nullptr;              // N, or null
+  tsdgpu::cpx *d_svg = nullptr, *d_last = nullptr, *d_prev_half = nullptr, *d_rest = nullptr;   // Ne, Ne, Ne/2, Ne
+  int nrest = 0;
+  int64_t cnt_ech = 0;                     // fourier.cc:779: starts at -Ne/2
+  int pending_blocks = -1;                 // >= 0 between analyse and synthese
+  tsdgpu::DevBuf frames, spectra, in_stage, out_stage;
+};
+
+namespace tsdgpu {
+namespace {
+
+// sample p of [rest ++ x]
+__device__ __forceinline__ cpx ola_src(const cpx *rest, int nrest, const cpx *x, int64_t p)
+{
+  return p < nrest ? rest[p] : x[p - nrest];
+}
+
+// frames[f][i]: Nz zeros, then the block (fourier.cc:850) or, windowed, frame 2b = window *
+// [second half of the previous block, first half of this one] (:885-886) and frame 2b+1 =
+// window * block (:910)
+__global__ void ola_frame_kernel(const cpx *__restrict__ rest, int nrest, const cpx *__restrict__ x,
+                                 const cpx *__restrict__ prev_half, const float *__restrict__ fen, cpx *__restrict__ frames,
+                                 int Ne, int N, int Nz, int windowed, int64_t total)
+{
+  const int64_t idx = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int64_t f = idx / N;
+  const int i = (int) (idx - f * N), j = i - Nz;
+  cpx v = make_float2(0.f, 0.f);
+  if (j >= 0) {
+    if (!windowed) {
+      v = ola_src(rest, nrest, x, f * Ne + j);
+    } else {
+      const int64_t b = f >> 1;
+      const int h = Ne / 2;
+      if ((f & 1) == 0) {
+        if (j < h) v = b == 0 ? prev_half[j] : ola_src(rest, nrest, x, (b - 1) * Ne + h + j);
+        else v = ola_src(rest, nrest, x, b * Ne + (j - h));
+      } else {
+        v = ola_src(rest, nrest, x, b * Ne + j);
+      }
+      const float w = fen[j];
+      v.x *= w;
+      v.y *= w;
+    }
+  }
+  frames[idx] = v;
+}
+
+// dst[i] = sample (p0 + i) of [rest ++ x]   (new prev_half / new rest)
+__global__ void ola_gather_kernel(const cpx *__restrict__ rest, int nrest, const cpx *__restrict__ x, int64_t p0,
+                                  cpx *__restrict__ dst, int count)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) dst[i] = ola_src(rest, nrest, x, p0 + i);
+}
+
+__global__ void ola_mul_kernel(cpx *__restrict__ X, const cpx *__restrict__ H, int N, int64_t total)
+{
+  const int64_t idx = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const cpx a = X[idx], b = H[idx % N];
+  X[idx] = make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+// simple OLA (fourier.cc:868-872): out_b = svg with its last Nz samples += x2_b.head(Nz),
+// svg <- x2_b.tail(Ne); the svg of block b > 0 is the tail of frame b-1.
+__global__ void ola_add_kernel(const cpx *__restrict__ fr, const cpx *__restrict__ svg, cpx *__restrict__ out, int Ne, int N,
+                               int Nz, int64_t total)
+{
+  const int64_t idx = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int64_t b = idx / Ne;
+  const int i = (int) (idx - b * Ne);
+  cpx v = b == 0 ? svg[i] : fr[(b - 1) * N + Nz + i];
+  if (i >= Ne - Nz) {
+    const cpx a = fr[b * N + (i - (Ne - Nz))];
+    v.x += a.x;
+    v.y += a.y;
+  }
+  out[idx] = v;
+}
+
+// windowed OLA (fourier.cc:883-923).  The reference walks the blocks with two carried vectors,
+// svg and last; unrolled, block b only needs the frames of blocks b-2 .. b:
+//   S_b[i]    = xb_b[Nz+i]                                   svg after the block        (:919)
+//   svgA_b[i] = S_{b-1}[i] + T(xa_b)[i]                      svg after the first add    (:892)
+//   L_b[i]    = (i < h ? svgA_b[h+i]/2 : 0) + (xa_b[Nz+i] + T(xb_b)[i])/2   last after the block (:901-918)
+//   out_b[i]  = L_{b-1}[i] + (i >= h ? svgA_b[i-h]/2 : 0)                                (:895-896)
+// with T(v)[i] = v[i-(Ne-Nz)] for i >= Ne-Nz, else 0; S_{-1}, L_{-1} = the handle's state.
+// The additions are made in the reference's order.
+struct OlaW {
+  const cpx *fr, *svg0;
+  int Ne, N, Nz;
+  __device__ __forceinline__ cpx T(const cpx *v, int i) const { return i >= Ne - Nz ? v[i - (Ne - Nz)] : make_float2(0.f, 0.f); }
+  __device__ __forceinline__ cpx svgA(int64_t b, int i) const
+  {
+    const cpx s = b == 0 ? svg0[i] : fr[(size_t) (2 * b - 1) * N + Nz + i];
+    const cpx t = T(fr + (size_t) (2 * b) * N, i);
+    return make_float2(s.x + t.x, s.y + t.y);
+  }
+  __device__ __forceinline__ cpx L(int64_t b, int i) const
+  {
+    const int h = Ne / 2;
+    cpx l = make_float2(0.f, 0.f);
+    if (i < h) {
+      const cpx a = svgA(b, h + i);
+      l = make_float2(a.x / 2.0f, a.y / 2.0f);
+    }
+    const cpx xa = fr[(size_t) (2 * b) * N + Nz + i], t = T(fr + (size_t) (2 * b + 1) * N, i);
+    const cpx sb = make_float2(xa.x + t.x, xa.y + t.y);
+    return make_float2(l.x + sb.x / 2.0f, l.y + sb.y / 2.0f);
+  }
+};
+
+__global__ void ola_add_windowed_kernel(OlaW w, const cpx *__restrict__ last0, cpx *__restrict__ out, int skip_first,
+                                        int64_t total)
+{
+  const int64_t idx = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int64_t b = idx / w.Ne + skip_first;
+  const int i = (int) (idx % w.Ne), h = w.Ne / 2;
+  cpx v = b == 0 ? last0[i] : w.L(b - 1, i);
+  if (i >= h) {
+    const cpx a = w.svgA(b, i - h);
+    v.x += a.x / 2.0f;
+    v.y += a.y / 2.0f;
+  }
+  out[idx] = v;
+}
+
+// new state: last <- L_{B-1} (reads the OLD svg when B == 1), then svg <- S_{B-1} in a later launch
+__global__ void ola_state_windowed_kernel(OlaW w, cpx *__restrict__ last, int64_t B)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < w.Ne) last[i] = w.L(B - 1, i);
+}
+
+inline unsigned nblk(int64_t total) { return (unsigned) cdiv(total, 256); }
+
+int ola_alloc(cpx **p, size_t count)
+{
+  TSD_HIP(hipMalloc((void **) p, std::max<size_t>(count, 1) * sizeof(cpx)));
+  TSD_HIP(hipMemset(*p, 0, std::max<size_t>(count, 1) * sizeof(cpx)));
+  return TSDGPU_OK;
+}
+
+}  // namespace
+}  // namespace tsdgpu
+
+using namespace tsdgpu;
+
+extern "C" {
+
+int tsdgpu_ola_create(tsdgpu_ola **out, int block_len, int min_zeros, const float *window)
+{
+  TSD_CHECK(out != nullptr, "ola_create: out is NULL");
+  *out = nullptr;
+  TSD_CHECK(min_zeros >= 0, "ola_create: negative zero count");
+  const int Ne = block_len > 0 ? block_len : 512;                          // fourier.cc:770-771
+  int64_t N = 1;
+  while (N < (int64_t) Ne + min_zeros) N <<= 1;                              // prochaine_puissance_de_2 (:776)
+  TSD_CHECK(N <= (1 << 24), "ola_create: FFT size %lld too large", (long long) N);
+  const int Nz = (int) N - Ne;
+  // the overlap of a frame is carried in ONE block-sized buffer (svg.tail(Nz), :870)
+  TSD_CHECK(Nz <= Ne, "ola_create: Nz = %d zeros exceed the block size Ne = %d", Nz, Ne);
+  TSD_CHECK(window == nullptr || (Ne & 1) == 0, "ola_create: the windowed mode needs an even block size (Ne = %d)", Ne);
+  tsdgpu_ola *h = new tsdgpu_ola();
+  h->Ne = Ne;
+  h->N = (int) N;
+  h->Nz = Nz;
+  h->windowed = window != nullptr;
+  h->cnt_ech = -(Ne / 2);
+  int rc = tsdgpu_fft_create(&h->plan, h->N, 1);
+  if (!rc) rc = ola_alloc(&h->d_svg, Ne);
+  if (!rc) rc = ola_alloc(&h->d_last, Ne);
+  if (!rc) rc = ola_alloc(&h->d_prev_half, Ne / 2);
+  if (!rc) rc = ola_alloc(&h->d_rest, Ne);
+  if (!rc && window) {
+    if (hipMalloc((void **) &h->d_fen, Ne * sizeof(float)) != hipSuccess ||
+        hipMemcpy(h->d_fen, window, Ne * sizeof(float), hipMemcpyDefault) != hipSuccess)
+      rc = set_err(TSDGPU_ERR_HIP, "ola_create: window upload failed: %s", hipGetErrorString(hipGetLastError()));
+  }
+  if (rc) {
+    tsdgpu_ola_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return TSDGPU_OK;
+}
+
+int tsdgpu_ola_fft_size(const tsdgpu_ola *h) { return h ? h->N : -1; }
+int tsdgpu_ola_block_len(const tsdgpu_ola *h) { return h ? h->Ne : -1; }
+
+int tsdgpu_ola_set_response(tsdgpu_ola *h, const void *H)
+{
+  TSD_CHECK(h != nullptr, "ola_set_response: NULL handle");
+  if (!H) {
+    if (h->d_H) (void) hipFree(h->d_H);
+    h->d_H = nullptr;
+    return TSDGPU_OK;
+  }
+  if (!h->d_H) TSD_HIP(hipMalloc((void **) &h->d_H, (size_t) h->N * sizeof(cpx)));
+  TSD_HIP(hipMemcpy(h->d_H, H, (size_t) h->N * sizeof(cpx), hipMemcpyDefault));
+  return TSDGPU_OK;
+}
+
+int64_t tsdgpu_ola_max_out(const tsdgpu_ola *h, int64_t n)
+{
+  if (!h || n < 0) return -1;
+  return ((h->nrest + n) / h->Ne) * h->Ne;
+}
+
+int tsdgpu_ola_analyse(tsdgpu_ola *h, const void *x, int64_t n, void **spectra, int *frames, void *stream)
+{
+  TSD_CHECK(h != nullptr, "ola_analyse: NULL handle");
+  TSD_CHECK(n >= 0 && (n == 0 || x != nullptr), "ola_analyse: bad input");
+  TSD_CHECK(h->pending_blocks < 0, "ola_analyse: the previous analyse has not been completed by ola_synthese");
+  hipStream_t st = (hipStream_t) stream;
+  const int Ne = h->Ne, N = h->N, per = h->windowed ? 2 : 1;
+  const void *dxv = nullptr;
+  int rc = stage_in(x, (size_t) n * sizeof(cpx), h->in_stage, st, &dxv);
+  if (rc) return rc;
+  const cpx *dx = (const cpx *) dxv;
+  const int64_t tot = (int64_t) h->nrest + n, B = tot / Ne;
+  TSD_CHECK(B * per <= (1 << 24), "ola_analyse: %lld blocks in one call", (long long) B);
+  if (B > 0) {
+    const int64_t fe = B * per * N;
+    if ((rc = h->frames.reserve((size_t) fe * sizeof(cpx)))) return rc;
+    if ((rc = h->spectra.reserve((size_t) fe * sizeof(cpx)))) return rc;
+    hipLaunchKernelGGL(ola_frame_kernel, dim3(nblk(fe)), dim3(256), 0, st, h->d_rest, h->nrest, dx, h->d_prev_half, h->d_fen,
+                       h->frames.as<cpx>(), Ne, N, h->Nz, h->windowed ? 1 : 0, fe);
+    TSD_HIP(hipGetLastError());
+    if ((rc = tsdgpu_fft_step(h->plan, h->frames.p, h->spectra.p, (int) (B * per), 1, st))) return rc;
+    if (h->windowed) {
+      hipLaunchKernelGGL(ola_gather_kernel, dim3(nblk(Ne / 2)), dim3(256), 0, st, h->d_rest, h->nrest, dx,
+                         (B - 1) * Ne + Ne / 2, h->d_prev_half, Ne / 2);                                    // :926
+      TSD_HIP(hipGetLastError());
+    }
+  }
+  // the samples after the last whole block wait for the next call
+  const int left = (int) (tot - B * Ne);
+  if (B > 0) {
+    if (left > 0) {
+      hipLaunchKernelGGL(ola_gather_kernel, dim3(nblk(left)), dim3(256), 0, st, h->d_rest, 0, dx, B * Ne - h->nrest, h->d_rest,
+                         left);                                    // lies inside x (B >= 1): rest is only written
+      TSD_HIP(hipGetLastError());
+    }
+  } else if (n > 0) {
+    TSD_HIP(hipMemcpyAsync(h->d_rest + h->nrest, dx, (size_t) n * sizeof(cpx), hipMemcpyDeviceToDevice, st));
+  }
+  h->nrest = left;
+  h->pending_blocks = (int) B;
+  if (dxv != x) TSD_HIP(hipStreamSynchronize(st));   // the staging buffer is reused by the next call
+  if (spectra) *spectra = B > 0 ? h->spectra.p : nullptr;
+  if (frames) *frames = (int) (B * per);
+  return TSDGPU_OK;
+}
+
+int tsdgpu_ola_synthese(tsdgpu_ola *h, void *y, int64_t *n_out, void *stream)
+{
+  TSD_CHECK(h != nullptr, "ola_synthese: NULL handle");
+  TSD_CHECK(h->pending_blocks >= 0, "ola_synthese: nothing analysed");
+  hipStream_t st = (hipStream_t) stream;
+  const int Ne = h->Ne, N = h->N, per = h->windowed ? 2 : 1;
+  const int64_t B = h->pending_blocks;
+  h->pending_blocks = -1;
+  if (n_out) *n_out = 0;
+  if (B == 0) return TSDGPU_OK;
+  const bool skip_first = h->windowed && h->cnt_ech < 0;
+  const int64_t nout = (B - (skip_first ? 1 : 0)) * Ne;
+  TSD_CHECK(y != nullptr || nout == 0, "ola_synthese: NULL output");
+  int rc = tsdgpu_fft_step(h->plan, h->spectra.p, h->frames.p, (int) (B * per), 0, st);
+  if (rc) return rc;
+  void *dyv = nullptr;
+  bool staged = false;
+  if ((rc = stage_out(y, (size_t) nout * sizeof(cpx), h->out_stage, &dyv, &staged))) return rc;
+  const cpx *fr = h->frames.as<cpx>();
+  if (!h->windowed) {
+    hipLaunchKernelGGL(ola_add_kernel, dim3(nblk(nout)), dim3(256), 0, st, fr, h->d_svg, (cpx *) dyv, Ne, N, h->Nz, nout);
+    TSD_HIP(hipGetLastError());
+    TSD_HIP(hipMemcpyAsync(h->d_svg, fr + (size_t) (B - 1) * N + h->Nz, (size_t) Ne * sizeof(cpx), hipMemcpyDeviceToDevice, st));
+  } else {
+    const OlaW w{fr, h->d_svg, Ne, N, h->Nz};
+    if (nout > 0) {
+      hipLaunchKernelGGL(ola_add_windowed_kernel, dim3(nblk(nout)), dim3(256), 0, st, w, h->d_last, (cpx *) dyv, skip_first ? 1 : 0,
+                         nout);
+      TSD_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(ola_state_windowed_kernel, dim3(nblk(Ne)), dim3(256), 0, st, w, h->d_last, B);
+    TSD_HIP(hipGetLastError());
+    TSD_HIP(hipMemcpyAsync(h->d_svg, fr + (size_t) (2 * B - 1) * N + h->Nz, (size_t) Ne * sizeof(cpx), hipMemcpyDeviceToDevice, st));
+  }
+  h->cnt_ech += B * Ne;
+  if (n_out) *n_out = nout;
+  return finish_out(y, (size_t) nout * sizeof(cpx), dyv, staged, st);
+}
+
+int tsdgpu_ola_apply_response(tsdgpu_ola *h, void *stream)
+{
+  TSD_CHECK(h != nullptr && h->pending_blocks >= 0, "ola_apply_response: nothing analysed");
+  const int64_t tot = (int64_t) h->pending_blocks * (h->windowed ? 2 : 1) * h->N;
+  if (!h->d_H || tot == 0) return TSDGPU_OK;
+  hipLaunchKernelGGL(ola_mul_kernel, dim3(nblk(tot)), dim3(256), 0, (hipStream_t) stream, h->spectra.as<cpx>(), h->d_H, h->N, tot);
+  TSD_HIP(hipGetLastError());
+  return TSDGPU_OK;
+}
+
+int tsdgpu_ola_read_spectra(tsdgpu_ola *h, void *host_dst, void *stream)
+{
+  TSD_CHECK(h != nullptr && h->pending_blocks >= 0, "ola_read_spectra: nothing analysed");
+  const size_t bytes = (size_t) h->pending_blocks * (h->windowed ? 2 : 1) * h->N * sizeof(cpx);
+  if (bytes == 0) return TSDGPU_OK;
+  TSD_CHECK(host_dst != nullptr, "ola_read_spectra: NULL destination");
+  TSD_HIP(hipMemcpyAsync(host_dst, h->spectra.p, bytes, hipMemcpyDefault, (hipStream_t) stream));
+  TSD_HIP(hipStreamSynchronize((hipStream_t) stream));
+  return TSDGPU_OK;
+}
+
+int tsdgpu_ola_write_spectra(tsdgpu_ola *h, const void *host_src, void *stream)
+{
+  TSD_CHECK(h != nullptr && h->pending_blocks >= 0, "ola_write_spectra: nothing analysed");
+  const size_t bytes = (size_t) h->pending_blocks * (h->windowed ? 2 : 1) * h->N * sizeof(cpx);
+  if (bytes == 0) return TSDGPU_OK;
+  TSD_CHECK(host_src != nullptr, "ola_write_spectra: NULL source");
+  TSD_HIP(hipMemcpyAsync(h->spectra.p, host_src, bytes, hipMemcpyDefault, (hipStream_t) stream));
+  TSD_HIP(hipStreamSynchronize((hipStream_t) stream));
+  return TSDGPU_OK;
+}
+
+int tsdgpu_ola_step(tsdgpu_ola *h, const void *x, int64_t n, void *y, int64_t *n_out, void *stream)
+{
+  TSD_CHECK(h != nullptr, "ola_step: NULL handle");
+  void *sp = nullptr;
+  int nf = 0;
+  int rc = tsdgpu_ola_analyse(h, x, n, &sp, &nf, stream);
+  if (rc) return rc;
+  (void) sp;
+  if ((rc = tsdgpu_ola_apply_response(h, stream))) return rc;
+  return tsdgpu_ola_synthese(h, y, n_out, stream);
+}
+
+int tsdgpu_ola_destroy(tsdgpu_ola *h)
+{
+  if (!h) return TSDGPU_OK;
+  if (h->plan) tsdgpu_fft_destroy(h->plan);
+  for (void *q : {(void *) h->d_fen, (void *) h->d_H, (void *) h->d_svg, (void *) h->d_last, (void *) h->d_prev_half, (void *) h->d_rest})
+    if (q) (void) hipFree(q);
+  h->frames.release();
+  h->spectra.release();
+  h->in_stage.release();
+  h->out_stage.release();
+  delete h;
+  return TSDGPU_OK;
+}
+
+}  // extern "C"

@@ -72,6 +72,7 @@ struct FFTFilterConfig : tsd::fourier::FiltreFFTConfig {
   int &minimum_zeros_count = nb_zeros_min;
   bool &enable_windowing = avec_fenetrage;
   std::function<void(Veccf &)> &freq_domain_processing = traitement_freq;
+  tsd::Veccf &frequency_response = réponse_freq;   // extension: device-side X *= H
 };
 inline std::tuple<sptr<Filter<cfloat, cfloat, tsd::fourier::FiltreFFTConfig>>, int> filter_fft(const FFTFilterConfig &config)
 { return tsd::fourier::filtre_fft(config); }

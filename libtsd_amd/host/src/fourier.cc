@@ -471,107 +471,58 @@ void ola_complexité_optimise(entier M, float &C_, entier &Nf_, entier &Nz_, ent
 namespace {
 
 struct OLAGpu : Filtre<cfloat, cfloat, FiltreFFTConfig> {
-  entier N = 0, Nz = 0, Ne = 0;
-  int64_t cnt_ech = 0;
-  Veccf svg, last, prev_half, reste;     // OLA carry, windowed-mode accumulator, last half block, pending inputs
-  Vecf fen;
-  tsdgpu_fft *plan = nullptr;
-  ~OLAGpu() override { tsdgpu_fft_destroy(plan); }
+  entier N = 0, Ne = 0;
+  tsdgpu_ola *h = nullptr;
+  ~OLAGpu() override { tsdgpu_ola_destroy(h); }
 
   void configure_impl(const FiltreFFTConfig &c) override
   {
-    if (!c.traitement_freq) échec("configuration OLA : traitement fréquentiel non précisé.");
-    Ne = c.dim_blocs_temporel > 0 ? c.dim_blocs_temporel : 512;
-    N = prochaine_puissance_de_2(Ne + c.nb_zeros_min);
-    Nz = N - Ne;
-    if (Nz > Ne) échec("filtre_fft: Nz = {} zeros exceed the block size Ne = {} (the overlap is carried in one block)", Nz, Ne);
-    if (c.avec_fenetrage && (Ne & 1)) échec("filtre_fft: the windowed mode needs an even block size (Ne = {})", Ne);
-    cnt_ech = -(Ne / 2);
-    svg = Veccf::zeros(Ne);
-    last = Veccf::zeros(Ne);
-    prev_half = Veccf::zeros(Ne / 2);
-    reste = Veccf();
-    if (c.avec_fenetrage) fen = tsd::filtrage::fenêtre("hn", Ne, false);
-    tsdgpu_fft_destroy(plan);
-    plan = nullptr;
-    if (tsdgpu_fft_create(&plan, N, 1)) échec("filtre_fft: {}", tsdgpu_last_error());
-  }
-
-  void batch_fft(Veccf &buf, entier count, bool avant)
-  {
-    if (count > 0 && tsdgpu_fft_step(plan, buf.data(), buf.data(), count, avant ? 1 : 0, nullptr))
+    if (!c.traitement_freq && c.réponse_freq.rows() == 0) échec("configuration OLA : traitement fréquentiel non précisé.");
+    tsdgpu_ola_destroy(h);
+    h = nullptr;
+    const entier ne = c.dim_blocs_temporel > 0 ? c.dim_blocs_temporel : 512;
+    Vecf fen;
+    if (c.avec_fenetrage) fen = tsd::filtrage::fenêtre("hn", ne, false);          // fourier.cc:795
+    if (tsdgpu_ola_create(&h, c.dim_blocs_temporel, c.nb_zeros_min, c.avec_fenetrage ? fen.data() : nullptr))
       échec("filtre_fft: {}", tsdgpu_last_error());
+    N = tsdgpu_ola_fft_size(h);
+    Ne = tsdgpu_ola_block_len(h);
+    if (c.réponse_freq.rows() > 0) {
+      if (c.réponse_freq.rows() != N) échec("filtre_fft: réponse_freq has {} values, the FFT size is {}", c.réponse_freq.rows(), N);
+      if (tsdgpu_ola_set_response(h, c.réponse_freq.data())) échec("filtre_fft: {}", tsdgpu_last_error());
+    }
   }
 
   void step(const Veccf &x, Veccf &y) override
   {
     const FiltreFFTConfig &c = Configurable<FiltreFFTConfig>::config;
-    if (Ne <= 0) échec("filtre_fft: not configured");
-    // re-blocking (tampon_création semantics): whole blocks of Ne are processed, the rest waits
-    const Veccf all = reste.rows() ? vconcat(reste, x) : x;
-    const entier B = all.rows() / Ne;
-    reste = all.tail(all.rows() - B * Ne).clone();
-    const entier per = c.avec_fenetrage ? 2 : 1;                 // frames per block
-    Veccf frames = Veccf::zeros(B * per * N);
-    for (entier b = 0; b < B; b++) {
-      const Veccf xb = all.segment(b * Ne, Ne);
-      if (!c.avec_fenetrage) {
-        frames.segment(b * N + Nz, Ne) = xb;                      // zeros first, the block last (:850)
-      } else {
-        // frame 1 = window * [second half of the previous block, first half of this one] (:885-886),
-        // frame 2 = window * this block (:910)
-        Veccf f1 = frames.segment((2 * b) * N + Nz, Ne), f2 = frames.segment((2 * b + 1) * N + Nz, Ne);
-        for (entier i = 0; i < Ne / 2; i++) {
-          f1(i) = prev_half(i) * fen(i);
-          f1(Ne / 2 + i) = xb(i) * fen(Ne / 2 + i);
+    if (!h) échec("filtre_fft: not configured");
+    Veccf out((entier) std::max<int64_t>(1, tsdgpu_ola_max_out(h, x.rows())));
+    int64_t nout = 0;
+    if (!c.traitement_freq) {
+      // device-side processing only: framing, FFTs, product and overlap-add in one call
+      if (tsdgpu_ola_step(h, x.data(), x.rows(), out.data(), &nout, nullptr)) échec("filtre_fft: {}", tsdgpu_last_error());
+    } else {
+      // the reference's host callback: the spectra of the call's frames visit the host once
+      void *sp = nullptr;
+      int nf = 0;
+      if (tsdgpu_ola_analyse(h, x.data(), x.rows(), &sp, &nf, nullptr)) échec("filtre_fft: {}", tsdgpu_last_error());
+      if (nf > 0) {
+        if (tsdgpu_ola_apply_response(h, nullptr)) échec("filtre_fft: {}", tsdgpu_last_error());   // réponse_freq first, if any
+        Veccf S(nf * N);
+        if (tsdgpu_ola_read_spectra(h, S.data(), nullptr)) échec("filtre_fft: {}", tsdgpu_last_error());
+        for (entier f = 0; f < nf; f++) {
+          Veccf X = S.segment(f * N, N);                          // a view: the callback edits the batch in place
+          c.traitement_freq(X);
+          if (X.rows() != N || X.data() != S.data() + (size_t) f * N)
+            échec("filtre_fft: traitement_freq must process the spectrum in place (dimension {})", N);
         }
-        for (entier i = 0; i < Ne; i++) f2(i) = xb(i) * fen(i);
-        prev_half = xb.tail(Ne / 2).clone();
+        if (tsdgpu_ola_write_spectra(h, S.data(), nullptr)) échec("filtre_fft: {}", tsdgpu_last_error());
       }
+      if (tsdgpu_ola_synthese(h, out.data(), &nout, nullptr)) échec("filtre_fft: {}", tsdgpu_last_error());
     }
-    batch_fft(frames, B * per, true);
-    for (entier f = 0; f < B * per; f++) {
-      Veccf X = frames.segment(f * N, N);                         // a view: the callback edits the batch in place
-      c.traitement_freq(X);
-      if (X.rows() != N || X.data() != frames.data() + (size_t) f * N)
-        échec("filtre_fft: traitement_freq must process the spectrum in place (dimension {})", N);
-    }
-    batch_fft(frames, B * per, false);
-    // sequential overlap-add over the blocks
-    std::vector<Veccf> out;
-    entier nout = 0;
-    for (entier b = 0; b < B; b++) {
-      if (!c.avec_fenetrage) {
-        const Veccf x2 = frames.segment(b * N, N);
-        for (entier i = 0; i < Nz; i++) svg(Ne - Nz + i) += x2(i);
-        out.push_back(svg.clone());
-        svg = x2.tail(Ne).clone();
-        cnt_ech += Ne;
-      } else {
-        const Veccf xa = frames.segment((2 * b) * N, N), xb2 = frames.segment((2 * b + 1) * N, N);
-        const entier h = Ne / 2;
-        for (entier i = 0; i < Nz; i++) svg(Ne - Nz + i) += xa(i);
-        for (entier i = 0; i < h; i++) last(h + i) += svg(i) / 2.0f;
-        out.push_back(cnt_ech >= 0 ? last.clone() : Veccf());
-        for (entier i = 0; i < h; i++) {
-          last(i) = svg(h + i) / 2.0f;
-          last(h + i) = 0;
-        }
-        svg = xa.tail(Ne).clone();
-        cnt_ech += h;
-        for (entier i = 0; i < Nz; i++) svg(Ne - Nz + i) += xb2(i);
-        for (entier i = 0; i < Ne; i++) last(i) += svg(i) / 2.0f;
-        svg = xb2.tail(Ne).clone();
-        cnt_ech += h;
-      }
-      nout += out.back().rows();
-    }
-    y.resize(nout);
-    entier k = 0;
-    for (const Veccf &o : out) {
-      for (entier i = 0; i < o.rows(); i++) y(k + i) = o(i);
-      k += o.rows();
-    }
+    y.resize((entier) nout);
+    for (entier i = 0; i < (entier) nout; i++) y(i) = out(i);
   }
 };
 

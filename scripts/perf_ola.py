@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""OLA frequency-domain engine (filtre_fft) with the device-side response, data resident in HBM:
+samples/s against the 16 B/sample of the in/out streams (the frames and spectra are internal)."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import libtsd_amd as t  # noqa: E402
+from scripts.perf_configs import timeit  # noqa: E402
+
+dev = torch.device("cuda", 0)
+n = 1 << 24
+x = torch.view_as_complex(torch.randn(n, 2, device=dev))
+for Ne, M, win in [(512, 127, False), (2048, 127, False), (4096, 1025, False), (8192, 127, False), (512, 0, True), (4096, 0, True)]:
+    w = (0.5 - 0.5 * np.cos(2 * np.pi * np.arange(Ne) / Ne)).astype(np.float32) if win else None
+    g = t.Ola(Ne, M, w)
+    g.set_response(np.ones(g.N, np.complex64))
+    ms = timeit(lambda: g.step(x), 10, 3)
+    print(json.dumps({"Ne": Ne, "zeros_min": M, "N": g.N, "windowed": win, "ms": round(ms, 3),
+                      "Msamples_per_s": round(n / ms / 1e3, 1), "frac_of_8TBps_at_16B": round(16.0 * n / (ms * 1e-3) / 8e12, 4)}), flush=True)

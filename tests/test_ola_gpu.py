@@ -1,0 +1,134 @@
+"""OLA frequency-domain engine (filtre_fft, fourier.cc:737-940) through the C ABI against the
+numpy restatement oracle/ola_oracle.py, plus size-independent properties: identity processing =
+the input delayed by one block (windowed mode: by half a block and halved, the case
+core/tests/test-filtre-fft.cc plots), X *= H with FiltreFFTRIF's H (fourier.cc:963-966) = the
+direct FIR delayed by Ne - M samples."""
+import numpy as np
+import pytest
+
+import libtsd_amd as t
+from oracle import ola_oracle, pyoracle as orc
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def relerr(a, b):
+    return float(np.max(np.abs(a - b)) / max(1e-30, np.max(np.abs(b))))
+
+
+def randc(rng, n):
+    return (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+
+
+def response(N, rng, K=33):
+    """FiltreFFTRIF's H: h2 = zeros(N), h2.tail(K) = h, H = fft(h2) * sqrt(N) (fourier.cc:963-966)."""
+    h = (rng.standard_normal(K) * np.hanning(K)).astype(np.float32)
+    h2 = np.zeros(N, np.complex64)
+    h2[N - K:] = h
+    return orc.fft(h2, True) * np.float32(np.sqrt(N)), h
+
+
+@pytest.mark.parametrize("Ne,nz,windowed", [(512, 0, False), (512, 100, False), (256, 256, False), (1000, 24, False),
+                                            (512, 0, True), (512, 127, True), (64, 64, True), (2048, 500, True)])
+def test_builtin_response_matches_oracle(Ne, nz, windowed):
+    rng = np.random.default_rng(Ne + nz + windowed)
+    win = ola_oracle.fen_hann_periodique(Ne) if windowed else None
+    g = t.Ola(Ne, nz, win)
+    H, _ = response(g.N, rng)
+    g.set_response(H)
+    ref = ola_oracle.Ola(Ne, nz, win, lambda X: X * H)
+    assert (g.N, g.Ne) == (ref.N, ref.Ne)
+    # ragged call lengths: whole blocks, partial blocks, empty calls
+    for n in [Ne, 3 * Ne, 17, 0, Ne - 17, 5 * Ne + 3, 1, 2 * Ne - 4]:
+        x = randc(rng, n)
+        y = g.step(x)
+        yr = ref.step(x)
+        assert y.shape == yr.shape, (n, y.shape, yr.shape)
+        if len(yr):
+            assert relerr(y, yr) <= TOL, (n, relerr(y, yr))
+
+
+@pytest.mark.parametrize("windowed", [False, True])
+def test_device_pointers_and_split_processing(windowed):
+    """analyse -> caller-side edit of the device spectra -> synthese == the built-in product."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(7)
+    Ne, nz = 512, 200
+    win = ola_oracle.fen_hann_periodique(Ne) if windowed else None
+    a, b = t.Ola(Ne, nz, win), t.Ola(Ne, nz, win)
+    H, _ = response(a.N, rng)
+    a.set_response(H)
+    Hd = torch.from_numpy(H).to(dev)
+    for n in [4 * Ne, Ne + 100, 3 * Ne - 100]:
+        x = randc(rng, n)
+        xd = torch.from_numpy(x).to(dev)
+        ya = a.step(xd).cpu().numpy()
+        sp, nf = b.analyse(xd)
+        if nf:
+            # a torch view over the handle's spectra buffer: the "device-side callback"
+            S = _wrap(sp, nf * b.N, dev).view(nf, b.N)
+            S.mul_(Hd)
+        torch.cuda.synchronize()
+        yb = b.synthese().cpu().numpy()
+        assert ya.shape == yb.shape
+        if len(ya):
+            assert relerr(yb, ya) <= 1e-6
+
+
+def _wrap(addr, count, dev):
+    """complex64 torch tensor over device memory owned by the library (no copy)."""
+    import torch
+
+    class _Holder:
+        pass
+    h = _Holder()
+    h.__cuda_array_interface__ = {"shape": (count,), "typestr": "<c8", "data": (addr, False), "version": 3, "strides": None}
+    return torch.as_tensor(h, device=dev)
+
+
+def test_identity_is_a_pure_delay():
+    """No processing: the input comes back one block later; windowed: half a block later and
+    halved (two Hann frames per block sum to 1, each weighted 1/2 -- fourier.cc:895,918), the first
+    block yielding nothing."""
+    rng = np.random.default_rng(3)
+    Ne = 512
+    x = randc(rng, 8 * Ne)
+    g = t.Ola(Ne, 0, None)
+    g.set_response(np.ones(g.N, np.complex64))
+    y = g.step(x)
+    assert len(y) == 8 * Ne and np.max(np.abs(y[:Ne])) == 0.0
+    assert relerr(y[Ne:], x[:-Ne]) <= TOL
+    gw = t.Ola(Ne, 0, ola_oracle.fen_hann_periodique(Ne))
+    gw.set_response(np.ones(gw.N, np.complex64))
+    y = gw.step(x)
+    assert len(y) == 7 * Ne
+    d = Ne // 2
+    assert relerr(y[d:], 0.5 * x[:len(y) - d]) <= 2e-5
+
+
+@pytest.mark.parametrize("Ne,K", [(512, 127), (512, 33), (1000, 24), (4096, 1025)])
+def test_product_with_H_is_the_delayed_fir(Ne, K):
+    """FiltreFFTRIF (fourier.cc:946-990): X *= H through the OLA engine = the direct FIR, Ne - K later."""
+    rng = np.random.default_rng(5)
+    g = t.Ola(Ne, K, None)
+    H, h = response(g.N, rng, K)
+    g.set_response(H)
+    x = randc(rng, 16 * Ne)
+    y = g.step(x)
+    yr = orc.fir(h, x)
+    d = Ne - K
+    assert relerr(y[d:], yr[:len(y) - d]) <= 2e-5
+
+
+def test_errors():
+    with pytest.raises(t.TsdGpuError):
+        t.Ola(100, 400, None)                      # Nz > Ne
+    with pytest.raises(t.TsdGpuError):
+        t.Ola(511, 0, np.ones(511, np.float32))   # odd block in the windowed mode
+    g = t.Ola(512, 0, None)
+    x = np.zeros(512, np.complex64)
+    g.analyse(x)
+    with pytest.raises(t.TsdGpuError):
+        g.analyse(x)                               # analyse twice without synthese
