@@ -75,16 +75,18 @@ struct DetecteurGpu : Detecteur {
       FiltreFFTConfig oc;
       oc.nb_zeros_min = M - 1;
       oc.dim_blocs_temporel = Ne;
-      oc.traitement_freq = [this](Veccf &X) {
-        for (entier i = 0; i < X.rows(); i++) X(i) *= std::conj(T_motif(i));
-      };
-      auto [f, n_fft] = filtre_fft(oc);
-      correlateur = f;
-      N = n_fft;
+      // the reference's callback X *= conj(T_motif) (detection.cc:166-169) as the engine's
+      // device-side response: the correlation never leaves the GPU between the two FFTs
+      N = prochaine_puissance_de_2(Ne + M - 1);
       if (2 * M > N) échec("détecteur: pattern of {} samples does not fit the {}-point OLA blocks", M, N);
       Veccf tmp = Veccf::zeros(N);
       tmp.head(M) = motif;
       T_motif = fft(tmp);
+      oc.réponse_freq = Veccf(N);
+      for (entier i = 0; i < N; i++) oc.réponse_freq(i) = std::conj(T_motif(i));
+      auto [f, n_fft] = filtre_fft(oc);
+      correlateur = f;
+      if (n_fft != N) échec("détecteur: OLA engine configured with N = {} instead of {}", n_fft, N);
       delais_corr = Ne;
       retard_energie = tsd::filtrage::ligne_a_retard<float>(delais_corr - M + 1);
     } else {
