@@ -450,10 +450,25 @@ int tsdgpu_sos_step(tsdgpu_sos *s, const void *x, void *y, int64_t n, void *stre
     TSD_HIP(hipMemcpyAsync(s->in_stage.p, dx, bytes, hipMemcpyDeviceToDevice, st));
     dx = s->in_stage.p;
   }
+  // the wave kernel moves 16 B per lane: a device pointer that is not 16-B aligned (a view into
+  // a larger vector) is bounced through an aligned buffer -- one extra copy, instead of leaving
+  // the whole vector to the sequential tail kernel
+  if (((uintptr_t) dx & 15) != 0) {
+    rc = s->in_stage.reserve(bytes);
+    if (rc) return rc;
+    TSD_HIP(hipMemcpyAsync(s->in_stage.p, dx, bytes, hipMemcpyDeviceToDevice, st));
+    dx = s->in_stage.p;
+  }
+  void *dy_user = nullptr;
+  if (((uintptr_t) dy & 15) != 0) {
+    rc = s->out_stage.reserve(bytes);
+    if (rc) return rc;
+    dy_user = dy;
+    dy = s->out_stage.p;
+  }
   const int nch = s->nch;
   const int64_t nfl = n * nch;                              // floats
-  const bool aligned = (((uintptr_t) dx | (uintptr_t) dy) & 15) == 0;
-  const int64_t n_sub = aligned ? nfl / SUB_FLOATS : 0;     // whole sub-tiles go to the wave kernel
+  const int64_t n_sub = nfl / SUB_FLOATS;                   // whole sub-tiles go to the wave kernel
   float *st_in = s->d_state[s->cur], *st_out = s->d_state[s->cur ^ 1];
   if (n_sub > 0) {
     const int64_t sub_samples = SUB_FLOATS / nch;
@@ -489,6 +504,10 @@ int tsdgpu_sos_step(tsdgpu_sos *s, const void *x, void *y, int64_t n, void *stre
       hipLaunchKernelGGL(sos_tail_kernel<2>, dim3(1), dim3(64), 0, st, (const float *) dx, (float *) dy, s->d_sec, s->nsec,
                          s->gain, stc, n0, n);
     TSD_HIP(hipGetLastError());
+  }
+  if (dy_user) {
+    TSD_HIP(hipMemcpyAsync(dy_user, dy, bytes, hipMemcpyDeviceToDevice, st));
+    dy = dy_user;
   }
   return finish_out(y, bytes, dy, staged, st);
 }

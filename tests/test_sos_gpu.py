@@ -163,3 +163,31 @@ def test_sos_shard_warmup_halo(tg, orc, cplx):
     g.step(x[cut - W:cut])                      # warm-up: state after the halo, output dropped
     y1 = g.step(x[cut:])
     assert relerr(y1, yref[cut:]) <= TOL
+
+
+# device views that are not 16-B aligned (x[1:], y[3:] ...): bounced through aligned buffers,
+# same results, and no fall-back to the sequential tail kernel
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("ox,oy", [(1, 0), (0, 3), (1, 1), (2, 3)])
+def test_sos_unaligned_device_views(tg, orc, cplx, ox, oy):
+    import time
+    import torch
+    dev = torch.device("cuda", 0)
+    ref, g = chains(orc, tg, 12, 0.25, cplx)
+    n = 1 << 22
+    x = rand(n + 8, cplx, 5)
+    xd = torch.from_numpy(x).to(dev)
+    yd = torch.zeros(n + 8, dtype=xd.dtype, device=dev)
+    g.step(xd[ox:ox + 1000], yd[oy:oy + 1000])             # first call: ragged and short
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    g.step(xd[ox + 1000:ox + n], yd[oy + 1000:oy + n])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert relerr(yd[oy:oy + n].cpu().numpy(), ref.step(x[ox:ox + n])) <= TOL
+    assert dt < 0.5, f"unaligned views took {dt:.2f} s"      # the sequential kernel would need seconds
+    # in place on an unaligned view
+    ref2, g2 = chains(orc, tg, 12, 0.25, cplx)
+    z = xd.clone()
+    g2.step(z[1:1 + n], z[1:1 + n])
+    assert relerr(z[1:1 + n].cpu().numpy(), ref2.step(x[1:1 + n])) <= TOL
