@@ -158,3 +158,83 @@ def test_fft_batch_past_2_31(env, orc):
     for i in range(0, batch, step):
         worst = max(worst, (z[i:i + step] - x[i:i + step]).abs().max().item())
     assert worst <= 3e-5
+
+
+@pytest.mark.parametrize("kind", ["decim", "halfband", "ups", "pick"])
+def test_integer_rate_stages_past_2_31(env, orc, kind):
+    """filtre_rif_decim / _demi_bande / _ups / decimateur on more than 2^31 complex samples:
+    oracle on slices (started on a multiple of R, warmed up on 64 inputs) + chunk invariance."""
+    t, torch, dev = env
+    R = 2
+    W = 20000
+    n = BIG if kind != "ups" else (1 << 30) + 61_731        # the upsampler's OUTPUT passes 2^31
+    x = fill(torch, dev, n, True, 21)
+    if kind == "halfband":
+        h = orc.design_rif_fen(15, "lp", 0.25)
+    else:
+        h = orc.design_rif_fen(15, "lp", 0.2)
+    code = {"decim": t.POLY_DECIM, "halfband": t.POLY_HALFBAND, "ups": t.POLY_UPS, "pick": t.POLY_PICK}[kind]
+    mk = lambda: t.PolyFir(code, t.C64, None if kind == "pick" else h, R)
+    y = mk().step(x)
+    torch.cuda.synchronize()
+    nout = y.shape[0]
+    if kind == "ups":
+        assert nout == n * R
+    elif kind == "pick":
+        assert nout == (n - _pick_phase(t, R) + R - 1) // R     # every sample with index = phase (mod R)
+    else:
+        assert nout == n // R
+
+    def oracle():
+        if kind == "ups":
+            return orc.PolyUps(h, R)
+        if kind == "pick":
+            return None
+        return orc.PolyDecim(h, R, 1 if kind == "halfband" else 0)
+
+    warm = 64
+    for s in slices(n, W):
+        s -= s % R
+        lo = max(0, s - warm)
+        xs = x[lo:s + W].cpu().numpy()
+        o = oracle()
+        if o is None:
+            # decimateur keeps every R-th sample of the stream (filtre-rt.cc:127-169): bit-exact pick
+            out_lo = (lo + R - 1) // R
+            got = y[out_lo:out_lo + 100].cpu().numpy()
+            phase = _pick_phase(t, R)
+            exp = x[out_lo * R + phase: out_lo * R + phase + 100 * R: R].cpu().numpy()
+            assert np.array_equal(got, exp), s
+            continue
+        ref = o.step(xs)
+        if kind == "ups":
+            a, b = s * R, (s + W) * R
+            r = ref[(s - lo) * R:]
+        else:
+            a, b = s // R, (s + W) // R
+            r = ref[(s - lo) // R:]
+        g = y[a:b].cpu().numpy()
+        m = min(len(g), len(r))
+        assert relerr(g[:m], r[:m]) <= TOL, (kind, s)
+    # chunk invariance with ragged cuts
+    f = mk()
+    cuts = [0, (1 << 29) + 3, n - 5, n]
+    pos = 0
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        yp = f.step(x[a:b])
+        m = yp.shape[0]
+        if m:
+            w = min(W, m)
+            for s in {0, max(0, m // 2 - w // 2), m - w}:
+                d = (yp[s:s + w] - y[pos + s:pos + s + w]).abs().max().item()
+                assert d == 0.0, (kind, a, s, d)
+        pos += m
+        del yp
+    assert pos == nout
+
+
+def _pick_phase(t, R):
+    """Index (mod R) of the samples decimateur keeps, read off a tiny call."""
+    x = np.arange(4 * R, dtype=np.float32)
+    y = t.PolyFir(t.POLY_PICK, t.F32, None, R).step(x)
+    return int(y[0])
