@@ -125,6 +125,52 @@ __global__ void rii_recursive_kernel(float *__restrict__ y, const float *__restr
   }
 }
 
+// The same recursion for Ky <= KMAX with the output memory in registers and the data staged
+// through LDS in coalesced tiles (the kernel above walks global memory sample by sample:
+// microseconds per sample).  Same operations in the same order: bit-identical results.
+constexpr int RII_TILE = 4096;      // floats per tile (all channels)
+template <int KMAX>
+__global__ __launch_bounds__(256) void rii_recursive_tiled_kernel(float *__restrict__ y, const float *__restrict__ denom,
+                                                                  int Ky, float *__restrict__ hist, int nch, int64_t n)
+{
+  __shared__ float tile[RII_TILE];
+  const int tid = threadIdx.x;
+  const int64_t nfl = n * nch;
+  float h[KMAX], d[KMAX];
+  const float d0 = denom[0];
+#pragma unroll
+  for (int k = 0; k < KMAX; k++) {
+    d[k] = k < Ky ? denom[k + 1] : 0.f;
+    h[k] = (tid < nch && k < Ky) ? hist[tid * Ky + k] : 0.f;
+  }
+  for (int64_t base = 0; base < nfl; base += RII_TILE) {
+    const int cnt = (int) min((int64_t) RII_TILE, nfl - base);       // a multiple of nch
+    for (int i = tid; i < cnt; i += 256) tile[i] = y[base + i];
+    __syncthreads();
+    if (tid < nch) {
+      for (int j = tid; j < cnt; j += nch) {
+        float somme = tile[j];
+#pragma unroll
+        for (int k = 0; k < KMAX; k++)
+          if (k < Ky) somme -= h[k] * d[k];
+        const float o = somme / d0;
+        tile[j] = o;
+#pragma unroll
+        for (int k = KMAX - 1; k > 0; k--) h[k] = h[k - 1];
+        h[0] = o;
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < cnt; i += 256) y[base + i] = tile[i];
+    __syncthreads();
+  }
+  if (tid < nch) {
+#pragma unroll
+    for (int k = 0; k < KMAX; k++)
+      if (k < Ky) hist[tid * Ky + k] = h[k];
+  }
+}
+
 }  // namespace tsdgpu
 
 using namespace tsdgpu;
@@ -427,7 +473,13 @@ int tsdgpu_rii_step(tsdgpu_rii *r, const void *x, void *y, int64_t n, void *stre
   rc = tsdgpu_fir_step(r->fir, dx, dy, n, stream);                      // (1) non-recursive part
   if (rc) return rc;
   const int nch = r->data_type == TSDGPU_C64 ? 2 : 1;
-  hipLaunchKernelGGL(rii_recursive_kernel, dim3(1), dim3(64), 0, st, (float *) dy, r->d_denom, r->Ky, r->d_hist, nch, n);
+#define RII_LAUNCH(KM) hipLaunchKernelGGL(rii_recursive_tiled_kernel<KM>, dim3(1), dim3(256), 0, st, (float *) dy, r->d_denom, r->Ky, r->d_hist, nch, n)
+  if (r->Ky <= 4) RII_LAUNCH(4);
+  else if (r->Ky <= 8) RII_LAUNCH(8);
+  else if (r->Ky <= 16) RII_LAUNCH(16);
+  else if (r->Ky <= 32) RII_LAUNCH(32);
+  else hipLaunchKernelGGL(rii_recursive_kernel, dim3(1), dim3(64), 0, st, (float *) dy, r->d_denom, r->Ky, r->d_hist, nch, n);
+#undef RII_LAUNCH
   TSD_HIP(hipGetLastError());                                           // (2) recursive part
   return finish_out(y, bytes, dy, staged, st);
 }

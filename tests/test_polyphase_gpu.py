@@ -112,3 +112,42 @@ def test_filtre_rii(tg, orc):
     x = rand(5000, False, 3)
     ref = orc.Rii(nu, de).step(x)
     assert relerr(chunks(tg.Rii(nu, de, tg.F32), x, 613), ref) <= TOL
+
+
+# FiltreRII of higher order (filtre-rt.cc:177-289): FIR kernel + the sequential recursive part,
+# bit-identical operation order; orders in every register bucket (<= 4, 8, 16, 32) and beyond,
+# real and complex data, ragged chunks.  The denominator is a product of stable real poles.
+@pytest.mark.parametrize("order", [3, 5, 9, 20, 40])
+@pytest.mark.parametrize("cplx", [False, True])
+def test_filtre_rii_high_order(tg, orc, order, cplx):
+    rng = np.random.default_rng(order)
+    r = 0.6 if order < 20 else 0.3                            # (a direct form of order 20+ is badly conditioned: keep the poles small)
+    poles = rng.uniform(-r, r, order)
+    de = np.poly(poles).astype(np.float32)
+    de = (de * np.float32(1.5)).astype(np.float32)            # denom[0] != 1: the division is exercised
+    nu = rng.standard_normal(order // 2 + 2).astype(np.float32)
+    n = 30000 if order <= 20 else 6000
+    x = rand(n, cplx, order)
+    if cplx:   # real coefficients on complex data act on the two components separately
+        ref = (orc.Rii(nu, de).step(x.real.copy()) + 1j * orc.Rii(nu, de).step(x.imag.copy())).astype(np.complex64)
+    else:
+        ref = orc.Rii(nu, de).step(x)
+    y = chunks(tg.Rii(nu, de, tg.C64 if cplx else tg.F32), x, 7001)
+    assert relerr(y, ref) <= TOL
+
+
+def test_filtre_rii_high_order_is_not_a_cliff(tg):
+    """2^22 samples through a 6th-order direct-form recursion: seconds with the per-sample
+    global-memory kernel, a fraction of a second with the tiled one."""
+    import time
+    import torch
+    dev = torch.device("cuda", 0)
+    de = np.poly([0.5, -0.4, 0.3, 0.2, -0.1, 0.6]).astype(np.float32)
+    f = tg.Rii([1.0, 0.5], de, tg.F32)
+    x = torch.randn(1 << 22, device=dev)
+    f.step(x[:1000])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    f.step(x)
+    torch.cuda.synchronize()
+    assert time.perf_counter() - t0 < 1.5
