@@ -219,3 +219,23 @@ def test_rfft_batched_device(tg, orc):
     y = yd.cpu().numpy()
     for b in range(batch):
         assert relerr(y[b], orc.rfft(x[b])) <= TOL
+
+
+# device views that are only 8-B aligned (x[1:], odd offsets): every plan kind uses 16-B global
+# accesses somewhere; results must not depend on the alignment of the caller's pointers
+@pytest.mark.parametrize("n,batch", [(16, 64), (64, 33), (1024, 9), (4096, 5), (16384, 3), (1 << 15, 2), (1 << 20, 2),
+                                     (1000, 7), (3 * 1024, 3), (1001, 5), (17, 40)])
+def test_fft_unaligned_device_views(tg, orc, n, batch):
+    import torch
+    dev = torch.device("cuda", 0)
+    x = crand(n * batch + 3, n)
+    xd = torch.from_numpy(x).to(dev)
+    yd = torch.zeros(n * batch + 3, dtype=torch.complex64, device=dev)
+    p = tg.Fft(n, batch)
+    for ox, oy in [(1, 0), (0, 1), (1, 3)]:
+        xi = xd[ox:ox + n * batch].view(batch, n)
+        yo = yd[oy:oy + n * batch].view(batch, n)
+        p.step(xi, True, yo)
+        got = yo.cpu().numpy()
+        for b in {0, batch - 1}:
+            assert relerr(got[b], orc.fft(x[ox + b * n:ox + (b + 1) * n])) <= TOL, (n, ox, oy, b)
