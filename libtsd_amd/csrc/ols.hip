@@ -21,9 +21,12 @@ namespace tsdgpu {
 
 using namespace w1024;
 constexpr int OLS_N = 1024;
-// complex values of the kernel: packed VGPR pairs (fft1024_wave.hpp), -DOLS_SCALAR=1 = the float2 flavour
+// complex values of the kernel: float2 with scalar fp32 arithmetic; -DOLS_SCALAR=0 selects the
+// packed (VOP3P) flavour of fft1024_wave.hpp -- half the VALU instructions, parity-green, but
+// measured 2 % SLOWER (0.2313 vs 0.2260 ms, three interleaved runs): the kernel runs at the
+// speed of its memory skeleton, so the arithmetic is not what it waits for
 #ifndef OLS_SCALAR
-#define OLS_SCALAR 0
+#define OLS_SCALAR 1
 #endif
 #ifndef OLS_WIDE   // experiment: 16-B global accesses (layout NOT the FFT's: ablation only)
 #define OLS_WIDE 0

@@ -1,8 +1,8 @@
 """CPU structural test of the in-wave 1024-point FFT (libtsd_amd/csrc/fft1024_wave.hpp): the
 header's scalar flavour is plain C++, so g++ emulates the 64 lanes phase by phase and checks
 forward() against a double-precision DFT and inverse(forward(x)) == N x
-(tests/cpu/test_fft1024_wave.cc).  The packed (VOP3P) flavour is covered on the GPU by the
-overlap-save parity tests."""
+(tests/cpu/test_fft1024_wave.cc).  The packed (VOP3P) flavour is an opt-in build (-DOLS_SCALAR=0) of the
+overlap-save kernel; the default build uses the scalar flavour tested here and on the GPU."""
 import os
 import subprocess
 
