@@ -473,6 +473,75 @@ __device__ __forceinline__ void lds_barrier()
 {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
+// ---- n = 4096 .. 16384 in batches: the Stockham kernel above with PERSISTENT workgroups -------
+// One transform per workgroup (n/16 threads) and few workgroups per CU (one for n = 16384): the
+// load, transform and store phases of fft_s16_kernel then run back to back on a CU.  Here a
+// workgroup walks transforms tr, tr + grid, ... and loads the next one into a second register
+// set before transforming the current one; the barriers wait for LDS only (lds_barrier), so
+// the loads -- and the previous transform's stores -- stay in flight through the passes.
+template <int R0>
+__device__ __forceinline__ void s16p_one(cpx (&v)[16], cpx *__restrict__ s, const cpx *__restrict__ TW, cpx *__restrict__ y,
+                                         int n, int tpt, int j, int inverse, float scale)
+{
+  if (inverse) {
+#pragma unroll
+    for (int m = 0; m < 16; m++) v[m].y = -v[m].y;
+  }
+  s16::pass0<R0>(v);
+  s16::pass0_store<R0>(s, v, j, tpt);
+  for (int Ns = R0;; Ns <<= 4) {
+    lds_barrier();
+#pragma unroll
+    for (int q = 0; q < 16; q++) v[q] = s[s16::pad(j + q * tpt)];
+    const int k = j & (Ns - 1);
+    s16::twiddle_powers(v, TW[k * (tpt / Ns)]);
+    w1024::dft16<false>(v);
+    const int base = (j - k) * 16 + k;
+    if (Ns * 16 == n) {
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        cpx o = cscale(v[q], scale);
+        if (inverse) o.y = -o.y;
+        y[base + q * Ns] = o;
+      }
+      break;
+    }
+    lds_barrier();
+#pragma unroll
+    for (int q = 0; q < 16; q++) s[s16::pad(base + q * Ns)] = v[q];
+  }
+  lds_barrier();     // the next transform's pass 0 rewrites the image
+}
+
+template <int R0>
+__global__ __launch_bounds__(1024) void fft_s16_persistent_kernel(const cpx *__restrict__ in, cpx *__restrict__ out,
+                                                                  const cpx *__restrict__ TW, int n, int tpt, int inverse,
+                                                                  float scale, int ntr)
+{
+  extern __shared__ __attribute__((aligned(16))) char s16_raw[];
+  cpx *s = reinterpret_cast<cpx *>(s16_raw);
+  const int j = threadIdx.x, G = gridDim.x;
+  int tr = blockIdx.x;
+  if (tr >= ntr) return;
+  cpx A[16], B[16];
+  auto fetch = [&](cpx (&v)[16], int t_) {
+    const cpx *x = in + (size_t) t_ * n + j;
+#pragma unroll
+    for (int m = 0; m < 16; m++) v[m] = x[m * tpt];
+  };
+  fetch(A, tr);
+  for (;;) {
+    if (tr + G < ntr) fetch(B, tr + G);
+    s16p_one<R0>(A, s, TW, out + (size_t) tr * n, n, tpt, j, inverse, scale);
+    tr += G;
+    if (tr >= ntr) break;
+    if (tr + G < ntr) fetch(A, tr + G);
+    s16p_one<R0>(B, s, TW, out + (size_t) tr * n, n, tpt, j, inverse, scale);
+    tr += G;
+    if (tr >= ntr) break;
+  }
+}
+
 struct LdsTw1 {   // [r - 1][lane]
   const cpx *p;
   __device__ __forceinline__ cpx operator[](int r) const { return p[(r - 1) * 64]; }
@@ -913,6 +982,9 @@ int plan_init(tsdgpu_fft *p, int n)
 #define S16_ATTR(R) (void) hipFuncSetAttribute((const void *) fft_s16_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
       S16_ATTR(16); S16_ATTR(8); S16_ATTR(4); S16_ATTR(2);
 #undef S16_ATTR
+#define S16P_ATTR(R) (void) hipFuncSetAttribute((const void *) fft_s16_persistent_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+      S16P_ATTR(16); S16P_ATTR(8); S16P_ATTR(4); S16P_ATTR(2);
+#undef S16P_ATTR
       (void) hipGetLastError();
     } else if (n <= LDS_MAX_N) {
       p->kind = tsdgpu_fft::POW2_LDS;
@@ -1101,6 +1173,25 @@ int step_device(tsdgpu_fft *p, const cpx *x, cpx *y, int batch, int forward, hip
       const size_t lds = (size_t) T * (n + n / 16) * sizeof(cpx);
       const unsigned grid = (unsigned) cdiv(batch, T);
       const int r0 = 1 << ((p->logn & 3) == 0 ? 4 : (p->logn & 3));
+      // one transform per workgroup and more transforms than the chip holds at once: persistent
+      // workgroups that prefetch their next transform
+      static const int PERSIST_MIN = getenv("TSDGPU_FFT_PERSIST_MIN") ? atoi(getenv("TSDGPU_FFT_PERSIST_MIN")) : 16384;   // measured: 16384 0.292 -> 0.252 ms per 2^26 points; 8192 and 4096 lose 1-10 %
+      if (n >= PERSIST_MIN && T == 1) {
+        static const int NCU = [] {
+          int dev = 0, c = 256;
+          if (hipGetDevice(&dev) == hipSuccess) (void) hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev);
+          return c > 0 ? c : 256;
+        }();
+        const int per_cu = std::max(1, std::min((int) (160 * 1024 / lds), 2048 / threads));
+        if (batch > 2 * NCU * per_cu) {
+          const unsigned g = (unsigned) (NCU * per_cu);
+#define S16P_LAUNCH(R) hipLaunchKernelGGL((fft_s16_persistent_kernel<R>), dim3(g), dim3(threads), lds, st, x, y, p->d_tw, n, tpt, inverse, scale, batch)
+          if (r0 == 16) S16P_LAUNCH(16); else if (r0 == 8) S16P_LAUNCH(8); else if (r0 == 4) S16P_LAUNCH(4); else S16P_LAUNCH(2);
+#undef S16P_LAUNCH
+          TSD_HIP(hipGetLastError());
+          return TSDGPU_OK;
+        }
+      }
 #define S16_LAUNCH(R) hipLaunchKernelGGL((fft_s16_kernel<R>), dim3(grid), dim3(threads), lds, st, x, y, p->d_tw, n, tpt, inverse, scale, batch)
       if (r0 == 16) S16_LAUNCH(16); else if (r0 == 8) S16_LAUNCH(8); else if (r0 == 4) S16_LAUNCH(4); else S16_LAUNCH(2);
 #undef S16_LAUNCH

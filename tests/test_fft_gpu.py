@@ -239,3 +239,19 @@ def test_fft_unaligned_device_views(tg, orc, n, batch):
         got = yo.cpu().numpy()
         for b in {0, batch - 1}:
             assert relerr(got[b], orc.fft(x[ox + b * n:ox + (b + 1) * n])) <= TOL, (n, ox, oy, b)
+
+
+# large batches of n = 16384 take the persistent, software-pipelined workgroups (8192 stays on the plain kernel)
+# (fft_s16_persistent_kernel): every transform of the batch, both directions, ragged batch counts
+@pytest.mark.parametrize("n,batch", [(8192, 1100), (16384, 531), (16384, 1025)])
+def test_fft_persistent_batches(tg, orc, n, batch):
+    x = crand((batch, n), n + batch)
+    p = tg.Fft(n, batch)
+    y = p.step(x)
+    for b in [0, 1, 255, 256, 257, 511, 512, 513, batch - 2, batch - 1]:
+        assert relerr(y[b], orc.fft(x[b])) <= TOL, (n, b)
+    # every transform: round trip (the inverse runs the same kernel) + Parseval per transform
+    z = p.step(y, False)
+    assert relerr(z, x) <= 3e-5
+    ex, ey = (np.abs(x) ** 2).sum(axis=1), (np.abs(y) ** 2).sum(axis=1)
+    assert np.max(np.abs(ey / ex - 1)) <= 1e-5
