@@ -275,6 +275,167 @@ __global__ __launch_bounds__(1024) void fft_s16_kernel(const cpx *__restrict__ i
   }
 }
 
+// ---- smooth sizes n = 2^a 3^b 5^c 7^d 11^e 13^f <= 16384: mixed-radix Stockham in LDS ---------
+// The reference reaches such sizes by even/odd splits down to an odd length and Bluestein
+// there (fourier.cc:391-464); the two-pass plan above does the same in two HBM passes.  When
+// every prime factor is small the transform is ONE kernel with one pass over HBM: the n points
+// sit in LDS and go through one autosort pass per factor (radix 16/8/4/2 for the power of two,
+// then 3, 5, 7, 11, 13): butterfly j of a radix-R pass with sub-transform length Ns reads
+// x[j + q n/R], multiplies by W_{R Ns}^(q k), k = j mod Ns (one table value W_n^(k n/(R Ns)) and
+// its successive powers), takes the R-point DFT and writes y[(j-k) R + k + q Ns] -- the same
+// indexing as fft_s16_kernel, any radix.  A thread keeps the inputs of all its butterflies of a
+// pass in registers (at most MR_PTS points), so one LDS image per transform is enough.
+// tpt threads per transform, blockDim/tpt transforms per workgroup; global accesses staged
+// through LDS, coalesced.
+constexpr int MR_PTS = 16;
+constexpr int MR_MAXF = 14;
+struct MrFactors { int nf; int r[MR_MAXF]; };
+template <int R> struct OddW;
+template <> struct OddW<3> { static constexpr float c[3] = {1.000000000e+00f, -5.000000000e-01f, -5.000000000e-01f}; static constexpr float s[3] = {-0.000000000e+00f, -8.660254038e-01f, 8.660254038e-01f}; };
+template <> struct OddW<5> { static constexpr float c[5] = {1.000000000e+00f, 3.090169944e-01f, -8.090169944e-01f, -8.090169944e-01f, 3.090169944e-01f}; static constexpr float s[5] = {-0.000000000e+00f, -9.510565163e-01f, -5.877852523e-01f, 5.877852523e-01f, 9.510565163e-01f}; };
+template <> struct OddW<7> { static constexpr float c[7] = {1.000000000e+00f, 6.234898019e-01f, -2.225209340e-01f, -9.009688679e-01f, -9.009688679e-01f, -2.225209340e-01f, 6.234898019e-01f}; static constexpr float s[7] = {-0.000000000e+00f, -7.818314825e-01f, -9.749279122e-01f, -4.338837391e-01f, 4.338837391e-01f, 9.749279122e-01f, 7.818314825e-01f}; };
+template <> struct OddW<11> { static constexpr float c[11] = {1.000000000e+00f, 8.412535328e-01f, 4.154150130e-01f, -1.423148383e-01f, -6.548607339e-01f, -9.594929736e-01f, -9.594929736e-01f, -6.548607339e-01f, -1.423148383e-01f, 4.154150130e-01f, 8.412535328e-01f}; static constexpr float s[11] = {-0.000000000e+00f, -5.406408175e-01f, -9.096319954e-01f, -9.898214419e-01f, -7.557495744e-01f, -2.817325568e-01f, 2.817325568e-01f, 7.557495744e-01f, 9.898214419e-01f, 9.096319954e-01f, 5.406408175e-01f}; };
+template <> struct OddW<13> { static constexpr float c[13] = {1.000000000e+00f, 8.854560257e-01f, 5.680647467e-01f, 1.205366803e-01f, -3.546048870e-01f, -7.485107482e-01f, -9.709418174e-01f, -9.709418174e-01f, -7.485107482e-01f, -3.546048870e-01f, 1.205366803e-01f, 5.680647467e-01f, 8.854560257e-01f}; static constexpr float s[13] = {-0.000000000e+00f, -4.647231720e-01f, -8.229838659e-01f, -9.927088741e-01f, -9.350162427e-01f, -6.631226582e-01f, -2.393156643e-01f, 2.393156643e-01f, 6.631226582e-01f, 9.350162427e-01f, 9.927088741e-01f, 8.229838659e-01f, 4.647231720e-01f}; };
+
+template <int R> __device__ __forceinline__ void mr_dft(cpx (&a)[R])
+{
+  if constexpr (R == 2) s16::dft2(a[0], a[1]);
+  else if constexpr (R == 4) w1024::dft4<false>(a[0], a[1], a[2], a[3]);
+  else if constexpr (R == 8) {
+    // s16::dft8 takes the samples in natural order and leaves X[q] at e[q]
+    s16::dft8(a);
+  } else if constexpr (R == 16) w1024::dft16<false>(a);
+  else {
+    cpx o[R];
+#pragma unroll
+    for (int q = 0; q < R; q++) {
+      cpx acc = a[0];
+#pragma unroll
+      for (int p = 1; p < R; p++) {
+        const int m = (p * q) % R;
+        acc = cadd(acc, cmul(a[p], cmk(OddW<R>::c[m], OddW<R>::s[m])));
+      }
+      o[q] = acc;
+    }
+#pragma unroll
+    for (int q = 0; q < R; q++) a[q] = o[q];
+  }
+}
+
+template <int R>
+__device__ __attribute__((noinline)) void mr_pass(int s_off, const cpx *__restrict__ TWn, int n, int Ns, int j0, int tpt)
+{
+  // (not inlined: every radix gets its own register allocation; the LDS image is named by its
+  // offset so that the accesses stay ds_read / ds_write -- a pointer argument would be generic)
+  extern __shared__ __attribute__((aligned(16))) char s16_raw[];
+  cpx *s = reinterpret_cast<cpx *>(s16_raw) + s_off;
+  constexpr int U = MR_PTS / R;
+  const int nb = n / R;
+  cpx v[U][R];
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const int j = j0 + u * tpt;
+    if (j < nb) {
+#pragma unroll
+      for (int q = 0; q < R; q++) v[u][q] = s[s16::pad(j + q * nb)];
+    }
+  }
+  __syncthreads();
+  const int tstep = n / (R * Ns);
+#pragma unroll
+  for (int u = 0; u < U; u++) {
+    const int j = j0 + u * tpt;
+    if (j < nb) {
+      const int k = (Ns & (Ns - 1)) == 0 ? (j & (Ns - 1)) : j % Ns;
+      if (Ns > 1) {
+        // (the table is global memory: say so, or the non-inlined function issues a flat load)
+        typedef float v2f_t __attribute__((ext_vector_type(2)));
+        const v2f_t wv = *(const __attribute__((address_space(1))) v2f_t *) (TWn + k * tstep);
+        const cpx w1 = cmk(wv.x, wv.y);
+        if constexpr (R == 16) s16::twiddle_powers(v[u], w1);
+        else {
+          cpx w = w1;
+#pragma unroll
+          for (int q = 1; q < R; q++) {
+            v[u][q] = cmul(v[u][q], w);
+            w = cmul(w, w1);
+          }
+        }
+      }
+      mr_dft<R>(v[u]);
+      const int base = (j - k) * R + k;
+#pragma unroll
+      for (int q = 0; q < R; q++) s[s16::pad(base + q * Ns)] = v[u][q];
+    }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void fft_mr_kernel(const cpx *__restrict__ in, cpx *__restrict__ out,
+                                                      const cpx *__restrict__ TWn, MrFactors F, int n, int tpt, int inverse,
+                                                      float scale, int ntr)
+{
+  extern __shared__ __attribute__((aligned(16))) char s16_raw[];
+  cpx *lds = reinterpret_cast<cpx *>(s16_raw);
+  const int t = threadIdx.x, T = blockDim.x / tpt;
+  const int tl = t / tpt, j0 = t - tl * tpt;
+  const int pn = s16::pad(n) + 1;
+  const int64_t g0 = (int64_t) blockIdx.x * T * n, gend = (int64_t) ntr * n;
+  const int tot = T * n;
+  const int nthr = blockDim.x;
+  // element e of the workgroup's T*n points lives at image e / n, index e mod n: tracked
+  // incrementally (e advances by nthr), no division per element
+  const int dq = nthr / n, dr = nthr - dq * n;
+  int tq = t / n, eq = t - tq * n;
+  for (int e0 = t; e0 < tot; e0 += 8 * nthr) {           // 8 loads in flight per thread
+    cpx a[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int e = e0 + u * nthr;
+      a[u] = cmk(0.f, 0.f);
+      if (e < tot && g0 + e < gend) a[u] = in[g0 + e];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int e = e0 + u * nthr;
+      if (e < tot) {
+        if (inverse) a[u].y = -a[u].y;
+        lds[tq * pn + s16::pad(eq)] = a[u];
+      }
+      tq += dq; eq += dr;
+      if (eq >= n) { eq -= n; tq++; }
+    }
+  }
+  __syncthreads();
+  int Ns = 1;
+  for (int f = 0; f < F.nf; f++) {
+    const int R = F.r[f];
+    const int so = tl * pn;
+    switch (R) {
+      case 2: mr_pass<2>(so, TWn, n, Ns, j0, tpt); break;
+      case 3: mr_pass<3>(so, TWn, n, Ns, j0, tpt); break;
+      case 4: mr_pass<4>(so, TWn, n, Ns, j0, tpt); break;
+      case 5: mr_pass<5>(so, TWn, n, Ns, j0, tpt); break;
+      case 7: mr_pass<7>(so, TWn, n, Ns, j0, tpt); break;
+      case 8: mr_pass<8>(so, TWn, n, Ns, j0, tpt); break;
+      case 11: mr_pass<11>(so, TWn, n, Ns, j0, tpt); break;
+      case 13: mr_pass<13>(so, TWn, n, Ns, j0, tpt); break;
+      default: mr_pass<16>(so, TWn, n, Ns, j0, tpt); break;
+    }
+    Ns *= R;
+  }
+  tq = t / n;
+  eq = t - tq * n;
+#pragma unroll 4
+  for (int e = t; e < tot; e += nthr) {
+    cpx a = cscale(lds[tq * pn + s16::pad(eq)], scale);
+    if (inverse) a.y = -a.y;
+    if (g0 + e < gend) out[g0 + e] = a;
+    tq += dq; eq += dr;
+    if (eq >= n) { eq -= n; tq++; }
+  }
+}
+
 // ---- four-step passes on the radix-16 Stockham engine (n = 2^15 .. 2^24, except 2^20) ---------
 // Column FFTs of a row-major [L][C] matrix (length L along the row index), CT adjacent
 // columns per workgroup (CT * 8 B row segments, 16-B accesses), each column transformed in LDS
@@ -872,7 +1033,7 @@ using namespace tsdgpu;
 
 struct tsdgpu_fft {
   int n = 0;
-  enum Kind { ONE, POW2_LDS, POW2_S16, POW2_W1024, POW2_W1M, POW2_4STEP, MIXED, EVEN, ODD } kind = ONE;
+  enum Kind { ONE, POW2_LDS, POW2_S16, POW2_W1024, POW2_W1M, POW2_4STEP, SMOOTH, MIXED, EVEN, ODD } kind = ONE;
   // pow2
   int logn = 0;
   cpx *d_tw = nullptr;        // W_n^k, k < n/2 (LDS path) ...
@@ -886,6 +1047,8 @@ struct tsdgpu_fft {
   cpx *d_rot = nullptr;       // W_n^k, k < n (even split)
   int n2 = 0;
   int mix_m = 0, mix_P = 0;   // MIXED: n = mix_m * mix_P
+  MrFactors mr{};             // SMOOTH: radix sequence; mr_tpt threads per transform
+  int mr_tpt = 0;
   bool blu_fused = false;     // ODD: the one-kernel Bluestein (n2 = 1024 .. 16384)
   cpx *d_wm = nullptr;        // W_m^j, j < m
   cpx *d_chirp = nullptr, *d_xc = nullptr;   // Bluestein chirp (2n-1) and FFT of its conjugate (n2)
@@ -936,6 +1099,48 @@ bool mixed_split(int n, int *m, int *P)
   if (q < 3 || q > 8191 || pw < 2 || pw > 4096 || n > (1 << 22)) return false;   // (W_n table: 8 n bytes)
   *m = q;
   *P = pw;
+  return true;
+}
+
+// n = 2^a 3^b 5^c 7^d 11^e 13^f, not a power of two, <= 16384: the one-kernel mixed-radix plan.
+// Radix sequence: 16s and the remaining 8 / 4 / 2, then the odd primes.  Threads per transform:
+// enough for every pass to keep its butterflies' inputs in MR_PTS registers.
+bool smooth_plan(int n, MrFactors *F, int *tpt_out)
+{
+  if (n < 3 || n > 16384 || (n & (n - 1)) == 0) return false;
+  int q = n, nf = 0, tpt = 1;
+  MrFactors f{};
+  auto push = [&](int r) {
+    if (nf < MR_MAXF) f.r[nf] = r;
+    nf++;
+    const int U = MR_PTS / r, nb = n / r;
+    tpt = std::max(tpt, (nb + U - 1) / U);
+  };
+  int odd = n;
+  while ((odd & 1) == 0) odd >>= 1;
+  {
+    int o = odd;
+    for (int pr : {3, 5, 7, 11, 13})
+      while (o % pr == 0) o /= pr;
+    if (o != 1) return false;                           // a larger prime factor remains
+  }
+  q = n / odd;                                          // the power of two goes first: Ns stays a power of
+  while (q % 16 == 0) { push(16); q /= 16; }            // two through its passes and k = j mod Ns is a mask
+  if (q > 1) push(q);                                   // 8, 4 or 2
+  q = odd;
+  for (int pr : {13, 11, 7, 5, 3})
+    while (q % pr == 0) { push(pr); q /= pr; }
+  q = n / odd;
+  // Parity: beyond an odd part of 31 the reference's result carries the rounding of its float32
+  // Bluestein chirp (1e-5 of the maximum and more); a more accurate transform would leave the 1e-5
+  // band around it, so those sizes stay on the plan that reproduces the chirp (MIXED / ODD).
+  if (n / q > 31) return false;
+  if (nf > MR_MAXF) return false;
+  tpt = (tpt + 7) / 8 * 8;
+  if (tpt > 1024) return false;
+  f.nf = nf;
+  *F = f;
+  *tpt_out = tpt;
   return true;
 }
 
@@ -1019,6 +1224,11 @@ int plan_init(tsdgpu_fft *p, int n)
       (void) hipFuncSetAttribute((const void *) fft_cols_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       (void) hipGetLastError();
     }
+  } else if (smooth_plan(n, &p->mr, &p->mr_tpt) && getenv("TSDGPU_FFT_GENERIC") == nullptr && getenv("TSDGPU_FFT_NO_SMOOTH") == nullptr) {
+    p->kind = tsdgpu_fft::SMOOTH;
+    if ((rc = upload(&p->d_rot, twiddle_table(n, n)))) return rc;            // W_n^j
+    (void) hipFuncSetAttribute((const void *) fft_mr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void) hipGetLastError();
   } else if ((n & 1) == 0 && mixed_split(n, &p->mix_m, &p->mix_P) && getenv("TSDGPU_FFT_GENERIC") == nullptr) {
     p->kind = tsdgpu_fft::MIXED;
     const int m = p->mix_m, P = p->mix_P;
@@ -1274,6 +1484,14 @@ int step_device(tsdgpu_fft *p, const cpx *x, cpx *y, int batch, int forward, hip
       hipLaunchKernelGGL(fft_cols_kernel<false>, dim3((unsigned) cdiv(p->N1, tile2), (unsigned) batch), dim3(FFT_THREADS),
                          (size_t) tile2 * (p->N2 + 1) * sizeof(cpx), st, z, y, p->d_tw2, p->N2, p->logN2, p->N1,
                          p->d_thi, p->d_tlo, inverse, scale, tile2);
+      TSD_HIP(hipGetLastError());
+      return TSDGPU_OK;
+    }
+    case tsdgpu_fft::SMOOTH: {
+      const int tpt = p->mr_tpt, T = std::max(1, 256 / tpt), threads = T * tpt;
+      const size_t lds = (size_t) T * (n + n / 16 + 1) * sizeof(cpx);
+      hipLaunchKernelGGL(fft_mr_kernel, dim3((unsigned) cdiv(batch, T)), dim3(threads), lds, st, x, y, p->d_rot, p->mr, n, tpt,
+                         inverse, 1.0f / std::sqrt((float) n), batch);
       TSD_HIP(hipGetLastError());
       return TSDGPU_OK;
     }

@@ -255,3 +255,19 @@ def test_fft_persistent_batches(tg, orc, n, batch):
     assert relerr(z, x) <= 3e-5
     ex, ey = (np.abs(x) ** 2).sum(axis=1), (np.abs(y) ** 2).sum(axis=1)
     assert np.max(np.abs(ey / ex - 1)) <= 1e-5
+
+
+# smooth sizes (odd part <= 31 made of 3, 5, 7, 11, 13): the one-kernel mixed-radix plan -- every
+# radix, several transforms per workgroup with a ragged last workgroup, both directions
+@pytest.mark.parametrize("n,batch", [(3, 1000), (6, 37), (9, 50), (12, 37), (15, 129), (21, 77), (24, 5), (27, 40), (48, 67),
+                                     (80, 33), (96, 19), (448, 9), (1408, 5), (3328, 3), (9216, 3), (10752, 2), (12288, 3),
+                                     (12800, 2), (13824, 2), (15360, 3), (7168, 4), (26, 21), (22, 300), (100, 64), (168, 11), (13, 9), (11, 70)])
+@pytest.mark.parametrize("forward", [True, False])
+def test_fft_smooth_sizes(tg, orc, n, batch, forward):
+    x = crand((batch, n), n * 3 + batch)
+    p = tg.Fft(n, batch)
+    y = p.step(x, forward)
+    for b in sorted({0, 1 % batch, batch // 2, batch - 1}):
+        assert relerr(y[b], orc.fft(x[b], forward)) <= TOL, (n, b)
+    z = p.step(y, not forward)
+    assert relerr(z, x) <= 3e-5
