@@ -126,6 +126,16 @@ int tsdgpu_ola_read_spectra(tsdgpu_ola *h, void *host_dst, void *stream);
 int tsdgpu_ola_write_spectra(tsdgpu_ola *h, const void *host_src, void *stream);
 int tsdgpu_ola_destroy(tsdgpu_ola *h);
 
+/* --------------------------------------------------------------------------------------
+ * psd_welch (src/fourier/freqestim.cc:7-20): segments i = 0, N/2, N, ... while i + N < n of
+ * x (cfloat), each multiplied by the window (N floats; the reference passes fenêtre(fen, N, non)),
+ * S[k] = sum over the segments of |FFT_N(segment)|^2 (unitary FFT), fftshift-ed
+ * (fourier.hpp:232-248).  S: N floats, linear power -- the caller applies pow2db.  Framing, ONE
+ * batched FFT and the reduction over the segments run on the device; only x (if it is a host
+ * buffer) and the N sums cross PCIe.  *n_segments (optional) receives the segment count.
+ * ------------------------------------------------------------------------------------ */
+int tsdgpu_welch(const void *x, int64_t n, int N, const float *window, float *S, int64_t *n_segments, void *stream);
+
 /* fftshift (include/tsd/fourier.hpp:232-248): pure index permutation, bit-exact */
 int tsdgpu_fftshift(const void *x, void *y, int n, int data_type, void *stream);
 

@@ -98,6 +98,7 @@ def _declare(L):
     L.tsdgpu_ola_read_spectra.argtypes = [vp, vp, vp]
     L.tsdgpu_ola_write_spectra.argtypes = [vp, vp, vp]
     L.tsdgpu_ola_destroy.argtypes = [vp]
+    L.tsdgpu_welch.argtypes = [vp, C.c_int64, i32, vp, vp, C.POINTER(C.c_int64), vp]
 
 
 def device_count():
@@ -307,6 +308,17 @@ class Ola:
             self.close()
         except Exception:
             pass
+
+
+def welch(x, N, window):
+    """psd_welch's sum of periodograms (freqestim.cc:7-20): -> (S[N] float32 linear, fftshift-ed; segments)."""
+    assert _dtype_code(x) == C64
+    w = np.ascontiguousarray(window, np.float32)
+    assert w.shape[0] == N
+    S = np.empty(N, np.float32)
+    nseg = C.c_int64(0)
+    _check(lib().tsdgpu_welch(_ptr(x), int(x.shape[0]), int(N), w.ctypes.data, S.ctypes.data, C.byref(nseg), _stream_of(x, None)))
+    return S, nseg.value
 
 
 def rfft(x):

@@ -151,6 +151,44 @@ __global__ void ola_state_windowed_kernel(OlaW w, cpx *__restrict__ last, int64_
   if (i < w.Ne) last[i] = w.L(B - 1, i);
 }
 
+// ---- psd_welch ------------------------------------------------------------------------------------
+__global__ void welch_frame_kernel(const cpx *__restrict__ x, const float *__restrict__ w, cpx *__restrict__ seg, int N, int pas,
+                                   int64_t total)
+{
+  const int64_t idx = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int64_t k = idx / N;
+  const int j = (int) (idx - k * N);
+  const cpx v = x[k * pas + j];
+  const float f = w[j];
+  seg[idx] = make_float2(v.x * f, v.y * f);                       // x.segment(i, N) * f  (:15)
+}
+
+// part[g][i] = sum over the segments of group g of |X[seg][src(i)]|^2, src = the fftshift map
+// (res.head(N/2) = X.tail(N/2), fourier.hpp:232-248); consecutive threads = consecutive bins
+__global__ void welch_power_kernel(const cpx *__restrict__ X, float *__restrict__ part, int N, int64_t nseg, int64_t per_group)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int h = N / 2;
+  const int src = i < h ? N - h + i : i - h;
+  const int64_t k0 = (int64_t) blockIdx.y * per_group, k1 = min(k0 + per_group, nseg);
+  float acc = 0.f;
+  for (int64_t k = k0; k < k1; k++) {
+    const cpx v = X[k * N + src];
+    acc += v.x * v.x + v.y * v.y;                                 // abs2 (:16)
+  }
+  part[(size_t) blockIdx.y * N + i] = acc;
+}
+__global__ void welch_sum_kernel(const float *__restrict__ part, float *__restrict__ S, int N, int groups)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  float acc = 0.f;
+  for (int g = 0; g < groups; g++) acc += part[(size_t) g * N + i];
+  S[i] = acc;
+}
+
 inline unsigned nblk(int64_t total) { return (unsigned) cdiv(total, 256); }
 
 int ola_alloc(cpx **p, size_t count)
@@ -353,6 +391,54 @@ int tsdgpu_ola_step(tsdgpu_ola *h, const void *x, int64_t n, void *y, int64_t *n
   (void) sp;
   if ((rc = tsdgpu_ola_apply_response(h, stream))) return rc;
   return tsdgpu_ola_synthese(h, y, n_out, stream);
+}
+
+int tsdgpu_welch(const void *x, int64_t n, int N, const float *window, float *S, int64_t *n_segments, void *stream)
+{
+  TSD_CHECK(N >= 1 && N <= (1 << 24), "welch: N = %d", N);
+  TSD_CHECK(n >= 0 && (n == 0 || x != nullptr) && window != nullptr && S != nullptr, "welch: bad arguments");
+  hipStream_t st = (hipStream_t) stream;
+  const int pas = std::max(N / 2, 1);
+  int64_t nseg = 0;
+  if (n > N) nseg = (n - N - 1) / pas + 1;                         // i = 0, pas, ... while i + N < n  (:13)
+  if (n_segments) *n_segments = nseg;
+  TSD_CHECK(nseg <= 0x7fffffff, "welch: %lld segments in one call", (long long) nseg);
+  DevBuf xin, seg, part, wbuf, sout;
+  const void *dxv = nullptr, *dwv = nullptr;
+  void *dS = nullptr;
+  bool staged = false;
+  int rc = stage_in(x, (size_t) n * sizeof(cpx), xin, st, &dxv);
+  if (!rc) rc = stage_in(window, (size_t) N * sizeof(float), wbuf, st, &dwv);
+  if (!rc) rc = stage_out(S, (size_t) N * sizeof(float), sout, &dS, &staged);
+  tsdgpu_fft *plan = nullptr;
+  if (!rc && nseg == 0) {
+    if (hipMemsetAsync(dS, 0, (size_t) N * sizeof(float), st) != hipSuccess) rc = set_err(TSDGPU_ERR_HIP, "welch: memset failed");
+  } else if (!rc) {
+    const int64_t total = nseg * N;
+    const int groups = (int) std::min<int64_t>(64, nseg);
+    const int64_t per_group = cdiv(nseg, groups);
+    rc = seg.reserve((size_t) total * sizeof(cpx));
+    if (!rc) rc = part.reserve((size_t) groups * N * sizeof(float));
+    if (!rc) rc = tsdgpu_fft_create(&plan, N, (int) nseg);
+    if (!rc) {
+      hipLaunchKernelGGL(welch_frame_kernel, dim3(nblk(total)), dim3(256), 0, st, (const cpx *) dxv, (const float *) dwv,
+                         seg.as<cpx>(), N, pas, total);
+      if (hipGetLastError() != hipSuccess) rc = set_err(TSDGPU_ERR_HIP, "welch: launch failed");
+    }
+    if (!rc) rc = tsdgpu_fft_step(plan, seg.p, seg.p, (int) nseg, 1, st);
+    if (!rc) {
+      hipLaunchKernelGGL(welch_power_kernel, dim3(nblk(N), (unsigned) groups), dim3(256), 0, st, seg.as<cpx>(), part.as<float>(), N,
+                         nseg, per_group);
+      hipLaunchKernelGGL(welch_sum_kernel, dim3(nblk(N)), dim3(256), 0, st, part.as<float>(), (float *) dS, N, groups);
+      if (hipGetLastError() != hipSuccess) rc = set_err(TSDGPU_ERR_HIP, "welch: launch failed");
+    }
+  }
+  if (!rc) rc = finish_out(S, (size_t) N * sizeof(float), dS, staged, st);
+  // the scratch buffers die with the call: wait for the work that uses them
+  (void) hipStreamSynchronize(st);
+  if (plan) tsdgpu_fft_destroy(plan);
+  xin.release(); seg.release(); part.release(); wbuf.release(); sout.release();
+  return rc;
 }
 
 int tsdgpu_ola_destroy(tsdgpu_ola *h)

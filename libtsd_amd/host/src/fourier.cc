@@ -352,22 +352,10 @@ std::tuple<Vecf, Vecf> psd_welch(const Veccf &x, entier N, cstring fen)
 {
   if (N < 1) échec("psd_welch: N = {}", N);
   const Vecf f = tsd::filtrage::fenêtre(fen, N, false);
-  // segments i = 0, N/2, N, ... while i + N < x.rows()  (freqestim.cc:13)
-  const entier pas = std::max<entier>(N / 2, 1);
-  entier nseg = 0;
-  for (entier i = 0; i + N < x.rows(); i += pas) nseg++;
-  Vecf S = Vecf::zeros(N);
-  if (nseg > 0) {
-    Veccf seg(nseg * N);
-    for (entier k = 0; k < nseg; k++)
-      for (entier j = 0; j < N; j++) seg(k * N + j) = x(k * pas + j) * f(j);
-    tsdgpu_fft *plan = nullptr;
-    if (tsdgpu_fft_create(&plan, N, nseg)) échec("psd_welch: {}", tsdgpu_last_error());
-    const int rc = tsdgpu_fft_step(plan, seg.data(), seg.data(), nseg, 1, nullptr);
-    tsdgpu_fft_destroy(plan);
-    if (rc) échec("psd_welch: {}", tsdgpu_last_error());
-    for (entier k = 0; k < nseg; k++) S += fftshift(abs2(seg.segment(k * N, N)));
-  }
+  // segments i = 0, N/2, N, ... while i + N < x.rows() (freqestim.cc:13): framing, one batched FFT
+  // and the sum of the periodograms run on the device (tsdgpu_welch); N floats come back
+  Vecf S(N);
+  if (tsdgpu_welch(x.data(), x.rows(), N, f.data(), S.data(), nullptr, nullptr)) échec("psd_welch: {}", tsdgpu_last_error());
   return {psd_freqs(N), pow2db(S)};
 }
 

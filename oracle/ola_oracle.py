@@ -82,3 +82,21 @@ class Ola:
         self.cnt_ech += h
         self.padded[Nz:Nz + h] = x[h:]                                    # :926
         return y
+
+
+def psd_welch_sum(x, N, window):
+    """psd_welch before pow2db (freqestim.cc:7-20): S += fftshift(abs2(fft(x.segment(i, N) * f)))
+    for i = 0, N/2, ... while i + N < len(x); fftshift as fourier.hpp:232-248."""
+    x = np.asarray(x, c64)
+    f = np.asarray(window, f32)
+    S = np.zeros(N, f32)
+    pas = max(N // 2, 1)
+    i, nseg = 0, 0
+    h = N // 2
+    while i + N < len(x):
+        X = orc.fft((x[i:i + N] * f).astype(c64), True)
+        p = (X.real * X.real + X.imag * X.imag).astype(f32)
+        S += np.concatenate([p[N - h:], p[:N - h]])
+        i += pas
+        nseg += 1
+    return S, nseg
