@@ -276,3 +276,49 @@ def test_polyphase_stages(orc):
     xp = np.concatenate([np.zeros(2, np.float32), xx])
     ref = np.array([np.dot(hh, xp[a:a + 3]) for a in range(1, 12, 2)], np.float32)
     assert np.array_equal(y, ref)
+
+
+# ---- OLA engine / psd_welch restatements (oracle/ola_oracle.py): no reference test holds numbers for
+# them (core/tests/test-filtre-fft.cc only plots), so they are pinned on what the reference code
+# implies: identity processing = pure delay, FiltreFFTRIF's H = the direct FIR delayed by Ne - M
+# (the contract core/tests/test-filtres.cc:514-554 checks through filtre_rif_fft), Welch = numpy.
+def test_ola_oracle_identity_and_fir(orc):
+    from oracle import ola_oracle
+    rng = np.random.default_rng(1)
+    x = (rng.standard_normal(8192) + 1j * rng.standard_normal(8192)).astype(np.complex64)
+    Ne = 512
+    y = ola_oracle.Ola(Ne, 0, None, lambda X: X).step(x)
+    assert np.abs(y[Ne:] - x[:-Ne]).max() < 1e-5 and np.abs(y[:Ne]).max() == 0
+    yw = ola_oracle.Ola(Ne, 0, ola_oracle.fen_hann_periodique(Ne), lambda X: X).step(x)
+    assert len(yw) == len(x) - Ne and np.abs(yw[Ne // 2:] - 0.5 * x[:len(yw) - Ne // 2]).max() < 1e-5
+    M = 127
+    h = orc.design_rif_fen(M, "lp", 0.02)                        # the design of test_rif_vs_rif_fft
+    o = ola_oracle.Ola(Ne, M, None, None)
+    h2 = np.zeros(o.N, np.complex64)
+    h2[o.N - M:] = h
+    H = orc.fft(h2, True) * np.float32(np.sqrt(o.N))             # fourier.cc:963-966
+    o.cb = lambda X: X * H
+    y = o.step(x)
+    ref = orc.fir(h, x)
+    d = Ne - M                                                   # = Nz - M for the reference's Ne = Nz = 512
+    assert np.abs(y[d:] - ref[:len(y) - d]).max() <= 1e-5 * np.abs(ref).max()
+
+
+def test_welch_oracle_against_numpy(orc):
+    from oracle import ola_oracle
+    rng = np.random.default_rng(2)
+    for N in (64, 100, 129):
+        x = (rng.standard_normal(20 * N + 3) + 1j * rng.standard_normal(20 * N + 3)).astype(np.complex64)
+        w = ola_oracle.fen_hann_periodique(N)
+        S, nseg = ola_oracle.psd_welch_sum(x, N, w)
+        ref = np.zeros(N)
+        k = 0
+        i = 0
+        while i + N < len(x):
+            X = np.fft.fft(x[i:i + N].astype(np.complex128) * w) / np.sqrt(N)
+            p = np.abs(X) ** 2
+            h = N // 2
+            ref += np.concatenate([p[N - h:], p[:N - h]])
+            i += max(N // 2, 1)
+            k += 1
+        assert k == nseg and np.abs(S - ref).max() <= 2e-5 * ref.max()
