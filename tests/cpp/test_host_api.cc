@@ -974,6 +974,85 @@ static void test_rt_spectrum()
   CHECK(threw, "rt_spectrum must reject a block of the wrong size");
 }
 
+// ---- test_ccorr (test-fourier.cc:575-607): circular correlation against its definition
+static void test_ccorr()
+{
+  for (int n : {1, 2, 3, 10, 15, 16, 21, 32}) {
+    Veccf a1 = randcn(n), a2 = randcn(n);
+    auto [lags, c] = ccorr(a1, a2);
+    float err = 0;
+    for (int i = 0; i < n; i++) {
+      cfloat s = 0;
+      for (int k = 0; k < n; k++) s += a1(k) * std::conj(a2((k + i) % n));
+      err = std::max(err, (float) std::abs(s / (float) n - c(i)));
+    }
+    CHECK(c.rows() == n && lags.rows() == n && err < 1e-5f, "ccorr n=%d err %g", n, err);
+  }
+}
+
+// ---- test_csym (test-fourier.cc:659-675): a spectrum forced conjugate-symmetric has a real inverse
+static void test_csym(int n)
+{
+  Veccf X = randcn(n);
+  csym_forçage(X);
+  Veccf x1 = ifft(X);
+  float e1 = 0, e2 = 0;
+  for (int i = 0; i < n; i++) e1 = std::max(e1, std::abs(x1(i).imag()));
+  // the direct inverse DFT in double (the reference's tfd<cfloat>(X, oui) yardstick)
+  for (int t = 0; t < n; t++) {
+    double im = 0;
+    for (int k = 0; k < n; k++) {
+      const double a = 2 * π * (double) ((long) k * t % n) / n;
+      im += X(k).real() * std::sin(a) + X(k).imag() * std::cos(a);
+    }
+    e2 = std::max(e2, (float) std::abs(im / std::sqrt((double) n)));
+  }
+  CHECK(e1 < 1e-3f && e2 < 2e-6f, "csym n=%d: imaginary residue %g (fft) %g (dft)", n, e1, e2);
+}
+
+// ---- test_rfftplan (test-fourier.cc:27-37) and test_fftshift (:39-72)
+static void test_rfftplan_ref()
+{
+  Vecf x = randn(101);
+  auto plan = rtfrplan_création();
+  Veccf y = plan->step(x), r = rfft(x);
+  float err = 0;
+  for (int i = 0; i < 101; i++) err = std::max(err, (float) std::abs(y(i) - r(i)));
+  CHECK(y.rows() == 101 && err < 1e-6f, "rfftplan err %g", err);
+}
+static void test_fftshift_ref(int n)
+{
+  Vecf x = linspace(0, n - 1, n), y = fftshift(x);
+  const int m = n / 2;
+  bool ok = y.rows() == n;
+  for (int i = 0; i < n && ok; i++) {
+    const float ref = (n & 1) ? (i < m ? m + 1 + i : i - m) : (i < m ? m + i : i - m);
+    ok = y(i) == ref;
+  }
+  CHECK(ok, "fftshift(%d)", n);
+}
+
+// ---- test_filtfilt (test-filtres.cc:267-293; the reference only plots -- "TODO : automatiser"):
+// forward-backward filtering = filter, reverse, filter, reverse, hence zero phase: a symmetric
+// input stays symmetric about the same point, while the one-way output is shifted by (K-1)/2
+static void test_filtfilt()
+{
+  const int n = 500;
+  Vecf x(n);
+  for (int i = 0; i < n / 2; i++) x(i) = x(n - 1 - i) = (float) i;
+  Vecf h = design_rif_fen(63, "lp", 0.05f);
+  Vecf y1 = filtrer(h, x), y = filtfilt(h, x);
+  Vecf manual = filtrer(h, filtrer(h, x).reverse()).reverse();
+  float e = 0, asym = 0, asym1 = 0;
+  for (int i = 0; i < n; i++) e = std::max(e, std::abs(y(i) - manual(i)));
+  for (int i = 100; i < 400; i++) {
+    asym = std::max(asym, std::abs(y(i) - y(n - 1 - i)));
+    asym1 = std::max(asym1, std::abs(y1(i) - y1(n - 1 - i)));
+  }
+  CHECK(y.rows() == n && e == 0.0f, "filtfilt vs its definition: %g", e);
+  CHECK(asym < 0.05f * 250 && asym1 > 20.0f, "filtfilt zero phase: asymmetry %g (one-way filter: %g)", asym, asym1);
+}
+
 // Spectrum's OpenMP loop calls plan->step on ONE plan from several threads (fourier.cc:1244-1252):
 // a plan must give every caller its own transform although the scratch buffers are shared.
 static void test_plan_concurrent(int n)
@@ -1035,6 +1114,12 @@ int main(int argc, char **argv)
   test_filtre_fft();
   test_psd();
   test_rt_spectrum();
+  test_ccorr();
+  for (int n : {3, 4, 5, 63, 64, 511, 512, 1000, 1001}) test_csym(n);
+  test_rfftplan_ref();
+  test_fftshift_ref(15);
+  test_fftshift_ref(16);
+  test_filtfilt();
   for (int n : {4096, 1 << 18, 3000, 1001}) test_plan_concurrent(n);
   test_ra();
   test_ligne_a_retard_ref(0);
