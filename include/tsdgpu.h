@@ -170,6 +170,12 @@ int tsdgpu_sos_destroy(tsdgpu_sos *s);
 typedef struct tsdgpu_resampler tsdgpu_resampler;
 int tsdgpu_resampler_create(tsdgpu_resampler **out, int data_type, float ratio,
                             const float *lut_host, int K, int nphases);
+/* The interpolators whose taps are a function of the float phase itself (src/reechan/itrp.cc:80-133):
+ * InterpolateurLineaire, coefs(tau) = {1 - tau, tau}, and InterpolateurLagrange of degree d
+ * (d + 1 taps, evaluated at (d-1)/2 + tau).  Same recurrence, schedule and state as above. */
+#define TSDGPU_ITRP_LINEAR 1
+#define TSDGPU_ITRP_LAGRANGE 2
+int tsdgpu_resampler_create_analytic(tsdgpu_resampler **out, int data_type, float ratio, int kind, int degree);
 /* number of outputs the next step of n inputs will produce (advances nothing) */
 int64_t tsdgpu_resampler_out_count(tsdgpu_resampler *r, int64_t n);
 int tsdgpu_resampler_step(tsdgpu_resampler *r, const void *x, int64_t n,

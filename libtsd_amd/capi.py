@@ -62,6 +62,7 @@ def _declare(L):
     L.tsdgpu_resampler_create.argtypes = [C.POINTER(vp), i32, fl, vp, i32, i32]
     L.tsdgpu_resampler_out_count.argtypes = [vp, i64]
     L.tsdgpu_resampler_out_count.restype = i64
+    L.tsdgpu_resampler_create_analytic.argtypes = [C.POINTER(vp), i32, fl, i32, i32]
     L.tsdgpu_resampler_step.argtypes = [vp, vp, i64, vp, i64, C.POINTER(i64), vp]
     L.tsdgpu_resampler_reset.argtypes = [vp]
     L.tsdgpu_resampler_seek.argtypes = [vp, i64, vp, vp]
@@ -398,8 +399,14 @@ class Resampler:
     """filtre_itrp<T>(ratio, itrp_sinc{K,nphases,fcut,"hn"}) (ra.cc:13-79,185-188).  With the
     defaults this is the interpolator filtre_reechan configures for a ratio in [0.5,2)."""
 
-    def __init__(self, ratio, data_type, K=15, nphases=256, fcut=None, lut=None):
+    def __init__(self, ratio, data_type, K=15, nphases=256, fcut=None, lut=None, analytic=None):
         ratio = float(np.float32(ratio))
+        if analytic is not None:          # ("lin", 0) = itrp_lineaire, ("lagrange", d) = itrp_lagrange(d)
+            kind, d = analytic
+            self.ratio, self.K, self.data_type = ratio, (2 if kind == "lin" else d + 1), data_type
+            self._h = C.c_void_p()
+            _check(lib().tsdgpu_resampler_create_analytic(C.byref(self._h), data_type, ratio, 1 if kind == "lin" else 2, int(d)))
+            return
         if lut is None:
             if fcut is None:
                 fcut = float(min(np.float32(0.4), np.float32(ratio) / np.float32(2)))      # ra.cc:149

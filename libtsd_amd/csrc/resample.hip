@@ -42,6 +42,7 @@ struct RsParams {
   float inc;          // 1/ratio as float (ra.cc:29)
   int K, nph, lstride, rec_cap;
   int lut_in_lds;     // generic kernel: LUT staged in LDS (1) or read from global memory (0: large K)
+  int mode;           // 0: table; 1: InterpolateurLineaire; 2: InterpolateurLagrange of degree K-1 (itrp.cc:80-133)
 };
 
 struct RsCk { uint32_t phase_bits; uint32_t cum; };
@@ -95,9 +96,10 @@ __global__ __launch_bounds__(RS_THREADS) void resample_kernel(const T *__restric
   float *lut_s = reinterpret_cast<float *>(smem_raw);                       // (nph+1) x lstride, 16-B aligned
   char *wbase = reinterpret_cast<char *>(lut_s + (P.lut_in_lds ? ((P.nph + 1) * lstride + 3) / 4 * 4 : 4));
   const int tile_elems = rs_tile_elems(K);
-  const size_t wbytes = ((size_t) tile_elems * sizeof(T) + (size_t) P.rec_cap * 4 + 15) / 16 * 16;
+  const size_t wbytes = ((size_t) tile_elems * sizeof(T) + (size_t) P.rec_cap * (P.mode ? 8 : 4) + 15) / 16 * 16;
   T *tile = reinterpret_cast<T *>(wbase + wv * wbytes);
   uint32_t *rec = reinterpret_cast<uint32_t *>(tile + tile_elems);
+  float *rec_tau = reinterpret_cast<float *>(rec + P.rec_cap);      // analytic interpolators: the phase itself
 
   // ---- stage the LUT once per (persistent) workgroup (a LUT too large for LDS is read in place)
   const int lut_n = P.lut_in_lds ? (P.nph + 1) * K : 0;
@@ -205,6 +207,7 @@ __global__ __launch_bounds__(RS_THREADS) void resample_kernel(const T *__restric
         if (live) {
           const int o = (int) (cum - cum_t0);
           rec[o] = ((uint32_t) (lane * RS_SEG + s) << 13) | (uint32_t) (int) (phase * fnph);   // itrp.cc:19
+          if (P.mode) rec_tau[o] = phase;
           last = o + 1;
         }
         phase = phase + inc;                                // ra.cc:71, float32 add
@@ -235,8 +238,22 @@ __global__ __launch_bounds__(RS_THREADS) void resample_kernel(const T *__restric
         }
 #pragma unroll
         for (int k = 0; k < 15; k++) acc = tap_mac(acc, hh[k], w[k]);   // filtrage.hpp:1877-1879 order
-      } else {
+      } else if (P.mode == 0) {
         for (int k = 0; k < K; k++) acc = tap_mac(acc, h[k], w[k]);
+      } else if (P.mode == 1) {
+        const float tau = rec_tau[o];                          // coefs(tau) = {1 - tau, tau}  (itrp.cc:83-86)
+        acc = tap_mac(acc, 1.f - tau, w[0]);
+        acc = tap_mac(acc, tau, w[1]);
+      } else {
+        // Lagrange of degree d through the points 0..d, evaluated at (d-1)/2 + tau (itrp.cc:112-132)
+        const int d = K - 1;
+        const float t = ((d - 1.0f) / 2) + rec_tau[o];
+        for (int j = 0; j <= d; j++) {
+          float p = 1.0f;
+          for (int k = 0; k <= d; k++)
+            if (k != j) p *= (t - k) / (j - k);
+          acc = tap_mac(acc, p, w[j]);
+        }
       }
       yt[o] = acc;
     }
@@ -426,7 +443,7 @@ __global__ void rs_hist_update_kernel(const T *__restrict__ x, const T *__restri
 using namespace tsdgpu;
 
 struct tsdgpu_resampler {
-  int data_type = 0, K = 0, nph = 0, lstride = 0;
+  int data_type = 0, K = 0, nph = 0, lstride = 0, mode = 0;
   float ratio = 1.f, inc = 1.f;
   float *d_lut = nullptr;
   void *d_hist[2] = {nullptr, nullptr};
@@ -596,6 +613,20 @@ int tsdgpu_resampler_create(tsdgpu_resampler **out, int data_type, float ratio, 
   return TSDGPU_OK;
 }
 
+int tsdgpu_resampler_create_analytic(tsdgpu_resampler **out, int data_type, float ratio, int kind, int degree)
+{
+  TSD_CHECK(out != nullptr, "resampler_create_analytic: out is NULL");
+  *out = nullptr;
+  TSD_CHECK(kind == TSDGPU_ITRP_LINEAR || kind == TSDGPU_ITRP_LAGRANGE, "resampler_create_analytic: kind %d", kind);
+  TSD_CHECK(kind == TSDGPU_ITRP_LINEAR || (degree >= 1 && degree <= 31), "resampler_create_analytic: Lagrange degree %d (1..31)", degree);
+  const int K = kind == TSDGPU_ITRP_LINEAR ? 2 : degree + 1;
+  std::vector<float> dummy((size_t) 2 * K, 0.f);       // no table: the taps come from the phase
+  int rc = tsdgpu_resampler_create(out, data_type, ratio, dummy.data(), K, 1);
+  if (rc) return rc;
+  (*out)->mode = kind;
+  return TSDGPU_OK;
+}
+
 int64_t tsdgpu_resampler_out_count(tsdgpu_resampler *r, int64_t n)
 {
   if (!r || n < 0) return -1;
@@ -644,13 +675,14 @@ int tsdgpu_resampler_step(tsdgpu_resampler *r, const void *x, int64_t n, void *y
   P.K = r->K;
   P.nph = r->nph;
   P.lstride = r->lstride;
+  P.mode = r->mode;
   // at most floor(1/inc)+1 outputs per input
   // outputs are spaced 1/ratio apart in input time (up to float32 rounding of the adds)
   P.rec_cap = ((int) ((double) RS_TI * (double) r->ratio * 1.0001) + 32 + 3) / 4 * 4;
   const int64_t tiles = cdiv(r->pos + n - P.tile0, RS_TI);
   TSD_CHECK(tiles <= 0x7fffffff, "resampler_step: n too large for one launch");
   const int lstride = r->K == 15 ? 20 : r->lstride;
-  const size_t wbytes = ((size_t) rs_tile_elems(r->K) * sz + (size_t) P.rec_cap * 4 + 15) / 16 * 16;
+  const size_t wbytes = ((size_t) rs_tile_elems(r->K) * sz + (size_t) P.rec_cap * (r->mode ? 8 : 4) + 15) / 16 * 16;
   P.lut_in_lds = (size_t) (r->nph + 1) * lstride * 4 <= (size_t) RS_LUT_LDS_BYTES ? 1 : 0;
   const size_t lds = (size_t) (P.lut_in_lds ? (r->nph + 1) * lstride + 4 : 8) * 4 + RS_WAVES * wbytes + 64;
   TSD_CHECK(lds <= 158 * 1024, "resampler_step: configuration needs %zu bytes of LDS", lds);
@@ -660,7 +692,7 @@ int tsdgpu_resampler_step(tsdgpu_resampler *r, const void *x, int64_t n, void *y
   const int64_t pgrid = std::min<int64_t>(cdiv(tiles, RS_WAVES), (int64_t) 256 * per_cu);
   const size_t wb15 = ((size_t) std::max(RS15_TILE_PAD, P.rec_cap) * sz + 15) / 16 * 16;
   const size_t lds15 = (size_t) ((r->nph + 1) * 20 + 4) * 4 + RS15_WAVES * wb15 + 64;
-  if (r->K == 15 && lds15 <= 158 * 1024) {     // fused kernel; larger ratios fall back to the generic one
+  if (r->K == 15 && r->mode == 0 && lds15 <= 158 * 1024) {     // fused kernel; larger ratios fall back to the generic one
     const int64_t g15 = std::min<int64_t>(cdiv(tiles, RS15_WAVES), 256);
     if (r->data_type == TSDGPU_C64)
       hipLaunchKernelGGL(resample15_kernel<float2>, dim3((unsigned) g15), dim3(64 * RS15_WAVES), lds15, st, (const float2 *) dx,

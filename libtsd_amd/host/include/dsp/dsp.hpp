@@ -34,6 +34,9 @@ template <typename T> sptr<FilterGen<T>> filter_fir_fft(const Vecf &h) { return 
 template <typename T> sptr<FilterGen<T>> filter_sois(const FRat<cfloat> &h, RIIStructure s = FormeDirecte2) { return tsd::filtrage::filtre_sois<T>(h, s); }
 template <typename T> sptr<FilterGen<T>> filter_sois(const FRat<float> &h, RIIStructure s = FormeDirecte2) { return tsd::filtrage::filtre_sois<T>(h, s); }
 template <typename T> sptr<Filter<T, T, float>> filter_resample(float ratio) { return tsd::filtrage::filtre_reechan<T>(ratio); }
+// interpolators (dsp/filter.hpp:1762-1805): linear, Lagrange, cubic spline, windowed sinc
+template <typename T> auto itrp_linear() { return tsd::filtrage::itrp_lineaire<T>(); }
+template <typename T> auto itrp_lagrange(int degree) { return tsd::filtrage::itrp_lagrange<T>(degree); }
 // dsp/filter.hpp:1128-1164,1288-1292,1354-1358,1407-1411,1578-1631,1827-1883,1910
 using Frequency = tsd::filtrage::Fréquence;
 inline float ema_coef(Frequency fc) { return tsd::filtrage::lexp_coef(fc); }

@@ -155,7 +155,8 @@ struct InterpolateurSincConfig {
 // Interpolators whose coefficients come from a table indexed by (int)(τ * nphases) -- the sinc
 // (itrp.cc:10-55) and the cubic spline (itrp.cc:56-79,293-320) -- expose it so that the GPU
 // resampler takes it as is.  itrp_lineaire / itrp_lagrange evaluate their coefficients from the
-// float phase itself (itrp.cc:81-135): they are not built.
+// float phase itself (itrp.cc:80-133): the GPU resampler evaluates the same formulas per output
+// (tsdgpu_resampler_create_analytic).
 template <typename T> struct InterpolateurLut : InterpolateurRIF<T> {
   entier nphases = 0;
   std::vector<float> lut;   // phase-major [(nphases+1) x K]
@@ -168,6 +169,33 @@ template <typename T> struct InterpolateurSinc : InterpolateurLut<T> {
 template <typename T> struct InterpolateurCSpline : InterpolateurLut<T> {
   explicit InterpolateurCSpline(entier n = 256, float c = 0);
 };
+template <typename T> struct InterpolateurLineaire : InterpolateurRIF<T> {      // itrp.cc:80-94
+  InterpolateurLineaire() { this->nom = "linéaire"; this->K = 2; this->delais = 0.5f; }
+  Vecf coefs(float τ) override { return Vecf::valeurs({1 - τ, τ}); }
+};
+template <typename T> struct InterpolateurLagrange : InterpolateurRIF<T> {      // itrp.cc:96-133
+  entier d;
+  explicit InterpolateurLagrange(entier d_) : d(d_)
+  {
+    this->nom = "Lagrange degré " + std::to_string(d);
+    this->K = d + 1;
+    this->delais = 0.5f * d;
+  }
+  Vecf coefs(float τ) override
+  {
+    Vecf h(d + 1);
+    const float t = ((d - 1.0f) / 2) + τ;
+    for (entier j = 0; j <= d; j++) {
+      float p = 1.0f;
+      for (entier k = 0; k <= d; k++)
+        if (k != j) p *= (t - k) / (j - k);
+      h(j) = p;
+    }
+    return h;
+  }
+};
+template <typename T> sptr<Interpolateur<T>> itrp_lineaire() { return std::make_shared<InterpolateurLineaire<T>>(); }
+template <typename T> sptr<Interpolateur<T>> itrp_lagrange(entier degré) { return std::make_shared<InterpolateurLagrange<T>>(degré); }
 template <typename T> sptr<Interpolateur<T>> itrp_cspline();
 template <typename T> sptr<Interpolateur<T>> itrp_sinc(const InterpolateurSincConfig &config);
 template <typename T> sptr<FiltreGen<T>> filtre_itrp(float ratio, sptr<Interpolateur<T>> itrp);

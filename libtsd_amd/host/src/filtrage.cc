@@ -555,14 +555,21 @@ template <typename T> sptr<Interpolateur<T>> itrp_sinc(const InterpolateurSincCo
 template sptr<Interpolateur<float>> itrp_sinc<float>(const InterpolateurSincConfig &);
 template sptr<Interpolateur<cfloat>> itrp_sinc<cfloat>(const InterpolateurSincConfig &);
 
-// AdaptationRythmeSimple (ra.cc:13-79) on the GPU resampler; needs a table-driven interpolator
+// AdaptationRythmeSimple (ra.cc:13-79) on the GPU resampler: table-driven or analytic interpolators
 template <typename T> struct AdaptationRythmeSimpleGpu : FiltreGen<T> {
   tsdgpu_resampler *h = nullptr;
   AdaptationRythmeSimpleGpu(float ratio, sptr<Interpolateur<T>> itrp)
   {
-    auto s = std::dynamic_pointer_cast<InterpolateurLut<T>>(itrp);
-    if (!s) échec("filtre_itrp: only table-driven interpolators (itrp_sinc, itrp_cspline) run on the GPU path");
-    if (tsdgpu_resampler_create(&h, dtype_of<T>(), ratio, s->lut.data(), s->K, s->nphases)) gpu_fail("filtre_itrp");
+    if (auto s = std::dynamic_pointer_cast<InterpolateurLut<T>>(itrp)) {
+      if (tsdgpu_resampler_create(&h, dtype_of<T>(), ratio, s->lut.data(), s->K, s->nphases)) gpu_fail("filtre_itrp");
+    } else if (std::dynamic_pointer_cast<InterpolateurLineaire<T>>(itrp)) {
+      if (tsdgpu_resampler_create_analytic(&h, dtype_of<T>(), ratio, TSDGPU_ITRP_LINEAR, 1)) gpu_fail("filtre_itrp");
+    } else if (auto l = std::dynamic_pointer_cast<InterpolateurLagrange<T>>(itrp)) {
+      if (tsdgpu_resampler_create_analytic(&h, dtype_of<T>(), ratio, TSDGPU_ITRP_LAGRANGE, l->d)) gpu_fail("filtre_itrp");
+    } else {
+      échec("filtre_itrp: interpolator '{}' is neither table-driven (itrp_sinc, itrp_cspline) nor one of itrp_lineaire / "
+            "itrp_lagrange: no GPU path for a user-defined coefs()", itrp ? itrp->nom : std::string("null"));
+    }
   }
   ~AdaptationRythmeSimpleGpu() override { tsdgpu_resampler_destroy(h); }
   void step(const Vecteur<T> &x, Vecteur<T> &y) override

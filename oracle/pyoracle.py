@@ -82,7 +82,7 @@ class SosStateC(C.Structure):
 class Ra(C.Structure):
     _fields_ = [("phase", C.c_float), ("ratio", C.c_float), ("increment", C.c_float),
                 ("K", C.c_int), ("nphases", C.c_int), ("lut", C.c_void_p),
-                ("fen_f", C.c_float * 256), ("fen_c", CF * 256)]
+                ("fen_f", C.c_float * 256), ("fen_c", CF * 256), ("mode", C.c_int)]
 
 
 def _declare(L):
@@ -106,6 +106,7 @@ def _declare(L):
     L.orc_next_pow2.argtypes = [i32]
     L.orc_next_pow2.restype = i32
     L.orc_itrp_sinc_lut.argtypes = [i32, i32, fl, vp]
+    L.orc_ra_init_analytic.argtypes = [vp, fl, i32, i32]
     L.orc_ra_init.argtypes = [vp, fl, i32, i32, vp]
     L.orc_ra_step_c.argtypes = [vp, vp, i64, vp]
     L.orc_ra_step_c.restype = i64
@@ -310,8 +311,15 @@ def reechan_config(ratio):
 class Resampler:
     """filtre_itrp<T>(ratio, itrp_sinc{K,nphases,fcut,"hn"}) (ra.cc:13-79)."""
 
-    def __init__(self, ratio, K=15, nphases=256, fcut=None):
+    def __init__(self, ratio, K=15, nphases=256, fcut=None, analytic=None):
         ratio = float(np.float32(ratio))
+        if analytic is not None:
+            # ("lin", 0) = itrp_lineaire, ("lagrange", d) = itrp_lagrange(d)  (itrp.cc:80-133)
+            kind, d = analytic
+            self.r = Ra()
+            lib().orc_ra_init_analytic(C.byref(self.r), ratio, 1 if kind == "lin" else 2, int(d))
+            self.ratio = ratio
+            return
         if fcut is None:
             fcut = min(np.float32(0.4), np.float32(ratio) / np.float32(2))
         self.lut = itrp_sinc_lut(K, nphases, float(fcut))

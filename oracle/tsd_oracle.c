@@ -543,6 +543,33 @@ void orc_ra_init(orc_ra *r, float ratio, int K, int nphases, const float *lut)
   r->K = K; r->nphases = nphases; r->lut = lut;
 }
 
+void orc_ra_init_analytic(orc_ra *r, float ratio, int mode, int degree)
+{
+  orc_ra_init(r, ratio, mode == 1 ? 2 : degree + 1, 1, NULL);
+  r->mode = mode;
+}
+
+/* coefs(tau): the table column (itrp.cc:16-22), InterpolateurLineaire::coefs (itrp.cc:83-86) or
+ * InterpolateurLagrange::coefs (itrp.cc:112-132) */
+static const float *ra_coefs(const orc_ra *r, float phase, float *buf)
+{
+  if (r->mode == 0) return r->lut + (size_t) ((int) (phase * r->nphases)) * r->K;
+  if (r->mode == 1) {
+    buf[0] = 1 - phase;
+    buf[1] = phase;
+    return buf;
+  }
+  const int d = r->K - 1;
+  const float t = ((d - 1.0f) / 2) + phase;
+  for (int j = 0; j <= d; j++) {
+    float p = 1.0f;
+    for (int k = 0; k <= d; k++)
+      if (k != j) p *= (t - k) / (j - k);
+    buf[j] = p;
+  }
+  return buf;
+}
+
 /* AdaptationRythmeSimple::step, ra.cc:39-77 with InterpolateurRIF::step
  * (filtrage.hpp:1873-1881) and InterpolateurSinc::coefs (itrp.cc:16-22) inlined. */
 int64_t orc_ra_step_c(orc_ra *r, const orc_cf *x, int64_t n, orc_cf *y)
@@ -555,8 +582,8 @@ int64_t orc_ra_step_c(orc_ra *r, const orc_cf *x, int64_t n, orc_cf *y)
     memmove(r->fen_c, r->fen_c + 1, sizeof(orc_cf) * (size_t) (K - 1));   /* :61 */
     r->fen_c[K - 1] = x[i];
     while (phase < 1) {
-      int lut_index = (int) (phase * r->nphases);
-      const float *h = r->lut + (size_t) lut_index * K;
+      float hbuf[256];
+      const float *h = ra_coefs(r, phase, hbuf);
       orc_cf res = cf(0, 0);
       for (int t = 0; t < K; t++) {            /* res += h(i) * x((i+k)%K), k = 0 */
         res.re += h[t] * r->fen_c[t].re;
@@ -581,8 +608,8 @@ int64_t orc_ra_step_f(orc_ra *r, const float *x, int64_t n, float *y)
     memmove(r->fen_f, r->fen_f + 1, sizeof(float) * (size_t) (K - 1));
     r->fen_f[K - 1] = x[i];
     while (phase < 1) {
-      int lut_index = (int) (phase * r->nphases);
-      const float *h = r->lut + (size_t) lut_index * K;
+      float hbuf[256];
+      const float *h = ra_coefs(r, phase, hbuf);
       float res = 0;
       for (int t = 0; t < K; t++) res += h[t] * r->fen_f[t];
       y[j++] = res;

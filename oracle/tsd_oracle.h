@@ -95,8 +95,11 @@ typedef struct {
   const float *lut;
   float  fen_f[256];
   orc_cf fen_c[256];
+  int   mode;                         /* 0: table (sinc / cspline); 1: InterpolateurLineaire; 2: InterpolateurLagrange */
 } orc_ra;
 void orc_ra_init(orc_ra *r, float ratio, int K, int nphases, const float *lut);
+/* analytic interpolators, src/reechan/itrp.cc:80-133: mode 1 = linear (K = 2), mode 2 = Lagrange of degree d (K = d+1) */
+void orc_ra_init_analytic(orc_ra *r, float ratio, int mode, int degree);
 /* AdaptationRythmeSimple::step. y must hold ceil(ratio*n)+10 samples. returns n_out.      */
 int64_t orc_ra_step_c(orc_ra *r, const orc_cf *x, int64_t n, orc_cf *y);
 int64_t orc_ra_step_f(orc_ra *r, const float *x, int64_t n, float *y);

@@ -783,6 +783,41 @@ static void test_ra()
       }
     }
     CHECK(std::abs(filtre_itrp<cfloat>(0.77f, itrp_cspline<cfloat>())->step(xs).rows() - 2310) <= 2, "cspline rows");
+    // the analytic interpolators of the same list (test-itrp.cc:65-72): itrp_lineaire, itrp_lagrange(1,2,3,5,6,7).
+    // Their taps sum to 1 for every phase, and the GPU resampler = the interpolator's own step() replayed
+    // on the host over AdaptationRythmeSimple's recurrence (ra.cc:56-77)
+    std::vector<sptr<Interpolateur<cfloat>>> lst{itrp_lineaire<cfloat>()};
+    for (int d : {1, 2, 3, 5, 6, 7}) lst.push_back(itrp_lagrange<cfloat>(d));
+    for (auto &it : lst) {
+      auto rif = std::dynamic_pointer_cast<InterpolateurRIF<cfloat>>(it);
+      float dev = 0;
+      for (float τ = 0; τ < 1; τ += 0.1f) {
+        const Vecf hc = rif->coefs(τ);
+        double sum = 0;
+        for (int k = 0; k < hc.rows(); k++) sum += hc(k);
+        dev = std::max(dev, (float) std::abs(sum - 1));
+      }
+      CHECK(dev < 1e-5f, "%s: taps sum to 1 (%g)", it->nom.c_str(), dev);
+      const float ratio = 1.3f;
+      Veccf ys = filtre_itrp<cfloat>(ratio, it)->step(xs);
+      const int K = it->K;
+      Veccf fen = Veccf::zeros(K), yr(ys.rows() + 8);
+      float phase = 0, inc = 1.0f / ratio;
+      int j = 0;
+      for (int i = 0; i < xs.rows(); i++) {
+        for (int k = 0; k + 1 < K; k++) fen(k) = fen(k + 1);
+        fen(K - 1) = xs(i);
+        while (phase < 1) {
+          if (j < yr.rows()) yr(j) = it->step(fen, 0, phase);
+          j++;
+          phase += inc;
+        }
+        phase -= 1;
+      }
+      float e = 0, m = 0;
+      for (int i = 0; i < std::min(j, ys.rows()); i++) { e = std::max(e, (float) std::abs(ys(i) - yr(i))); m = std::max(m, (float) std::abs(yr(i))); }
+      CHECK(j == ys.rows() && e <= 1e-5f * m, "filtre_itrp(%s): %d vs %d outputs, err %g", it->nom.c_str(), ys.rows(), j, e);
+    }
   }
   for (int R : {2, 3, 4, 5, 8}) test_ra_unit("rif decim", 1.0f / R, filtre_rif_decim<float, float>(design_rif_fen(15, "lp", 0.5f / R, "hn"), R));
 }

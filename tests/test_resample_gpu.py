@@ -142,3 +142,32 @@ def test_resample_bad_arguments(tg):
         tg.Resampler(0.0, tg.F32)
     with pytest.raises(tg.TsdGpuError):
         tg.Resampler(1.5, tg.F32, K=15, nphases=8192, lut=np.zeros((8193, 15), np.float32))   # nphases <= 8191
+
+
+# interpolators whose taps are a function of the float phase itself: itrp_lineaire and
+# itrp_lagrange(d), the degrees of the reference's interpolator list (test-itrp.cc:63-72)
+@pytest.mark.parametrize("analytic", [("lin", 0), ("lagrange", 1), ("lagrange", 2), ("lagrange", 3), ("lagrange", 5),
+                                      ("lagrange", 6), ("lagrange", 7)])
+@pytest.mark.parametrize("ratio", [1.5, 0.77, 160.0 / 147.0, 1.0, 3.1])
+@pytest.mark.parametrize("cplx", [False, True])
+def test_analytic_interpolators(tg, orc, analytic, ratio, cplx):
+    x = rand(60000, cplx, 17)
+    ref = orc.Resampler(ratio, analytic=analytic)
+    g = tg.Resampler(ratio, tg.C64 if cplx else tg.F32, analytic=analytic)
+    # ragged chunks: the window and the phase carry over
+    got, exp = [], []
+    for a, b in [(0, 1), (1, 4097), (4097, 4100), (4100, 60000)]:
+        got.append(g.step(x[a:b]))
+        exp.append(ref.step(x[a:b]))
+    y, r = np.concatenate(got), np.concatenate(exp)
+    assert y.shape == r.shape
+    assert relerr(y, r) <= TOL
+
+
+def test_linear_interpolator_on_a_ramp(tg):
+    """Linear interpolation reproduces a ramp exactly (up to rounding): y_j = x(t_j - 1), t_j = j / ratio."""
+    ratio = np.float32(1.25)
+    x = np.arange(5000, dtype=np.float32)
+    y = tg.Resampler(ratio, tg.F32, analytic=("lin", 0)).step(x)
+    t = np.arange(len(y), dtype=np.float64) / float(ratio)
+    assert np.max(np.abs(y[2:] - (t[2:] - 1.0))) < 2e-3
