@@ -1195,7 +1195,7 @@ int plan_init(tsdgpu_fft *p, int n)
       p->kind = tsdgpu_fft::POW2_LDS;
       rc = upload(&p->d_tw, twiddle_table(n, n / 2));
     } else {
-      TSD_CHECK(p->logn <= 24, "fft: n = %d exceeds the four-step limit 2^24", n);
+      TSD_CHECK(p->logn <= 28, "fft: n = %d exceeds the four-step limit 2^28 (two passes of at most 16384-point columns)", n);
       p->kind = tsdgpu_fft::POW2_4STEP;
       p->logN1 = p->logn / 2;
       p->logN2 = p->logn - p->logN1;
@@ -1593,7 +1593,7 @@ int tsdgpu_fft_create(tsdgpu_fft **out, int n, int batch_hint)
   TSD_CHECK(out != nullptr, "fft_create: out is NULL");
   *out = nullptr;
   TSD_CHECK(n >= 1, "fft_create: n must be >= 1 (got %d)", n);
-  TSD_CHECK(n <= (1 << 24), "fft_create: n = %d too large", n);
+  TSD_CHECK(n <= (1 << 28), "fft_create: n = %d too large (limit 2^28)", n);
   return plan_create(out, n);
 }
 

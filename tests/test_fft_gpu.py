@@ -271,3 +271,15 @@ def test_fft_smooth_sizes(tg, orc, n, batch, forward):
         assert relerr(y[b], orc.fft(x[b], forward)) <= TOL, (n, b)
     z = p.step(y, not forward)
     assert relerr(z, x) <= 3e-5
+
+
+# single transforms beyond 2^24 points (four-step with columns of up to 16384 points)
+@pytest.mark.parametrize("logn", [25, 26])
+def test_fft_very_large(tg, orc, logn):
+    n = 1 << logn
+    x = crand(n, logn)
+    y = tg.fft(x)
+    ref = orc.fft(x)
+    assert relerr(y, ref) <= TOL
+    z = tg.fft(y, False)
+    assert relerr(z, x) <= 3e-5
