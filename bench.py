@@ -55,7 +55,7 @@ def _time_cpu(fn, units_per_call, unit, what, seconds_target=12.0):
     t0 = time.perf_counter()
     fn()
     dt = time.perf_counter() - t0
-    reps = max(1, min(64, int(seconds_target / max(dt, 1e-3))))
+    reps = max(1, min(4096, int(seconds_target / max(dt, 1e-4))))   # ~12 s of CPU work
     t0 = time.perf_counter()
     for _ in range(reps):
         fn()
