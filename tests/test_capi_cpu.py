@@ -47,3 +47,31 @@ def test_product_never_touches_oracle():
     assert not bad, bad
     out = os.popen(f"ldd {os.path.join(ROOT, 'libtsd_amd', 'lib', 'libtsdgpu.so')}").read()
     assert "liborc" not in out
+
+
+def _build_c_example(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "fir_from_c")
+    libdir = os.path.join(ROOT, "libtsd_amd", "lib")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "examples", "fir_from_c.c"), "-L" + libdir, "-ltsdgpu", "-lm",
+                    "-Wl,-rpath," + libdir, "-o", exe], check=True, capture_output=True)
+    return exe
+
+
+def test_plain_c_example_builds_and_refuses_cpu(tmp_path):
+    """examples/fir_from_c.c: the ABI is usable from C99 with nothing but the header and the .so;
+    without a GPU the program reports it and exits with status 2 (no CPU fallback)."""
+    import subprocess
+    import libtsd_amd
+    exe = _build_c_example(tmp_path)
+    if libtsd_amd.device_count() == 0:
+        r = subprocess.run([exe], capture_output=True, text=True)
+        assert r.returncode == 2 and "no GPU" in r.stderr
+
+
+@pytest.mark.gpu
+def test_plain_c_example_runs(tmp_path):
+    import subprocess
+    r = subprocess.run([_build_c_example(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "C ABI example OK" in r.stdout, r.stdout + r.stderr
