@@ -458,7 +458,13 @@ __global__ __launch_bounds__(1024) void fft_cols16_kernel(const cpx *__restrict_
   const size_t boff = (size_t) blockIdx.y * (size_t) L * C;
   const cpx *x = in + boff;
   cpx *y = out + boff;
-  const int c0 = blockIdx.x * CT, h = CT >> 1;
+  // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs, so blockIdx.x, +8, +16 ...
+  // share an L2.  Tiles narrower than a 128-B line (CT < 16) split cache lines with their
+  // neighbours: give neighbouring tiles to the SAME XCD, back to back, so that the second one
+  // finds the line in L2 instead of fetching it again from HBM.
+  int tile = blockIdx.x;
+  if (CT < 16 && (gridDim.x & 7) == 0) tile = (int) (blockIdx.x & 7) * (int) (gridDim.x >> 3) + (int) (blockIdx.x >> 3);
+  const int c0 = tile * CT, h = CT >> 1;
   if (ragged) {
     // C is not a multiple of CT (or odd): 8-B accesses, columns beyond C read as zero
     for (int q = t; q < L * CT; q += nthr) {
