@@ -177,8 +177,11 @@ __global__ __launch_bounds__(256) void fft1024_rows_kernel(const cpx *__restrict
 template <int R0>
 __global__ __launch_bounds__(1024) void fft_s16_kernel(const cpx *__restrict__ in, cpx *__restrict__ out,
                                                        const cpx *__restrict__ TW, int n, int tpt, int inverse,
-                                                       float scale, int ntr)
+                                                       float scale, int ntr, const cpx *__restrict__ rrot)
 {
+  // rrot != nullptr: REAL FFT of 2n points per transform (RTFRPlan::step, fourier.cc:315-347): the n
+  // complex points are the packed pairs, and the untangling + forced conjugate symmetry below
+  // replace the plain store -- the half-size spectrum never goes to HBM.
   extern __shared__ __attribute__((aligned(16))) char s16_raw[];
   cpx *lds = reinterpret_cast<cpx *>(s16_raw);
   const int t = threadIdx.x;
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(1024) void fft_s16_kernel(const cpx *__restrict__ i
       w1024::dft16<false>(v);
       const int base = (j - k) * 16 + k;
       const bool last = Ns * 16 == n;
-      if (last && !staged) {
+      if (last && !staged && !rrot) {
         if (live) {
           cpx *y = out + (size_t) tr * n;
 #pragma unroll
@@ -261,8 +264,34 @@ __global__ __launch_bounds__(1024) void fft_s16_kernel(const cpx *__restrict__ i
       if (last) break;
     }
   }
-  // staged store: coalesced 16 B per lane
   __syncthreads();
+  if (rrot) {
+    // y(i) = r2 (Xt(i) + conj Xt(h-i)) - j2 (Xt(i) - conj Xt(h-i)) rot(i), i = 0..h, h = n; y(2h-i) = conj y(i)
+    // (the arithmetic of rfft_untangle_kernel, on the transform still in LDS)
+    const int h = n, per = h + 1, tot = T * per;
+    const float c = 0.35355339059327373f;                    // (float) (0.5 / sqrt(2.0))
+    int tq = t / per, i = t - tq * per;
+    const int dq = (int) blockDim.x / per, dr = (int) blockDim.x - dq * per;
+    for (int e = t; e < tot; e += blockDim.x) {
+      const int trq = blockIdx.x * T + tq;
+      if (trq < ntr) {
+        const cpx *X = lds + tq * pn;
+        const cpx X1 = cscale(X[s16::pad(i == h ? 0 : i)], scale), X2c = cconj(cscale(X[s16::pad(i > 0 ? h - i : 0)], scale));
+        const cpx a = cscale(cadd(X1, X2c), c);
+        const cpx d = csub(X1, X2c);
+        const cpx jd = cmk(-d.y * c, d.x * c);
+        cpx v = csub(a, cmul(jd, rrot[i]));
+        if (i == 0 || i == h) v.y = 0.f;
+        cpx *Y = out + (size_t) trq * 2 * h;
+        Y[i] = v;
+        if (i > 0 && i < h) Y[2 * h - i] = cconj(v);
+      }
+      tq += dq; i += dr;
+      if (i >= per) { i -= per; tq++; }
+    }
+    return;
+  }
+  // staged store: coalesced 16 B per lane
   const int tot2 = (T * n) >> 1;
   for (int i = t; i < tot2; i += blockDim.x) {
     const int e = 2 * i;
@@ -1408,7 +1437,7 @@ int step_device(tsdgpu_fft *p, const cpx *x, cpx *y, int batch, int forward, hip
           return TSDGPU_OK;
         }
       }
-#define S16_LAUNCH(R) hipLaunchKernelGGL((fft_s16_kernel<R>), dim3(grid), dim3(threads), lds, st, x, y, p->d_tw, n, tpt, inverse, scale, batch)
+#define S16_LAUNCH(R) hipLaunchKernelGGL((fft_s16_kernel<R>), dim3(grid), dim3(threads), lds, st, x, y, p->d_tw, n, tpt, inverse, scale, batch, (const cpx *) nullptr)
       if (r0 == 16) S16_LAUNCH(16); else if (r0 == 8) S16_LAUNCH(8); else if (r0 == 4) S16_LAUNCH(4); else S16_LAUNCH(2);
 #undef S16_LAUNCH
       TSD_HIP(hipGetLastError());
@@ -1727,7 +1756,18 @@ int tsdgpu_rfft_step(tsdgpu_rfft *p, const void *x, void *y, int batch, void *st
   if (rc) return rc;
   rc = stage_out(y, out_bytes, p->out_stage, &dy, &staged);
   if (rc) return rc;
-  if ((n & 1) == 0) {
+  if ((n & 1) == 0 && p->sub->kind == tsdgpu_fft::POW2_S16 && getenv("TSDGPU_RFFT_TWO_PASS") == nullptr) {
+    // half-size Stockham transform with the untangling fused into its store: one pass over HBM
+    const int h = n / 2, tpt = h / 16, threads = std::max(256, tpt), T = threads / tpt;
+    const size_t lds = (size_t) T * (h + h / 16) * sizeof(cpx);
+    const unsigned grid = (unsigned) cdiv(batch, T);
+    const int r0 = 1 << ((p->sub->logn & 3) == 0 ? 4 : (p->sub->logn & 3));
+    const float scale = 1.0f / std::sqrt((float) h);
+#define S16R_LAUNCH(R) hipLaunchKernelGGL((fft_s16_kernel<R>), dim3(grid), dim3(threads), lds, st, (const cpx *) dx, (cpx *) dy, p->sub->d_tw, h, tpt, 0, scale, batch, (const cpx *) p->d_rot)
+    if (r0 == 16) S16R_LAUNCH(16); else if (r0 == 8) S16R_LAUNCH(8); else if (r0 == 4) S16R_LAUNCH(4); else S16R_LAUNCH(2);
+#undef S16R_LAUNCH
+    TSD_HIP(hipGetLastError());
+  } else if ((n & 1) == 0) {
     const int h = n / 2;
     rc = p->work.reserve((size_t) h * batch * sizeof(cpx));
     if (rc) return rc;

@@ -283,3 +283,21 @@ def test_fft_very_large(tg, orc, logn):
     assert relerr(y, ref) <= TOL
     z = tg.fft(y, False)
     assert relerr(z, x) <= 3e-5
+
+
+# real FFT with the untangling fused into the half-size Stockham kernel (n/2 = 16 .. 16384): every
+# kernel variant (several transforms per workgroup, ragged batches, staged and direct loads)
+@pytest.mark.parametrize("n,batch", [(32, 1000), (64, 37), (128, 5), (256, 129), (512, 33), (1024, 9), (2048, 7), (4096, 5),
+                                     (8192, 3), (16384, 3), (32768, 2)])
+def test_rfft_fused_sizes(tg, orc, n, batch):
+    rng = np.random.default_rng(n + batch)
+    x = rng.standard_normal((batch, n)).astype(np.float32)
+    y = tg.Rfft(n).step(x)
+    for b in sorted({0, batch // 2, batch - 1}):
+        assert relerr(y[b], orc.rfft(x[b])) <= TOL, (n, b)
+    h = n // 2
+    assert np.all(y[:, 0].imag == 0) and np.all(y[:, h].imag == 0)
+    assert np.array_equal(y[:, h + 1:], np.conj(y[:, 1:h][:, ::-1]))
+    # Parseval per transform (unitary): sum |Y|^2 == sum x^2
+    ex, ey = (x.astype(np.float64) ** 2).sum(axis=1), (np.abs(y).astype(np.float64) ** 2).sum(axis=1)
+    assert np.max(np.abs(ey / ex - 1)) <= 1e-5
