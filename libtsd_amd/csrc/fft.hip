@@ -1620,6 +1620,10 @@ int step_device(tsdgpu_fft *p, const cpx *x, cpx *y, int batch, int forward, hip
 
 }  // namespace
 
+namespace tsdgpu {
+const float2 *fft_s16_twiddles(const tsdgpu_fft *p) { return (p && p->kind == tsdgpu_fft::POW2_S16) ? p->d_tw : nullptr; }
+}
+
 extern "C" {
 
 int tsdgpu_fft_create(tsdgpu_fft **out, int n, int batch_hint)

@@ -4,9 +4,10 @@
 // per block, full-vector copies in between); here all the whole blocks of a call are framed by
 // one kernel, transformed by ONE batched FFT each way, and overlap-added by one kernel.
 #include "common.hpp"
+#include "fft1024_wave.hpp"
+#include "stockham16.hpp"
 #include <algorithm>
-
-namespace tsdgpu { using cpx = float2; }
+#include <cmath>
 
 struct tsdgpu_ola {
   int Ne = 0, N = 0, Nz = 0;
@@ -18,6 +19,8 @@ struct tsdgpu_ola {
   int nrest = 0;
   int64_t cnt_ech = 0;                     // fourier.cc:779: starts at -Ne/2
   int pending_blocks = -1;                 // >= 0 between analyse and synthese
+  bool fuse_response = false;              // set by tsdgpu_ola_step: the forward transform applies H itself
+  bool response_applied = false;
   tsdgpu::DevBuf frames, spectra, in_stage, out_stage;
 };
 
@@ -60,6 +63,88 @@ __global__ void ola_frame_kernel(const cpx *__restrict__ rest, int nrest, const 
     }
   }
   frames[idx] = v;
+}
+
+// ---- framing fused into the forward transform (N = 16 .. 16384) ---------------------------------
+// The frame kernel above writes 2N values per block and the FFT reads them back; here the
+// Stockham transform of a frame (stockham16.hpp, N/16 threads) gathers its inputs straight from
+// [rest ++ x] (zeros, window and the half-block overlap applied on the fly), and its store applies
+// the optional response H or keeps only the power |X|^2 (psd_welch).
+struct FrameSrc {
+  const cpx *rest, *x, *prev_half;
+  const float *fen;
+  int nrest, Ne, N, Nz, mode;     // mode 0: simple OLA, 1: windowed OLA, 2: Welch segments (stride Ne, window fen)
+  __device__ __forceinline__ cpx get(int64_t f, int i) const
+  {
+    if (mode == 2) {
+      const cpx v = x[f * Ne + i];
+      const float w = fen[i];
+      return make_float2(v.x * w, v.y * w);
+    }
+    const int j = i - Nz;
+    if (j < 0) return make_float2(0.f, 0.f);
+    if (mode == 0) return ola_src(rest, nrest, x, f * Ne + j);
+    const int64_t b = f >> 1;
+    const int h = Ne / 2;
+    cpx v;
+    if ((f & 1) == 0) v = j < h ? (b == 0 ? prev_half[j] : ola_src(rest, nrest, x, (b - 1) * Ne + h + j)) : ola_src(rest, nrest, x, b * Ne + (j - h));
+    else v = ola_src(rest, nrest, x, b * Ne + j);
+    const float w = fen[j];
+    return make_float2(v.x * w, v.y * w);
+  }
+};
+
+template <int R0>
+__global__ __launch_bounds__(1024) void framed_fft_kernel(FrameSrc S, const cpx *__restrict__ TW, int tpt, float scale, int64_t nfr,
+                                                          const cpx *__restrict__ H, cpx *__restrict__ outc,
+                                                          float *__restrict__ outp)
+{
+  extern __shared__ __attribute__((aligned(16))) char fr_raw[];
+  cpx *lds = reinterpret_cast<cpx *>(fr_raw);
+  const int N = S.N, t = threadIdx.x, T = blockDim.x / tpt;
+  const int tl = t / tpt, j = t - tl * tpt;
+  const int64_t f = (int64_t) blockIdx.x * T + tl;
+  const bool live = f < nfr;
+  cpx *s = lds + tl * (N + (N >> 4));
+  cpx v[16];
+#pragma unroll
+  for (int m = 0; m < 16; m++) v[m] = live ? S.get(f, j + m * tpt) : make_float2(0.f, 0.f);
+  s16::transform<R0>(v, s, TW, N, j, tpt, []() { __syncthreads(); });
+  if (!live) return;
+#pragma unroll
+  for (int q = 0; q < 16; q++) {
+    const int k = j + q * tpt;
+    cpx X = make_float2(v[q].x * scale, v[q].y * scale);
+    if (H) {
+      const cpx b = H[k];
+      X = make_float2(X.x * b.x - X.y * b.y, X.x * b.y + X.y * b.x);
+    }
+    if (outc) outc[f * N + k] = X;
+    else outp[f * N + k] = X.x * X.x + X.y * X.y;
+  }
+}
+
+// launches the fused kernel when the plan runs on the radix-16 Stockham engine; false otherwise
+bool framed_fft_launch(const tsdgpu_fft *plan, const FrameSrc &S, int64_t nfr, const cpx *H, cpx *outc, float *outp, hipStream_t st)
+{
+  const cpx *TW = fft_s16_twiddles(plan);
+  static const bool off = getenv("TSDGPU_OLA_UNFUSED") != nullptr;
+  if (!TW || off || nfr <= 0) return false;
+  const int N = S.N, tpt = N / 16, threads = std::max(256, tpt), T = threads / tpt;
+  const size_t lds = (size_t) T * (N + N / 16) * sizeof(cpx);
+  int logn = 0;
+  while ((1 << logn) < N) logn++;
+  const int r0 = 1 << ((logn & 3) == 0 ? 4 : (logn & 3));
+  const float scale = 1.0f / std::sqrt((float) N);
+  const unsigned grid = (unsigned) cdiv(nfr, T);
+#define FR_LAUNCH(R)                                                                                                      \
+  do {                                                                                                                    \
+    (void) hipFuncSetAttribute((const void *) framed_fft_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    hipLaunchKernelGGL((framed_fft_kernel<R>), dim3(grid), dim3(threads), lds, st, S, TW, tpt, scale, nfr, H, outc, outp);  \
+  } while (0)
+  if (r0 == 16) FR_LAUNCH(16); else if (r0 == 8) FR_LAUNCH(8); else if (r0 == 4) FR_LAUNCH(4); else FR_LAUNCH(2);
+#undef FR_LAUNCH
+  return true;
 }
 
 // dst[i] = sample (p0 + i) of [rest ++ x]   (new prev_half / new rest)
@@ -166,6 +251,18 @@ __global__ void welch_frame_kernel(const cpx *__restrict__ x, const float *__res
 
 // part[g][i] = sum over the segments of group g of |X[seg][src(i)]|^2, src = the fftshift map
 // (res.head(N/2) = X.tail(N/2), fourier.hpp:232-248); consecutive threads = consecutive bins
+// the same reduction over segment powers already formed by the fused transform
+__global__ void welch_power_sum_kernel(const float *__restrict__ P, float *__restrict__ part, int N, int64_t nseg, int64_t per_group)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int h = N / 2;
+  const int src = i < h ? N - h + i : i - h;
+  const int64_t k0 = (int64_t) blockIdx.y * per_group, k1 = min(k0 + per_group, nseg);
+  float acc = 0.f;
+  for (int64_t k = k0; k < k1; k++) acc += P[k * N + src];
+  part[(size_t) blockIdx.y * N + i] = acc;
+}
 __global__ void welch_power_kernel(const cpx *__restrict__ X, float *__restrict__ part, int N, int64_t nseg, int64_t per_group)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -281,10 +378,18 @@ int tsdgpu_ola_analyse(tsdgpu_ola *h, const void *x, int64_t n, void **spectra, 
     const int64_t fe = B * per * N;
     if ((rc = h->frames.reserve((size_t) fe * sizeof(cpx)))) return rc;
     if ((rc = h->spectra.reserve((size_t) fe * sizeof(cpx)))) return rc;
-    hipLaunchKernelGGL(ola_frame_kernel, dim3(nblk(fe)), dim3(256), 0, st, h->d_rest, h->nrest, dx, h->d_prev_half, h->d_fen,
-                       h->frames.as<cpx>(), Ne, N, h->Nz, h->windowed ? 1 : 0, fe);
-    TSD_HIP(hipGetLastError());
-    if ((rc = tsdgpu_fft_step(h->plan, h->frames.p, h->spectra.p, (int) (B * per), 1, st))) return rc;
+    const FrameSrc S{h->d_rest, dx, h->d_prev_half, h->d_fen, h->nrest, Ne, N, h->Nz, h->windowed ? 1 : 0};
+    const cpx *Hf = h->fuse_response ? h->d_H : nullptr;
+    h->response_applied = false;
+    if (framed_fft_launch(h->plan, S, B * per, Hf, h->spectra.as<cpx>(), nullptr, st)) {
+      TSD_HIP(hipGetLastError());
+      h->response_applied = Hf != nullptr;
+    } else {
+      hipLaunchKernelGGL(ola_frame_kernel, dim3(nblk(fe)), dim3(256), 0, st, h->d_rest, h->nrest, dx, h->d_prev_half, h->d_fen,
+                         h->frames.as<cpx>(), Ne, N, h->Nz, h->windowed ? 1 : 0, fe);
+      TSD_HIP(hipGetLastError());
+      if ((rc = tsdgpu_fft_step(h->plan, h->frames.p, h->spectra.p, (int) (B * per), 1, st))) return rc;
+    }
     if (h->windowed) {
       hipLaunchKernelGGL(ola_gather_kernel, dim3(nblk(Ne / 2)), dim3(256), 0, st, h->d_rest, h->nrest, dx,
                          (B - 1) * Ne + Ne / 2, h->d_prev_half, Ne / 2);                                    // :926
@@ -353,7 +458,8 @@ int tsdgpu_ola_apply_response(tsdgpu_ola *h, void *stream)
 {
   TSD_CHECK(h != nullptr && h->pending_blocks >= 0, "ola_apply_response: nothing analysed");
   const int64_t tot = (int64_t) h->pending_blocks * (h->windowed ? 2 : 1) * h->N;
-  if (!h->d_H || tot == 0) return TSDGPU_OK;
+  if (!h->d_H || tot == 0 || h->response_applied) return TSDGPU_OK;
+  h->response_applied = true;
   hipLaunchKernelGGL(ola_mul_kernel, dim3(nblk(tot)), dim3(256), 0, (hipStream_t) stream, h->spectra.as<cpx>(), h->d_H, h->N, tot);
   TSD_HIP(hipGetLastError());
   return TSDGPU_OK;
@@ -386,7 +492,9 @@ int tsdgpu_ola_step(tsdgpu_ola *h, const void *x, int64_t n, void *y, int64_t *n
   TSD_CHECK(h != nullptr, "ola_step: NULL handle");
   void *sp = nullptr;
   int nf = 0;
+  h->fuse_response = true;
   int rc = tsdgpu_ola_analyse(h, x, n, &sp, &nf, stream);
+  h->fuse_response = false;
   if (rc) return rc;
   (void) sp;
   if ((rc = tsdgpu_ola_apply_response(h, stream))) return rc;
@@ -415,20 +523,31 @@ int tsdgpu_welch(const void *x, int64_t n, int N, const float *window, float *S,
     if (hipMemsetAsync(dS, 0, (size_t) N * sizeof(float), st) != hipSuccess) rc = set_err(TSDGPU_ERR_HIP, "welch: memset failed");
   } else if (!rc) {
     const int64_t total = nseg * N;
-    const int groups = (int) std::min<int64_t>(64, nseg);
+    // enough groups to fill the chip whatever N: N/256 x groups workgroups, <= 512 partial sums per bin
+    const int groups = (int) std::max<int64_t>(1, std::min<int64_t>(512, std::min<int64_t>(cdiv(nseg, 16), cdiv(262144, N))));
     const int64_t per_group = cdiv(nseg, groups);
     rc = seg.reserve((size_t) total * sizeof(cpx));
     if (!rc) rc = part.reserve((size_t) groups * N * sizeof(float));
     if (!rc) rc = tsdgpu_fft_create(&plan, N, (int) nseg);
+    bool fused = false;
     if (!rc) {
+      // fused: segments gathered and windowed by the transform itself, which stores |X|^2 only
+      const FrameSrc S{nullptr, (const cpx *) dxv, nullptr, (const float *) dwv, 0, pas, N, 0, 2};
+      fused = framed_fft_launch(plan, S, nseg, nullptr, nullptr, seg.as<float>(), st);
+    }
+    if (!rc && !fused) {
       hipLaunchKernelGGL(welch_frame_kernel, dim3(nblk(total)), dim3(256), 0, st, (const cpx *) dxv, (const float *) dwv,
                          seg.as<cpx>(), N, pas, total);
       if (hipGetLastError() != hipSuccess) rc = set_err(TSDGPU_ERR_HIP, "welch: launch failed");
+      if (!rc) rc = tsdgpu_fft_step(plan, seg.p, seg.p, (int) nseg, 1, st);
     }
-    if (!rc) rc = tsdgpu_fft_step(plan, seg.p, seg.p, (int) nseg, 1, st);
     if (!rc) {
-      hipLaunchKernelGGL(welch_power_kernel, dim3(nblk(N), (unsigned) groups), dim3(256), 0, st, seg.as<cpx>(), part.as<float>(), N,
-                         nseg, per_group);
+      if (fused)
+        hipLaunchKernelGGL(welch_power_sum_kernel, dim3(nblk(N), (unsigned) groups), dim3(256), 0, st, seg.as<float>(),
+                           part.as<float>(), N, nseg, per_group);
+      else
+        hipLaunchKernelGGL(welch_power_kernel, dim3(nblk(N), (unsigned) groups), dim3(256), 0, st, seg.as<cpx>(), part.as<float>(), N,
+                           nseg, per_group);
       hipLaunchKernelGGL(welch_sum_kernel, dim3(nblk(N)), dim3(256), 0, st, part.as<float>(), (float *) dS, N, groups);
       if (hipGetLastError() != hipSuccess) rc = set_err(TSDGPU_ERR_HIP, "welch: launch failed");
     }

@@ -22,3 +22,9 @@ for Ne, M, win in [(512, 127, False), (2048, 127, False), (4096, 1025, False), (
     ms = timeit(lambda: g.step(x), 10, 3)
     print(json.dumps({"Ne": Ne, "zeros_min": M, "N": g.N, "windowed": win, "ms": round(ms, 3),
                       "Msamples_per_s": round(n / ms / 1e3, 1), "frac_of_8TBps_at_16B": round(16.0 * n / (ms * 1e-3) / 8e12, 4)}), flush=True)
+
+# psd_welch on the same resident data: segments of N with half overlap
+for N in (256, 1024, 4096, 1000):
+    w = (0.5 - 0.5 * np.cos(2 * np.pi * np.arange(N) / N)).astype(np.float32)
+    ms = timeit(lambda: t.welch(x, N, w), 10, 3)
+    print(json.dumps({"welch_N": N, "ms": round(ms, 3), "Msamples_per_s": round(n / ms / 1e3, 1)}), flush=True)
