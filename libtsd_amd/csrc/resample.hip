@@ -43,6 +43,8 @@ struct RsParams {
   int K, nph, lstride, rec_cap;
   int lut_in_lds;     // generic kernel: LUT staged in LDS (1) or read from global memory (0: large K)
   int mode;           // 0: table; 1: InterpolateurLineaire; 2: InterpolateurLagrange of degree K-1 (itrp.cc:80-133)
+  int gl;             // row pitch of the table in global memory: K rounded up to a multiple of 4 (16-B row reads)
+  float inv_den[32];  // Lagrange: 1 / prod_{k != j} (j - k)
 };
 
 struct RsCk { uint32_t phase_bits; uint32_t cum; };
@@ -105,10 +107,10 @@ __global__ __launch_bounds__(RS_THREADS) void resample_kernel(const T *__restric
   const int lut_n = P.lut_in_lds ? (P.nph + 1) * K : 0;
   for (int i = threadIdx.x; i < lut_n; i += RS_THREADS) {
     const int c = i / K, k = i - c * K;
-    lut_s[c * lstride + k] = lut[i];
+    lut_s[c * lstride + k] = lut[c * P.gl + k];
   }
   const float *lutp = P.lut_in_lds ? lut_s : lut;
-  const int lrow = P.lut_in_lds ? lstride : K;
+  const int lrow = P.lut_in_lds ? lstride : P.gl;         // both multiples of 4: rows are read 16 B at a time
   if (KT == 15)
     for (int c = threadIdx.x; c <= P.nph; c += RS_THREADS) lut_s[c * lstride + 15] = 0.f;   // 16th tap
   __syncthreads();
@@ -239,7 +241,16 @@ __global__ __launch_bounds__(RS_THREADS) void resample_kernel(const T *__restric
 #pragma unroll
         for (int k = 0; k < 15; k++) acc = tap_mac(acc, hh[k], w[k]);   // filtrage.hpp:1877-1879 order
       } else if (P.mode == 0) {
-        for (int k = 0; k < K; k++) acc = tap_mac(acc, h[k], w[k]);
+        // taps 16 B at a time (a row per lane: scalar reads cost one cache line or LDS access per tap)
+        const int K4 = K & ~3;
+        for (int k = 0; k < K4; k += 4) {
+          const float4 q4 = *reinterpret_cast<const float4 *>(h + k);
+          acc = tap_mac(acc, q4.x, w[k]);
+          acc = tap_mac(acc, q4.y, w[k + 1]);
+          acc = tap_mac(acc, q4.z, w[k + 2]);
+          acc = tap_mac(acc, q4.w, w[k + 3]);
+        }
+        for (int k = K4; k < K; k++) acc = tap_mac(acc, h[k], w[k]);
       } else if (P.mode == 1) {
         const float tau = rec_tau[o];                          // coefs(tau) = {1 - tau, tau}  (itrp.cc:83-86)
         acc = tap_mac(acc, 1.f - tau, w[0]);
@@ -248,10 +259,13 @@ __global__ __launch_bounds__(RS_THREADS) void resample_kernel(const T *__restric
         // Lagrange of degree d through the points 0..d, evaluated at (d-1)/2 + tau (itrp.cc:112-132)
         const int d = K - 1;
         const float t = ((d - 1.0f) / 2) + rec_tau[o];
+        // p_j = prod_{k != j} (t - k) / (j - k): the constant denominators are folded into one
+        // host-computed reciprocal per tap (the K^2 correctly-rounded divisions of the literal form
+        // cost 10x the rest of the kernel; the weights move by a few ulp)
         for (int j = 0; j <= d; j++) {
-          float p = 1.0f;
+          float p = P.inv_den[j];
           for (int k = 0; k <= d; k++)
-            if (k != j) p *= (t - k) / (j - k);
+            if (k != j) p *= (t - k);
           acc = tap_mac(acc, p, w[j]);
         }
       }
@@ -294,7 +308,7 @@ __global__ __launch_bounds__(64 * RS15_WAVES) void resample15_kernel(const T *__
 
   for (int i = threadIdx.x; i < (P.nph + 1) * K; i += 64 * RS15_WAVES) {
     const int c = i / K, k = i - c * K;
-    lut_s[c * LS + k] = lut[i];
+    lut_s[c * LS + k] = lut[c * P.gl + k];
   }
   for (int c = threadIdx.x; c <= P.nph; c += 64 * RS15_WAVES) lut_s[c * LS + 15] = 0.f;
   __syncthreads();
@@ -443,8 +457,9 @@ __global__ void rs_hist_update_kernel(const T *__restrict__ x, const T *__restri
 using namespace tsdgpu;
 
 struct tsdgpu_resampler {
-  int data_type = 0, K = 0, nph = 0, lstride = 0, mode = 0;
+  int data_type = 0, K = 0, nph = 0, lstride = 0, gl = 0, mode = 0;
   float ratio = 1.f, inc = 1.f;
+  float inv_den[32] = {0};
   float *d_lut = nullptr;
   void *d_hist[2] = {nullptr, nullptr};
   int cur = 0;
@@ -588,16 +603,19 @@ int tsdgpu_resampler_create(tsdgpu_resampler **out, int data_type, float ratio, 
   r->data_type = data_type;
   r->K = K;
   r->nph = nphases;
-  r->lstride = (K % 2 == 0) ? K + 1 : K + 2;
+  r->gl = (K + 3) / 4 * 4;
+  r->lstride = r->gl + (((r->gl / 4) & 1) ? 0 : 4);      // LDS pitch: a multiple of 4 floats with an odd number of 16-B units
   r->ratio = ratio;
   r->inc = 1.f / ratio;                      // ra.cc:29
-  const size_t lut_bytes = (size_t) (nphases + 1) * K * sizeof(float);
+  const size_t lut_bytes = (size_t) (nphases + 1) * ((K + 3) / 4 * 4) * sizeof(float);
   const size_t hb = (size_t) std::max(K - 1, 1) * dtype_size(data_type);
   int rc = TSDGPU_OK;
   if (hipMalloc((void **) &r->d_lut, lut_bytes) != hipSuccess || hipMalloc(&r->d_hist[0], hb) != hipSuccess ||
       hipMalloc(&r->d_hist[1], hb) != hipSuccess)
     rc = set_err(TSDGPU_ERR_HIP, "resampler_create: hipMalloc failed: %s", hipGetErrorString(hipGetLastError()));
-  else if (hipMemcpy(r->d_lut, lut_host, lut_bytes, hipMemcpyHostToDevice) != hipSuccess ||
+  else if (hipMemset(r->d_lut, 0, lut_bytes) != hipSuccess ||
+           hipMemcpy2D(r->d_lut, (size_t) r->gl * sizeof(float), lut_host, (size_t) K * sizeof(float), (size_t) K * sizeof(float),
+                       (size_t) nphases + 1, hipMemcpyHostToDevice) != hipSuccess ||
            hipMemset(r->d_hist[0], 0, hb) != hipSuccess || hipMemset(r->d_hist[1], 0, hb) != hipSuccess)
     rc = set_err(TSDGPU_ERR_HIP, "resampler_create: upload failed: %s", hipGetErrorString(hipGetLastError()));
   if (rc) {
@@ -624,6 +642,12 @@ int tsdgpu_resampler_create_analytic(tsdgpu_resampler **out, int data_type, floa
   int rc = tsdgpu_resampler_create(out, data_type, ratio, dummy.data(), K, 1);
   if (rc) return rc;
   (*out)->mode = kind;
+  for (int j = 0; j < K; j++) {
+    double den = 1.0;
+    for (int k = 0; k < K; k++)
+      if (k != j) den *= (double) (j - k);
+    (*out)->inv_den[j] = (float) (1.0 / den);
+  }
   return TSDGPU_OK;
 }
 
@@ -676,6 +700,8 @@ int tsdgpu_resampler_step(tsdgpu_resampler *r, const void *x, int64_t n, void *y
   P.nph = r->nph;
   P.lstride = r->lstride;
   P.mode = r->mode;
+  P.gl = r->gl;
+  for (int j = 0; j < 32; j++) P.inv_den[j] = r->inv_den[j];
   // at most floor(1/inc)+1 outputs per input
   // outputs are spaced 1/ratio apart in input time (up to float32 rounding of the adds)
   P.rec_cap = ((int) ((double) RS_TI * (double) r->ratio * 1.0001) + 32 + 3) / 4 * 4;
