@@ -23,6 +23,9 @@
 #include "common.hpp"
 #include <cmath>
 #include <cstdlib>
+#include <map>
+#include <memory>
+#include <mutex>
 
 namespace tsdgpu {
 
@@ -456,6 +459,37 @@ __global__ void rs_hist_update_kernel(const T *__restrict__ x, const T *__restri
 
 using namespace tsdgpu;
 
+// The schedule of the float32 phase recurrence depends on the increment alone: it is simulated
+// ONCE per ratio and per process -- checkpoints every RS_CK inputs up to the end of the first
+// period -- and shared by all the handles of that ratio (a rééchan()-style one-shot call creates
+// a handle per call: without the cache every call replayed up to 8 M sequential steps, tens of ms).
+struct RsSched {
+  std::mutex mtx;
+  std::vector<RsCk> ck;       // checkpoints every RS_CK inputs of the canonical sequence
+  int64_t sim_i = 0;          // inputs simulated so far (canonical)
+  float sim_phase = 0.f;
+  int64_t sim_cum = 0;
+  // Brent cycle detection on the phase at input boundaries
+  uint32_t tort_bits = 0;
+  int64_t brent_power = 1, brent_lam = 0;
+  bool cyc = false;
+  int64_t mu = 0, lambda = 0, opp = 0;
+};
+static std::shared_ptr<RsSched> sched_for(float inc)
+{
+  static std::mutex m;
+  static std::map<uint32_t, std::shared_ptr<RsSched>> cache;
+  std::lock_guard<std::mutex> lock(m);
+  uint32_t key;
+  memcpy(&key, &inc, 4);
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  if (cache.size() >= 32) cache.erase(cache.begin());        // (handles keep their own reference)
+  auto sp = std::make_shared<RsSched>();
+  cache[key] = sp;
+  return sp;
+}
+
 struct tsdgpu_resampler {
   int data_type = 0, K = 0, nph = 0, lstride = 0, gl = 0, mode = 0;
   float ratio = 1.f, inc = 1.f;
@@ -465,16 +499,20 @@ struct tsdgpu_resampler {
   int cur = 0;
   // stream position
   int64_t pos = 0, cum_pos = 0;
-  // host schedule: checkpoints every RS_CK inputs of the canonical sequence
-  std::vector<RsCk> ck;
-  int64_t sim_i = 0;          // inputs simulated so far (canonical)
-  float sim_phase = 0.f;
-  int64_t sim_cum = 0;
-  // Brent cycle detection on the phase at input boundaries
-  uint32_t tort_bits = 0;
-  int64_t brent_power = 1, brent_lam = 0;
-  bool cyc = false;
-  int64_t mu = 0, lambda = 0, opp = 0;
+  // host schedule (shared by every handle of the same ratio, see RsSched)
+  std::shared_ptr<RsSched> sch;
+  std::vector<RsCk> &ck;
+  int64_t &sim_i;
+  float &sim_phase;
+  int64_t &sim_cum;
+  uint32_t &tort_bits;
+  int64_t &brent_power, &brent_lam;
+  bool &cyc;
+  int64_t &mu, &lambda, &opp;
+  explicit tsdgpu_resampler(std::shared_ptr<RsSched> s_)
+      : sch(std::move(s_)), ck(sch->ck), sim_i(sch->sim_i), sim_phase(sch->sim_phase), sim_cum(sch->sim_cum),
+        tort_bits(sch->tort_bits), brent_power(sch->brent_power), brent_lam(sch->brent_lam), cyc(sch->cyc), mu(sch->mu),
+        lambda(sch->lambda), opp(sch->opp) {}
   RsCk *d_ck = nullptr;
   size_t d_ck_cap = 0, d_ck_n = 0;
   DevBuf in_stage, out_stage;
@@ -484,8 +522,8 @@ namespace {
 
 inline void sim_one(float &phase, int64_t &cum, float inc)
 {
-  // volatile: keep every addition an IEEE binary32 operation whatever the optimiser prefers
-  volatile float p = phase;
+  // plain binary32 adds (SSE scalar ops; this file is compiled without fast-math or contraction)
+  float p = phase;
   while (p < 1.f) { p = p + inc; cum++; }
   p = p - 1.f;
   phase = p;
@@ -599,7 +637,7 @@ int tsdgpu_resampler_create(tsdgpu_resampler **out, int data_type, float ratio, 
                    "ratios into [0.5,2) with half-band stages first)", (double) ratio);
   if (K < 1 || K > RS_KMAX || nphases < 1 || nphases > 8191)
     return set_err(TSDGPU_ERR_UNSUPPORTED, "resampler_create: K=%d nphases=%d unsupported (K <= %d, nphases <= 8191)", K, nphases, RS_KMAX);
-  tsdgpu_resampler *r = new tsdgpu_resampler();
+  tsdgpu_resampler *r = new tsdgpu_resampler(sched_for(1.f / ratio));
   r->data_type = data_type;
   r->K = K;
   r->nph = nphases;
@@ -656,6 +694,7 @@ int64_t tsdgpu_resampler_out_count(tsdgpu_resampler *r, int64_t n)
   if (!r || n < 0) return -1;
   float ph;
   int64_t c;
+  std::lock_guard<std::mutex> lock(r->sch->mtx);
   state_at(r, r->pos + n, &ph, &c);
   return c - r->cum_pos;
 }
@@ -671,6 +710,8 @@ int tsdgpu_resampler_step(tsdgpu_resampler *r, const void *x, int64_t n, void *y
   hipStream_t st = (hipStream_t) stream;
   float ph_end;
   int64_t cum_end;
+  // (the schedule is shared between the handles of a ratio: held while this call reads or extends it)
+  std::lock_guard<std::mutex> lock(r->sch->mtx);
   state_at(r, r->pos + n, &ph_end, &cum_end);
   const int64_t nout = cum_end - r->cum_pos;
   TSD_CHECK(nout <= y_capacity, "resampler_step: output needs %lld samples, capacity is %lld", (long long) nout,
@@ -767,7 +808,10 @@ int tsdgpu_resampler_seek(tsdgpu_resampler *r, int64_t pos, const void *hist, vo
   hipStream_t st = (hipStream_t) stream;
   float ph;
   int64_t c;
-  state_at(r, pos, &ph, &c);
+  {
+    std::lock_guard<std::mutex> lock(r->sch->mtx);
+    state_at(r, pos, &ph, &c);
+  }
   r->pos = pos;
   r->cum_pos = c;
   const size_t hb = (size_t) std::max(r->K - 1, 1) * dtype_size(r->data_type);
