@@ -171,3 +171,30 @@ def test_linear_interpolator_on_a_ramp(tg):
     y = tg.Resampler(ratio, tg.F32, analytic=("lin", 0)).step(x)
     t = np.arange(len(y), dtype=np.float64) / float(ratio)
     assert np.max(np.abs(y[2:] - (t[2:] - 1.0))) < 2e-3
+
+
+def test_shared_schedule_is_thread_safe(tg, orc):
+    """Handles of one ratio share the host phase schedule (simulated once per process): several threads
+    creating and stepping their own handles at the same time -- one of them far enough to trigger the
+    cycle detection -- all get the single-threaded result."""
+    import threading
+    ratio = np.float32(0.8371)                      # a ratio no other test has used: the schedule starts empty
+    x = rand(3_000_000, True, 23)
+    ref = orc.Resampler(ratio).step(x[:400_000])
+    out = [None] * 4
+
+    def work(i):
+        g = tg.Resampler(ratio, tg.C64)
+        n = [400_000, 3_000_000, 400_000, 1_000_000][i]
+        parts = [g.step(x[a:min(a + 250_000, n)]) for a in range(0, n, 250_000)]
+        out[i] = np.concatenate(parts)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for q in th:
+        q.start()
+    for q in th:
+        q.join()
+    for i in range(4):
+        assert out[i] is not None and np.array_equal(out[i][:len(ref)], out[0][:len(ref)]), i
+    assert relerr(out[0], ref) <= TOL
+    assert np.array_equal(out[1][:len(out[3])], out[3])
