@@ -45,6 +45,25 @@ int tsdgpu_device_count(void);
 const char *tsdgpu_version(void);
 
 /* --------------------------------------------------------------------------------------
+ * Device memory for RESIDENT vectors.  libtsd's array type can wrap foreign memory without owning
+ * it (TabT::map, include/tsd/tableau.hpp:1067-1077; src/tableau.cc:723-739) and resize() to the
+ * current size is a no-op (tableau.cc:702-705), so a Vecf/Veccf mapped on memory from
+ * tsdgpu_malloc goes through every operator below without ever visiting the host.  tsdgpu_memcpy
+ * copies in any direction (host<->device, device<->device); it returns once a host buffer
+ * involved is safe to reuse.  tsdgpu_malloc_host gives page-locked host memory: host vectors
+ * allocated from it are staged at the full PCIe rate and overlap their copies with the kernels
+ * (the chunked pipeline of tsdgpu_fir_step / tsdgpu_sos_step on large host buffers).
+ * ------------------------------------------------------------------------------------ */
+int tsdgpu_malloc(void **out, size_t bytes);
+int tsdgpu_free(void *p);
+int tsdgpu_malloc_host(void **out, size_t bytes);
+int tsdgpu_free_host(void *p);
+int tsdgpu_memcpy(void *dst, const void *src, size_t bytes, void *stream);
+int tsdgpu_synchronize(void *stream);
+/* 1 when p is memory a kernel can dereference (device, managed or registered host memory) */
+int tsdgpu_is_device_pointer(const void *p);
+
+/* --------------------------------------------------------------------------------------
  * FIR:  FiltreRIF<T,Tc>::step, factory filtre_rif<Tc,T>(coefs)
  *       (src/filtrage/filtre-rt.cc:53-109,171-175; include/tsd/filtrage.hpp:1367-1368)
  *       and the FFT-domain variant filtre_rif_fft<T> (src/fourier/fourier.cc:946-990).
@@ -213,6 +232,14 @@ int tsdgpu_polyfir_destroy(tsdgpu_polyfir *p);
 typedef struct tsdgpu_rii tsdgpu_rii;
 int tsdgpu_rii_create(tsdgpu_rii **out, int data_type, const float *numer_host, int Kx,
                       const float *denom_host, int Kd);
+/* coefficients of type coef_type (TSDGPU_F32, or TSDGPU_C64 = filtre_rii<cfloat,cfloat>, complex data only).
+ * Real coefficients: the denominator is factored on the host and the recursion runs block-parallel as
+ * zero-seeded sections on the SOS kernel whenever that cascade reproduces the direct form to 2e-6 on a
+ * create-time check; otherwise, and for complex coefficients, the literal sequential recursion runs.
+ * tsdgpu_rii_path: 0 = sections only, 1 = FIR kernel + sections, 2 = FIR kernel + literal recursion. */
+int tsdgpu_rii_create2(tsdgpu_rii **out, int data_type, int coef_type, const void *numer_host, int Kx,
+                       const void *denom_host, int Kd);
+int tsdgpu_rii_path(const tsdgpu_rii *r);
 int tsdgpu_rii_step(tsdgpu_rii *r, const void *x, void *y, int64_t n, void *stream);
 int tsdgpu_rii_destroy(tsdgpu_rii *r);
 

@@ -76,6 +76,15 @@ def _declare(L):
     L.tsdgpu_polyfir_reset.argtypes = [vp]
     L.tsdgpu_polyfir_destroy.argtypes = [vp]
     L.tsdgpu_rii_create.argtypes = [C.POINTER(vp), i32, vp, i32, vp, i32]
+    L.tsdgpu_rii_create2.argtypes = [C.POINTER(vp), i32, i32, vp, i32, vp, i32]
+    L.tsdgpu_rii_path.argtypes = [vp]
+    L.tsdgpu_malloc.argtypes = [C.POINTER(vp), C.c_size_t]
+    L.tsdgpu_free.argtypes = [vp]
+    L.tsdgpu_malloc_host.argtypes = [C.POINTER(vp), C.c_size_t]
+    L.tsdgpu_free_host.argtypes = [vp]
+    L.tsdgpu_memcpy.argtypes = [vp, vp, C.c_size_t, vp]
+    L.tsdgpu_synchronize.argtypes = [vp]
+    L.tsdgpu_is_device_pointer.argtypes = [vp]
     L.tsdgpu_rii_step.argtypes = [vp, vp, vp, i64, vp]
     L.tsdgpu_rii_destroy.argtypes = [vp]
     L.tsdgpu_fft_create.argtypes = [C.POINTER(vp), i32, i32]
@@ -112,16 +121,32 @@ def _check(rc):
 
 
 def _ptr(a):
-    """Address of a numpy array (host) or a torch tensor (host or device)."""
+    """Address of a numpy array (host) or a torch tensor (host or device).  The C ABI reads packed
+    float32 / complex64 samples: anything else (float64, integers, a strided view such as x[::2])
+    is refused here instead of being reinterpreted."""
+    _dtype_code(a)
     if isinstance(a, np.ndarray):
+        if not a.flags.c_contiguous:
+            raise TsdGpuError("non-contiguous numpy array: pass np.ascontiguousarray(x)")
         return a.ctypes.data
+    if not a.is_contiguous():
+        raise TsdGpuError("non-contiguous tensor: pass x.contiguous()")
     return a.data_ptr()
 
 
 def _dtype_code(a):
     if isinstance(a, np.ndarray):
-        return C64 if np.iscomplexobj(a) else F32
-    return C64 if a.is_complex() else F32
+        if a.dtype == np.float32:
+            return F32
+        if a.dtype == np.complex64:
+            return C64
+        raise TsdGpuError(f"dtype {a.dtype} is not served: the C ABI takes float32 or complex64 (convert with astype)")
+    import torch
+    if a.dtype == torch.float32:
+        return F32
+    if a.dtype == torch.complex64:
+        return C64
+    raise TsdGpuError(f"dtype {a.dtype} is not served: the C ABI takes float32 or complex64")
 
 
 def _stream_of(a, stream):
@@ -489,14 +514,22 @@ class PolyFir:
 
 
 class Rii:
-    """filtre_rii<float,T> (filtre-rt.cc:177-289): numer / denom in powers of z^-1."""
+    """filtre_rii<Tc,T> (filtre-rt.cc:177-289): numer / denom in powers of z^-1, real or complex.
+    path: 0 = block-parallel sections, 1 = FIR kernel + block-parallel sections, 2 = literal recursion."""
 
     def __init__(self, numer, denom, data_type):
-        nu = np.ascontiguousarray(numer, dtype=np.float32)
-        de = np.ascontiguousarray(denom, dtype=np.float32)
+        cplx = np.iscomplexobj(numer) or np.iscomplexobj(denom)
+        ct = np.complex64 if cplx else np.float32
+        nu = np.ascontiguousarray(numer, dtype=ct)
+        de = np.ascontiguousarray(denom, dtype=ct)
         self.data_type = data_type
         self._h = C.c_void_p()
-        _check(lib().tsdgpu_rii_create(C.byref(self._h), data_type, nu.ctypes.data, len(nu), de.ctypes.data, len(de)))
+        _check(lib().tsdgpu_rii_create2(C.byref(self._h), data_type, C64 if cplx else F32, nu.ctypes.data, len(nu),
+                                        de.ctypes.data, len(de)))
+
+    @property
+    def path(self):
+        return lib().tsdgpu_rii_path(self._h)
 
     def step(self, x, y=None, stream=None):
         assert _dtype_code(x) == self.data_type

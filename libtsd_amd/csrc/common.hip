@@ -131,6 +131,56 @@ int tsdgpu_device_count(void)
   return n;
 }
 
-const char *tsdgpu_version(void) { return "libtsd_amd 0.1 (gfx950)"; }
+const char *tsdgpu_version(void) { return "libtsd_amd 0.2 (gfx950)"; }
+
+int tsdgpu_malloc(void **out, size_t bytes)
+{
+  TSD_CHECK(out != nullptr, "tsdgpu_malloc: out is NULL");
+  *out = nullptr;
+  if (bytes == 0) return TSDGPU_OK;
+  hipError_t e = hipMalloc(out, bytes);
+  if (e != hipSuccess) {
+    *out = nullptr;
+    return tsdgpu::set_err(TSDGPU_ERR_ALLOC, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  }
+  return TSDGPU_OK;
+}
+int tsdgpu_free(void *p)
+{
+  if (p) TSD_HIP(hipFree(p));
+  return TSDGPU_OK;
+}
+int tsdgpu_malloc_host(void **out, size_t bytes)
+{
+  TSD_CHECK(out != nullptr, "tsdgpu_malloc_host: out is NULL");
+  *out = nullptr;
+  if (bytes == 0) return TSDGPU_OK;
+  hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    *out = nullptr;
+    return tsdgpu::set_err(TSDGPU_ERR_ALLOC, "hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  }
+  return TSDGPU_OK;
+}
+int tsdgpu_free_host(void *p)
+{
+  if (p) TSD_HIP(hipHostFree(p));
+  return TSDGPU_OK;
+}
+int tsdgpu_memcpy(void *dst, const void *src, size_t bytes, void *stream)
+{
+  if (bytes == 0) return TSDGPU_OK;
+  TSD_CHECK(dst != nullptr && src != nullptr, "tsdgpu_memcpy: NULL pointer");
+  hipStream_t st = (hipStream_t) stream;
+  TSD_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, st));
+  if (!(tsdgpu::is_device_ptr(dst) && tsdgpu::is_device_ptr(src))) TSD_HIP(hipStreamSynchronize(st));
+  return TSDGPU_OK;
+}
+int tsdgpu_synchronize(void *stream)
+{
+  TSD_HIP(hipStreamSynchronize((hipStream_t) stream));
+  return TSDGPU_OK;
+}
+int tsdgpu_is_device_pointer(const void *p) { return tsdgpu::is_device_ptr(p) ? 1 : 0; }
 
 }  // extern "C"

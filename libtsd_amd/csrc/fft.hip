@@ -738,13 +738,27 @@ __global__ __launch_bounds__(1024) void fft_s16_persistent_kernel(const cpx *__r
   }
 }
 
+// complex type of the 1M-point column kernel: -DF1M_PACKED=1 selects the packed (VOP3P) flavour of
+// fft1024_wave.hpp (a complex = one 64-bit VGPR pair, half the VALU instructions)
+#ifndef F1M_PACKED
+#define F1M_PACKED 0
+#endif
+#if F1M_PACKED
+using f1c = w1024::v2f;
+__device__ __forceinline__ f1c f1mul(f1c a, cpx w) { return w1024::cmul(a, (f1c){w.x, w.y}); }
+__device__ __forceinline__ f1c f1out(f1c a, float s, int inverse) { a = a * s; if (inverse) a.y = -a.y; return a; }
+#else
+using f1c = cpx;
+__device__ __forceinline__ f1c f1mul(f1c a, cpx w) { return cmul(a, w); }
+__device__ __forceinline__ f1c f1out(f1c a, float s, int inverse) { a = cscale(a, s); if (inverse) a.y = -a.y; return a; }
+#endif
 struct LdsTw1 {   // [r - 1][lane]
-  const cpx *p;
-  __device__ __forceinline__ cpx operator[](int r) const { return p[(r - 1) * 64]; }
+  const f1c *p;
+  __device__ __forceinline__ f1c operator[](int r) const { return p[(r - 1) * 64]; }
 };
 struct LdsTw2 {   // [r][lane & 3]
-  const cpx *p;
-  __device__ __forceinline__ cpx operator[](int r) const { return p[r * 4]; }
+  const f1c *p;
+  __device__ __forceinline__ f1c operator[](int r) const { return p[r * 4]; }
 };
 
 struct F1mCtx {
@@ -798,10 +812,11 @@ __device__ __forceinline__ void f1m_tile(const F1mCtx &k, int id, float4 (&q)[8]
   if (PASS == 1 && k.t < 256) k.ltd[k.t] = td;
   if (PREFETCH) f1m_issue<PASS>(k, id + k.grid, q, ta, td);   // in flight until the next tile's LDS write
   lds_barrier();
-  cpx v[16];
+  f1c v[16];
+  f1c *colc = reinterpret_cast<f1c *>(col);
 #pragma unroll
-  for (int r = 0; r < 16; r++) v[r] = col[(64 * r + lane) * P];
-  w1024::forward<P>(v, col, lane, k.tw1, k.tw2, wave_fence);
+  for (int r = 0; r < 16; r++) v[r] = colc[(64 * r + lane) * P];
+  w1024::forward<P>(v, colc, lane, k.tw1, k.tw2, wave_fence);
   const int c0 = (id & 63) * 16, c = c0 + k.wv;
   cpx *y = k.out + (size_t) (id >> 6) * 1024 * k.opitch;
   wave_fence();
@@ -813,7 +828,7 @@ __device__ __forceinline__ void f1m_tile(const F1mCtx &k, int id, float4 (&q)[8]
 #pragma unroll
     for (int r = 0; r < 16; r++) {
       const cpx w = cmul(ta_cur, k.ltd[k.wv * 16 + r]);
-      col[(k0 + 64 * (r >> 2) + 256 * (r & 3)) * P] = cmul(v[r], w);
+      colc[(k0 + 64 * (r >> 2) + 256 * (r & 3)) * P] = f1mul(v[r], w);
     }
     wave_fence();
 #pragma unroll
@@ -824,9 +839,7 @@ __device__ __forceinline__ void f1m_tile(const F1mCtx &k, int id, float4 (&q)[8]
   } else {
 #pragma unroll
     for (int r = 0; r < 16; r++) {
-      cpx o = cscale(v[r], k.scale);
-      if (k.inverse) o.y = -o.y;
-      col[(k0 + 64 * (r >> 2) + 256 * (r & 3)) * P] = o;
+      colc[(k0 + 64 * (r >> 2) + 256 * (r & 3)) * P] = f1out(v[r], k.scale, k.inverse);
     }
     lds_barrier();
     char *yb = reinterpret_cast<char *>(y + c0);
@@ -856,7 +869,7 @@ __global__ __launch_bounds__(1024) void fft1m_cols_kernel(const cpx *__restrict_
   F1mCtx k;
   k.in = in; k.out = out; k.TA = TA; k.TD = TD;
   k.tile = tile; k.col = tile + wv; k.ltd = ltd;           // this wave's column: slots e*P + wv
-  k.tw1 = LdsTw1{ltw1 + lane}; k.tw2 = LdsTw2{ltw2 + (lane & 3)};
+  k.tw1 = LdsTw1{reinterpret_cast<const f1c *>(ltw1) + lane}; k.tw2 = LdsTw2{reinterpret_cast<const f1c *>(ltw2) + (lane & 3)};
   k.ipitch = PASS == 1 ? 1024 : zp; k.opitch = PASS == 1 ? zp : 1024;
   k.inverse = inverse; k.t = t; k.lane = lane; k.wv = wv;
   k.rr = t >> 3; k.cc = 2 * (t & 7);                       // 8 threads x 16 B per 128-B row segment

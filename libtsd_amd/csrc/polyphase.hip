@@ -9,7 +9,10 @@
 // rates or tap counts that do not fit its LDS tile fall back to compositions of the FIR
 // kernels of fir.hip / ols.hip with small permutation kernels on device scratch.
 #include "common.hpp"
+#include <algorithm>
+#include <array>
 #include <cmath>
+#include <complex>
 #include <cstdlib>
 #include <vector>
 
@@ -171,6 +174,58 @@ __global__ __launch_bounds__(256) void rii_recursive_tiled_kernel(float *__restr
   }
 }
 
+// Complex-coefficient flavour of the literal recursion (filtre_rii<cfloat, cfloat>): one lane walks
+// the complex stream; tiles staged through LDS like above, the output memory (most recent first) in LDS.
+constexpr int RII_KC_MAX = 256;
+__global__ __launch_bounds__(256) void rii_recursive_cplx_kernel(float2 *__restrict__ y, const float2 *__restrict__ denom, int Ky,
+                                                                 float2 *__restrict__ hist, int64_t n)
+{
+  __shared__ float2 tile[RII_TILE / 2];
+  __shared__ float2 h[RII_KC_MAX], d[RII_KC_MAX];
+  const int tid = threadIdx.x;
+  for (int k = tid; k < Ky; k += 256) {
+    h[k] = hist[k];
+    d[k] = denom[k + 1];
+  }
+  const float2 d0 = denom[0];
+  const float nd0 = d0.x * d0.x + d0.y * d0.y;
+  int head = 0;   // h is circular: h[(head + k) % Ky] = y[-1-k]
+  __syncthreads();
+  for (int64_t base = 0; base < n; base += RII_TILE / 2) {
+    const int cnt = (int) min((int64_t) (RII_TILE / 2), n - base);
+    for (int i = tid; i < cnt; i += 256) tile[i] = y[base + i];
+    __syncthreads();
+    if (tid == 0) {
+      for (int j = 0; j < cnt; j++) {
+        float2 somme = tile[j];
+        for (int k = 0; k < Ky; k++) {
+          int idx = head + k;
+          if (idx >= Ky) idx -= Ky;
+          const float2 w = h[idx], c = d[k];
+          somme.x -= w.x * c.x - w.y * c.y;
+          somme.y -= w.x * c.y + w.y * c.x;
+        }
+        // somme / d0 (limited-range complex division, as -fcx-limited-range compiles it)
+        const float2 o = make_float2((somme.x * d0.x + somme.y * d0.y) / nd0, (somme.y * d0.x - somme.x * d0.y) / nd0);
+        tile[j] = o;
+        if (Ky > 0) {
+          head = head == 0 ? Ky - 1 : head - 1;
+          h[head] = o;
+        }
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < cnt; i += 256) y[base + i] = tile[i];
+    __syncthreads();
+  }
+  if (tid == 0)
+    for (int k = 0; k < Ky; k++) {
+      int idx = head + k;
+      if (idx >= Ky) idx -= Ky;
+      hist[k] = h[idx];
+    }
+}
+
 }  // namespace tsdgpu
 
 using namespace tsdgpu;
@@ -193,10 +248,15 @@ int sos_create_ex(tsdgpu_sos **out, int data_type, const float *coefs_host, int 
 }
 
 struct tsdgpu_rii {
-  int data_type = 0, Ky = 0;
-  tsdgpu_sos *sos = nullptr;      // Kx <= 3 and Ky <= 2: one zero-seeded DF1 section on the block-parallel kernel
+  int data_type = 0, coef_type = 0, Ky = 0, Kx = 0;
+  // path 0: the whole H(z) as zero-seeded FormeDirecte1 sections on the block-parallel SOS kernel
+  //         (numerator of <= 3 taps folded into the first section)
+  // path 1: numerator on the FIR kernel, then the all-pole part 1/D as sections on the SOS kernel
+  // path 2: numerator on the FIR kernel, then the literal sequential recursion (reference operation order)
+  int path = 2;
+  tsdgpu_sos *sos = nullptr;
   tsdgpu_fir *fir = nullptr;
-  float *d_denom = nullptr, *d_hist = nullptr;
+  float *d_denom = nullptr, *d_hist = nullptr;     // literal path: denominator (float or float2) and output memory
   DevBuf in_stage, out_stage;
 };
 
@@ -417,33 +477,223 @@ int tsdgpu_polyfir_destroy(tsdgpu_polyfir *p)
 }
 
 // ---- FiltreRII ------------------------------------------------------------------------------
-int tsdgpu_rii_create(tsdgpu_rii **out, int data_type, const float *numer_host, int Kx, const float *denom_host, int Kd)
+// Block-parallel plan: the denominator D(z^-1) = d0 prod (1 + a1 z^-1 + a2 z^-2) is factored on the host
+// (Aberth iteration in double, conjugate / real roots paired) and the recursion runs as a cascade of
+// zero-seeded FormeDirecte1 sections on the SOS kernel -- the same transfer function from the same
+// zero initial state, computed in one HBM pass at a few hundred Gsamples/s instead of one sample per
+// dependent-FMA latency.  A cascade rounds differently from the direct form, so every filter is
+// checked at creation: the float direct-form recursion (the reference's own operation order) and the
+// float cascade are both run on the host over 8192 noise samples, and the cascade is used only when
+// they agree to 2e-6 of the peak; otherwise (clustered roots, unstable or ill-conditioned direct forms)
+// the literal sequential kernels above serve, bit-faithful to the reference's order.
+}  // extern "C" (host helpers below have C++ linkage)
+
+namespace {
+
+typedef std::complex<double> cd;
+
+// roots of c[0] z^p + c[1] z^(p-1) + ... + c[p] (c[0] != 0): Aberth-Ehrlich, then a coefficient check
+bool poly_roots(const std::vector<double> &c, std::vector<cd> &r)
+{
+  const int p = (int) c.size() - 1;
+  r.assign((size_t) p, cd(0, 0));
+  if (p <= 0) return true;
+  double rad = 0;
+  for (int k = 1; k <= p; k++) rad = std::max(rad, std::pow(std::fabs(c[k] / c[0]), 1.0 / k));
+  rad = std::max(2 * rad, 1e-3);
+  for (int k = 0; k < p; k++) r[k] = std::polar(rad * (0.5 + 0.5 * (k + 1) / p), 2 * M_PI * k / p + 0.4);
+  auto eval = [&](cd z, cd &dv) {
+    cd v = c[0];
+    dv = 0;
+    for (int k = 1; k <= p; k++) {
+      dv = dv * z + v;
+      v = v * z + c[k];
+    }
+    return v;
+  };
+  for (int it = 0; it < 400; it++) {
+    double delta = 0;
+    for (int i = 0; i < p; i++) {
+      cd dv;
+      const cd v = eval(r[i], dv);
+      if (v == cd(0, 0)) continue;
+      const cd nw = v / dv;
+      cd sum = 0;
+      for (int j = 0; j < p; j++)
+        if (j != i) sum += 1.0 / (r[i] - r[j]);
+      const cd w = nw / (1.0 - nw * sum);
+      r[i] -= w;
+      delta = std::max(delta, std::abs(w) / std::max(1e-30, std::abs(r[i])));
+    }
+    if (delta < 1e-15) break;
+  }
+  // expand prod (z - r_i) and compare with the monic coefficients
+  std::vector<cd> e(1, cd(1, 0));
+  for (int i = 0; i < p; i++) {
+    e.push_back(0);
+    for (int k = (int) e.size() - 1; k > 0; k--) e[k] -= r[i] * e[k - 1];
+  }
+  double err = 0, nrm = 0;
+  for (int k = 0; k <= p; k++) {
+    err = std::max(err, std::abs(e[k] - c[k] / c[0]));
+    nrm = std::max(nrm, std::fabs(c[k] / c[0]));
+  }
+  return std::isfinite(err) && err <= 1e-9 * nrm;
+}
+
+// all-pole sections (a1, a2) of D(z^-1) / d0 from its coefficient list; false when the factoring is unreliable
+bool factor_denominator(const float *den, int Kd, std::vector<std::array<float, 2>> &sec)
+{
+  int p = Kd - 1;
+  while (p > 0 && den[p] == 0.f) p--;                      // trailing zeros: poles at the origin
+  sec.clear();
+  if (p == 0) return true;
+  std::vector<double> c((size_t) p + 1);
+  for (int k = 0; k <= p; k++) c[k] = den[k];
+  std::vector<cd> r;
+  if (!poly_roots(c, r)) return false;
+  std::vector<cd> cplx;
+  std::vector<double> reel;
+  for (const cd &z : r) {
+    if (!(std::abs(z) < 1.0)) return false;                // unstable or marginal: leave it to the literal kernel
+    if (std::fabs(z.imag()) <= 1e-12 * std::max(1.0, std::abs(z))) reel.push_back(z.real());
+    else cplx.push_back(z);
+  }
+  // conjugate pairs: every root of positive imaginary part takes the closest remaining conjugate
+  std::vector<bool> pris(cplx.size(), false);
+  for (size_t i = 0; i < cplx.size(); i++) {
+    if (pris[i] || cplx[i].imag() < 0) continue;
+    pris[i] = true;
+    int best = -1;
+    double bd = 1e300;
+    for (size_t j = 0; j < cplx.size(); j++)
+      if (!pris[j] && cplx[j].imag() < 0 && std::abs(cplx[j] - std::conj(cplx[i])) < bd) {
+        bd = std::abs(cplx[j] - std::conj(cplx[i]));
+        best = (int) j;
+      }
+    if (best < 0 || bd > 1e-7 * std::max(1.0, std::abs(cplx[i]))) return false;
+    pris[(size_t) best] = true;
+    const cd m = 0.5 * (cplx[i] + std::conj(cplx[(size_t) best]));
+    sec.push_back({(float) (-2 * m.real()), (float) std::norm(m)});
+  }
+  for (size_t i = 0; i < cplx.size(); i++)
+    if (!pris[i]) return false;
+  std::sort(reel.begin(), reel.end(), [](double a, double b) { return std::fabs(a) > std::fabs(b); });
+  for (size_t i = 0; i + 1 < reel.size(); i += 2) sec.push_back({(float) (-(reel[i] + reel[i + 1])), (float) (reel[i] * reel[i + 1])});
+  if (reel.size() & 1) sec.push_back({(float) (-reel.back()), 0.f});
+  return true;
+}
+
+// create-time check of the cascade against the reference's direct form, both in float, zero memory
+bool cascade_matches_direct_form(const float *num, int Kx, const float *den, int Kd, const std::vector<float> &coefs5, float gain,
+                                 bool num_in_cascade)
+{
+  const int N = 8192, Ky = Kd - 1, ns = (int) coefs5.size() / 5;
+  std::vector<float> x((size_t) N), u((size_t) N), yd((size_t) N), yc((size_t) N);
+  uint32_t lcg = 12345u;
+  for (int i = 0; i < N; i++) {
+    lcg = lcg * 1664525u + 1013904223u;
+    x[i] = (float) ((int32_t) lcg) * (1.0f / 2147483648.0f);
+  }
+  for (int j = 0; j < N; j++) {                            // (1) non-recursive part, oldest sample first
+    float s = 0;
+    for (int i = Kx - 1; i >= 0; i--)
+      if (j - i >= 0) s += x[j - i] * num[i];
+    u[j] = s;
+  }
+  for (int j = 0; j < N; j++) {                            // (2) recursive part (filtre-rt.cc:251-279)
+    float s = u[j];
+    for (int k = 1; k <= Ky; k++)
+      if (j - k >= 0) s -= yd[j - k] * den[k];
+    yd[j] = s / den[0];
+  }
+  const std::vector<float> &in = num_in_cascade ? x : u;
+  std::vector<float> st((size_t) ns * 4, 0.f);             // x1, x2, y1, y2 per section
+  for (int j = 0; j < N; j++) {
+    float v = in[j];
+    for (int q = 0; q < ns; q++) {
+      const float *c = &coefs5[(size_t) q * 5];
+      float *m = &st[(size_t) q * 4];
+      const float o = c[0] * v + c[1] * m[0] + c[2] * m[1] - c[3] * m[2] - c[4] * m[3];
+      m[1] = m[0]; m[0] = v; m[3] = m[2]; m[2] = o;
+      v = o;
+    }
+    yc[j] = v * gain;
+  }
+  float peak = 0, err = 0;
+  for (int j = 0; j < N; j++) {
+    if (!std::isfinite(yd[j]) || !std::isfinite(yc[j])) return false;
+    peak = std::max(peak, std::fabs(yd[j]));
+    err = std::max(err, std::fabs(yd[j] - yc[j]));
+  }
+  return peak > 0 && err <= 2e-6f * peak;
+}
+
+}  // namespace
+
+extern "C" {
+
+int tsdgpu_rii_create2(tsdgpu_rii **out, int data_type, int coef_type, const void *numer_host, int Kx, const void *denom_host, int Kd)
 {
   TSD_CHECK(out != nullptr, "rii_create: out is NULL");
   *out = nullptr;
   TSD_CHECK(data_type == TSDGPU_F32 || data_type == TSDGPU_C64, "rii_create: bad data_type %d", data_type);
+  TSD_CHECK(coef_type == TSDGPU_F32 || coef_type == TSDGPU_C64, "rii_create: bad coef_type %d", coef_type);
+  TSD_CHECK(coef_type == TSDGPU_F32 || data_type == TSDGPU_C64, "rii_create: complex coefficients need complex data");
   TSD_CHECK(numer_host && Kx > 0 && denom_host && Kd > 0, "rii_create: numerator and denominator need >= 1 coefficient");
-  TSD_CHECK(denom_host[0] != 0.f, "rii_create: denom[0] must be non zero");
+  // complex coefficients whose imaginary parts all vanish are real coefficients
+  std::vector<float> nr((size_t) Kx), dr((size_t) Kd);
+  bool reel = true;
+  if (coef_type == TSDGPU_C64) {
+    const float *a = (const float *) numer_host, *b = (const float *) denom_host;
+    for (int i = 0; i < Kx; i++) { nr[i] = a[2 * i]; reel = reel && a[2 * i + 1] == 0.f; }
+    for (int i = 0; i < Kd; i++) { dr[i] = b[2 * i]; reel = reel && b[2 * i + 1] == 0.f; }
+    TSD_CHECK(b[0] != 0.f || b[1] != 0.f, "rii_create: denom[0] must be non zero");
+    TSD_CHECK(reel || Kd - 1 <= RII_KC_MAX, "rii_create: complex denominators of more than %d coefficients are not built", RII_KC_MAX + 1);
+  } else {
+    std::copy((const float *) numer_host, (const float *) numer_host + Kx, nr.begin());
+    std::copy((const float *) denom_host, (const float *) denom_host + Kd, dr.begin());
+  }
+  if (reel) TSD_CHECK(dr[0] != 0.f, "rii_create: denom[0] must be non zero");
   tsdgpu_rii *r = new tsdgpu_rii();
   r->data_type = data_type;
+  r->coef_type = reel ? TSDGPU_F32 : TSDGPU_C64;
   r->Ky = Kd - 1;
-  if (Kx <= 3 && Kd <= 3) {
-    // y = (n0 x + n1 x1 + n2 x2 - d1 y1 - d2 y2) / d0 from zero memory == one FormeDirecte1
-    // section with zero seed; coefficients pre-divided by d0 (the reference divides the sum)
-    const float d0 = denom_host[0];
-    float c[5] = {numer_host[0] / d0, Kx > 1 ? numer_host[1] / d0 : 0.f, Kx > 2 ? numer_host[2] / d0 : 0.f,
-                  Kd > 1 ? denom_host[1] / d0 : 0.f, Kd > 2 ? denom_host[2] / d0 : 0.f};
-    const int rc0 = tsdgpu::sos_create_ex(&r->sos, data_type, c, 1, 1.0f, nullptr, 1, 0);
-    if (rc0) { delete r; return rc0; }
-    *out = r;
-    return TSDGPU_OK;
+  r->Kx = Kx;
+  int rc = TSDGPU_OK;
+  static const bool litteral = getenv("TSDGPU_RII_LITERAL") != nullptr;
+  if (reel && !litteral) {
+    std::vector<std::array<float, 2>> poles;
+    if (factor_denominator(dr.data(), Kd, poles) && (int) poles.size() <= 32) {
+      const bool plie = Kx <= 3;                            // numerator folded into the first section
+      const float d0 = dr[0];
+      std::vector<float> c5;
+      if (poles.empty()) poles.push_back({0.f, 0.f});
+      for (size_t q = 0; q < poles.size(); q++) {
+        if (q == 0 && plie) { c5.push_back(nr[0] / d0); c5.push_back(Kx > 1 ? nr[1] / d0 : 0.f); c5.push_back(Kx > 2 ? nr[2] / d0 : 0.f); }
+        else { c5.push_back(1.f); c5.push_back(0.f); c5.push_back(0.f); }
+        c5.push_back(poles[q][0]);
+        c5.push_back(poles[q][1]);
+      }
+      const float gain = plie ? 1.0f : 1.0f / d0;
+      if (cascade_matches_direct_form(nr.data(), Kx, dr.data(), Kd, c5, gain, plie)) {
+        rc = tsdgpu::sos_create_ex(&r->sos, data_type, c5.data(), (int) poles.size(), gain, nullptr, 1, 0);
+        if (!rc && !plie) rc = tsdgpu_fir_create(&r->fir, data_type, TSDGPU_F32, nr.data(), Kx, TSDGPU_FIR_AUTO);
+        if (rc) { tsdgpu_rii_destroy(r); return rc; }
+        r->path = plie ? 0 : 1;
+        *out = r;
+        return TSDGPU_OK;
+      }
+    }
   }
-  int rc = tsdgpu_fir_create(&r->fir, data_type, TSDGPU_F32, numer_host, Kx, TSDGPU_FIR_AUTO);
+  // literal path
+  r->path = 2;
+  const size_t cw = reel ? sizeof(float) : sizeof(float2);
+  rc = tsdgpu_fir_create(&r->fir, data_type, reel ? TSDGPU_F32 : TSDGPU_C64, reel ? (const void *) nr.data() : numer_host, Kx, TSDGPU_FIR_AUTO);
   const size_t hb = (size_t) std::max(r->Ky, 1) * 2 * sizeof(float);
-  if (!rc && (hipMalloc((void **) &r->d_denom, (size_t) Kd * sizeof(float)) != hipSuccess ||
-              hipMalloc((void **) &r->d_hist, hb) != hipSuccess))
+  if (!rc && (hipMalloc((void **) &r->d_denom, (size_t) Kd * cw) != hipSuccess || hipMalloc((void **) &r->d_hist, hb) != hipSuccess))
     rc = set_err(TSDGPU_ERR_HIP, "rii_create: hipMalloc failed: %s", hipGetErrorString(hipGetLastError()));
-  if (!rc && (hipMemcpy(r->d_denom, denom_host, (size_t) Kd * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
+  if (!rc && (hipMemcpy(r->d_denom, reel ? (const void *) dr.data() : denom_host, (size_t) Kd * cw, hipMemcpyHostToDevice) != hipSuccess ||
               hipMemset(r->d_hist, 0, hb) != hipSuccess))
     rc = set_err(TSDGPU_ERR_HIP, "rii_create: upload failed: %s", hipGetErrorString(hipGetLastError()));
   if (rc) {
@@ -454,13 +704,20 @@ int tsdgpu_rii_create(tsdgpu_rii **out, int data_type, const float *numer_host, 
   return TSDGPU_OK;
 }
 
+int tsdgpu_rii_create(tsdgpu_rii **out, int data_type, const float *numer_host, int Kx, const float *denom_host, int Kd)
+{
+  return tsdgpu_rii_create2(out, data_type, TSDGPU_F32, numer_host, Kx, denom_host, Kd);
+}
+
+int tsdgpu_rii_path(const tsdgpu_rii *r) { return r ? r->path : -1; }
+
 int tsdgpu_rii_step(tsdgpu_rii *r, const void *x, void *y, int64_t n, void *stream)
 {
   TSD_CHECK(r != nullptr, "rii_step: NULL handle");
   TSD_CHECK(n >= 0, "rii_step: negative length");
   if (n == 0) return TSDGPU_OK;
   TSD_CHECK(x != nullptr && y != nullptr, "rii_step: NULL buffer");
-  if (r->sos) return tsdgpu_sos_step(r->sos, x, y, n, stream);
+  if (r->path == 0) return tsdgpu_sos_step(r->sos, x, y, n, stream);
   hipStream_t st = (hipStream_t) stream;
   const size_t bytes = (size_t) n * dtype_size(r->data_type);
   const void *dx = nullptr;
@@ -472,6 +729,17 @@ int tsdgpu_rii_step(tsdgpu_rii *r, const void *x, void *y, int64_t n, void *stre
   if (rc) return rc;
   rc = tsdgpu_fir_step(r->fir, dx, dy, n, stream);                      // (1) non-recursive part
   if (rc) return rc;
+  if (r->path == 1) {
+    rc = tsdgpu_sos_step(r->sos, dy, dy, n, stream);                    // (2) all-pole cascade, in place
+    if (rc) return rc;
+    return finish_out(y, bytes, dy, staged, st);
+  }
+  if (r->coef_type == TSDGPU_C64) {
+    hipLaunchKernelGGL(rii_recursive_cplx_kernel, dim3(1), dim3(256), 0, st, (float2 *) dy, (const float2 *) r->d_denom, r->Ky,
+                       (float2 *) r->d_hist, n);
+    TSD_HIP(hipGetLastError());
+    return finish_out(y, bytes, dy, staged, st);
+  }
   const int nch = r->data_type == TSDGPU_C64 ? 2 : 1;
 #define RII_LAUNCH(KM) hipLaunchKernelGGL(rii_recursive_tiled_kernel<KM>, dim3(1), dim3(256), 0, st, (float *) dy, r->d_denom, r->Ky, r->d_hist, nch, n)
   if (r->Ky <= 4) RII_LAUNCH(4);

@@ -6,54 +6,16 @@
 //   (filtre_reechan, filtre_itrp);  core/include/tsd/filtrage/frat.hpp (FRat / Poly subset).
 #pragma once
 #include "tsd/tsd.hpp"
+#include "tsd/filtrage/frat.hpp"   // Poly / FRat live in namespace tsd, like in libtsd
 
 namespace tsd::filtrage {
-
-// ---- rational transfer functions (subset of frat.hpp:16,501) ---------------------------------
-// A polynomial is either a coefficient list (ascending powers) or, in "mode_racines", a list
-// of roots with a leading multiplier `mlt`: mlt * prod (z - coefs[i]).
-template <typename T> struct Poly {
-  Vecteur<T> coefs;
-  T mlt = T(1);
-  bool mode_racines = false;
-  std::string vname = "z";
-  static Poly from_roots(const Vecteur<T> &r)
-  {
-    Poly p;
-    p.coefs = r;
-    p.mode_racines = true;
-    return p;
-  }
-  // roots of the polynomial (identity in mode_racines, frat.cc:43-46; companion-free
-  // Durand-Kerner iteration otherwise -- the reference uses Eigen's PolynomialSolver there)
-  Vecteur<std::complex<float>> roots() const;
-};
-
-template <typename T> struct FRat {
-  Poly<T> numer, denom;
-  // H(z^-1) = (a0 + a1 z^-1 + ...) / (b0 + b1 z^-1 + ...), coefficient form
-  static FRat rii(const Vecteur<T> &numer, const Vecteur<T> &denom)
-  {
-    FRat h;
-    h.numer.coefs = numer;
-    h.numer.vname = "z^-1";
-    h.denom.coefs = denom;
-    h.denom.vname = "z^-1";
-    return h;
-  }
-  static FRat rif(const Vecteur<T> &c)
-  {
-    FRat h = rii(c, Vecteur<T>::ones(1));
-    return h;
-  }
-  bool est_rif() const { return !denom.mode_racines && denom.coefs.rows() == 1; }
-};
 
 // ---- Design (filtrage.hpp:24-85) ---------------------------------------------------------------
 struct Design {
   Design(const FRat<cfloat> &f) : est_complexe(true), est_rif(false), frat_c(f) {}
   Design(const FRat<float> &f) : est_complexe(false), est_rif(false), frat(f) {}
   Design(const Vecf &c) : est_complexe(false), est_rif(true), coefs(c) {}
+  Design(const Vecf &coefs_numer, const Vecf &coefs_dénom) : est_complexe(false), est_rif(false), frat(FRat<float>::rii(coefs_numer, coefs_dénom)) {}
   Design() {}
   bool est_complexe = false, est_rif = false;
   FRat<float> frat;
@@ -75,6 +37,7 @@ float sinc(float T, float f);
 
 // ---- stateful operators (factories) ------------------------------------------------------------
 template <typename Tc, typename T = Tc> sptr<FiltreGen<T>> filtre_rif(const Vecteur<Tc> &h);
+template <typename T> sptr<FiltreGen<T>> filtre_id();                                        // filtrage.hpp:1376-1377
 template <typename T> sptr<FiltreGen<T>> filtre_rif_fft(const Vecf &h);
 template <typename T> sptr<FiltreGen<T>> filtre_sois(const FRat<cfloat> &h, RIIStructure structure = FormeDirecte2);
 template <typename T> sptr<FiltreGen<T>> filtre_sois(const FRat<float> &h, RIIStructure structure = FormeDirecte2);
@@ -194,10 +157,10 @@ template <typename T> struct InterpolateurLagrange : InterpolateurRIF<T> {      
     return h;
   }
 };
-template <typename T> sptr<Interpolateur<T>> itrp_lineaire() { return std::make_shared<InterpolateurLineaire<T>>(); }
-template <typename T> sptr<Interpolateur<T>> itrp_lagrange(entier degré) { return std::make_shared<InterpolateurLagrange<T>>(degré); }
-template <typename T> sptr<Interpolateur<T>> itrp_cspline();
-template <typename T> sptr<Interpolateur<T>> itrp_sinc(const InterpolateurSincConfig &config);
+template <typename T> sptr<InterpolateurRIF<T>> itrp_lineaire();
+template <typename T> sptr<InterpolateurRIF<T>> itrp_lagrange(entier degré);
+template <typename T> sptr<InterpolateurRIF<T>> itrp_cspline();
+template <typename T> sptr<InterpolateurRIF<T>> itrp_sinc(const InterpolateurSincConfig &config);
 template <typename T> sptr<FiltreGen<T>> filtre_itrp(float ratio, sptr<Interpolateur<T>> itrp);
 template <typename T> sptr<Filtre<T, T, float>> filtre_reechan(float ratio);
 
@@ -213,8 +176,8 @@ template <typename T> Vecteur<T> filtrer(const Design &d, const Vecteur<T> &x)
     return f->step(x);
   }
   if (d.frat.est_rif()) {
-    // coefficient-form FIR: the reference reverses the numerator here (filtrage.hpp:1702-1704)
-    auto f = filtre_rif<float, T>(d.frat.numer.coefs.reverse());
+    // a FRat that is an FIR: numerator in z, reversed to get the taps (filtrage.hpp:1702-1704)
+    auto f = filtre_rif<T, T>(Vecteur<T>(d.frat.numer.coefs.reverse()));
     return f->step(x);
   }
   auto f = filtre_sois<T>(d.frat);

@@ -88,12 +88,7 @@ struct FiltreFFTConfig {
   entier nb_zeros_min = 0;
   bouléen avec_fenetrage = false;
   fonction<void(Veccf &)> traitement_freq;
-  // Extension (not in libtsd): a frequency response applied ON THE DEVICE, X *= réponse_freq (N
-  // values, N = prochaine_puissance_de_2(dim_blocs_temporel + nb_zeros_min)), the device-side form
-  // of the callback FiltreFFTRIF installs (fourier.cc:956-959).  When set, traitement_freq may be
-  // left empty and no spectrum crosses PCIe.
-  Veccf réponse_freq;
-};
+};   // (the device-side response X *= H is an extension: tsd_amd/extensions.hpp, filtre_fft_reponse)
 std::tuple<sptr<Filtre<cfloat, cfloat, FiltreFFTConfig>>, entier> filtre_fft(const FiltreFFTConfig &config);
 // cost model of the OLA engine (fourier.cc:700-735): flops per input sample, FFT size, zeros
 void ola_complexité(entier M, entier Ne, float &C, entier &Nf, entier &Nz);

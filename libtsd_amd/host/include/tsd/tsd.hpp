@@ -8,6 +8,7 @@
 //   linspace, sigimp, randn ...        core/include/tsd/tsd.hpp:916-931, core/src/tsd.cc:179-483
 // Not a reimplementation of libtsd's array runtime: only what the hot path and its tests use.
 #pragma once
+#define TSD_AMD_MIRROR 1   // tells the adaptor TUs which header set they are compiled against
 #include <algorithm>
 #include <cmath>
 #include <complex>

@@ -1,0 +1,165 @@
+// design.cc -- mirror runtime: the host-side design helpers the hot path's configurations need
+// (run once per filter, on the CPU, like in libtsd).  Mirror only: against libtsd itself these come
+// from libtsd's own rif-fen.cc / fenetres.cc / rii.cc / frat.cc / filtrage.cc.
+#include "tsd/filtrage.hpp"
+
+namespace tsd {
+namespace filtrage {
+
+// ---- design: windowed sinc (rif-fen.cc:31-108, fenetres.cc:16-60,127-130, divers.cc:6-12) --
+float sinc(float T, float f)
+{
+  const float a = π_f * T * f;
+  if (std::abs(a) < 1e-7f) return T;
+  return std::sin(a) / (π_f * f);
+}
+
+static Vecf fen_inter(entier n, bool sym)
+{
+  float tmin, tmax;
+  if ((n & 1) == 0) {
+    tmin = (float) (-n / 2);
+    tmax = sym ? (float) (n / 2) : (float) ((n - 1) / 2);
+  } else {
+    tmin = (float) (-n / 2);
+    tmax = sym ? (float) (n / 2) : (float) (n / 2) - ((float) n - 1) / n;
+  }
+  return linspace(tmin / n, tmax / n, n);
+}
+
+Vecf fenêtre(cstring type, entier n, bouléen symetrique)
+{
+  Vecf x = Vecf::zeros(n);
+  if (type == "re" || type == "rect" || type == "none") {
+    x.setConstant(1);
+    return x;
+  }
+  const Vecf t = fen_inter(n, symetrique);
+  if (type == "hn" || type == "hann" || type == "hm" || type == "hamming") {
+    const float a = (type[1] == 'n' || type == "hann") ? 0.5f : 0.54f;
+    for (entier i = 0; i < n; i++) x(i) = a + (1 - a) * std::cos((float) (2 * π) * t(i));
+    return x;
+  }
+  if (type == "tr" || type == "triangle") {
+    for (entier i = 0; i < n; i++) x(i) = t(i) < 0 ? 2 * (0.5f + t(i)) : 2 * (0.5f - t(i));
+    return x;
+  }
+  échec("fenêtre: window type '{}' is not built in this hot-path mirror (have hn, hm, re, tr)", type);
+}
+
+Vecf fenêtre(Fenetre type, entier n, bouléen symetrique)
+{
+  switch (type) {
+    case Fenetre::AUCUNE: return fenêtre("re", n, symetrique);
+    case Fenetre::HANN: return fenêtre("hn", n, symetrique);
+    case Fenetre::TRIANGLE: return fenêtre("tr", n, symetrique);
+    case Fenetre::HAMMING: return fenêtre("hm", n, symetrique);
+    default: échec("fenêtre: this window is not built in the hot-path mirror (have AUCUNE, HANN, TRIANGLE, HAMMING)");
+  }
+}
+
+static Vecf coefs_filtre_sinc(entier n, float fc)
+{
+  if (n & 1) return Vecf::int_expr(n, [&](entier i) { return sinc(2 * fc, (float) (i - n / 2)); });
+  return Vecf::int_expr(n, [&](entier i) { return sinc(2 * fc, (float) (i - (n - 1) / 2)); });
+}
+
+Vecf design_rif_fen(entier n, cstring type, float fc, cstring fen, float fc2)
+{
+  (void) fc2;
+  const Vecf f = fenêtre(fen, n, true);
+  Vecf h;
+  if (type == "lp" || type == "pb") {
+    h = coefs_filtre_sinc(n, fc);
+  } else if (type == "hp" || type == "ph") {
+    h = -coefs_filtre_sinc(n, fc);
+    h((n - 1) / 2) += 1.0f;
+  } else {
+    échec("design_rif_fen: type '{}' is not built in this hot-path mirror (have lp/pb, hp/ph)", type);
+  }
+  Vecf h2 = h * f;
+  if (type == "lp") h2 /= h2.somme();     // only the literal "lp" is normalised (rif-fen.cc:96-98)
+  return h2;
+}
+
+Vecf design_rif_prod(const Vecf &h1, const Vecf &h2)
+{
+  // filtrage.cc:47-52: filtrer(h1, [h2, 0 ... 0])
+  const Vecf h2p = vconcat(h2, Vecf::zeros(h1.rows() - 1));
+  return filtrer<float>(Design(h1), h2p);
+}
+
+// ---- design: Butterworth low-pass through the bilinear transform (rii.cc:20-23,41-73,
+//      173-187,195-215,405-452) --------------------------------------------------------------
+FRat<cfloat> design_riia(entier n, cstring type, cstring prototype, float fc, float, float)
+{
+  if (!(type == "lp" || type == "pb") || prototype.substr(0, 1) != "b")
+    échec("design_riia: only the Butterworth low-pass (\"lp\", \"butt\") is built in this hot-path mirror "
+          "(got type '{}', prototype '{}'); other prototypes are design-time code outside the path",
+          type, prototype);
+  const float wd = (float) (2 * π * fc);
+  const float wa = 2 * 1.0f * std::tan(wd / (2 * 1.0f));
+  Veccf z(n), p(n);
+  cfloat gain = 1.0f;
+  for (entier i = 0; i < n; i++) {
+    const float k = (float) (i + 1);
+    const float ang = ((float) π * (2 * k + (float) (n - 1))) / (float) (2 * n);
+    const cfloat pa = cfloat(std::cos(ang), std::sin(ang)) * wa;
+    p(i) = (pa + 2.0f) / (-pa + 2.0f);
+    z(i) = cfloat(-1.f, 0.f);
+    gain /= (2.0f - pa);
+  }
+  FRat<cfloat> h;
+  h.numer = Poly<cfloat>::from_roots(z);
+  h.denom = Poly<cfloat>::from_roots(p);
+  h.numer.mlt = cfloat((float) std::pow((double) wa, (double) n), 0.f) * gain;
+  h.denom.mlt = cfloat(1.f, 0.f);
+  return h;
+}
+
+// ---- polynomial roots -----------------------------------------------------------------------
+}  // namespace filtrage
+
+template <typename T> Veccf Poly<T>::roots() const
+{
+  if (mode_racines) return Veccf(coefs.template as<cfloat>());
+  // coefficient form, ascending powers: sum c_k x^k.  Durand-Kerner on the monic polynomial.
+  entier deg = coefs.rows() - 1;
+  while (deg > 0 && std::abs(cfloat(coefs(deg))) == 0.f) deg--;
+  Veccf r(std::max(deg, 0));
+  if (deg <= 0) return r;
+  std::vector<cdouble> a((size_t) deg + 1), x((size_t) deg);
+  for (entier k = 0; k <= deg; k++) a[k] = cdouble(cfloat(coefs(k))) / cdouble(cfloat(coefs(deg)));
+  for (entier k = 0; k < deg; k++) x[k] = std::pow(cdouble(0.4, 0.9), k);
+  for (int it = 0; it < 500; it++) {
+    double delta = 0;
+    for (entier i = 0; i < deg; i++) {
+      cdouble num = 1, xp = 1;
+      num = 0;
+      for (entier k = 0; k <= deg; k++) { num += a[k] * xp; xp *= x[i]; }
+      cdouble den = 1;
+      for (entier j = 0; j < deg; j++) if (j != i) den *= (x[i] - x[j]);
+      const cdouble d = num / den;
+      x[i] -= d;
+      delta = std::max(delta, std::abs(d));
+    }
+    if (delta < 1e-14) break;
+  }
+  for (entier i = 0; i < deg; i++) r(i) = cfloat(x[i]);
+  return r;
+}
+template struct Poly<float>;
+template struct Poly<cfloat>;
+
+namespace filtrage {
+
+
+// ---- first-order smoother helpers (src/filtrage/filtrage.cc:121-139) ----------------------------------
+float lexp_coef(Fréquence fc) { return (float) (1.0 - std::exp(-fc.value * 2 * π)); }
+float lexp_tc_vers_coef(float τ) { return lexp_coef((float) (1.0 / (2 * π * τ))); }
+Fréquence lexp_fcoupure(float γ) { return (float) (-std::log(1.0 - γ) / (2 * π)); }
+float lexp_coef_vers_tc(float γ) { return (float) (1.0 / (2 * π * lexp_fcoupure(γ).value)); }
+
+
+}  // namespace filtrage
+}  // namespace tsd

@@ -3,6 +3,7 @@
 // per-sample streams it works on (correlation with the pattern, sliding energy) come from the
 // MI355X operators: filtre_fft (OLA engine, batched FFTs) or filtre_rif, and filtre_mg.
 #include "tsd/fourier.hpp"
+#include "tsd_amd/extensions.hpp"
 #include "tsd/filtrage.hpp"
 #include <algorithm>
 #include <vector>
@@ -82,9 +83,9 @@ struct DetecteurGpu : Detecteur {
       Veccf tmp = Veccf::zeros(N);
       tmp.head(M) = motif;
       T_motif = fft(tmp);
-      oc.réponse_freq = Veccf(N);
-      for (entier i = 0; i < N; i++) oc.réponse_freq(i) = std::conj(T_motif(i));
-      auto [f, n_fft] = filtre_fft(oc);
+      Veccf réponse(N);
+      for (entier i = 0; i < N; i++) réponse(i) = std::conj(T_motif(i));
+      auto [f, n_fft] = tsd_amd::filtre_fft_reponse(oc, réponse);
       correlateur = f;
       if (n_fft != N) échec("détecteur: OLA engine configured with N = {} instead of {}", n_fft, N);
       delais_corr = Ne;

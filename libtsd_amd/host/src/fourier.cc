@@ -1,70 +1,17 @@
-// fourier.cc -- FFTPlan on the MI355X C ABI, the fftplan_defaut hook and the real-FFT plan.
+// fourier.cc -- mirror runtime: the free functions of libtsd's fourier.cc around the plan hook
+// (tfrplan_création, rtfrplan_création, csym, correlations, délais, psd, rt_spectrum).  Mirror only:
+// against libtsd itself these are libtsd's own and reach the GPU through fftplan_defaut.
 #include "tsd/fourier.hpp"
 #include "tsd/filtrage.hpp"
 #include <limits>
 #include <vector>
-#include "../../../include/tsdgpu.h"
+#include "tsd_amd/extensions.hpp"
+#include "tsdgpu.h"
 
 namespace tsd::fourier {
 
-namespace {
-
-// TFRPlanDefaut's contract (fourier.cc:360-467): (re)configures itself when the input size
-// changes, unitary scaling in both directions, `normalize` accepted and ignored.
-struct FFTPlanGpu : FFTPlan {
-  tsdgpu_fft *h = nullptr;
-  entier n = -1;
-  bouléen avant_defaut = true;
-  ~FFTPlanGpu() override { tsdgpu_fft_destroy(h); }
-  void configure(entier n_, bouléen avant, bouléen) override
-  {
-    avant_defaut = avant;
-    if (n_ == n) return;
-    tsdgpu_fft_destroy(h);
-    h = nullptr;
-    n = n_;
-    if (n < 1) return;
-    if (tsdgpu_fft_create(&h, n, 1)) échec("FFTPlan::configure({}): {}", n, tsdgpu_last_error());
-  }
-  void step(const Veccf &x, Veccf &y, bouléen avant) override
-  {
-    if (x.rows() <= 0) échec("FFTPlan::step: empty input");          // assertion(x.rows() > 0), fourier.cc:414
-    if (x.rows() != n) configure(x.rows(), avant_defaut, true);
-    if (x.data() != y.data()) y.resize(n);
-    if (tsdgpu_fft_step(h, x.data(), y.data(), 1, avant ? 1 : 0, nullptr)) échec("FFTPlan::step: {}", tsdgpu_last_error());
-  }
-};
-
-// RTFRPlan (fourier.cc:280-355) on tsdgpu_rfft: packed n/2-point complex FFT, untangling with
-// the 0.5/sqrt(2) factors and the forced conjugate symmetry all run on the device.
-struct RTFRPlanGpu : FiltreGen<float, cfloat> {
-  entier n = -1;
-  tsdgpu_rfft *h = nullptr;
-  explicit RTFRPlanGpu(entier n_) { configure(n_); }
-  ~RTFRPlanGpu() override { tsdgpu_rfft_destroy(h); }
-  void configure(entier n_)
-  {
-    if (n_ == n) return;
-    tsdgpu_rfft_destroy(h);
-    h = nullptr;
-    n = n_;
-    if (n > 0 && tsdgpu_rfft_create(&h, n)) échec("rtfrplan_création({}): {}", n, tsdgpu_last_error());
-  }
-  void step(const Vecf &x, Veccf &y) override
-  {
-    if (x.rows() != n) configure(x.rows());
-    if (n <= 0) {
-      y.resize(0);
-      return;
-    }
-    y.resize(n);
-    if (tsdgpu_rfft_step(h, x.data(), y.data(), 1, nullptr)) échec("rfft: {}", tsdgpu_last_error());
-  }
-};
-
-}  // namespace
-
-fonction<sptr<FFTPlan>()> fftplan_defaut = []() -> sptr<FFTPlan> { return std::make_shared<FFTPlanGpu>(); };
+// the plug point (fourier.hpp:35): the mirror starts with the MI355X plan installed
+fonction<sptr<FFTPlan>()> fftplan_defaut = tsd_amd::fftplan_gpu;
 
 sptr<FFTPlan> tfrplan_création(entier n, bouléen avant, bouléen normalize)
 {
@@ -73,7 +20,7 @@ sptr<FFTPlan> tfrplan_création(entier n, bouléen avant, bouléen normalize)
   return res;
 }
 
-sptr<FiltreGen<float, cfloat>> rtfrplan_création(entier n) { return std::make_shared<RTFRPlanGpu>(n); }
+sptr<FiltreGen<float, cfloat>> rtfrplan_création(entier n) { return tsd_amd::rtfrplan_gpu(n); }
 
 void csym_forçage_impl(Veccf &X)
 {
@@ -456,114 +403,5 @@ void ola_complexité_optimise(entier M, float &C_, entier &Nf_, entier &Nz_, ent
   }
 }
 
-namespace {
-
-struct OLAGpu : Filtre<cfloat, cfloat, FiltreFFTConfig> {
-  entier N = 0, Ne = 0;
-  tsdgpu_ola *h = nullptr;
-  ~OLAGpu() override { tsdgpu_ola_destroy(h); }
-
-  void configure_impl(const FiltreFFTConfig &c) override
-  {
-    if (!c.traitement_freq && c.réponse_freq.rows() == 0) échec("configuration OLA : traitement fréquentiel non précisé.");
-    tsdgpu_ola_destroy(h);
-    h = nullptr;
-    const entier ne = c.dim_blocs_temporel > 0 ? c.dim_blocs_temporel : 512;
-    Vecf fen;
-    if (c.avec_fenetrage) fen = tsd::filtrage::fenêtre("hn", ne, false);          // fourier.cc:795
-    if (tsdgpu_ola_create(&h, c.dim_blocs_temporel, c.nb_zeros_min, c.avec_fenetrage ? fen.data() : nullptr))
-      échec("filtre_fft: {}", tsdgpu_last_error());
-    N = tsdgpu_ola_fft_size(h);
-    Ne = tsdgpu_ola_block_len(h);
-    if (c.réponse_freq.rows() > 0) {
-      if (c.réponse_freq.rows() != N) échec("filtre_fft: réponse_freq has {} values, the FFT size is {}", c.réponse_freq.rows(), N);
-      if (tsdgpu_ola_set_response(h, c.réponse_freq.data())) échec("filtre_fft: {}", tsdgpu_last_error());
-    }
-  }
-
-  void step(const Veccf &x, Veccf &y) override
-  {
-    const FiltreFFTConfig &c = Configurable<FiltreFFTConfig>::config;
-    if (!h) échec("filtre_fft: not configured");
-    Veccf out((entier) std::max<int64_t>(1, tsdgpu_ola_max_out(h, x.rows())));
-    int64_t nout = 0;
-    if (!c.traitement_freq) {
-      // device-side processing only: framing, FFTs, product and overlap-add in one call
-      if (tsdgpu_ola_step(h, x.data(), x.rows(), out.data(), &nout, nullptr)) échec("filtre_fft: {}", tsdgpu_last_error());
-    } else {
-      // the reference's host callback: the spectra of the call's frames visit the host once
-      void *sp = nullptr;
-      int nf = 0;
-      if (tsdgpu_ola_analyse(h, x.data(), x.rows(), &sp, &nf, nullptr)) échec("filtre_fft: {}", tsdgpu_last_error());
-      if (nf > 0) {
-        if (tsdgpu_ola_apply_response(h, nullptr)) échec("filtre_fft: {}", tsdgpu_last_error());   // réponse_freq first, if any
-        Veccf S(nf * N);
-        if (tsdgpu_ola_read_spectra(h, S.data(), nullptr)) échec("filtre_fft: {}", tsdgpu_last_error());
-        for (entier f = 0; f < nf; f++) {
-          Veccf X = S.segment(f * N, N);                          // a view: the callback edits the batch in place
-          c.traitement_freq(X);
-          if (X.rows() != N || X.data() != S.data() + (size_t) f * N)
-            échec("filtre_fft: traitement_freq must process the spectrum in place (dimension {})", N);
-        }
-        if (tsdgpu_ola_write_spectra(h, S.data(), nullptr)) échec("filtre_fft: {}", tsdgpu_last_error());
-      }
-      if (tsdgpu_ola_synthese(h, out.data(), &nout, nullptr)) échec("filtre_fft: {}", tsdgpu_last_error());
-    }
-    y.resize((entier) nout);
-    for (entier i = 0; i < (entier) nout; i++) y(i) = out(i);
-  }
-};
-
-}  // namespace
-
-std::tuple<sptr<Filtre<cfloat, cfloat, FiltreFFTConfig>>, entier> filtre_fft(const FiltreFFTConfig &config)
-{
-  auto res = std::make_shared<OLAGpu>();
-  res->configure(config);
-  return {res, res->N};
-}
-
 }  // namespace tsd::fourier
 
-// ---- tampon_création (core/src/tsd.cc:307-381) ----------------------------------------------------
-namespace tsd {
-namespace {
-template <typename T> struct TamponBlocs : Sink<T, entier> {
-  entier N = 0, rempli = 0;
-  fonction<void(const Vecteur<T> &)> callback;
-  Vecteur<T> bloc;
-  TamponBlocs(entier N_, fonction<void(const Vecteur<T> &)> cb) : callback(std::move(cb)) { Configurable<entier>::configure(N_); }
-  void configure_impl(const entier &N_) override
-  {
-    N = N_;
-    rempli = 0;
-  }
-  void step(const Vecteur<T> &x) override
-  {
-    if (rempli == 0 && x.rows() == N) {                     // a ready-made block goes straight through
-      if (callback) callback(x);
-      return;
-    }
-    if (bloc.rows() == 0 && N > 0) bloc.resize(N);
-    entier i = 0;
-    const entier n = x.rows();
-    while (i < n) {
-      const entier k = std::min(N - rempli, n - i);
-      bloc.segment(rempli, k) = x.segment(i, k);
-      i += k;
-      rempli += k;
-      if (rempli == N) {
-        if (callback) callback(bloc);
-        rempli = 0;
-      }
-    }
-  }
-};
-}  // namespace
-template <typename T> sptr<Sink<T, entier>> tampon_création(entier N, fonction<void(const Vecteur<T> &)> callback)
-{
-  return std::make_shared<TamponBlocs<T>>(N, std::move(callback));
-}
-template sptr<Sink<float, entier>> tampon_création<float>(entier, fonction<void(const Vecf &)>);
-template sptr<Sink<cfloat, entier>> tampon_création<cfloat>(entier, fonction<void(const Veccf &)>);
-}  // namespace tsd

@@ -91,6 +91,7 @@ def _declare(L):
     L.orc_fir_cf.argtypes = [vp, i32, vp, vp, vp, vp, i64]
     L.orc_fir_cc.argtypes = [vp, i32, vp, vp, vp, vp, i64]
     L.orc_rii_f.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, i64]
+    L.orc_rii_c.argtypes = [vp, i32, vp, i32, vp, vp, vp, vp, vp, vp, i64]
     L.orc_sos_from_zpk.argtypes = [vp, vp, vp, i32, CF, CF, i32]
     L.orc_sos_from_zpk.restype = i32
     L.orc_sos_state_init_f.argtypes = [vp]
@@ -186,6 +187,26 @@ class Rii:
         x = np.ascontiguousarray(x, dtype=f32)
         y = np.empty_like(x)
         lib().orc_rii_f(_p(self.numer), len(self.numer), _p(self.denom), len(self.denom) - 1,
+                        _p(self.wndx), _p(self.wndy), C.byref(self.ix), C.byref(self.iy),
+                        _p(x), _p(y), len(x))
+        return y
+
+
+class RiiC:
+    """FiltreRII<cfloat,cfloat> (filtre-rt.cc:177-289,795): complex coefficients, complex data."""
+
+    def __init__(self, numer, denom):
+        self.numer = np.ascontiguousarray(numer, dtype=c64)
+        self.denom = np.ascontiguousarray(denom, dtype=c64)
+        self.wndx = np.zeros(len(self.numer), c64)
+        self.wndy = np.zeros(max(len(self.denom) - 1, 1), c64)
+        self.ix = C.c_int(0)
+        self.iy = C.c_int(0)
+
+    def step(self, x):
+        x = np.ascontiguousarray(x, dtype=c64)
+        y = np.empty_like(x)
+        lib().orc_rii_c(_p(self.numer), len(self.numer), _p(self.denom), len(self.denom) - 1,
                         _p(self.wndx), _p(self.wndy), C.byref(self.ix), C.byref(self.iy),
                         _p(x), _p(y), len(x))
         return y

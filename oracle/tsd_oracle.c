@@ -129,6 +129,43 @@ void orc_rii_f(const float *numer, int Kx, const float *denom, int Ky,
   *index = idx; *index_y = idy;
 }
 
+/* the same for T = Tc = complex<float> (filtre_rii<cfloat,cfloat>, instantiated at filtre-rt.cc:795):
+ * interleaved (re, im); products and the final division in limited-range complex arithmetic, the
+ * way -fcx-limited-range (core/std-makefile-defs:176) compiles std::complex<float> */
+void orc_rii_c(const float *numer, int Kx, const float *denom, int Ky,
+               float *wndx, float *wndy, int *index, int *index_y,
+               const float *x, float *y, int64_t n)
+{
+  int idx = *index, idy = *index_y;
+  for (int64_t j = 0; j < n; j++) {
+    float sr = 0, si = 0;
+    wndx[2 * idx] = x[2 * j]; wndx[2 * idx + 1] = x[2 * j + 1];
+    idx = (idx + 1) % Kx;
+    for (int i = 0; i < Kx; i++) {                       /* oldest sample x last coefficient first */
+      const float *w = wndx + 2 * ((idx + i) % Kx), *c = numer + 2 * (Kx - 1 - i);
+      sr += w[0] * c[0] - w[1] * c[1];
+      si += w[0] * c[1] + w[1] * c[0];
+    }
+    y[2 * j] = sr; y[2 * j + 1] = si;
+  }
+  const float d0r = denom[0], d0i = denom[1], nd = d0r * d0r + d0i * d0i;
+  for (int64_t j = 0; j < n; j++) {
+    float sr = y[2 * j], si = y[2 * j + 1];
+    for (int i = 0; i < Ky; i++) {
+      const float *w = wndy + 2 * ((idy + i) % Ky), *c = denom + 2 * (1 + i);
+      sr -= w[0] * c[0] - w[1] * c[1];
+      si -= w[0] * c[1] + w[1] * c[0];
+    }
+    y[2 * j] = (sr * d0r + si * d0i) / nd;
+    y[2 * j + 1] = (si * d0r - sr * d0i) / nd;
+    if (Ky > 0) {
+      idy = (idy + Ky - 1) % Ky;
+      wndy[2 * idy] = y[2 * j]; wndy[2 * idy + 1] = y[2 * j + 1];
+    }
+  }
+  *index = idx; *index_y = idy;
+}
+
 /* ======================================================================================
  * SOS chain -- src/filtrage/filtre-rt.cc:440-572
  * ==================================================================================== */

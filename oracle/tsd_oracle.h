@@ -41,6 +41,10 @@ void orc_fir_cc(const orc_cf *coefs, int K, orc_cf *fen, int *index,
 void orc_rii_f(const float *numer, int Kx, const float *denom, int Ky,
                float *wndx, float *wndy, int *index, int *index_y,
                const float *x, float *y, int64_t n);
+/* FiltreRII<cfloat,cfloat>: complex coefficients on complex data, interleaved (re, im) */
+void orc_rii_c(const float *numer, int Kx, const float *denom, int Ky,
+               float *wndx, float *wndy, int *index, int *index_y,
+               const float *x, float *y, int64_t n);
 
 /* ---- second-order sections, src/filtrage/filtre-rt.cc:303-400,407-437,440-572 --------- */
 typedef struct {

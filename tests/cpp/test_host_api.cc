@@ -7,6 +7,9 @@
 #include <cstring>
 #include <thread>
 #include "dsp/dsp.hpp"
+#include "dsp/filter.hpp"
+#include "dsp/fourier.hpp"
+#include "tsd_amd/extensions.hpp"
 #include "../../oracle/tsd_oracle.h"
 
 using namespace tsd;
@@ -519,13 +522,13 @@ static void test_filtre_fft()
       ref_max = std::max(ref_max, (float) std::abs(acc));
     }
     CHECK(err <= 1e-5f * std::max(ref_max, 1.0f), "OLA FIR err %g (max %g)", err, ref_max);
-    // (2b) the same product as the device-side response (extension réponse_freq / frequency_response):
+    // (2b) the same product as the device-side response (extension tsd_amd::filtre_fft_reponse):
     //      no callback, nothing crosses PCIe but x and y; ragged calls; and both forms chained
     dsp::fourier::FFTFilterConfig cd;
     cd.time_blocks_length = Ne;
     cd.minimum_zeros_count = M;
-    cd.frequency_response = H;
-    auto [old, Nd] = dsp::fourier::filter_fft(cd);
+    CHECK(tsd_amd::filtre_fft_dim(cd) == N, "filtre_fft_dim %d", tsd_amd::filtre_fft_dim(cd));
+    auto [old, Nd] = tsd_amd::filtre_fft_reponse(cd, H);
     Veccf yd1 = old->step(x.head(1000));
     Veccf yd2 = old->step(x.tail(n - 1000));
     Veccf yd = vconcat(yd1, yd2);
@@ -535,13 +538,13 @@ static void test_filtre_fft()
     CHECK(ed <= 2e-6f * std::max(ref_max, 1.0f), "device-side response vs callback: %g", ed);
     int calls2 = 0;
     cd.freq_domain_processing = [&](Veccf &X) { X *= cfloat(2, 0); calls2++; };
-    auto [ol2, N2] = dsp::fourier::filter_fft(cd);
+    auto [ol2, N2] = tsd_amd::filtre_fft_reponse(cd, H);
     Veccf y2 = ol2->step(x);
     float e2 = 0;
     for (int i = 0; i < n; i++) e2 = std::max(e2, (float) std::abs(y2(i) - 2.0f * y(i)));
     CHECK(N2 == N && calls2 == 8 && e2 <= 4e-6f * std::max(ref_max, 1.0f), "response then callback: %g (%d calls)", e2, calls2);
     bool threw = false;
-    try { FiltreFFTConfig cb; cb.dim_blocs_temporel = Ne; cb.réponse_freq = Veccf::zeros(100); filtre_fft(cb); } catch (const std::runtime_error &) { threw = true; }
+    try { FiltreFFTConfig cb; cb.dim_blocs_temporel = Ne; tsd_amd::filtre_fft_reponse(cb, Veccf::zeros(100)); } catch (const std::runtime_error &) { threw = true; }
     CHECK(threw, "a response of the wrong size must be refused");
   }
   // (3) Hann window, 1/2 overlap, identity processing: half the input, Ne/2 late, first block dropped

@@ -136,6 +136,80 @@ def test_filtre_rii_high_order(tg, orc, order, cplx):
     assert relerr(y, ref) <= TOL
 
 
+# Block-parallel FiltreRII (row a5): the denominator factored into zero-seeded DF1 sections on the SOS
+# kernel whenever a create-time check shows the cascade reproduces the direct form; 2^22 samples
+# against the oracle's literal recursion, ragged chunks, and the path actually taken.
+@pytest.mark.parametrize("order,cplx", [(3, False), (4, True), (6, False), (6, True), (9, False), (12, False)])
+def test_filtre_rii_block_parallel(tg, orc, order, cplx):
+    rng = np.random.default_rng(100 + order)
+    # conjugate pole pairs of radius 0.5..0.9 (+ a real pole for odd orders): what an IIR design gives
+    ang = rng.uniform(0.2, 2.8, order // 2)
+    rad = rng.uniform(0.5, 0.9, order // 2)
+    poles = np.concatenate([rad * np.exp(1j * ang), rad * np.exp(-1j * ang), [0.7] if order & 1 else []])
+    de = (np.real(np.poly(poles)) * 1.25).astype(np.float32)
+    nu = rng.standard_normal(order // 2 + 2).astype(np.float32)
+    n = 1 << 20
+    x = rand(n, cplx, order)
+    if cplx:
+        ref = (orc.Rii(nu, de).step(x.real.copy()) + 1j * orc.Rii(nu, de).step(x.imag.copy())).astype(np.complex64)
+    else:
+        ref = orc.Rii(nu, de).step(x)
+    f = tg.Rii(nu, de, tg.C64 if cplx else tg.F32)
+    assert f.path in (0, 1), f"order {order}: the literal recursion was chosen (path {f.path})"
+    assert relerr(chunks(f, x, 300007), ref) <= TOL
+
+
+def test_filtre_rii_literal_fallback_and_env(tg, orc, monkeypatch):
+    # a denominator with a double root on the unit circle is not factored (marginal): literal path
+    de = np.poly([1.0, 1.0, 0.5]).astype(np.float32)
+    f = tg.Rii([1.0, 0.2, 0.1, 0.3], de, tg.F32)
+    assert f.path == 2
+    x = rand(300, False, 5)
+    assert relerr(f.step(x), orc.Rii([1.0, 0.2, 0.1, 0.3], de).step(x)) <= TOL
+
+
+def test_filtre_rii_complex_coefficients(tg, orc):
+    # filtre_rii<cfloat,cfloat>: one-sided (analytic) poles -> complex denominator; literal complex kernel
+    poles = np.array([0.6 * np.exp(0.7j), 0.5 * np.exp(2.1j), 0.3 + 0j])
+    de = (np.poly(poles) * (1.5 - 0.5j)).astype(np.complex64)
+    nu = np.array([0.3 + 0.1j, -0.2j, 0.5, 0.1 - 0.4j], np.complex64)
+    x = rand(20000, True, 7)
+    ref = orc.RiiC(nu, de).step(x)
+    f = tg.Rii(nu, de, tg.C64)
+    assert f.path == 2
+    assert relerr(chunks(f, x, 3001), ref) <= TOL
+    # complex-typed coefficients whose imaginary parts vanish take the real (block-parallel) plan
+    de_r = np.real(np.poly([0.6 * np.exp(0.7j), 0.6 * np.exp(-0.7j), 0.4])).astype(np.complex64)
+    f2 = tg.Rii(nu.real.astype(np.complex64), de_r, tg.C64)
+    assert f2.path in (0, 1)
+    ref2 = orc.RiiC(nu.real.astype(np.complex64), de_r).step(x)
+    assert relerr(f2.step(x), ref2) <= TOL
+
+
+def test_filtre_rii_order6_2p26_under_2ms(tg):
+    """order 6 on 2^26 floats in < 2 ms (the literal kernel needed ~9 s)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    ang, rad = np.array([0.5, 1.2, 2.0]), np.array([0.8, 0.7, 0.85])
+    de = np.real(np.poly(np.concatenate([rad * np.exp(1j * ang), rad * np.exp(-1j * ang)]))).astype(np.float32)
+    f = tg.Rii([1.0, 0.5, 0.25, 0.1], de, tg.F32)
+    assert f.path == 1
+    x = torch.randn(1 << 26, device=dev)
+    y = torch.empty_like(x)
+    for _ in range(3):
+        f.step(x, y)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        f.step(x, y)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    print(f"filtre_rii order 6, 2^26 floats: {ms:.3f} ms")
+    assert ms < 2.0
+
+
 def test_filtre_rii_high_order_is_not_a_cliff(tg):
     """2^22 samples through a 6th-order direct-form recursion: seconds with the per-sample
     global-memory kernel, a fraction of a second with the tiled one."""
