@@ -59,7 +59,11 @@ int tsdgpu_free(void *p);
 int tsdgpu_malloc_host(void **out, size_t bytes);
 int tsdgpu_free_host(void *p);
 int tsdgpu_memcpy(void *dst, const void *src, size_t bytes, void *stream);
+int tsdgpu_memset(void *dev, int value, size_t bytes, void *stream);
 int tsdgpu_synchronize(void *stream);
+/* y[i] <- (Re y[i], 0) for n complex samples, device or host memory (what FiltreFFTRIF<cfloat> does to its
+ * output, src/fourier/fourier.cc:976) */
+int tsdgpu_zero_imag(void *y, int64_t n, void *stream);
 /* 1 when p is memory a kernel can dereference (device, managed or registered host memory) */
 int tsdgpu_is_device_pointer(const void *p);
 
@@ -171,6 +175,7 @@ int tsdgpu_sos_create(tsdgpu_sos **out, int data_type, const float *coefs_host, 
                       float gain, const float *rii1_host, int forme);
 int tsdgpu_sos_step(tsdgpu_sos *s, const void *x, void *y, int64_t n, void *stream);
 int tsdgpu_sos_reset(tsdgpu_sos *s);
+int tsdgpu_sos_reset_on(tsdgpu_sos *s, void *stream);   /* the same, ordered on `stream` (no host wait) */
 /* number of warm-up samples a chunk needs before its first output for the carried state
  * to be exact to 2^-30 (multi-GPU halo size); -1 if the filter decays too slowly.       */
 int64_t tsdgpu_sos_halo(const tsdgpu_sos *s);
@@ -234,7 +239,7 @@ int tsdgpu_rii_create(tsdgpu_rii **out, int data_type, const float *numer_host, 
                       const float *denom_host, int Kd);
 /* coefficients of type coef_type (TSDGPU_F32, or TSDGPU_C64 = filtre_rii<cfloat,cfloat>, complex data only).
  * Real coefficients: the denominator is factored on the host and the recursion runs block-parallel as
- * zero-seeded sections on the SOS kernel whenever that cascade reproduces the direct form to 2e-6 on a
+ * zero-seeded sections on the SOS kernel whenever that cascade reproduces the direct form to 4e-6 on a
  * create-time check; otherwise, and for complex coefficients, the literal sequential recursion runs.
  * tsdgpu_rii_path: 0 = sections only, 1 = FIR kernel + sections, 2 = FIR kernel + literal recursion. */
 int tsdgpu_rii_create2(tsdgpu_rii **out, int data_type, int coef_type, const void *numer_host, int Kx,
@@ -242,6 +247,41 @@ int tsdgpu_rii_create2(tsdgpu_rii **out, int data_type, int coef_type, const voi
 int tsdgpu_rii_path(const tsdgpu_rii *r);
 int tsdgpu_rii_step(tsdgpu_rii *r, const void *x, void *y, int64_t n, void *stream);
 int tsdgpu_rii_destroy(tsdgpu_rii *r);
+
+/* --------------------------------------------------------------------------------------
+ * Several GPUs, ONE process: a long vector cut into contiguous chunks (shard g = samples
+ * [n g / N, n (g+1) / N)), one operator handle per shard, and the one small left-neighbour halo each
+ * operator needs -- FIR: K-1 input samples; SOS: the warm-up samples of tsdgpu_sos_halo; resampler:
+ * its K-1-sample window and the absolute stream position.  The reference is single-threaded and has no
+ * multi-device notion: this stands behind the SAME step() of FiltreRIF / ChaineSOIS /
+ * AdaptationRythmeSimple (src/filtrage/filtre-rt.cc:53-109,440-572; src/reechan/ra.cc:13-79) for
+ * vectors that are worth spreading over a node.  No collective, nothing exchanged but the halos.
+ * devices: nshards device ordinals (NULL: shard g on device g % device_count); several shards may name
+ * the same device.  Calls are synchronous and keep the streaming contract (the tail of one call is the
+ * halo of the next call's first shard).
+ *   tsdgpu_sharded_step_host   x, y HOST vectors: each shard stages its chunk on its own thread and
+ *                              stream; the halos are read from the host vector itself.
+ *   tsdgpu_sharded_step_parts  x_parts[g] / y_parts[g] RESIDENT on device g (counts[g] samples): halos
+ *                              move device to device (hipMemcpyPeerAsync over xGMI).  For the resampler
+ *                              y_capacities[g] bounds the outputs of shard g, out_counts[g] returns them.
+ * ------------------------------------------------------------------------------------ */
+typedef struct tsdgpu_sharded tsdgpu_sharded;
+int tsdgpu_fir_sharded_create(tsdgpu_sharded **out, int data_type, int tap_type, const void *taps_host, int ntaps, int method,
+                              int nshards, const int *devices);
+int tsdgpu_sos_sharded_create(tsdgpu_sharded **out, int data_type, const float *coefs_host, int nsec, float gain,
+                              const float *rii1_host, int forme, int nshards, const int *devices);
+int tsdgpu_resampler_sharded_create(tsdgpu_sharded **out, int data_type, float ratio, const float *lut_host, int K, int nphases,
+                                    int nshards, const int *devices);
+int tsdgpu_sharded_count(const tsdgpu_sharded *h);
+int64_t tsdgpu_sharded_halo(const tsdgpu_sharded *h);                     /* halo length in samples */
+int tsdgpu_sharded_device(const tsdgpu_sharded *h, int shard);
+void tsdgpu_sharded_bounds(const tsdgpu_sharded *h, int64_t n, int shard, int64_t *lo, int64_t *hi);
+int64_t tsdgpu_sharded_out_count(tsdgpu_sharded *h, int64_t n);           /* outputs of the next n inputs */
+int tsdgpu_sharded_step_host(tsdgpu_sharded *h, const void *x, int64_t n, void *y, int64_t y_capacity, int64_t *n_out);
+int tsdgpu_sharded_step_parts(tsdgpu_sharded *h, const void *const *x_parts, const int64_t *counts, void *const *y_parts,
+                              const int64_t *y_capacities, int64_t *out_counts);
+int tsdgpu_sharded_reset(tsdgpu_sharded *h);
+int tsdgpu_sharded_destroy(tsdgpu_sharded *h);
 
 #ifdef __cplusplus
 }

@@ -78,6 +78,21 @@ def _declare(L):
     L.tsdgpu_rii_create.argtypes = [C.POINTER(vp), i32, vp, i32, vp, i32]
     L.tsdgpu_rii_create2.argtypes = [C.POINTER(vp), i32, i32, vp, i32, vp, i32]
     L.tsdgpu_rii_path.argtypes = [vp]
+    L.tsdgpu_fir_sharded_create.argtypes = [C.POINTER(vp), i32, i32, vp, i32, i32, i32, vp]
+    L.tsdgpu_sos_sharded_create.argtypes = [C.POINTER(vp), i32, vp, i32, fl, vp, i32, i32, vp]
+    L.tsdgpu_resampler_sharded_create.argtypes = [C.POINTER(vp), i32, fl, vp, i32, i32, i32, vp]
+    L.tsdgpu_sharded_count.argtypes = [vp]
+    L.tsdgpu_sharded_halo.argtypes = [vp]
+    L.tsdgpu_sharded_halo.restype = i64
+    L.tsdgpu_sharded_device.argtypes = [vp, i32]
+    L.tsdgpu_sharded_bounds.argtypes = [vp, i64, i32, C.POINTER(i64), C.POINTER(i64)]
+    L.tsdgpu_sharded_bounds.restype = None
+    L.tsdgpu_sharded_out_count.argtypes = [vp, i64]
+    L.tsdgpu_sharded_out_count.restype = i64
+    L.tsdgpu_sharded_step_host.argtypes = [vp, vp, i64, vp, i64, C.POINTER(i64)]
+    L.tsdgpu_sharded_step_parts.argtypes = [vp, C.POINTER(vp), C.POINTER(i64), C.POINTER(vp), C.POINTER(i64), C.POINTER(i64)]
+    L.tsdgpu_sharded_reset.argtypes = [vp]
+    L.tsdgpu_sharded_destroy.argtypes = [vp]
     L.tsdgpu_malloc.argtypes = [C.POINTER(vp), C.c_size_t]
     L.tsdgpu_free.argtypes = [vp]
     L.tsdgpu_malloc_host.argtypes = [C.POINTER(vp), C.c_size_t]
@@ -542,5 +557,92 @@ class Rii:
         try:
             if self._h:
                 lib().tsdgpu_rii_destroy(self._h)
+        except Exception:
+            pass
+
+
+class Sharded:
+    """One process, several GPUs (tsdgpu_sharded_*): contiguous chunks + the operator's small halo.
+    kind = "fir" (taps, method), "sos" (coefs [nsec,5], gain, rii1, forme) or "resampler" (ratio, lut).
+    devices: one ordinal per shard (several shards may share a device)."""
+
+    def __init__(self, kind, data_type, nshards, devices=None, **kw):
+        self.kind, self.data_type, self.nshards = kind, data_type, nshards
+        self._h = C.c_void_p()
+        dv = None if devices is None else (C.c_int * nshards)(*devices)
+        if kind == "fir":
+            taps = np.ascontiguousarray(kw["taps"])
+            tt = C64 if np.iscomplexobj(taps) else F32
+            taps = taps.astype(np.complex64 if tt == C64 else np.float32)
+            _check(lib().tsdgpu_fir_sharded_create(C.byref(self._h), data_type, tt, taps.ctypes.data, len(taps),
+                                                   kw.get("method", FIR_AUTO), nshards, dv))
+        elif kind == "sos":
+            co = np.ascontiguousarray(kw["coefs"], dtype=np.float32).reshape(-1, 5)
+            r1 = kw.get("rii1")
+            r1 = None if r1 is None else np.ascontiguousarray(r1, dtype=np.float32)
+            _check(lib().tsdgpu_sos_sharded_create(C.byref(self._h), data_type, co.ctypes.data, co.shape[0], float(kw.get("gain", 1.0)),
+                                                   None if r1 is None else r1.ctypes.data, kw.get("forme", 2), nshards, dv))
+        elif kind == "resampler":
+            ratio = float(np.float32(kw["ratio"]))
+            K, nph = kw.get("K", 15), kw.get("nphases", 256)
+            lut = kw.get("lut")
+            if lut is None:
+                lut = itrp_sinc_lut(K, nph, float(min(np.float32(0.4), np.float32(ratio) / np.float32(2))))
+            lut = np.ascontiguousarray(lut, dtype=np.float32)
+            _check(lib().tsdgpu_resampler_sharded_create(C.byref(self._h), data_type, ratio, lut.ctypes.data, K, nph, nshards, dv))
+        else:
+            raise ValueError(kind)
+
+    @property
+    def halo(self):
+        return lib().tsdgpu_sharded_halo(self._h)
+
+    def bounds(self, n, g):
+        lo, hi = C.c_int64(0), C.c_int64(0)
+        lib().tsdgpu_sharded_bounds(self._h, n, g, C.byref(lo), C.byref(hi))
+        return lo.value, hi.value
+
+    def out_count(self, n):
+        return lib().tsdgpu_sharded_out_count(self._h, n)
+
+    def step_host(self, x, y=None):
+        """x: one host numpy vector -> y host numpy vector."""
+        assert isinstance(x, np.ndarray) and _dtype_code(x) == self.data_type
+        n = x.shape[0]
+        cap = self.out_count(n)
+        if y is None:
+            y = np.empty(cap, x.dtype)
+        got = C.c_int64(0)
+        _check(lib().tsdgpu_sharded_step_host(self._h, _ptr(x) if n else None, n, _ptr(y) if cap else None, y.shape[0], C.byref(got)))
+        return y[: got.value]
+
+    def step_parts(self, xs, ys=None, capacities=None):
+        """xs: list of torch tensors, xs[g] resident on the device of shard g -> list of output tensors."""
+        N = self.nshards
+        assert len(xs) == N
+        cnt = (C.c_int64 * N)(*[int(t.shape[0]) for t in xs])
+        if ys is None:
+            if self.kind == "resampler":
+                ys = [t.new_empty(int(c)) for t, c in zip(xs, capacities)]
+            else:
+                ys = [t.new_empty(t.shape) for t in xs]
+        caps = (C.c_int64 * N)(*[int(t.shape[0]) for t in ys])
+        got = (C.c_int64 * N)()
+        xp = (C.c_void_p * N)(*[_ptr(t) if t.shape[0] else None for t in xs])
+        yp = (C.c_void_p * N)(*[_ptr(t) if t.shape[0] else None for t in ys])
+        _check(lib().tsdgpu_sharded_step_parts(self._h, xp, cnt, yp, caps, got))
+        return [t[: got[g]] for g, t in enumerate(ys)]
+
+    def reset(self):
+        _check(lib().tsdgpu_sharded_reset(self._h))
+
+    def close(self):
+        if self._h:
+            lib().tsdgpu_sharded_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
         except Exception:
             pass

@@ -1,5 +1,7 @@
 // common.hip -- error reporting and host/device staging for the C-ABI shim.
 #include "common.hpp"
+#include <algorithm>
+#include <cstdlib>
 
 namespace tsdgpu {
 
@@ -115,6 +117,88 @@ int finish_out(void *dst, size_t bytes, const void *dev, bool staged, hipStream_
   return TSDGPU_OK;
 }
 
+__global__ void zero_imag_kernel(float2 *__restrict__ y, int64_t n)
+{
+  const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i].y = 0.f;
+}
+
+namespace {
+struct HostPipe {
+  hipStream_t s_in = nullptr, s_k = nullptr, s_out = nullptr;
+  hipEvent_t e_in[2] = {nullptr, nullptr}, e_k[2] = {nullptr, nullptr}, e_out[2] = {nullptr, nullptr}, e_user = nullptr;
+  DevBuf bin[2], bout[2];
+  bool ready = false;
+  int init()
+  {
+    if (ready) return TSDGPU_OK;
+    TSD_HIP(hipStreamCreateWithFlags(&s_in, hipStreamNonBlocking));
+    TSD_HIP(hipStreamCreateWithFlags(&s_k, hipStreamNonBlocking));
+    TSD_HIP(hipStreamCreateWithFlags(&s_out, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) {
+      TSD_HIP(hipEventCreateWithFlags(&e_in[i], hipEventDisableTiming));
+      TSD_HIP(hipEventCreateWithFlags(&e_k[i], hipEventDisableTiming));
+      TSD_HIP(hipEventCreateWithFlags(&e_out[i], hipEventDisableTiming));
+    }
+    TSD_HIP(hipEventCreateWithFlags(&e_user, hipEventDisableTiming));
+    ready = true;
+    return TSDGPU_OK;
+  }
+};
+HostPipe &host_pipe()
+{
+  static thread_local HostPipe p;     // one per calling thread: handles are not shared between threads mid-step
+  return p;
+}
+}  // namespace
+
+int pipelined_host_step(const void *x, void *y, int64_t n, size_t esz, hipStream_t user,
+                        const std::function<int(const void *, void *, int64_t, hipStream_t)> &step)
+{
+  HostPipe &P = host_pipe();
+  int rc = P.init();
+  if (rc) return rc;
+  static const size_t CHUNK = getenv("TSDGPU_PIPE_CHUNK_MB") ? (size_t) atoi(getenv("TSDGPU_PIPE_CHUNK_MB")) << 20 : PIPE_CHUNK_BYTES;
+  const int64_t per = std::max<int64_t>(1024, (int64_t) (CHUNK / esz));
+  const int64_t nchunks = (n + per - 1) / per;
+  for (int b = 0; b < 2; b++) {
+    rc = P.bin[b].reserve((size_t) std::min(per, n) * esz);
+    if (!rc) rc = P.bout[b].reserve((size_t) std::min(per, n) * esz);
+    if (rc) return rc;
+  }
+  // work already queued on the caller's stream (e.g. a history upload) comes first
+  TSD_HIP(hipEventRecord(P.e_user, user));
+  TSD_HIP(hipStreamWaitEvent(P.s_in, P.e_user, 0));
+  TSD_HIP(hipStreamWaitEvent(P.s_k, P.e_user, 0));
+  const char *xs = (const char *) x;
+  char *ys = (char *) y;
+  for (int64_t c = 0; c < nchunks; c++) {
+    const int b = (int) (c & 1);
+    const int64_t off = c * per, cnt = std::min(per, n - off);
+    if (c >= 2) TSD_HIP(hipStreamWaitEvent(P.s_in, P.e_k[b], 0));          // chunk c-2's kernels have read bin[b]
+    TSD_HIP(hipMemcpyAsync(P.bin[b].p, xs + (size_t) off * esz, (size_t) cnt * esz, hipMemcpyHostToDevice, P.s_in));
+    TSD_HIP(hipEventRecord(P.e_in[b], P.s_in));
+    TSD_HIP(hipStreamWaitEvent(P.s_k, P.e_in[b], 0));
+    if (c >= 2) TSD_HIP(hipStreamWaitEvent(P.s_k, P.e_out[b], 0));         // chunk c-2's D2H has read bout[b]
+    rc = step(P.bin[b].p, P.bout[b].p, cnt, P.s_k);
+    if (rc) {
+      (void) hipStreamSynchronize(P.s_k);
+      (void) hipStreamSynchronize(P.s_out);
+      return rc;
+    }
+    TSD_HIP(hipEventRecord(P.e_k[b], P.s_k));
+    TSD_HIP(hipStreamWaitEvent(P.s_out, P.e_k[b], 0));
+    TSD_HIP(hipMemcpyAsync(ys + (size_t) off * esz, P.bout[b].p, (size_t) cnt * esz, hipMemcpyDeviceToHost, P.s_out));
+    TSD_HIP(hipEventRecord(P.e_out[b], P.s_out));
+  }
+  TSD_HIP(hipStreamSynchronize(P.s_out));
+  TSD_HIP(hipStreamSynchronize(P.s_k));
+  // later work on the caller's stream sees the operator's new state
+  TSD_HIP(hipEventRecord(P.e_user, P.s_k));
+  TSD_HIP(hipStreamWaitEvent(user, P.e_user, 0));
+  return TSDGPU_OK;
+}
+
 }  // namespace tsdgpu
 
 extern "C" {
@@ -174,6 +258,26 @@ int tsdgpu_memcpy(void *dst, const void *src, size_t bytes, void *stream)
   hipStream_t st = (hipStream_t) stream;
   TSD_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, st));
   if (!(tsdgpu::is_device_ptr(dst) && tsdgpu::is_device_ptr(src))) TSD_HIP(hipStreamSynchronize(st));
+  return TSDGPU_OK;
+}
+int tsdgpu_memset(void *dev, int value, size_t bytes, void *stream)
+{
+  if (bytes == 0) return TSDGPU_OK;
+  TSD_CHECK(dev != nullptr, "tsdgpu_memset: NULL pointer");
+  TSD_HIP(hipMemsetAsync(dev, value, bytes, (hipStream_t) stream));
+  return TSDGPU_OK;
+}
+int tsdgpu_zero_imag(void *y, int64_t n, void *stream)
+{
+  if (n <= 0) return TSDGPU_OK;
+  TSD_CHECK(y != nullptr, "tsdgpu_zero_imag: NULL pointer");
+  if (!tsdgpu::is_device_ptr(y)) {
+    float *f = (float *) y;
+    for (int64_t i = 0; i < n; i++) f[2 * i + 1] = 0.f;
+    return TSDGPU_OK;
+  }
+  hipLaunchKernelGGL(tsdgpu::zero_imag_kernel, dim3((unsigned) ((n + 255) / 256)), dim3(256), 0, (hipStream_t) stream, (float2 *) y, n);
+  TSD_HIP(hipGetLastError());
   return TSDGPU_OK;
 }
 int tsdgpu_synchronize(void *stream)

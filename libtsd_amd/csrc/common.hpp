@@ -2,6 +2,7 @@
 // pointer staging).  Product code: never includes or links anything under oracle/.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <functional>
 #include <mutex>
 #include <cstdarg>
 #include <cstdint>
@@ -50,6 +51,18 @@ int stage_in(const void *src, size_t bytes, DevBuf &buf, hipStream_t st, const v
 // else `buf`.  finish_out() copies back to the host buffer and synchronises when staged.
 int stage_out(void *dst, size_t bytes, DevBuf &buf, void **dev, bool *staged);
 int finish_out(void *dst, size_t bytes, const void *dev, bool staged, hipStream_t st);
+
+// Large HOST buffers through a same-length streaming operator (FIR, SOS, RII): the vector is cut in
+// chunks that are copied in, processed and copied out on three streams, so that H2D of chunk i+1, the
+// kernels of chunk i and D2H of chunk i-1 overlap (the operator's state lives on the device and is
+// carried from chunk to chunk exactly as between two step() calls).  With page-locked host memory
+// (tsdgpu_malloc_host, hipHostRegister) the copies are asynchronous and PCIe runs in both directions
+// at once; with pageable memory the runtime stages each copy itself and only the kernels overlap.
+// step(dx, dy, count, stream) must enqueue the operator on device pointers.  Returns after y is complete.
+constexpr size_t PIPE_MIN_BYTES = (size_t) 8 << 20;      // below this one H2D / kernel / D2H round is as good
+constexpr size_t PIPE_CHUNK_BYTES = (size_t) 16 << 20;
+int pipelined_host_step(const void *x, void *y, int64_t n, size_t elem_bytes, hipStream_t user_stream,
+                        const std::function<int(const void *, void *, int64_t, hipStream_t)> &step);
 
 // Serialises use of a handle's scratch buffers: host threads through the mutex, streams through
 // an event (a step on another stream waits for the previous step's work).  libtsd's Spectrum calls

@@ -299,6 +299,11 @@ int tsdgpu_fir_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, void *stre
   TSD_CHECK(x != nullptr && y != nullptr, "fir_step: NULL buffer");
   hipStream_t st = (hipStream_t) stream;
   const size_t bytes = (size_t) n * dtype_size(f->data_type);
+  if (bytes >= PIPE_MIN_BYTES && !is_device_ptr(x) && !is_device_ptr(y)) {
+    // large host vectors: chunked H2D / kernel / D2H pipeline (the history carries from chunk to chunk)
+    return pipelined_host_step(x, y, n, dtype_size(f->data_type), st,
+                               [f](const void *cx, void *cy, int64_t cnt, hipStream_t s) { return tsdgpu_fir_step(f, cx, cy, cnt, s); });
+  }
 
   const void *dx = nullptr;
   void *dy = nullptr;
@@ -332,6 +337,7 @@ int tsdgpu_fir_reset(tsdgpu_fir *f)
   TSD_CHECK(f != nullptr, "fir_reset: NULL handle");
   const size_t hbytes = (size_t) f->HL * dtype_size(f->data_type);
   TSD_HIP(hipMemset(f->hist[f->cur], 0, hbytes));
+  TSD_HIP(hipStreamSynchronize(nullptr));      // see tsdgpu_sos_reset
   return TSDGPU_OK;
 }
 

@@ -454,7 +454,10 @@ int tsdgpu_polyfir_reset(tsdgpu_polyfir *p)
 {
   TSD_CHECK(p != nullptr, "polyfir_reset: NULL handle");
   p->cnt = 0;
-  if (p->fused) TSD_HIP(hipMemset(p->d_hist[p->cur], 0, (size_t) p->HW * dtype_size(p->data_type)));
+  if (p->fused) {
+    TSD_HIP(hipMemset(p->d_hist[p->cur], 0, (size_t) p->HW * dtype_size(p->data_type)));
+    TSD_HIP(hipStreamSynchronize(nullptr));
+  }
   for (auto *f : p->fir) {
     const int rc = tsdgpu_fir_reset(f);
     if (rc) return rc;
@@ -484,7 +487,7 @@ int tsdgpu_polyfir_destroy(tsdgpu_polyfir *p)
 // dependent-FMA latency.  A cascade rounds differently from the direct form, so every filter is
 // checked at creation: the float direct-form recursion (the reference's own operation order) and the
 // float cascade are both run on the host over 8192 noise samples, and the cascade is used only when
-// they agree to 2e-6 of the peak; otherwise (clustered roots, unstable or ill-conditioned direct forms)
+// they agree to 4e-6 of the peak; otherwise (clustered roots, unstable or ill-conditioned direct forms)
 // the literal sequential kernels above serve, bit-faithful to the reference's order.
 }  // extern "C" (host helpers below have C++ linkage)
 
@@ -626,7 +629,7 @@ bool cascade_matches_direct_form(const float *num, int Kx, const float *den, int
     peak = std::max(peak, std::fabs(yd[j]));
     err = std::max(err, std::fabs(yd[j] - yc[j]));
   }
-  return peak > 0 && err <= 2e-6f * peak;
+  return peak > 0 && err <= 4e-6f * peak;   // bar: 1e-5 of the peak on any stream; 2.5x margin for the extremes of long streams
 }
 
 }  // namespace
@@ -720,6 +723,9 @@ int tsdgpu_rii_step(tsdgpu_rii *r, const void *x, void *y, int64_t n, void *stre
   if (r->path == 0) return tsdgpu_sos_step(r->sos, x, y, n, stream);
   hipStream_t st = (hipStream_t) stream;
   const size_t bytes = (size_t) n * dtype_size(r->data_type);
+  if (bytes >= PIPE_MIN_BYTES && !is_device_ptr(x) && !is_device_ptr(y))
+    return pipelined_host_step(x, y, n, dtype_size(r->data_type), st,
+                               [r](const void *cx, void *cy, int64_t cnt, hipStream_t q) { return tsdgpu_rii_step(r, cx, cy, cnt, q); });
   const void *dx = nullptr;
   void *dy = nullptr;
   bool staged = false;

@@ -799,6 +799,7 @@ int tsdgpu_resampler_reset(tsdgpu_resampler *r)
   r->cum_pos = 0;
   const size_t hb = (size_t) std::max(r->K - 1, 1) * dtype_size(r->data_type);
   TSD_HIP(hipMemset(r->d_hist[r->cur], 0, hb));
+  TSD_HIP(hipStreamSynchronize(nullptr));      // a device memset may return before it has run
   return TSDGPU_OK;
 }
 

@@ -1,0 +1,498 @@
+// sharded.hip -- one process, several GPUs: a long vector cut into contiguous chunks, one stateful
+// operator handle per chunk, and the ONE small left-neighbour halo each operator needs
+// (north_star: "long vectors shard by contiguous chunk with halo exchange"):
+//   FIR        the K-1 input samples before the chunk           -> tsdgpu_fir_set_history
+//   SOS        W warm-up samples (state transition < 1e-9)      -> reset + step on the halo
+//   resampler  the K-1-sample window + the absolute position    -> tsdgpu_resampler_seek
+// No collective and no data-path exchange beyond those few samples: shards run concurrently, one
+// host thread and one stream per shard.  Two forms:
+//   *_step_host   one HOST vector in, one out: every shard stages its chunk (and reads its halo straight
+//                 from the host vector); this is what the C++ adaptors call for large host vectors
+//   *_step_parts  chunk g already RESIDENT on device g: the halo moves device-to-device
+//                 (hipMemcpyPeerAsync over xGMI), nothing touches the host
+// Shards are logical: several may name the same device (how the single-GPU tests run N shards and
+// compare with one handle, bit for bit where the operator is chunk-invariant).
+// The streaming contract is kept across calls: the tail of call c is the halo of shard 0 in call c+1.
+#include "common.hpp"
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <thread>
+
+using namespace tsdgpu;
+
+namespace {
+enum Kind { K_FIR = 0, K_SOS = 1, K_RES = 2 };
+
+// reusable barrier for the shard threads (C++17: no std::barrier)
+struct Rendezvous {
+  std::mutex m;
+  std::condition_variable cv;
+  int n = 0, arrived = 0, phase = 0;
+  void wait()
+  {
+    std::unique_lock<std::mutex> l(m);
+    const int ph = phase;
+    if (++arrived == n) {
+      arrived = 0;
+      phase++;
+      cv.notify_all();
+    } else {
+      cv.wait(l, [&] { return phase != ph; });
+    }
+  }
+};
+}  // namespace
+
+struct tsdgpu_sharded {
+  int kind = 0, data_type = 0, nshards = 0;
+  int64_t H = 0;                         // halo length in samples
+  int K = 0;                             // resampler / FIR taps
+  std::vector<int> dev;
+  std::vector<void *> handle;            // tsdgpu_fir* / tsdgpu_sos* / tsdgpu_resampler*
+  std::vector<hipStream_t> stream;
+  std::vector<DevBuf> halo, in, out, scratch;
+  std::vector<char> carry;               // host: the last H inputs of the stream (zeros before its start)
+  int64_t seen = 0;                      // inputs consumed so far (all calls)
+  int64_t out_total = 0;                 // resampler: outputs produced so far
+  size_t esz() const { return dtype_size(data_type); }
+};
+
+namespace {
+
+int with_device(int d, const std::function<int()> &fn)
+{
+  int prev = 0;
+  TSD_HIP(hipGetDevice(&prev));
+  if (prev != d) TSD_HIP(hipSetDevice(d));
+  const int rc = fn();
+  if (prev != d) (void) hipSetDevice(prev);
+  return rc;
+}
+
+int sharded_alloc(tsdgpu_sharded **out, int kind, int data_type, int nshards, const int *devices)
+{
+  TSD_CHECK(out != nullptr, "sharded_create: out is NULL");
+  *out = nullptr;
+  TSD_CHECK(nshards >= 1 && nshards <= 64, "sharded_create: %d shards (1..64)", nshards);
+  const int ndev = tsdgpu_device_count();
+  TSD_CHECK(ndev > 0, "sharded_create: no HIP device");
+  tsdgpu_sharded *h = new tsdgpu_sharded();
+  h->kind = kind;
+  h->data_type = data_type;
+  h->nshards = nshards;
+  for (int g = 0; g < nshards; g++) {
+    const int d = devices ? devices[g] : g % ndev;
+    if (d < 0 || d >= ndev) {
+      delete h;
+      return set_err(TSDGPU_ERR_INVALID, "sharded_create: device %d of shard %d does not exist (%d devices)", d, g, ndev);
+    }
+    h->dev.push_back(d);
+  }
+  h->handle.assign((size_t) nshards, nullptr);
+  h->stream.assign((size_t) nshards, nullptr);
+  h->halo.resize((size_t) nshards);
+  h->in.resize((size_t) nshards);
+  h->out.resize((size_t) nshards);
+  h->scratch.resize((size_t) nshards);
+  *out = h;
+  return TSDGPU_OK;
+}
+
+int sharded_finish_create(tsdgpu_sharded *h)
+{
+  h->carry.assign((size_t) std::max<int64_t>(h->H, 1) * h->esz(), 0);
+  for (int g = 0; g < h->nshards; g++) {
+    const int rc = with_device(h->dev[g], [&]() -> int {
+      TSD_HIP(hipStreamCreateWithFlags(&h->stream[g], hipStreamNonBlocking));
+      return h->halo[g].reserve((size_t) std::max<int64_t>(h->H, 1) * h->esz());
+    });
+    if (rc) return rc;
+  }
+  // neighbours exchange halos device to device in the resident form
+  for (int g = 1; g < h->nshards; g++)
+    if (h->dev[g] != h->dev[g - 1])
+      (void) with_device(h->dev[g], [&]() -> int {
+        int can = 0;
+        if (hipDeviceCanAccessPeer(&can, h->dev[g], h->dev[g - 1]) == hipSuccess && can) {
+          if (hipDeviceEnablePeerAccess(h->dev[g - 1], 0) != hipSuccess) (void) hipGetLastError();   // already enabled is fine
+        }
+        return TSDGPU_OK;
+      });
+  return TSDGPU_OK;
+}
+
+// the operator on shard g: halo (H samples, device pointer on this shard's device, `avail` of them real
+// stream samples at its END), then the chunk dx -> dy of cnt samples.  For the resampler dy receives
+// out_cnt outputs.  Must be called with the shard's device current.
+int run_shard(tsdgpu_sharded *h, int g, const void *halo, int64_t avail, int64_t pos, const void *dx, void *dy, int64_t cnt,
+              int64_t ycap, int64_t *out_cnt)
+{
+  hipStream_t st = h->stream[g];
+  const size_t esz = h->esz();
+  if (h->kind == K_FIR) {
+    tsdgpu_fir *f = (tsdgpu_fir *) h->handle[g];
+    if (h->H > 0) {
+      const int rc = tsdgpu_fir_set_history(f, halo, st);
+      if (rc) return rc;
+    }
+    return cnt > 0 ? tsdgpu_fir_step(f, dx, dy, cnt, st) : TSDGPU_OK;
+  }
+  if (h->kind == K_SOS) {
+    tsdgpu_sos *s = (tsdgpu_sos *) h->handle[g];
+    if (pos > 0) {
+      // not the start of the stream: warm the sections up on the samples before the chunk.  When these
+      // reach back to the very first sample the warm-up IS the stream (first-sample seed included)
+      int rc = tsdgpu_sos_reset_on(s, st);
+      if (rc) return rc;
+      if (avail > 0) {
+        rc = h->scratch[g].reserve((size_t) avail * esz);
+        if (rc) return rc;
+        rc = tsdgpu_sos_step(s, (const char *) halo + (size_t) (h->H - avail) * esz, h->scratch[g].p, avail, st);
+        if (rc) return rc;
+      }
+    }
+    return cnt > 0 ? tsdgpu_sos_step(s, dx, dy, cnt, st) : TSDGPU_OK;
+  }
+  tsdgpu_resampler *r = (tsdgpu_resampler *) h->handle[g];
+  int rc = tsdgpu_resampler_seek(r, pos, h->H > 0 ? halo : nullptr, st);
+  if (rc) return rc;
+  *out_cnt = 0;
+  if (cnt <= 0) return TSDGPU_OK;
+  return tsdgpu_resampler_step(r, dx, cnt, dy, ycap, out_cnt, st);
+}
+
+// new carry = last H samples of (old carry ++ x[0, n)), x on the host
+void update_carry_host(tsdgpu_sharded *h, const char *x, int64_t n)
+{
+  const size_t esz = h->esz();
+  const int64_t H = h->H;
+  if (H <= 0) return;
+  if (n >= H) {
+    std::memcpy(h->carry.data(), x + (size_t) (n - H) * esz, (size_t) H * esz);
+  } else if (n > 0) {
+    std::memmove(h->carry.data(), h->carry.data() + (size_t) n * esz, (size_t) (H - n) * esz);
+    std::memcpy(h->carry.data() + (size_t) (H - n) * esz, x, (size_t) n * esz);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int tsdgpu_fir_sharded_create(tsdgpu_sharded **out, int data_type, int tap_type, const void *taps_host, int ntaps, int method,
+                              int nshards, const int *devices)
+{
+  int rc = sharded_alloc(out, K_FIR, data_type, nshards, devices);
+  if (rc) return rc;
+  tsdgpu_sharded *h = *out;
+  h->K = ntaps;
+  h->H = std::max(ntaps - 1, 0);
+  for (int g = 0; g < nshards && !rc; g++)
+    rc = with_device(h->dev[g], [&] { return tsdgpu_fir_create((tsdgpu_fir **) &h->handle[g], data_type, tap_type, taps_host, ntaps, method); });
+  if (!rc) rc = sharded_finish_create(h);
+  if (rc) {
+    tsdgpu_sharded_destroy(h);
+    *out = nullptr;
+  }
+  return rc;
+}
+
+int tsdgpu_sos_sharded_create(tsdgpu_sharded **out, int data_type, const float *coefs_host, int nsec, float gain, const float *rii1_host,
+                              int forme, int nshards, const int *devices)
+{
+  int rc = sharded_alloc(out, K_SOS, data_type, nshards, devices);
+  if (rc) return rc;
+  tsdgpu_sharded *h = *out;
+  for (int g = 0; g < nshards && !rc; g++)
+    rc = with_device(h->dev[g], [&] { return tsdgpu_sos_create((tsdgpu_sos **) &h->handle[g], data_type, coefs_host, nsec, gain, rii1_host, forme); });
+  if (!rc) {
+    h->H = tsdgpu_sos_halo((tsdgpu_sos *) h->handle[0]);
+    if (h->H < 0 || h->H > ((int64_t) 1 << 24))
+      rc = set_err(TSDGPU_ERR_UNSUPPORTED, "sos_sharded_create: this cascade decays too slowly for warm-up sharding (halo %lld samples)",
+                   (long long) h->H);
+  }
+  if (!rc) rc = sharded_finish_create(h);
+  if (rc) {
+    tsdgpu_sharded_destroy(h);
+    *out = nullptr;
+  }
+  return rc;
+}
+
+int tsdgpu_resampler_sharded_create(tsdgpu_sharded **out, int data_type, float ratio, const float *lut_host, int K, int nphases,
+                                    int nshards, const int *devices)
+{
+  int rc = sharded_alloc(out, K_RES, data_type, nshards, devices);
+  if (rc) return rc;
+  tsdgpu_sharded *h = *out;
+  h->K = K;
+  h->H = std::max(K - 1, 0);
+  for (int g = 0; g < nshards && !rc; g++)
+    rc = with_device(h->dev[g], [&] { return tsdgpu_resampler_create((tsdgpu_resampler **) &h->handle[g], data_type, ratio, lut_host, K, nphases); });
+  if (!rc) rc = sharded_finish_create(h);
+  if (rc) {
+    tsdgpu_sharded_destroy(h);
+    *out = nullptr;
+  }
+  return rc;
+}
+
+int tsdgpu_sharded_count(const tsdgpu_sharded *h) { return h ? h->nshards : 0; }
+int64_t tsdgpu_sharded_halo(const tsdgpu_sharded *h) { return h ? h->H : -1; }
+int tsdgpu_sharded_device(const tsdgpu_sharded *h, int shard) { return (h && shard >= 0 && shard < h->nshards) ? h->dev[shard] : -1; }
+
+void tsdgpu_sharded_bounds(const tsdgpu_sharded *h, int64_t n, int shard, int64_t *lo, int64_t *hi)
+{
+  const int N = h ? h->nshards : 1;
+  *lo = (int64_t) (((__int128) n * shard) / N);
+  *hi = (int64_t) (((__int128) n * (shard + 1)) / N);
+}
+
+int64_t tsdgpu_sharded_out_count(tsdgpu_sharded *h, int64_t n)
+{
+  if (!h || n < 0) return -1;
+  if (h->kind != K_RES) return n;
+  // outputs of the next n inputs: position-based, read from shard 0's handle (shared schedule)
+  tsdgpu_resampler *r = (tsdgpu_resampler *) h->handle[0];
+  int64_t a = 0, b = 0;
+  if (with_device(h->dev[0], [&]() -> int {
+        int rc = tsdgpu_resampler_seek(r, h->seen, nullptr, h->stream[0]);
+        if (rc) return rc;
+        a = tsdgpu_resampler_out_offset(r);
+        rc = tsdgpu_resampler_seek(r, h->seen + n, nullptr, h->stream[0]);
+        if (rc) return rc;
+        b = tsdgpu_resampler_out_offset(r);
+        return TSDGPU_OK;
+      }))
+    return -1;
+  return b - a;
+}
+
+int tsdgpu_sharded_step_host(tsdgpu_sharded *h, const void *x, int64_t n, void *y, int64_t y_capacity, int64_t *n_out)
+{
+  TSD_CHECK(h != nullptr, "sharded_step_host: NULL handle");
+  TSD_CHECK(n >= 0, "sharded_step_host: negative length");
+  if (n_out) *n_out = 0;
+  if (n == 0) return TSDGPU_OK;
+  TSD_CHECK(x != nullptr && y != nullptr, "sharded_step_host: NULL buffer");
+  TSD_CHECK(!is_device_ptr(x) && !is_device_ptr(y), "sharded_step_host: x and y must be host vectors (resident chunks go through tsdgpu_sharded_step_parts)");
+  const size_t esz = h->esz();
+  const int N = h->nshards;
+  const int64_t H = h->H;
+  const char *xs = (const char *) x;
+  char *ys = (char *) y;
+  // output placement (resampler): offsets from the schedule
+  std::vector<int64_t> off((size_t) N + 1, 0);
+  if (h->kind == K_RES) {
+    tsdgpu_resampler *r = (tsdgpu_resampler *) h->handle[0];
+    const int rc = with_device(h->dev[0], [&]() -> int {
+      for (int g = 0; g <= N; g++) {
+        int64_t lo, hi;
+        tsdgpu_sharded_bounds(h, n, std::min(g, N - 1), &lo, &hi);
+        const int64_t p = h->seen + (g < N ? lo : n);
+        const int rc2 = tsdgpu_resampler_seek(r, p, nullptr, h->stream[0]);
+        if (rc2) return rc2;
+        off[(size_t) g] = tsdgpu_resampler_out_offset(r);
+      }
+      return TSDGPU_OK;
+    });
+    if (rc) return rc;
+    TSD_CHECK(off[(size_t) N] - off[0] <= y_capacity, "sharded_step_host: output capacity %lld < %lld outputs", (long long) y_capacity,
+              (long long) (off[(size_t) N] - off[0]));
+  } else {
+    TSD_CHECK(y_capacity >= n, "sharded_step_host: output capacity %lld < %lld", (long long) y_capacity, (long long) n);
+  }
+  // the halo of shard 0 comes from the previous calls; save the tail of this one first (y may be x)
+  const std::vector<char> carry_avant = h->carry;
+  const int64_t seen_avant = h->seen;
+  update_carry_host(h, xs, n);
+
+  std::vector<int> rcs((size_t) N, TSDGPU_OK);
+  std::vector<std::string> msgs((size_t) N);
+  std::vector<int64_t> outs((size_t) N, 0);
+  Rendezvous rdv;
+  rdv.n = N;
+  auto work = [&](int g) {
+    int rc = TSDGPU_OK;
+    int64_t lo, hi;
+    tsdgpu_sharded_bounds(h, n, g, &lo, &hi);
+    const int64_t cnt = hi - lo;
+    do {
+      if (hipSetDevice(h->dev[g]) != hipSuccess) { rc = set_err(TSDGPU_ERR_HIP, "hipSetDevice(%d) failed", h->dev[g]); break; }
+      hipStream_t st = h->stream[g];
+      // (1) stage the halo and the chunk: everything read from the host vector BEFORE anyone writes y
+      std::vector<char> hal((size_t) std::max<int64_t>(H, 1) * esz, 0);
+      const int64_t du_x = std::min(H, lo);            // halo samples found in x, the rest in the carry
+      if (du_x > 0) std::memcpy(hal.data() + (size_t) (H - du_x) * esz, xs + (size_t) (lo - du_x) * esz, (size_t) du_x * esz);
+      if (du_x < H) std::memcpy(hal.data(), carry_avant.data() + (size_t) du_x * esz, (size_t) (H - du_x) * esz);
+      if (H > 0 && hipMemcpyAsync(h->halo[g].p, hal.data(), (size_t) H * esz, hipMemcpyHostToDevice, st) != hipSuccess) {
+        rc = set_err(TSDGPU_ERR_HIP, "halo upload failed: %s", hipGetErrorString(hipGetLastError()));
+      }
+      if (!rc && cnt > 0) rc = h->in[g].reserve((size_t) cnt * esz);
+      const int64_t ocap = h->kind == K_RES ? off[(size_t) g + 1] - off[(size_t) g] : cnt;
+      if (!rc && ocap > 0) rc = h->out[g].reserve((size_t) ocap * esz);
+      if (!rc && cnt > 0 && hipMemcpyAsync(h->in[g].p, xs + (size_t) lo * esz, (size_t) cnt * esz, hipMemcpyHostToDevice, st) != hipSuccess)
+        rc = set_err(TSDGPU_ERR_HIP, "chunk upload failed: %s", hipGetErrorString(hipGetLastError()));
+      if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = set_err(TSDGPU_ERR_HIP, "upload sync failed");
+    } while (0);
+    rdv.wait();                                         // every shard holds its inputs: y may now be written
+    if (!rc) {
+      const int64_t ocap = h->kind == K_RES ? off[(size_t) g + 1] - off[(size_t) g] : cnt;
+      int64_t got = 0;
+      rc = run_shard(h, g, h->halo[g].p, std::min(H, seen_avant + lo), seen_avant + lo, h->in[g].p, h->out[g].p, cnt, ocap, &got);
+      if (h->kind != K_RES) got = cnt;
+      if (!rc && h->kind == K_RES && got != ocap)
+        rc = set_err(TSDGPU_ERR_INVALID, "shard %d produced %lld outputs, the schedule says %lld", g, (long long) got, (long long) ocap);
+      const int64_t o0 = h->kind == K_RES ? off[(size_t) g] - off[0] : lo;
+      if (!rc && got > 0 &&
+          hipMemcpyAsync(ys + (size_t) o0 * esz, h->out[g].p, (size_t) got * esz, hipMemcpyDeviceToHost, h->stream[g]) != hipSuccess)
+        rc = set_err(TSDGPU_ERR_HIP, "download failed: %s", hipGetErrorString(hipGetLastError()));
+      if (hipStreamSynchronize(h->stream[g]) != hipSuccess && !rc) rc = set_err(TSDGPU_ERR_HIP, "shard %d: stream sync failed", g);
+      outs[(size_t) g] = got;
+    }
+    rcs[(size_t) g] = rc;
+    if (rc) msgs[(size_t) g] = tsdgpu_last_error();
+  };
+  std::vector<std::thread> th;
+  for (int g = 1; g < N; g++) th.emplace_back(work, g);
+  int prev = 0;
+  (void) hipGetDevice(&prev);
+  work(0);
+  for (auto &t : th) t.join();
+  (void) hipSetDevice(prev);
+  int64_t total = 0;
+  for (int g = 0; g < N; g++) {
+    if (rcs[(size_t) g]) return set_err(rcs[(size_t) g], "shard %d: %s", g, msgs[(size_t) g].c_str());
+    total += outs[(size_t) g];
+  }
+  h->seen += n;
+  h->out_total += total;
+  if (n_out) *n_out = total;
+  return TSDGPU_OK;
+}
+
+int tsdgpu_sharded_step_parts(tsdgpu_sharded *h, const void *const *x_parts, const int64_t *counts, void *const *y_parts,
+                              const int64_t *y_capacities, int64_t *out_counts)
+{
+  TSD_CHECK(h != nullptr && x_parts != nullptr && counts != nullptr && y_parts != nullptr, "sharded_step_parts: NULL argument");
+  const size_t esz = h->esz();
+  const int N = h->nshards;
+  const int64_t H = h->H;
+  int64_t n = 0;
+  std::vector<int64_t> lo((size_t) N + 1, 0);
+  for (int g = 0; g < N; g++) {
+    TSD_CHECK(counts[g] >= 0, "sharded_step_parts: negative count");
+    TSD_CHECK(counts[g] == 0 || (x_parts[g] && y_parts[g]), "sharded_step_parts: NULL part %d", g);
+    lo[(size_t) g + 1] = lo[(size_t) g] + counts[g];
+  }
+  n = lo[(size_t) N];
+  if (n == 0) return TSDGPU_OK;
+  int prev = 0;
+  TSD_HIP(hipGetDevice(&prev));
+  // (1) halos, device to device: the last H samples before each shard, walking back over the parts and
+  //     ending in the carry of the previous calls
+  int rc = TSDGPU_OK;
+  for (int g = 0; g < N && !rc; g++) {
+    TSD_HIP(hipSetDevice(h->dev[g]));
+    int64_t need = H;
+    char *dst = (char *) h->halo[g].p;
+    for (int p = g - 1; p >= 0 && need > 0; p--) {
+      const int64_t take = std::min(need, counts[p]);
+      if (take > 0) {
+        const char *src = (const char *) x_parts[p] + (size_t) (counts[p] - take) * esz;
+        if (h->dev[p] == h->dev[g]) TSD_HIP(hipMemcpyAsync(dst + (size_t) (need - take) * esz, src, (size_t) take * esz, hipMemcpyDeviceToDevice, h->stream[g]));
+        else TSD_HIP(hipMemcpyPeerAsync(dst + (size_t) (need - take) * esz, h->dev[g], src, h->dev[p], (size_t) take * esz, h->stream[g]));
+        need -= take;
+      }
+    }
+    if (need > 0) TSD_HIP(hipMemcpyAsync(dst, h->carry.data() + (size_t) (H - need) * esz, (size_t) need * esz, hipMemcpyHostToDevice, h->stream[g]));
+  }
+  // the new carry: the tail of this call, gathered to the host (small) before any shard writes in place
+  {
+    std::vector<char> nc = h->carry;
+    int64_t need = std::min(H, n), kept = H - need;
+    if (kept > 0 && need > 0) std::memmove(nc.data(), nc.data() + (size_t) need * esz, (size_t) kept * esz);
+    int64_t fill = H;
+    for (int p = N - 1; p >= 0 && need > 0; p--) {
+      const int64_t take = std::min(need, counts[p]);
+      if (take > 0) {
+        TSD_HIP(hipSetDevice(h->dev[p]));
+        TSD_HIP(hipMemcpy(nc.data() + (size_t) (fill - take) * esz, (const char *) x_parts[p] + (size_t) (counts[p] - take) * esz,
+                          (size_t) take * esz, hipMemcpyDeviceToHost));
+        fill -= take;
+        need -= take;
+      }
+    }
+    for (int g = 0; g < N; g++) {
+      TSD_HIP(hipSetDevice(h->dev[g]));
+      TSD_HIP(hipStreamSynchronize(h->stream[g]));     // halos landed: in-place shards may start
+    }
+    h->carry.swap(nc);
+  }
+  // (2) the shards, concurrently (one stream each; the enqueue itself is cheap)
+  std::vector<int64_t> got((size_t) N, 0);
+  for (int g = 0; g < N && !rc; g++) {
+    TSD_HIP(hipSetDevice(h->dev[g]));
+    const int64_t pos = h->seen + lo[(size_t) g];
+    const int64_t ycap = y_capacities ? y_capacities[g] : counts[g];
+    rc = run_shard(h, g, h->halo[g].p, std::min(H, pos), pos, x_parts[g], y_parts[g], counts[g], ycap, &got[(size_t) g]);
+    if (h->kind != K_RES) got[(size_t) g] = counts[g];
+  }
+  for (int g = 0; g < N; g++) {
+    (void) hipSetDevice(h->dev[g]);
+    if (hipStreamSynchronize(h->stream[g]) != hipSuccess && !rc) rc = set_err(TSDGPU_ERR_HIP, "shard %d: stream sync failed", g);
+  }
+  (void) hipSetDevice(prev);
+  if (rc) return rc;
+  int64_t total = 0;
+  for (int g = 0; g < N; g++) {
+    if (out_counts) out_counts[g] = got[(size_t) g];
+    total += got[(size_t) g];
+  }
+  h->seen += n;
+  h->out_total += total;
+  return TSDGPU_OK;
+}
+
+int tsdgpu_sharded_reset(tsdgpu_sharded *h)
+{
+  TSD_CHECK(h != nullptr, "sharded_reset: NULL handle");
+  std::fill(h->carry.begin(), h->carry.end(), 0);
+  h->seen = 0;
+  h->out_total = 0;
+  for (int g = 0; g < h->nshards; g++) {
+    const int rc = with_device(h->dev[g], [&]() -> int {
+      if (h->kind == K_FIR) return tsdgpu_fir_reset((tsdgpu_fir *) h->handle[g]);
+      if (h->kind == K_SOS) return tsdgpu_sos_reset((tsdgpu_sos *) h->handle[g]);
+      return tsdgpu_resampler_reset((tsdgpu_resampler *) h->handle[g]);
+    });
+    if (rc) return rc;
+  }
+  return TSDGPU_OK;
+}
+
+int tsdgpu_sharded_destroy(tsdgpu_sharded *h)
+{
+  if (!h) return TSDGPU_OK;
+  int prev = 0;
+  (void) hipGetDevice(&prev);
+  for (int g = 0; g < h->nshards; g++) {
+    (void) hipSetDevice(h->dev[g]);
+    if (h->handle[g]) {
+      if (h->kind == K_FIR) tsdgpu_fir_destroy((tsdgpu_fir *) h->handle[g]);
+      else if (h->kind == K_SOS) tsdgpu_sos_destroy((tsdgpu_sos *) h->handle[g]);
+      else tsdgpu_resampler_destroy((tsdgpu_resampler *) h->handle[g]);
+    }
+    if (h->stream[g]) (void) hipStreamDestroy(h->stream[g]);
+    h->halo[g].release();
+    h->in[g].release();
+    h->out[g].release();
+    h->scratch[g].release();
+  }
+  (void) hipSetDevice(prev);
+  delete h;
+  return TSDGPU_OK;
+}
+
+}  // extern "C"

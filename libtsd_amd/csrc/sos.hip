@@ -436,6 +436,11 @@ int tsdgpu_sos_step(tsdgpu_sos *s, const void *x, void *y, int64_t n, void *stre
   TSD_CHECK(x != nullptr && y != nullptr, "sos_step: NULL buffer");
   hipStream_t st = (hipStream_t) stream;
   const size_t bytes = (size_t) n * dtype_size(s->data_type);
+  if (bytes >= PIPE_MIN_BYTES && !is_device_ptr(x) && !is_device_ptr(y)) {
+    // large host vectors: chunked H2D / kernel / D2H pipeline (the section states carry from chunk to chunk)
+    return pipelined_host_step(x, y, n, dtype_size(s->data_type), st,
+                               [s](const void *cx, void *cy, int64_t cnt, hipStream_t q) { return tsdgpu_sos_step(s, cx, cy, cnt, q); });
+  }
   const void *dx = nullptr;
   void *dy = nullptr;
   bool staged = false;
@@ -515,7 +520,16 @@ int tsdgpu_sos_step(tsdgpu_sos *s, const void *x, void *y, int64_t n, void *stre
 int tsdgpu_sos_reset(tsdgpu_sos *s)
 {
   TSD_CHECK(s != nullptr, "sos_reset: NULL handle");
+  // (a memset of device memory may return before it has run: wait, so that a step enqueued on ANY
+  // stream afterwards -- non-blocking ones are not ordered with the null stream -- sees the zeros)
   TSD_HIP(hipMemset(s->d_state[s->cur], 0, STATE_FLOATS * 4));
+  TSD_HIP(hipStreamSynchronize(nullptr));
+  return TSDGPU_OK;
+}
+int tsdgpu_sos_reset_on(tsdgpu_sos *s, void *stream)
+{
+  TSD_CHECK(s != nullptr, "sos_reset: NULL handle");
+  TSD_HIP(hipMemsetAsync(s->d_state[s->cur], 0, STATE_FLOATS * 4, (hipStream_t) stream));
   return TSDGPU_OK;
 }
 

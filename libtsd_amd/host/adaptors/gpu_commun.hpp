@@ -17,6 +17,8 @@
 #include "tsd/fourier.hpp"
 #include "tsdgpu.h"
 #include <complex>
+#include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 
@@ -39,13 +41,75 @@ template <typename V> inline void dimensionne(V &y, int n)
   if (y.rows() != n) y.resize(n);
 }
 
+// bytes from anywhere to anywhere: plain memcpy between host buffers, the C ABI's copy as soon as one
+// side is device memory (resident vectors)
+inline void copie_octets(void *dst, const void *src, size_t octets)
+{
+  if (octets == 0) return;
+  if (tsdgpu_is_device_pointer(dst) || tsdgpu_is_device_pointer(src)) {
+    if (tsdgpu_memcpy(dst, src, octets, nullptr)) gpu_fail("copy");
+  } else {
+    std::memcpy(dst, src, octets);
+  }
+}
+// grow-only device scratch owned by an adaptor object
+struct TamponGpu {
+  void *p = nullptr;
+  size_t cap = 0;
+  TamponGpu() {}
+  TamponGpu(const TamponGpu &) = delete;
+  TamponGpu &operator=(const TamponGpu &) = delete;
+  ~TamponGpu() { tsdgpu_free(p); }
+  void *reserve(size_t octets)
+  {
+    if (octets > cap) {
+      tsdgpu_free(p);
+      p = nullptr;
+      cap = 0;
+      if (tsdgpu_malloc(&p, octets + octets / 8 + 256)) gpu_fail("device scratch");
+      cap = octets + octets / 8 + 256;
+    }
+    return p;
+  }
+};
+
+// ---- several GPUs behind one operator object --------------------------------------------------------
+// A large HOST vector handed to a FIR / SOS / resampler object is cut into contiguous chunks, one per
+// GPU of the node (tsdgpu_sharded_step_host: chunk + the operator's small halo per device, all devices
+// at once).  The choice is made at the object's first step() and kept (the stream state then lives in
+// the sharded handle): shards = the device count when there are several, or tsd_amd::fixe_fragments(n)
+// / TSD_AMD_SHARDS=n (n logical shards spread over the devices present; 0 or 1: off).
+int &fragments_forces();                 // -1: automatic
+inline int nb_fragments()
+{
+  if (fragments_forces() >= 0) return fragments_forces();
+  static const int n = [] {
+    if (const char *e = std::getenv("TSD_AMD_SHARDS")) return std::atoi(e);
+    const int d = tsdgpu_device_count();
+    return d > 1 ? d : 0;
+  }();
+  return n;
+}
+constexpr int SEUIL_FRAGMENTS = 1 << 22;     // samples: below this one GPU is as good
+template <typename VX, typename VY> inline bool choisit_fragments(const VX &x, const VY &y)
+{
+  return nb_fragments() >= 2 && x.rows() >= SEUIL_FRAGMENTS && !tsdgpu_is_device_pointer(x.data()) &&
+         !(y.rows() > 0 && tsdgpu_is_device_pointer(y.data()));
+}
+template <typename VX> inline void exige_hote_fragments(const VX &x, const char *qui)
+{
+  if (x.rows() > 0 && tsdgpu_is_device_pointer(x.data()))
+    échec("{}: this object runs in multi-GPU host mode (its first step() took a large host vector); resident vectors need their own object", qui);
+}
+
 // step() of a stage whose output length differs from its input length: `lance(ptr)` fills cap
 // elements.  x and y may be the same object (y = f->step(y) style chains): then a temporary is filled.
 template <typename VX, typename VY, typename F> inline void sortie_variable(const VX &x, VY &y, long long cap, F lance)
 {
   if (cap < 0 || cap > 0x7fffffffLL) échec("output size {} not representable in a Vecteur", cap);
   if ((const void *) x.data() == (const void *) y.data() && y.rows() != (int) cap) {
-    VY tmp((int) cap);
+    VY tmp;
+    tmp.resize((int) cap);
     lance(tmp.data());
     y = std::move(tmp);
     return;

@@ -70,6 +70,13 @@ struct RTFRPlanGpu : FiltreGen<float, cfloat> {
 };
 sptr<FiltreGen<float, cfloat>> rtfrplan_gpu(entier n) { return std::make_shared<RTFRPlanGpu>(n); }
 
+int &fragments_forces()
+{
+  static int n = -1;
+  return n;
+}
+void fixe_fragments(int n) { fragments_forces() = n; }
+
 // ---- device memory helpers for resident vectors ------------------------------------------------------
 void *alloue_gpu(size_t octets)
 {

@@ -40,15 +40,24 @@ struct OLAGpu : Filtre<cfloat, cfloat, FiltreFFTConfig> {
     }
   }
 
+  TamponGpu sortie_gpu;
   void step(const Veccf &x, Veccf &y)
   {
     const FiltreFFTConfig &c = Configurable<FiltreFFTConfig>::config;
     if (!h) échec("filtre_fft: not configured");
-    std::vector<cfloat> out((size_t) std::max<int64_t>(1, tsdgpu_ola_max_out(h, x.rows())));
+    // the engine tells the output count only when it is done: it writes a scratch of the bounded size --
+    // device memory when x is resident (nothing crosses PCIe), host memory otherwise -- and the
+    // outputs go from there to y
+    const size_t borne = (size_t) std::max<int64_t>(1, tsdgpu_ola_max_out(h, x.rows()));
+    const bool résident = x.rows() > 0 && tsdgpu_is_device_pointer(x.data());
+    std::vector<cfloat> sortie_hote;
+    cfloat *out;
+    if (résident) out = static_cast<cfloat *>(sortie_gpu.reserve(borne * sizeof(cfloat)));
+    else { sortie_hote.resize(borne); out = sortie_hote.data(); }
     int64_t nout = 0;
     if (!c.traitement_freq) {
       // device-side processing only: framing, FFTs, product and overlap-add in one call
-      if (tsdgpu_ola_step(h, x.data(), x.rows(), out.data(), &nout, nullptr)) gpu_fail("filtre_fft");
+      if (tsdgpu_ola_step(h, x.data(), x.rows(), out, &nout, nullptr)) gpu_fail("filtre_fft");
     } else {
       void *sp = nullptr;
       int nf = 0;
@@ -59,17 +68,17 @@ struct OLAGpu : Filtre<cfloat, cfloat, FiltreFFTConfig> {
         if (tsdgpu_ola_read_spectra(h, S.data(), nullptr)) gpu_fail("filtre_fft");
         Veccf X(N);
         for (entier f = 0; f < nf; f++) {
-          std::copy(S.begin() + (size_t) f * N, S.begin() + (size_t) (f + 1) * N, X.data());
+          copie_octets(X.data(), S.data() + (size_t) f * N, (size_t) N * sizeof(cfloat));
           c.traitement_freq(X);
           if (X.rows() != N) échec("filtre_fft: traitement_freq must keep the dimension of the spectrum ({})", (int) N);
-          std::copy(X.data(), X.data() + N, S.begin() + (size_t) f * N);
+          copie_octets(S.data() + (size_t) f * N, X.data(), (size_t) N * sizeof(cfloat));
         }
         if (tsdgpu_ola_write_spectra(h, S.data(), nullptr)) gpu_fail("filtre_fft");
       }
-      if (tsdgpu_ola_synthese(h, out.data(), &nout, nullptr)) gpu_fail("filtre_fft");
+      if (tsdgpu_ola_synthese(h, out, &nout, nullptr)) gpu_fail("filtre_fft");
     }
     dimensionne(y, (entier) nout);
-    std::copy(out.begin(), out.begin() + nout, y.data());
+    copie_octets(y.data(), out, (size_t) nout * sizeof(cfloat));
   }
 };
 
@@ -92,28 +101,43 @@ entier filtre_fft_dim(const FiltreFFTConfig &c)
 // kernel (one HBM pass, 60 % of roofline), the delay line lives here.
 template <typename T> struct FiltreFFTRIFGpu : FiltreGen<T> {
   tsdgpu_fir *h = nullptr;
-  std::vector<T> retard;      // the last Nz - M outputs not yet delivered
+  size_t d = 0;               // Nz - M
+  void *retard = nullptr;     // device: the last d outputs not yet delivered
+  TamponGpu z;                // device: the filter output of the current call
   explicit FiltreFFTRIFGpu(const Vecf &c)
   {
     const entier M = c.rows(), Ne = 512;
     if (M <= 0) échec("filtre_rif_fft: no coefficient");
     const entier N = prochaine_puissance_de_2(Ne + M), Nz = N - Ne;
     if (Nz > Ne) échec("filtre_rif_fft: {} coefficients need Nz = {} > Ne = {} (the reference's OLA limit)", (int) M, (int) Nz, (int) Ne);
-    retard.assign((size_t) (Nz - M), T(0));
+    d = (size_t) (Nz - M);
+    if (d > 0) {
+      if (tsdgpu_malloc(&retard, d * sizeof(T)) || tsdgpu_memset(retard, 0, d * sizeof(T), nullptr)) gpu_fail("filtre_rif_fft");
+    }
     if (tsdgpu_fir_create(&h, dtype_of<T>(), TSDGPU_F32, c.data(), M, TSDGPU_FIR_OVERLAP_SAVE)) gpu_fail("filtre_rif_fft");
   }
-  ~FiltreFFTRIFGpu() { tsdgpu_fir_destroy(h); }
+  ~FiltreFFTRIFGpu()
+  {
+    tsdgpu_fir_destroy(h);
+    tsdgpu_free(retard);
+  }
   void step(const Vecteur<T> &x, Vecteur<T> &y)
   {
-    const size_t n = (size_t) x.rows(), d = retard.size();
-    std::vector<T> tout(d + n);
-    std::copy(retard.begin(), retard.end(), tout.begin());
-    if (n > 0 && tsdgpu_fir_step(h, x.data(), tout.data() + d, (int64_t) n, nullptr)) gpu_fail("filtre_rif_fft::step");
+    const size_t n = (size_t) x.rows(), sz = sizeof(T);
+    if (n == 0) {
+      dimensionne(y, 0);
+      return;
+    }
+    // z = FIR(x) on the device (the input may be a host or a resident vector); only its real part for
+    // complex data (fourier.cc:976); then y = (retard ++ z)[0, n), retard <- the rest
+    char *zz = static_cast<char *>(z.reserve((n + d) * sz));
+    if (tsdgpu_fir_step(h, x.data(), zz + d * sz, (int64_t) n, nullptr)) gpu_fail("filtre_rif_fft::step");
     if constexpr (std::is_same_v<T, cfloat>)
-      for (size_t i = d; i < d + n; i++) tout[i] = cfloat(tout[i].real(), 0.f);   // real(...) re-widened (fourier.cc:976)
+      if (tsdgpu_zero_imag(zz + d * sz, (int64_t) n, nullptr)) gpu_fail("filtre_rif_fft::step");
+    if (d > 0) copie_octets(zz, retard, d * sz);
     if (x.data() != y.data()) dimensionne(y, (entier) n);
-    std::copy(tout.begin(), tout.begin() + n, y.data());
-    std::copy(tout.begin() + n, tout.end(), retard.begin());
+    copie_octets(y.data(), zz, n * sz);
+    if (d > 0) copie_octets(retard, zz + n * sz, d * sz);
   }
 };
 

@@ -15,16 +15,33 @@ using tsd_amd::gpu_fail;
 // ---- FIR: FiltreRIF<T,Tc> (filtre-rt.cc:53-109) ----------------------------------------------------
 template <typename T, typename Tc> struct FiltreRIFGpu : FiltreGen<T> {
   tsdgpu_fir *h = nullptr;
-  explicit FiltreRIFGpu(const Vecteur<Tc> &c, int method = TSDGPU_FIR_AUTO)
+  tsdgpu_sharded *hs = nullptr;      // several GPUs (see gpu_commun.hpp)
+  std::vector<Tc> coefs;
+  int methode, mode = -1;            // mode: -1 undecided, 0 one GPU, 1 sharded over the node
+  explicit FiltreRIFGpu(const Vecteur<Tc> &c, int method = TSDGPU_FIR_AUTO) : coefs(c.data(), c.data() + std::max(c.rows(), 0)), methode(method)
   {
     if (c.rows() <= 0) échec("filtre_rif: K > 0 required (K = {})", (int) c.rows());      // assertion(K > 0), :69
     if (tsdgpu_fir_create(&h, dtype_of<T>(), dtype_of<Tc>(), c.data(), c.rows(), method)) gpu_fail("filtre_rif");
   }
-  ~FiltreRIFGpu() { tsdgpu_fir_destroy(h); }
+  ~FiltreRIFGpu()
+  {
+    tsdgpu_fir_destroy(h);
+    tsdgpu_sharded_destroy(hs);
+  }
   void step(const Vecteur<T> &x, Vecteur<T> &y)
   {
     const entier n = x.rows();
     if (x.data() != y.data()) dimensionne(y, n);                           // in place allowed (:76-80)
+    if (mode < 0 && n > 0) mode = tsd_amd::choisit_fragments(x, y) ? 1 : 0;
+    if (mode == 1) {
+      tsd_amd::exige_hote_fragments(x, "filtre_rif");
+      if (!hs && tsdgpu_fir_sharded_create(&hs, dtype_of<T>(), dtype_of<Tc>(), coefs.data(), (int) coefs.size(), methode,
+                                           tsd_amd::nb_fragments(), nullptr))
+        gpu_fail("filtre_rif (multi-GPU)");
+      int64_t got = 0;
+      if (tsdgpu_sharded_step_host(hs, x.data(), n, y.data(), n, &got)) gpu_fail("filtre_rif::step (multi-GPU)");
+      return;
+    }
     if (tsdgpu_fir_step(h, x.data(), y.data(), n, nullptr)) gpu_fail("filtre_rif::step");
   }
 };
@@ -43,6 +60,10 @@ template sptr<FiltreGen<cfloat>> filtre_rif<cfloat, cfloat>(const Vecteur<cfloat
 // that carries the gain (:530-556), otherwise y *= gain (:558-559,570).
 template <typename T> struct ChaineSOISGpu : FiltreGen<T> {
   tsdgpu_sos *h = nullptr;
+  tsdgpu_sharded *hs = nullptr;      // several GPUs (see gpu_commun.hpp)
+  std::vector<float> coefs_sections, rii1_v;
+  float gain_v = 1.0f;
+  int forme = 2, mode = -1;
   ChaineSOISGpu(const FRat<cfloat> &f, RIIStructure structure)
   {
     const Vecteur<cfloat> z = f.numer.roots(), p = f.denom.roots();
@@ -89,12 +110,31 @@ template <typename T> struct ChaineSOISGpu : FiltreGen<T> {
     if (tsdgpu_sos_create(&h, dtype_of<T>(), coefs.data(), (int) (coefs.size() / 5), gain, avec_rii1 ? rii1 : nullptr,
                           structure == FormeDirecte2 ? 2 : 1))
       gpu_fail("filtre_sois");
+    coefs_sections = coefs;
+    if (avec_rii1) rii1_v.assign(rii1, rii1 + 3);
+    gain_v = gain;
+    forme = structure == FormeDirecte2 ? 2 : 1;
   }
-  ~ChaineSOISGpu() { tsdgpu_sos_destroy(h); }
+  ~ChaineSOISGpu()
+  {
+    tsdgpu_sos_destroy(h);
+    tsdgpu_sharded_destroy(hs);
+  }
   void step(const Vecteur<T> &x, Vecteur<T> &y)
   {
     const entier n = x.rows();
     if (x.data() != y.data()) dimensionne(y, n);
+    // warm-up sharding needs a cascade that forgets its past within a bounded halo
+    if (mode < 0 && n > 0) mode = (tsd_amd::choisit_fragments(x, y) && tsdgpu_sos_halo(h) >= 0 && tsdgpu_sos_halo(h) <= (1 << 20)) ? 1 : 0;
+    if (mode == 1) {
+      tsd_amd::exige_hote_fragments(x, "filtre_sois");
+      if (!hs && tsdgpu_sos_sharded_create(&hs, dtype_of<T>(), coefs_sections.data(), (int) (coefs_sections.size() / 5), gain_v,
+                                           rii1_v.empty() ? nullptr : rii1_v.data(), forme, tsd_amd::nb_fragments(), nullptr))
+        gpu_fail("filtre_sois (multi-GPU)");
+      int64_t got = 0;
+      if (tsdgpu_sharded_step_host(hs, x.data(), n, y.data(), n, &got)) gpu_fail("filtre_sois::step (multi-GPU)");
+      return;
+    }
     if (tsdgpu_sos_step(h, x.data(), y.data(), n, nullptr)) gpu_fail("filtre_sois::step");
   }
 };
@@ -207,12 +247,14 @@ template <typename T> struct LigneARetardHote : FiltreGen<T> {
   explicit LigneARetardHote(entier n) : mem((size_t) (n < 0 ? 0 : n), T(0)) {}
   void step(const Vecteur<T> &x, Vecteur<T> &y)
   {
-    const size_t d = mem.size(), n = (size_t) x.rows();
-    std::vector<T> tout(mem);
-    tout.insert(tout.end(), x.data(), x.data() + n);
-    dimensionne(y, (entier) n);
-    std::copy(tout.begin(), tout.begin() + n, y.data());
-    std::copy(tout.begin() + n, tout.begin() + n + d, mem.begin());
+    const size_t d = mem.size(), n = (size_t) x.rows(), sz = sizeof(T);
+    // tout = mem ++ x (copies work from host or device vectors alike)
+    std::vector<T> tout(d + n);
+    std::copy(mem.begin(), mem.end(), tout.begin());
+    tsd_amd::copie_octets(tout.data() + d, x.data(), n * sz);
+    if (x.data() != y.data()) dimensionne(y, (entier) n);
+    tsd_amd::copie_octets(y.data(), tout.data(), n * sz);
+    std::copy(tout.begin() + n, tout.end(), mem.begin());
   }
 };
 template <typename T> sptr<FiltreGen<T>> ligne_a_retard(entier n) { return std::make_shared<LigneARetardHote<T>>(n); }
@@ -225,7 +267,7 @@ template <typename T> struct FiltreIdHote : FiltreGen<T> {
   {
     if (x.data() == y.data()) return;
     dimensionne(y, x.rows());
-    std::copy(x.data(), x.data() + x.rows(), y.data());
+    tsd_amd::copie_octets(y.data(), x.data(), (size_t) x.rows() * sizeof(T));
   }
 };
 template <typename T> sptr<FiltreGen<T>> filtre_id() { return std::make_shared<FiltreIdHote<T>>(); }

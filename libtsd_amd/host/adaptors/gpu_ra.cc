@@ -97,10 +97,14 @@ template <typename T> static SondeItrp sonde_interpolateur(const sptr<Interpolat
 // ---- AdaptationRythmeSimple (ra.cc:13-79) on the GPU resampler ---------------------------------------
 template <typename T> struct AdaptationRythmeSimpleGpu : FiltreGen<T> {
   tsdgpu_resampler *h = nullptr;
-  AdaptationRythmeSimpleGpu(float ratio, sptr<Interpolateur<T>> itrp)
+  tsdgpu_sharded *hs = nullptr;      // several GPUs (see gpu_commun.hpp); table-driven interpolators only
+  SondeItrp s;
+  float ratio_v = 1;
+  int mode = -1;
+  AdaptationRythmeSimpleGpu(float ratio, sptr<Interpolateur<T>> itrp) : ratio_v(ratio)
   {
     if (!itrp) échec("filtre_itrp: null interpolator");
-    const SondeItrp s = sonde_interpolateur<T>(itrp);
+    s = sonde_interpolateur<T>(itrp);
     switch (s.genre) {
       case SondeItrp::TABLE:
         if (tsdgpu_resampler_create(&h, dtype_of<T>(), ratio, s.lut.data(), s.K, s.nphases)) gpu_fail("filtre_itrp");
@@ -116,10 +120,26 @@ template <typename T> struct AdaptationRythmeSimpleGpu : FiltreGen<T> {
               "over at most 8191 phases) nor itrp_lineaire / itrp_lagrange: no GPU path for this coefs()", itrp->nom);
     }
   }
-  ~AdaptationRythmeSimpleGpu() { tsdgpu_resampler_destroy(h); }
+  ~AdaptationRythmeSimpleGpu()
+  {
+    tsdgpu_resampler_destroy(h);
+    tsdgpu_sharded_destroy(hs);
+  }
   void step(const Vecteur<T> &x, Vecteur<T> &y)
   {
     const entier n = x.rows();
+    if (mode < 0 && n > 0) mode = (s.genre == SondeItrp::TABLE && tsd_amd::choisit_fragments(x, y)) ? 1 : 0;
+    if (mode == 1) {
+      tsd_amd::exige_hote_fragments(x, "filtre_itrp");
+      if (!hs && tsdgpu_resampler_sharded_create(&hs, dtype_of<T>(), ratio_v, s.lut.data(), s.K, s.nphases, tsd_amd::nb_fragments(), nullptr))
+        gpu_fail("filtre_itrp (multi-GPU)");
+      const int64_t capm = tsdgpu_sharded_out_count(hs, n);
+      tsd_amd::sortie_variable(x, y, capm, [&](T *out) {
+        int64_t got = 0;
+        if (n > 0 && tsdgpu_sharded_step_host(hs, x.data(), n, out, capm, &got)) gpu_fail("filtre_itrp::step (multi-GPU)");
+      });
+      return;
+    }
     const int64_t cap = n > 0 ? tsdgpu_resampler_out_count(h, n) : 0;
     tsd_amd::sortie_variable(x, y, cap, [&](T *out) {
       int64_t got = 0;
@@ -171,7 +191,7 @@ template <typename T> struct AdaptationRythmeArbitraireGpu : Filtre<T, T, float>
     if (ratio == 1) {                                                         // (ra.cc:162-163)
       if (x.data() != y.data()) {
         tsd_amd::dimensionne(y, x.rows());
-        std::copy(x.data(), x.data() + x.rows(), y.data());
+        tsd_amd::copie_octets(y.data(), x.data(), (size_t) x.rows() * sizeof(T));
       }
       return;
     }

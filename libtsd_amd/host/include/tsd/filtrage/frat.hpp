@@ -67,7 +67,7 @@ template <typename T> struct Poly {
     r.coefs = Vecteur<T>::ones(1);
     for (entier i = 0; i < coefs.rows(); i++) {
       Poly m;
-      m.coefs = Vecteur<T>(2);
+      m.coefs = Vecteur<T>::hote(2);
       m.coefs.data()[0] = -coefs.data()[i];
       m.coefs.data()[1] = T(1.0f);
       r = r * m;

@@ -91,6 +91,37 @@ template <typename T> constexpr bool est_complexe()
   return std::is_same_v<T, cfloat> || std::is_same_v<T, cdouble>;
 }
 
+// ---- device residency ("device-buffer side-channel") -------------------------
+// A Vecteur may live in GPU memory.  Every operator of the path takes such vectors as they are (the C
+// ABI accepts device pointers), so a chain filtrer -> fft -> rééchan never crosses PCIe; only
+// element-wise host code (operator(), arithmetic) refuses them.  Three ways in:
+//   Vecteur<T>::sur_gpu(n) / x.vers_gpu()       explicit device vectors
+//   Vecteur<T>::map(device_ptr, n)              foreign device memory (torch, hipMalloc)
+//   { ResidenceGpu r; y = filtrer(h, x); }      while the guard lives, every vector an operator SIZES
+//                                               on this thread (resize(): step() outputs, temporaries of
+//                                               operator chains) is device memory; vectors built by
+//                                               constructors / zeros() / valeurs() -- what host code fills
+//                                               element by element -- stay on the host
+// Host vectors of 1 MiB and more are page-locked, so the chunked staging pipeline of the C ABI runs
+// their H2D / D2H copies asynchronously and in both directions at once.
+namespace detail {
+void *gpu_alloc(size_t octets);
+void gpu_free(void *p);
+void *hote_alloc(size_t octets, bool *verrouillée);      // page-locked when a GPU is present
+void hote_free(void *p, bool verrouillée);
+void gpu_copie(void *dst, const void *src, size_t octets);   // host<->device, device<->device
+void gpu_zero(void *p, size_t octets);
+bool est_ptr_gpu(const void *p);
+bool &residence_active();
+}  // namespace detail
+struct ResidenceGpu {
+  bool avant;
+  ResidenceGpu() : avant(detail::residence_active()) { detail::residence_active() = true; }
+  ~ResidenceGpu() { detail::residence_active() = avant; }
+  ResidenceGpu(const ResidenceGpu &) = delete;
+  ResidenceGpu &operator=(const ResidenceGpu &) = delete;
+};
+
 // ---- Vecteur<T>: contiguous column vector, int-indexed -------------------------------------
 // Semantics kept from TabT<T,1> (tableau.hpp:530-592, pinned by core/tests/test-tab.cc):
 // copy construction = deep copy, move = steal, head/tail/segment = views aliasing the parent,
@@ -100,6 +131,7 @@ template <typename T> class Vecteur {
   T *p_ = nullptr;
   entier n_ = 0;
   bool vue_ = false;
+  bool gpu_ = false;     // p_ is device memory
 
  public:
   using Scalar = T;
@@ -107,20 +139,22 @@ template <typename T> class Vecteur {
   explicit Vecteur(entier n) { alloc(n); }
   Vecteur(const Vecteur &o)
   {
-    alloc(o.n_);
-    std::copy(o.p_, o.p_ + o.n_, p_);
+    alloc(o.n_, o.gpu_);          // a copy lives where its source lives
+    copie_depuis(o);
   }
-  Vecteur(Vecteur &&o) noexcept : buf_(std::move(o.buf_)), p_(o.p_), n_(o.n_), vue_(o.vue_)
+  Vecteur(Vecteur &&o) noexcept : buf_(std::move(o.buf_)), p_(o.p_), n_(o.n_), vue_(o.vue_), gpu_(o.gpu_)
   {
     o.p_ = nullptr;
     o.n_ = 0;
     o.vue_ = false;
+    o.gpu_ = false;
   }
   // widening: real -> complex (tableau.hpp:515-521)
   template <typename U, typename = std::enable_if_t<!std::is_same_v<U, T> && std::is_convertible_v<U, T>>>
   Vecteur(const Vecteur<U> &o)
   {
-    alloc(o.rows());
+    o.exige_hote("conversion");
+    alloc(o.rows(), false);
     for (entier i = 0; i < n_; i++) p_[i] = (T) o.data()[i];
   }
   Vecteur &operator=(const Vecteur &o)
@@ -128,11 +162,10 @@ template <typename T> class Vecteur {
     if (this == &o) return *this;
     if (vue_) {
       if (o.n_ != n_) échec("Vecteur: assignment into a view of {} elements from {} elements", n_, o.n_);
-      std::copy(o.p_, o.p_ + n_, p_);
-    } else {
-      if (o.n_ != n_) alloc(o.n_);
-      std::copy(o.p_, o.p_ + n_, p_);
+    } else if (o.n_ != n_ || o.gpu_ != gpu_) {
+      alloc(o.n_, o.gpu_);
     }
+    copie_depuis(o);
     return *this;
   }
   Vecteur &operator=(Vecteur &&o)
@@ -143,9 +176,11 @@ template <typename T> class Vecteur {
     p_ = o.p_;
     n_ = o.n_;
     vue_ = o.vue_;
+    gpu_ = o.gpu_;
     o.p_ = nullptr;
     o.n_ = 0;
     o.vue_ = false;
+    o.gpu_ = false;
     return *this;
   }
 
@@ -155,7 +190,34 @@ template <typename T> class Vecteur {
     v.p_ = ptr;
     v.n_ = n;
     v.vue_ = true;
+    v.gpu_ = n > 0 && detail::est_ptr_gpu(ptr);
     return v;
+  }
+  // ---- device residency ----
+  static Vecteur sur_gpu(entier n)
+  {
+    Vecteur v;
+    v.alloc(n, true);
+    return v;
+  }
+  bool est_sur_gpu() const { return gpu_; }
+  Vecteur vers_gpu() const
+  {
+    Vecteur v;
+    v.alloc(n_, true);
+    v.copie_depuis(*this);
+    return v;
+  }
+  Vecteur vers_hote() const
+  {
+    Vecteur v;
+    v.alloc(n_, false);
+    v.copie_depuis(*this);
+    return v;
+  }
+  void exige_hote(const char *quoi) const
+  {
+    if (gpu_) échec("Vecteur: {} on a device-resident vector (bring it back with vers_hote())", quoi);
   }
   static Vecteur zeros(entier n)
   {
@@ -165,19 +227,19 @@ template <typename T> class Vecteur {
   }
   static Vecteur ones(entier n)
   {
-    Vecteur v(n);
+    Vecteur v(n, false);
     v.setConstant((T) 1);
     return v;
   }
   static Vecteur valeurs(std::initializer_list<T> l)
   {
-    Vecteur v((entier) l.size());
+    Vecteur v((entier) l.size(), false);
     std::copy(l.begin(), l.end(), v.p_);
     return v;
   }
   template <typename F> static Vecteur int_expr(entier n, F f)
   {
-    Vecteur v(n);
+    Vecteur v(n, false);
     for (entier i = 0; i < n; i++) v.p_[i] = (T) f(i);
     return v;
   }
@@ -191,24 +253,30 @@ template <typename T> class Vecteur {
   {
     if (n == n_) return;
     if (vue_) échec("Vecteur::resize on a view");
-    alloc(n);
+    alloc(n, gpu_ || detail::residence_active());
   }
-  void setZero() { std::fill(p_, p_ + n_, T()); }
+  void setZero()
+  {
+    if (gpu_) detail::gpu_zero(p_, (size_t) n_ * sizeof(T));
+    else std::fill(p_, p_ + n_, T());
+  }
   void setZero(entier n)
   {
     resize(n);
     setZero();
   }
-  void setConstant(T v) { std::fill(p_, p_ + n_, v); }
+  void setConstant(T v) { exige_hote("setConstant"); std::fill(p_, p_ + n_, v); }
   Vecteur clone() const { return Vecteur(*this); }
 
   T &operator()(entier i)
   {
+    exige_hote("element access");
     if (i < 0 || i >= n_) échec("Vecteur: index {} out of range (dim = {})", i, n_);
     return p_[i];
   }
   const T &operator()(entier i) const
   {
+    exige_hote("element access");
     if (i < 0 || i >= n_) échec("Vecteur: index {} out of range (dim = {})", i, n_);
     return p_[i];
   }
@@ -221,36 +289,41 @@ template <typename T> class Vecteur {
     v.p_ = p_ + i;
     v.n_ = n;
     v.vue_ = true;
+    v.gpu_ = gpu_;
     return v;
   }
   Vecteur head(entier n) const { return segment(0, n); }
   Vecteur tail(entier n) const { return segment(n_ - n, n); }
   Vecteur reverse() const
   {
-    Vecteur v(n_);
+    exige_hote("reverse");
+    Vecteur v;
+    v.alloc(n_, false);
     for (entier i = 0; i < n_; i++) v.p_[i] = p_[n_ - 1 - i];
     return v;
   }
   Vecteur<cfloat> as_complex() const
   {
-    Vecteur<cfloat> v(n_);
+    exige_hote("as_complex");
+    Vecteur<cfloat> v = Vecteur<cfloat>::hote(n_);
     for (entier i = 0; i < n_; i++) v.data()[i] = cfloat(p_[i]);
     return v;
   }
   template <typename U> Vecteur<U> as() const
   {
-    Vecteur<U> v(n_);
+    exige_hote("as");
+    Vecteur<U> v = Vecteur<U>::hote(n_);
     for (entier i = 0; i < n_; i++) v.data()[i] = (U) p_[i];
     return v;
   }
 
   // element-wise arithmetic used around the hot path
-  Vecteur &operator*=(T s) { for (entier i = 0; i < n_; i++) p_[i] *= s; return *this; }
-  Vecteur &operator/=(T s) { for (entier i = 0; i < n_; i++) p_[i] /= s; return *this; }
+  Vecteur &operator*=(T s) { exige_hote("arithmetic"); for (entier i = 0; i < n_; i++) p_[i] *= s; return *this; }
+  Vecteur &operator/=(T s) { exige_hote("arithmetic"); for (entier i = 0; i < n_; i++) p_[i] /= s; return *this; }
   Vecteur &operator+=(const Vecteur &o) { chk(o); for (entier i = 0; i < n_; i++) p_[i] += o.p_[i]; return *this; }
   Vecteur &operator-=(const Vecteur &o) { chk(o); for (entier i = 0; i < n_; i++) p_[i] -= o.p_[i]; return *this; }
   Vecteur &operator*=(const Vecteur &o) { chk(o); for (entier i = 0; i < n_; i++) p_[i] *= o.p_[i]; return *this; }
-  Vecteur operator-() const { Vecteur v(*this); for (entier i = 0; i < n_; i++) v.p_[i] = -v.p_[i]; return v; }
+  Vecteur operator-() const { exige_hote("arithmetic"); Vecteur v(*this); for (entier i = 0; i < n_; i++) v.p_[i] = -v.p_[i]; return v; }
   friend Vecteur operator+(const Vecteur &a, const Vecteur &b) { Vecteur v(a); v += b; return v; }
   friend Vecteur operator-(const Vecteur &a, const Vecteur &b) { Vecteur v(a); v -= b; return v; }
   friend Vecteur operator*(const Vecteur &a, const Vecteur &b) { Vecteur v(a); v *= b; return v; }
@@ -261,6 +334,7 @@ template <typename T> class Vecteur {
   // reductions accumulate in double (tableau.hpp:656-717)
   T somme() const
   {
+    exige_hote("somme");
     if constexpr (est_complexe<T>()) {
       cdouble s = 0;
       for (entier i = 0; i < n_; i++) s += cdouble(p_[i]);
@@ -272,21 +346,47 @@ template <typename T> class Vecteur {
     }
   }
   T moyenne() const { return n_ ? somme() / (T) n_ : T(); }
-  T valeur_max() const { tsd_assertion(n_ > 0); return *std::max_element(p_, p_ + n_); }
-  T valeur_min() const { tsd_assertion(n_ > 0); return *std::min_element(p_, p_ + n_); }
-  entier index_max() const { return n_ ? (entier) (std::max_element(p_, p_ + n_) - p_) : -1; }
+  T valeur_max() const { exige_hote("valeur_max"); tsd_assertion(n_ > 0); return *std::max_element(p_, p_ + n_); }
+  T valeur_min() const { exige_hote("valeur_min"); tsd_assertion(n_ > 0); return *std::min_element(p_, p_ + n_); }
+  entier index_max() const { exige_hote("index_max"); return n_ ? (entier) (std::max_element(p_, p_ + n_) - p_) : -1; }
 
  private:
-  void alloc(entier n)
+  explicit Vecteur(entier n, bool sur_gpu_) { alloc(n, sur_gpu_); }
+ public:
+  // a host vector whatever the residency guard says (results that host code reads element by element)
+  static Vecteur hote(entier n) { return Vecteur(n, false); }
+ private:
+  void alloc(entier n) { alloc(n, false); }
+  void alloc(entier n, bool sur_gpu_)
   {
     if (n < 0) échec("Vecteur: negative size {}", n);
-    buf_ = n ? std::shared_ptr<T[]>(new T[(size_t) n]) : nullptr;
+    const size_t octets = (size_t) n * sizeof(T);
+    if (n == 0) {
+      buf_ = nullptr;
+    } else if (sur_gpu_) {
+      buf_ = std::shared_ptr<T[]>(static_cast<T *>(detail::gpu_alloc(octets)), [](T *p) { detail::gpu_free(p); });
+    } else if (octets >= ((size_t) 1 << 20)) {
+      bool verr = false;
+      T *p = static_cast<T *>(detail::hote_alloc(octets, &verr));
+      buf_ = std::shared_ptr<T[]>(p, [verr](T *q) { detail::hote_free(q, verr); });
+    } else {
+      buf_ = std::shared_ptr<T[]>(new T[(size_t) n]);
+    }
     p_ = buf_.get();
     n_ = n;
     vue_ = false;
+    gpu_ = n > 0 && sur_gpu_;
+  }
+  void copie_depuis(const Vecteur &o)
+  {
+    if (n_ == 0) return;
+    if (gpu_ || o.gpu_) detail::gpu_copie(p_, o.p_, (size_t) n_ * sizeof(T));
+    else std::copy(o.p_, o.p_ + n_, p_);
   }
   void chk(const Vecteur &o) const
   {
+    exige_hote("arithmetic");
+    o.exige_hote("arithmetic");
     if (o.n_ != n_) échec("Vecteur: size mismatch ({} vs {})", n_, o.n_);
   }
 };
@@ -298,37 +398,39 @@ using Veci = Vecteur<int32_t>;
 
 template <typename T> Vecteur<float> abs(const Vecteur<T> &x)
 {
-  Vecteur<float> y(x.rows());
+  x.exige_hote("abs");
+  Vecteur<float> y = Vecteur<float>::hote(x.rows());
   for (entier i = 0; i < x.rows(); i++) y.data()[i] = std::abs(x.data()[i]);
   return y;
 }
 // |x|^2 element-wise and power -> dB (core/include/tsd/tsd.hpp:414-421, tableau.hpp abs2)
 template <typename T> Vecteur<float> abs2(const Vecteur<T> &x)
 {
-  Vecteur<float> y(x.rows());
+  x.exige_hote("abs2");
+  Vecteur<float> y = Vecteur<float>::hote(x.rows());
   for (entier i = 0; i < x.rows(); i++) y(i) = std::norm(x.data()[i]);
   return y;
 }
 inline Vecf pow2db(const Vecf &x)
 {
-  Vecf y(x.rows());
+  Vecf y = Vecf::hote(x.rows());
   for (entier i = 0; i < x.rows(); i++) y(i) = 10 * std::log10(x(i));
   return y;
 }
-inline Vecf real(const Veccf &x) { return Vecf::int_expr(x.rows(), [&](entier i) { return x.data()[i].real(); }); }
-inline Vecf imag(const Veccf &x) { return Vecf::int_expr(x.rows(), [&](entier i) { return x.data()[i].imag(); }); }
+inline Vecf real(const Veccf &x) { x.exige_hote("real"); return Vecf::int_expr(x.rows(), [&](entier i) { return x.data()[i].real(); }); }
+inline Vecf imag(const Veccf &x) { x.exige_hote("imag"); return Vecf::int_expr(x.rows(), [&](entier i) { return x.data()[i].imag(); }); }
 template <typename T> Vecteur<T> vconcat(const Vecteur<T> &a, const Vecteur<T> &b)
 {
-  Vecteur<T> v(a.rows() + b.rows());
-  std::copy(a.data(), a.data() + a.rows(), v.data());
-  std::copy(b.data(), b.data() + b.rows(), v.data() + a.rows());
+  Vecteur<T> v(a.rows() + b.rows());      // follows the residency guard; the two halves are views
+  if (a.rows() > 0) v.head(a.rows()) = a;
+  if (b.rows() > 0) v.tail(b.rows()) = b;
   return v;
 }
 
 // linspace (tsd.hpp:916-931): step in double, samples rounded to float
 inline Vecf linspace(float a, float b, entier n)
 {
-  Vecf x(n);
+  Vecf x = Vecf::hote(n);
   if (n > 0) x(0) = a;
   if (n > 1) {
     const double step = ((double) b - a) / (n - 1);
@@ -347,14 +449,15 @@ inline Vecf sigimp(entier n, entier p = 0)
 template <typename T> Vecteur<T> sousech(const Vecteur<T> &x, entier R)
 {
   const entier n = x.dim();
-  Vecteur<T> y(n / R);
+  Vecteur<T> y = Vecteur<T>::hote(n / R);
   for (entier i = 0; i < n / R; i++) y(i) = x(i * R);
   return y;
 }
 template <typename T> Vecteur<T> surech(const Vecteur<T> &x, entier R)
 {
   const entier n = x.dim();
-  Vecteur<T> y = Vecteur<T>::zeros(n * R);
+  Vecteur<T> y = Vecteur<T>::hote(n * R);
+  y.setZero();
   for (entier i = 0; i < n; i++) y(i * R) = x(i);
   return y;
 }

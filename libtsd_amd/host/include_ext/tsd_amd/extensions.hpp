@@ -29,6 +29,14 @@ filtre_fft_reponse(const tsd::fourier::FiltreFFTConfig &config, const Veccf &H);
 // FFT size N the OLA engine picks for a configuration (what H must be sized to)
 entier filtre_fft_dim(const tsd::fourier::FiltreFFTConfig &config);
 
+// ---- several GPUs behind one operator object -----------------------------------------------------------
+// filtre_rif / filtre_sois / filtre_itrp (hence filtrer, rééchan ...) cut a large host vector (>= 2^22
+// samples) into one contiguous chunk per GPU of the node, each with its small halo, and run all devices
+// at once (include/tsdgpu.h: tsdgpu_sharded_step_host).  Automatic when the process sees several GPUs;
+// fixe_fragments(n) forces n logical shards (spread round-robin over the devices present; 0 or 1: off,
+// -1: automatic again), like the environment variable TSD_AMD_SHARDS.
+void fixe_fragments(int n);
+
 // ---- device memory for resident vectors ------------------------------------------------------------
 // A vector mapped on device memory, TabT<T,1>::map(ptr, n) (tableau.hpp:1067-1077), is accepted by
 // every adaptor as input, and as output when it already has the size the step produces (resize() to

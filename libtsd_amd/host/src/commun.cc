@@ -2,8 +2,123 @@
 // tampon_création (libtsd core/src/tsd.cc:45-126,173,287-291,307-381,410-483).  Mirror only: against
 // libtsd itself these come from libtsd's own tsd.cc.
 #include "tsd/tsd.hpp"
+#include "tsdgpu.h"
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <unordered_map>
 
 namespace tsd {
+
+// ---- device residency plumbing (tsd.hpp: detail::*) over the C ABI ----------------------------------
+namespace detail {
+// Large vectors come and go with every one-shot call (filtrer() allocates its output, libtsd-style):
+// page-locking 512 MiB costs ~85 ms and a device allocation + free synchronises the GPU, so freed
+// blocks are kept and handed out again (best fit within 25 %, at most `limite` bytes kept per kind).
+namespace {
+struct CacheBlocs {
+  std::mutex m;
+  std::multimap<size_t, void *> libres;
+  std::unordered_map<void *, size_t> tailles;     // capacity of every live block of this kind
+  size_t garde = 0, limite;
+  explicit CacheBlocs(size_t lim) : limite(lim) {}
+  void *prend(size_t octets)
+  {
+    std::lock_guard<std::mutex> l(m);
+    auto it = libres.lower_bound(octets);
+    if (it == libres.end() || it->first > octets + octets / 4) return nullptr;
+    void *p = it->second;
+    garde -= it->first;
+    libres.erase(it);
+    return p;
+  }
+  void note(void *p, size_t octets)
+  {
+    std::lock_guard<std::mutex> l(m);
+    tailles[p] = octets;
+  }
+  // true: kept for reuse; false: the caller frees it
+  bool rend(void *p)
+  {
+    std::lock_guard<std::mutex> l(m);
+    auto it = tailles.find(p);
+    if (it == tailles.end()) return false;
+    if (garde + it->second > limite) {
+      tailles.erase(it);
+      return false;
+    }
+    garde += it->second;
+    libres.emplace(it->second, p);
+    return true;
+  }
+};
+size_t limite_cache(const char *var, size_t defaut_mio)
+{
+  const char *e = std::getenv(var);
+  return ((size_t) (e ? std::atoll(e) : (long long) defaut_mio)) << 20;
+}
+CacheBlocs &cache_gpu()
+{
+  static CacheBlocs *c = new CacheBlocs(limite_cache("TSD_AMD_CACHE_GPU_MIB", 8192));     // never destroyed: outlives the HIP runtime teardown
+  return *c;
+}
+CacheBlocs &cache_hote()
+{
+  static CacheBlocs *c = new CacheBlocs(limite_cache("TSD_AMD_CACHE_HOTE_MIB", 4096));
+  return *c;
+}
+}  // namespace
+
+void *gpu_alloc(size_t octets)
+{
+  if (void *q = cache_gpu().prend(octets)) return q;
+  void *p = nullptr;
+  if (tsdgpu_malloc(&p, octets)) échec("Vecteur (device): {}", tsdgpu_last_error());
+  cache_gpu().note(p, octets);
+  return p;
+}
+void gpu_free(void *p)
+{
+  if (p && !cache_gpu().rend(p)) tsdgpu_free(p);
+}
+void *hote_alloc(size_t octets, bool *verrouillée)
+{
+  void *p = nullptr;
+  static const bool gpu = tsdgpu_device_count() > 0 && std::getenv("TSD_AMD_NO_PINNED") == nullptr;
+  if (gpu) {
+    *verrouillée = true;
+    if (void *q = cache_hote().prend(octets)) return q;
+    if (tsdgpu_malloc_host(&p, octets) == 0 && p) {
+      cache_hote().note(p, octets);
+      return p;
+    }
+  }
+  *verrouillée = false;
+  p = std::malloc(octets);
+  if (!p) échec("Vecteur: out of memory ({} bytes)", octets);
+  return p;
+}
+void hote_free(void *p, bool verrouillée)
+{
+  if (!p) return;
+  if (!verrouillée) std::free(p);
+  else if (!cache_hote().rend(p)) tsdgpu_free_host(p);
+}
+void gpu_copie(void *dst, const void *src, size_t octets)
+{
+  if (tsdgpu_memcpy(dst, src, octets, nullptr)) échec("Vecteur (device copy): {}", tsdgpu_last_error());
+}
+void gpu_zero(void *p, size_t octets)
+{
+  if (tsdgpu_memset(p, 0, octets, nullptr)) échec("Vecteur (device setZero): {}", tsdgpu_last_error());
+}
+bool est_ptr_gpu(const void *p) { return tsdgpu_is_device_pointer(p) != 0; }
+bool &residence_active()
+{
+  static thread_local bool actif = false;
+  return actif;
+}
+}  // namespace detail
 
 // ---- commons ---------------------------------------------------------------------------------
 logger_t &get_logger()
