@@ -182,6 +182,33 @@ def test_cfg3_fft_2p20(tg, orc):
     assert relerr(xb.cpu().numpy(), x) <= TOL
 
 
+# BASELINE configs[2] at the BENCHMARKED shape: batch 256 (2 GiB in, 2 GiB out) on the persistent,
+# software-pipelined grid, whose tile -> workgroup schedule depends on the batch.  Oracle on the first,
+# a middle and the last transform; Parseval and the inverse on all 256.
+def test_cfg3_fft_2p20_batch256(tg, orc):
+    import torch
+    n, batch = 1 << 20, 256
+    g = torch.Generator(device="cuda").manual_seed(3)
+    xd = torch.view_as_complex(torch.randn(batch, n, 2, device="cuda", generator=g))
+    p = tg.Fft(n, batch)
+    yd = p.step(xd)
+    torch.cuda.synchronize()
+    for b in (0, 131, 255):
+        ref = orc.fft(xd[b].cpu().numpy())
+        assert relerr(yd[b].cpu().numpy(), ref) <= TOL, b
+    ex = (xd.real.double() ** 2 + xd.imag.double() ** 2).sum(dim=1)
+    ey = (yd.real.double() ** 2 + yd.imag.double() ** 2).sum(dim=1)
+    assert float(((ey / ex) - 1).abs().max()) <= 1e-5               # unitary: every transform keeps its energy
+    zd = p.step(yd, False)
+    torch.cuda.synchronize()
+    err = (zd - xd).abs().amax(dim=1) / xd.abs().amax(dim=1)
+    assert float(err.max()) <= TOL
+    # (and the inverse in place, the other direction of the pipelined schedule)
+    p.step(yd, False, yd)
+    torch.cuda.synchronize()
+    assert float(((yd - xd).abs().amax(dim=1) / xd.abs().amax(dim=1)).max()) <= TOL
+
+
 # fftshift (test-fourier.cc:39-72): exact index permutation
 @pytest.mark.parametrize("n", [15, 16, 1, 2, 1001])
 def test_fftshift_exact(tg, orc, n):

@@ -243,6 +243,41 @@ def test_riia_butterworth_template(orc):
     assert np.isfinite(y).all() and np.abs(y[2000:]).max() < 1e-6
 
 
+# The DATA PATH of the SOS chain tied to what test_riia holds (test-filtres.cc:668-679 -> test_design,
+# :327-404): the template of design_riia(12, "lp", "butt", 0.25, 0.1, 60) sampled by frmag at 2048
+# frequencies of [0, 0.5) -- pass band = the first 800 bins within 0.1 of gain 1, stop band = the last
+# 800 bins within 0.1 of gain 0.  Here the bins are MEASURED through the recursion itself (DF2 sections,
+# first-sample seed, final gain: filtre-rt.cc:361-381,562-571): a complex exponential of each bin
+# frequency goes through the chain and the steady-state output amplitude is the gain.  (Exact sample
+# values of this path stay "parity unpinned": no reference test holds one.)
+RIIA_TEMPLATE_BINS_PASS = (0, 100, 400, 700, 799)
+RIIA_TEMPLATE_BINS_STOP = (1248, 1300, 1500, 1800, 2047)
+
+
+def riia_template_gain(step, bin_index, n=20000):
+    f = 0.5 * bin_index / 2048.0
+    x = np.exp(2j * np.pi * f * np.arange(n)).astype(np.complex64)
+    y = step(x)
+    return float(np.abs(y[n // 2:]).mean())
+
+
+def butter12_gain(f, fc=0.25):
+    return 1.0 / np.sqrt(1.0 + (np.tan(np.pi * f) / np.tan(np.pi * fc)) ** 24)
+
+
+def test_riia_template_through_the_oracle_recursion(orc):
+    z, p, mn, md = orc.design_butter_lp(12, 0.25)
+    for forme in (2, 1):
+        for k in RIIA_TEMPLATE_BINS_PASS + RIIA_TEMPLATE_BINS_STOP:
+            g = riia_template_gain(lambda x: orc.SosChain(z, p, mn, md, forme).step(x), k)
+            if k < 800:
+                assert abs(g - 1.0) <= 0.1, (forme, k, g)          # test_design: emax_bp <= err_max = 0.1
+            else:
+                assert g <= 0.1, (forme, k, g)                     # emax_bc <= 0.1
+            # and the Butterworth law itself, what "butt" designs: |H|^2 = 1 / (1 + (tan pi f / tan pi fc)^24)
+            assert abs(g - butter12_gain(0.5 * k / 2048.0)) <= 2e-3, (forme, k, g)
+
+
 # ---- integer-rate stages ------------------------------------------------------------------
 # test-filtres.cc:186-200  test_decimateur: R = 3 on 0..89 in blocks of 4 -> exactly 0,3,...,87
 def test_decimateur(orc):

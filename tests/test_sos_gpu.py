@@ -191,3 +191,20 @@ def test_sos_unaligned_device_views(tg, orc, cplx, ox, oy):
     z = xd.clone()
     g2.step(z[1:1 + n], z[1:1 + n])
     assert relerr(z[1:1 + n].cpu().numpy(), ref2.step(x[1:1 + n])) <= TOL
+
+
+# The GPU data path tied to what the reference's test_riia holds (test-filtres.cc:668-679,327-404): the
+# magnitude template of design_riia(12, "lp", "butt", 0.25) measured THROUGH tsdgpu_sos by steady-state
+# sinusoids at the template's bin frequencies (same check on the oracle: tests/test_oracle_pins.py)
+@pytest.mark.parametrize("forme", [2, 1])
+def test_sos_riia_template_through_the_gpu_recursion(tg, orc, forme):
+    from test_oracle_pins import (RIIA_TEMPLATE_BINS_PASS, RIIA_TEMPLATE_BINS_STOP, butter12_gain, riia_template_gain)
+    z, p, mn, md = orc.design_butter_lp(12, 0.25)
+    co, gain, r1 = orc.SosChain(z, p, mn, md, forme).coefs()
+    for k in RIIA_TEMPLATE_BINS_PASS + RIIA_TEMPLATE_BINS_STOP:
+        g = riia_template_gain(lambda x: tg.Sos(co, gain, tg.C64, r1, forme).step(x), k, n=1 << 17)
+        if k < 800:
+            assert abs(g - 1.0) <= 0.1, (k, g)
+        else:
+            assert g <= 0.1, (k, g)
+        assert abs(g - butter12_gain(0.5 * k / 2048.0)) <= 2e-3, (k, g)
