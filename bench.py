@@ -31,14 +31,38 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 LOG2N = 26
 K_TAPS = 127
-# HBM bytes per step from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs; FETCH x2 is
-# the gfx950 correction of MI355X_MICROARCH.md), measured offline: profiles/r1_pmc_traffic.txt
-TRAFFIC_PMC_BYTES = {
-    ("fir", "overlap-save", 26): (2 * 269971 + 524289) * 1024.0,
-    ("fft", 20, 256): (2 * 1062610 + 2100220 + 2 * 1048730 + 2097150) * 1024.0,     # both four-step passes
-    ("sos", 26): (2 * 147515 + 262144) * 1024.0,
-    ("resample", 27): (2 * 603488 + 1146790) * 1024.0,
+# HBM bytes per step: read at run time from the newest committed profiles/r*_pmc_traffic.txt (rocprofv3 --pmc
+# FETCH_SIZE / WRITE_SIZE in separate passes, scripts/profile_round.sh; mean KB per launch of each kernel).
+# gfx950 correction of MI355X_MICROARCH.md (HBM section): FETCH_SIZE counts 64 B per 128-B request on wide
+# coalesced reads -> x2; WRITE_SIZE is exact.  The dominant kernels of each workload:
+TRAFFIC_KERNELS = {
+    "fir": ["ols_kernel<false>"],
+    "fft": ["fft1m_cols_kernel<1>", "fft1m_cols_kernel<2>"],
+    "sos": ["sos_kernel"],
+    "resample": ["resample15_kernel"],
 }
+
+
+def pmc_traffic(workload):
+    """-> (bytes per step or None, source file or None)"""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.txt")),
+                   key=lambda f: int(re.search(r"r(\d+)_pmc_traffic", f).group(1)))
+    if not files:
+        return None, None
+    src = files[-1]
+    total, found = 0.0, 0
+    for ln in open(src):
+        m = re.match(r"pmc (.*?)\s+(FETCH_SIZE|WRITE_SIZE)\s+n=\s*\d+\s+mean=([0-9.e+]+)", ln)
+        if not m:
+            continue
+        if any(("::" + k) in m.group(1) or m.group(1).startswith("void tsdgpu::" + k) for k in TRAFFIC_KERNELS[workload]):
+            total += float(m.group(3)) * 1024.0 * (2.0 if m.group(2) == "FETCH_SIZE" else 1.0)
+            found += 1
+    if found != 2 * len(TRAFFIC_KERNELS[workload]):
+        return None, None
+    return total, os.path.relpath(src, ROOT)
 
 
 def design_lowpass(n, fc):
@@ -92,7 +116,7 @@ class FirWorkload:
                                    "on 2^%d-sample Veccf per GPU, inputs resident in HBM" % args.log2n,
                        "method": self.method, "samples_per_gpu": self.n,
                        "sharding": "contiguous chunks, K-1 halo via RCCL send/recv" if world > 1 else "single GPU"}
-        self.traffic = TRAFFIC_PMC_BYTES.get(("fir", self.method, args.log2n))
+        self.traffic_ok = self.method == "overlap-save" and args.log2n == LOG2N     # the shape the PMC passes were run on
 
     def exchange(self):
         if self.world == 1:
@@ -148,7 +172,7 @@ class FftWorkload:
         self.dtype = "f32 (complex64)"
         self.config = {"workload": "configs[2]: fft() of 256 x Veccf[2^20] per GPU, unitary scaling, inputs resident in HBM",
                        "sharding": "batch index split, no exchange" if world > 1 else "single GPU"}
-        self.traffic = TRAFFIC_PMC_BYTES.get(("fft", 20, self.batch))
+        self.traffic_ok = self.batch == 256
 
     def exchange(self):
         pass
@@ -190,7 +214,7 @@ class SosWorkload:
         self.config = {"workload": "configs[3]: 6 DF2 biquads (Butterworth order 12, fc 0.25) on 2^%d-sample Vecf per GPU" % args.log2n,
                        "halo_samples": self.halo,
                        "sharding": "contiguous chunks, warm-up halo via RCCL send/recv" if world > 1 else "single GPU"}
-        self.traffic = TRAFFIC_PMC_BYTES.get(("sos", args.log2n))
+        self.traffic_ok = args.log2n == LOG2N
 
     def exchange(self):
         from libtsd_amd import sharding
@@ -238,7 +262,7 @@ class ResampleWorkload:
         self.config = {"workload": "configs[4]: filtre_reechan(160/147) interpolator on a 2^27-sample Veccf shard per GPU "
                                    "(2^30 over 8 GPUs)", "outputs_per_gpu": self.nout,
                        "sharding": "contiguous input chunks, 14-sample halo via RCCL send/recv + seek" if world > 1 else "single GPU"}
-        self.traffic = TRAFFIC_PMC_BYTES.get(("resample", 27))
+        self.traffic_ok = True
 
     def exchange(self):
         from libtsd_amd import sharding
@@ -334,7 +358,12 @@ def main():
     torch.cuda.synchronize()
     dt, kern_ms = run(w, args.steps, args.warmup)
     value = w.units * world * args.steps / dt / 1e6
+    # two clocks, both reported under their own names: HIP events around the operator on its stream
+    # (the kernel's launch duration: `achieved` / `frac`, what the roofline is about) and the wall clock
+    # of the K timed steps (`value`, `ms_per_step`; `achieved_wall` / `frac_wall`: launch gaps included)
     achieved = w.alg_bytes / (kern_ms * 1e-3) / 1e9
+    achieved_wall = w.alg_bytes * args.steps / dt / 1e9
+    traffic, traffic_src = pmc_traffic(args.workload) if w.traffic_ok else (None, None)
 
     out = None
     if rank == 0:
@@ -348,9 +377,10 @@ def main():
             "dtype": w.dtype, "data": "synthetic", "config": cfg,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         # HBM bytes per step from rocprofv3 --pmc passes (profiles/r1_pmc_traffic.txt)
-                         "traffic": w.traffic,
-                         "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": w.alg_bytes},
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "timer": "HIP events on the operator's stream, mean of the timed steps",
+                         "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": w.alg_bytes,
+                         "achieved_wall": round(achieved_wall, 1), "frac_wall": round(achieved_wall / HBM_PEAK_GBS, 4)},
         }
     if world == 1:
         if args.workload == "fir":

@@ -230,6 +230,59 @@ int fir_update_history(tsdgpu_fir *f, const void *x, int64_t n, hipStream_t st)
   return TSDGPU_OK;
 }
 
+__global__ void fir_accumulate_kernel(float *__restrict__ y, const float *__restrict__ t, int64_t nfl)
+{
+  const int64_t i = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 3 < nfl) {
+    float4 a = *reinterpret_cast<const float4 *>(y + i);
+    const float4 b = *reinterpret_cast<const float4 *>(t + i);
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    *reinterpret_cast<float4 *>(y + i) = a;
+  } else {
+    for (int64_t k = i; k < nfl; k++) y[k] += t[k];
+  }
+}
+
+// More than 12289 taps (the reference's FiltreRIF has no tap limit): partitioned convolution.  The taps are
+// cut in segments of part_S; segment p is an ordinary filter (long-filter overlap-save plan) applied to the
+// input delayed by p * part_S samples, which it reads straight out of [history ++ x]; the partial sums are
+// added up in segment order.  dx, dy: device pointers (dy may be dx).
+int fir_partitioned_step(tsdgpu_fir *f, const void *dx, void *dy, int64_t n, hipStream_t st)
+{
+  const size_t sz = dtype_size(f->data_type);
+  const int64_t H = f->K - 1;
+  const int64_t pad = (16 - H % 16) % 16;                       // x starts on a 128-B boundary inside X (part_S is a multiple of 16)
+  int rc = f->part_x.reserve((size_t) (pad + H + n) * sz + 64);
+  if (!rc && f->parts.size() > 1) rc = f->part_t.reserve((size_t) n * sz + 64);
+  if (rc) return rc;
+  char *X = (char *) f->part_x.p + (size_t) pad * sz;
+  const char *hist = (const char *) f->hist[f->cur] + (size_t) (f->HL - H) * sz;
+  TSD_HIP(hipMemcpyAsync(X, hist, (size_t) H * sz, hipMemcpyDeviceToDevice, st));
+  TSD_HIP(hipMemcpyAsync(X + (size_t) H * sz, dx, (size_t) n * sz, hipMemcpyDeviceToDevice, st));
+  for (size_t p = 0; p < f->parts.size(); p++) {
+    tsdgpu_fir *c = f->parts[p];
+    const int64_t start = H - (int64_t) p * f->part_S;          // element of X that is this segment's x[0]
+    if (c->K > 1) {
+      rc = tsdgpu_fir_set_history(c, X + (size_t) (start - (c->K - 1)) * sz, st);
+      if (rc) return rc;
+    }
+    void *dst = p == 0 ? dy : f->part_t.p;
+    rc = tsdgpu_fir_step(c, X + (size_t) start * sz, dst, n, st);
+    if (rc) return rc;
+    if (p > 0) {
+      const int64_t nfl = n * (int64_t) (sz / 4);
+      hipLaunchKernelGGL(fir_accumulate_kernel, dim3((unsigned) cdiv(cdiv(nfl, 4), 256)), dim3(256), 0, st, (float *) dy,
+                         (const float *) f->part_t.p, nfl);
+      TSD_HIP(hipGetLastError());
+    }
+  }
+  // history <- the last K-1 samples of [history ++ x]
+  const int nxt = f->cur ^ 1;
+  TSD_HIP(hipMemcpyAsync((char *) f->hist[nxt] + (size_t) (f->HL - H) * sz, X + (size_t) n * sz, (size_t) H * sz, hipMemcpyDeviceToDevice, st));
+  f->cur = nxt;
+  return TSDGPU_OK;
+}
+
 }  // namespace tsdgpu
 
 using namespace tsdgpu;
@@ -278,6 +331,17 @@ int tsdgpu_fir_create(tsdgpu_fir **out, int data_type, int tap_type, const void 
       rc = set_err(TSDGPU_ERR_HIP, "fir_create: upload failed: %s", hipGetErrorString(hipGetLastError()));
       break;
     }
+    if (ntaps > 12289) {
+      // beyond the long-filter plan (and beyond what the direct kernel can stage in LDS): partitioned
+      f->method = TSDGPU_FIR_OVERLAP_SAVE;
+      f->part_S = 8192;
+      for (int o = 0; o < ntaps && !rc; o += f->part_S) {
+        tsdgpu_fir *c = nullptr;
+        rc = tsdgpu_fir_create(&c, data_type, tap_type, (const char *) taps_host + (size_t) o * tsz, std::min(f->part_S, ntaps - o), TSDGPU_FIR_AUTO);
+        if (!rc) f->parts.push_back(c);
+      }
+      break;
+    }
     f->method = method == TSDGPU_FIR_DIRECT ? TSDGPU_FIR_DIRECT
                 : method == TSDGPU_FIR_OVERLAP_SAVE ? TSDGPU_FIR_OVERLAP_SAVE
                 : (ols_preferred(f) ? TSDGPU_FIR_OVERLAP_SAVE : TSDGPU_FIR_DIRECT);
@@ -312,6 +376,11 @@ int tsdgpu_fir_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, void *stre
   if (rc) return rc;
   rc = stage_out(y, bytes, f->out_stage, &dy, &staged);
   if (rc) return rc;
+  if (!f->parts.empty()) {
+    rc = fir_partitioned_step(f, dx, dy, n, st);
+    if (rc) return rc;
+    return finish_out(y, bytes, dy, staged, st);
+  }
   if (dx == dy) {
     // in-place on device (allowed by the reference, filtre-rt.cc:76-80): tiles read their
     // neighbours' inputs, so filter from a private copy
@@ -373,6 +442,9 @@ int tsdgpu_fir_destroy(tsdgpu_fir *f)
 {
   if (!f) return TSDGPU_OK;
   ols_plan_destroy(f);
+  for (tsdgpu_fir *c : f->parts) tsdgpu_fir_destroy(c);
+  f->part_x.release();
+  f->part_t.release();
   if (f->d_hrev) (void) hipFree(f->d_hrev);
   if (f->hist[0]) (void) hipFree(f->hist[0]);
   if (f->hist[1]) (void) hipFree(f->hist[1]);

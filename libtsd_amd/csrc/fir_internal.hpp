@@ -21,6 +21,11 @@ struct tsdgpu_fir {
   int ols_L = 0;            // valid outputs per block = N - (K-1)
   int ols_grid = 0;         // persistent grid size (waves)
   bool ols_long = false;    // long-filter plan (ols_long.hip): N = 4096..16384, H in natural order + W_N table
+  // partitioned plan for more than 12289 taps: the taps cut in segments of part_S, one child filter per
+  // segment (each on the long-filter overlap-save plan), y = sum_p child_p(x delayed by p * part_S)
+  std::vector<tsdgpu_fir *> parts;
+  int part_S = 0;
+  tsdgpu::DevBuf part_x, part_t;   // [history ++ x] and the partial sum of one segment
 };
 
 namespace tsdgpu {

@@ -421,10 +421,14 @@ int tsdgpu_ola_synthese(tsdgpu_ola *h, void *y, int64_t *n_out, void *stream)
   TSD_CHECK(h->pending_blocks >= 0, "ola_synthese: nothing analysed");
   hipStream_t st = (hipStream_t) stream;
   const int Ne = h->Ne, N = h->N, per = h->windowed ? 2 : 1;
+  // (the handle's state -- pending_blocks, cnt_ech -- is committed only once every launch of this call has
+  // been accepted: a failed call leaves the analysed blocks pending, and synthese can be called again)
   const int64_t B = h->pending_blocks;
-  h->pending_blocks = -1;
   if (n_out) *n_out = 0;
-  if (B == 0) return TSDGPU_OK;
+  if (B == 0) {
+    h->pending_blocks = -1;
+    return TSDGPU_OK;
+  }
   const bool skip_first = h->windowed && h->cnt_ech < 0;
   const int64_t nout = (B - (skip_first ? 1 : 0)) * Ne;
   TSD_CHECK(y != nullptr || nout == 0, "ola_synthese: NULL output");
@@ -449,9 +453,12 @@ int tsdgpu_ola_synthese(tsdgpu_ola *h, void *y, int64_t *n_out, void *stream)
     TSD_HIP(hipGetLastError());
     TSD_HIP(hipMemcpyAsync(h->d_svg, fr + (size_t) (2 * B - 1) * N + h->Nz, (size_t) Ne * sizeof(cpx), hipMemcpyDeviceToDevice, st));
   }
+  rc = finish_out(y, (size_t) nout * sizeof(cpx), dyv, staged, st);
+  if (rc) return rc;
+  h->pending_blocks = -1;
   h->cnt_ech += B * Ne;
   if (n_out) *n_out = nout;
-  return finish_out(y, (size_t) nout * sizeof(cpx), dyv, staged, st);
+  return TSDGPU_OK;
 }
 
 int tsdgpu_ola_apply_response(tsdgpu_ola *h, void *stream)

@@ -474,7 +474,11 @@ struct RsSched {
   int64_t brent_power = 1, brent_lam = 0;
   bool cyc = false;
   int64_t mu = 0, lambda = 0, opp = 0;
+  // the table grows 8 B per RS_CK inputs until the period is found, and counts outputs in 32 bits: a
+  // recurrence whose period were not found within RS_SIM_MAX inputs is refused instead of growing on
+  bool failed = false;
 };
+constexpr int64_t RS_SIM_MAX = (int64_t) 1 << 29;      // inputs (a 256 MiB table); 160/147 needs 8 M
 static std::shared_ptr<RsSched> sched_for(float inc)
 {
   static std::mutex m;
@@ -543,7 +547,11 @@ void state_at_canonical(const tsdgpu_resampler *r, int64_t ic, float *phase, int
 // advance the host simulation until it covers canonical index `upto` or the cycle is known
 void extend(tsdgpu_resampler *r, int64_t upto)
 {
-  while (!r->cyc && r->sim_i < upto + RS_CK) {
+  while (!r->cyc && !r->sch->failed && r->sim_i < upto + RS_CK) {
+    if (r->sim_i >= RS_SIM_MAX || r->sim_cum >= (int64_t) 0xFFFF0000ll) {
+      r->sch->failed = true;
+      return;
+    }
     if (r->sim_i % RS_CK == 0) r->ck.push_back(RsCk{f2bits(r->sim_phase), (uint32_t) r->sim_cum});
     // Brent: compare the state at this input boundary with the tortoise
     const uint32_t bits = f2bits(r->sim_phase);
@@ -660,6 +668,21 @@ int tsdgpu_resampler_create(tsdgpu_resampler **out, int data_type, float ratio, 
     tsdgpu_resampler_destroy(r);
     return rc;
   }
+  {
+    // the generic kernel's LDS need (the same arithmetic as in tsdgpu_resampler_step): refuse here what no
+    // step could launch -- a large ratio with wide complex tiles -- instead of failing at every step
+    const size_t sz = dtype_size(data_type);
+    const int rec_cap = ((int) ((double) RS_TI * (double) ratio * 1.0001) + 32 + 3) / 4 * 4;
+    const size_t wbytes = ((size_t) rs_tile_elems(K) * sz + (size_t) rec_cap * 8 + 15) / 16 * 16;   // 8: the analytic mode's records
+    const int lstride = K == 15 ? 20 : r->lstride;
+    const bool in_lds = (size_t) (nphases + 1) * lstride * 4 <= (size_t) RS_LUT_LDS_BYTES;
+    const size_t lds = (size_t) (in_lds ? (nphases + 1) * lstride + 4 : 8) * 4 + RS_WAVES * wbytes + 64;
+    if (lds > 158 * 1024) {
+      tsdgpu_resampler_destroy(r);
+      return set_err(TSDGPU_ERR_UNSUPPORTED, "resampler_create: ratio %g with %d taps on %s data needs %zu bytes of LDS per workgroup (limit 158 KiB): "
+                     "fold the ratio with half-band stages first (filtre_reechan does)", (double) ratio, K, data_type == TSDGPU_C64 ? "complex" : "real", lds);
+    }
+  }
   (void) hipFuncSetAttribute((const void *) resample_kernel<float, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void) hipFuncSetAttribute((const void *) resample_kernel<float2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void) hipFuncSetAttribute((const void *) resample15_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -696,6 +719,10 @@ int64_t tsdgpu_resampler_out_count(tsdgpu_resampler *r, int64_t n)
   int64_t c;
   std::lock_guard<std::mutex> lock(r->sch->mtx);
   state_at(r, r->pos + n, &ph, &c);
+  if (r->sch->failed) {
+    set_err(TSDGPU_ERR_UNSUPPORTED, "resampler: the float32 phase recurrence of ratio %g shows no period within 2^29 inputs", (double) r->ratio);
+    return -1;
+  }
   return c - r->cum_pos;
 }
 
@@ -713,6 +740,9 @@ int tsdgpu_resampler_step(tsdgpu_resampler *r, const void *x, int64_t n, void *y
   // (the schedule is shared between the handles of a ratio: held while this call reads or extends it)
   std::lock_guard<std::mutex> lock(r->sch->mtx);
   state_at(r, r->pos + n, &ph_end, &cum_end);
+  if (r->sch->failed)
+    return set_err(TSDGPU_ERR_UNSUPPORTED, "resampler_step: the float32 phase recurrence of ratio %g shows no period within 2^29 inputs",
+                   (double) r->ratio);
   const int64_t nout = cum_end - r->cum_pos;
   TSD_CHECK(nout <= y_capacity, "resampler_step: output needs %lld samples, capacity is %lld", (long long) nout,
             (long long) y_capacity);
@@ -812,6 +842,9 @@ int tsdgpu_resampler_seek(tsdgpu_resampler *r, int64_t pos, const void *hist, vo
   {
     std::lock_guard<std::mutex> lock(r->sch->mtx);
     state_at(r, pos, &ph, &c);
+    if (r->sch->failed)
+      return set_err(TSDGPU_ERR_UNSUPPORTED, "resampler_seek: the float32 phase recurrence of ratio %g shows no period within 2^29 inputs",
+                     (double) r->ratio);
   }
   r->pos = pos;
   r->cum_pos = c;

@@ -20,6 +20,17 @@ def test_bench_help_lists_the_contract_flags():
         assert flag in r.stdout
 
 
+def test_bench_reads_its_traffic_from_the_committed_pmc_file():
+    sys.path.insert(0, ROOT)
+    import bench
+    for w in ("fir", "fft", "sos", "resample"):
+        tr, src = bench.pmc_traffic(w)
+        assert tr and src and os.path.exists(os.path.join(ROOT, src)), w
+        # the kernels of the path move at least their algorithmic bytes and less than 2.5 x that
+        alg = {"fir": 16.0 * 2 ** 26, "fft": 16.0 * 2 ** 28, "sos": 8.0 * 2 ** 26, "resample": (8 + 8 * 160 / 147) * 2 ** 27}[w]
+        assert 0.98 * alg <= tr <= 2.5 * alg, (w, tr, alg)
+
+
 def test_committed_bench_lines_follow_the_contract():
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_*.json")))
     assert files, "no bench line committed under profiles/"
@@ -33,6 +44,14 @@ def test_committed_bench_lines_follow_the_contract():
         for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
             assert k in rf, (f, k)
         assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+        if os.path.basename(f) >= "r2":
+            # from round 2: both clocks named, traffic read from a committed PMC file (or null) with its source
+            for k in ("traffic_source", "timer", "achieved_wall", "frac_wall"):
+                assert k in rf, (f, k)
+            assert rf["frac_wall"] <= rf["frac"] * 1.02
+            assert (rf["traffic"] is None) == (rf["traffic_source"] is None)
+            if rf["traffic_source"]:
+                assert os.path.exists(os.path.join(ROOT, rf["traffic_source"]))
         cb = d["cpu_baseline"]
         for k in ("value", "unit", "cores", "kind", "sample"):
             assert k in cb, (f, k)

@@ -179,3 +179,29 @@ def test_cfg2_full_size_properties(tg, orc, method):
     ys = f.step(xs)
     torch.cuda.synchronize()
     assert float((ys[d:] - y[:n - d]).abs().max()) <= 1e-5 * float(y.abs().max())
+
+
+# tap counts beyond the long-filter plan (12289) used to create fine and fail at every step
+# (the direct kernel's LDS need passes 160 KiB at K > 14312).  They are served by partitioned convolution:
+# 8192-tap segments on the long-filter plan, partial sums added in segment order.
+@pytest.mark.parametrize("K,cplx_taps", [(12290, False), (14313, False), (14313, True), (65536, False), (100001, True)])
+def test_fir_very_long_filters(tg, orc, K, cplx_taps):
+    rng = np.random.default_rng(K)
+    h = rng.standard_normal(K).astype(np.float32) / np.float32(np.sqrt(K))
+    if cplx_taps:
+        h = (h + 1j * rng.standard_normal(K).astype(np.float32) / np.float32(np.sqrt(K))).astype(np.complex64)
+    n = 150000
+    x = rand(n, True, K + 1)
+    # reference: exact convolution in double (an FFT), then the 1e-5 band; the oracle's K-tap time loop agrees with it
+    full = np.fft.ifft(np.fft.fft(x.astype(np.complex128), 1 << 19) * np.fft.fft(h.astype(np.complex128), 1 << 19))[:n]
+    f = tg.Fir(h, tg.C64)
+    y = np.concatenate([f.step(x[:50001].copy()), f.step(x[50001:50002].copy()), f.step(x[50002:].copy())])
+    assert relerr(y, full.astype(np.complex64)) <= TOL
+    m = 3000
+    assert relerr(y[:m], orc.fir(h, x[:m])) <= TOL
+    # streaming history hooks still work on the partitioned plan
+    g = tg.Fir(h, tg.C64)
+    g.step(x[:70000].copy())
+    hist = np.empty(K - 1, np.complex64)
+    g.get_history(hist)
+    assert np.array_equal(hist[-min(K - 1, 70000):], x[70000 - min(K - 1, 70000):70000])

@@ -198,3 +198,13 @@ def test_shared_schedule_is_thread_safe(tg, orc):
         assert out[i] is not None and np.array_equal(out[i][:len(ref)], out[0][:len(ref)]), i
     assert relerr(out[0], ref) <= TOL
     assert np.array_equal(out[1][:len(out[3])], out[3])
+
+
+# a configuration no step could launch (LDS need of the generic kernel) is refused at creation
+def test_resampler_create_refuses_what_no_step_can_launch(tg):
+    lut = tg.itrp_sinc_lut(15, 256, 0.4)
+    with pytest.raises(tg.TsdGpuError, match="LDS"):
+        tg.Resampler(8.0, tg.C64, lut=lut)
+    r = tg.Resampler(5.0, tg.F32, lut=lut)          # a large ratio that does fit keeps working
+    x = np.ones(1000, np.float32)
+    assert abs(len(r.step(x)) - 5000) <= 2
