@@ -249,6 +249,42 @@ int tsdgpu_rii_step(tsdgpu_rii *r, const void *x, void *y, int64_t n, void *stre
 int tsdgpu_rii_destroy(tsdgpu_rii *r);
 
 /* --------------------------------------------------------------------------------------
+ * Pattern detector: Detecteur::step (src/fourier/detection.cc:100-400; include/tsd/fourier.hpp:545-660).
+ * Per block of the stream: correlation with the unit-energy pattern (mode 0: the OLA engine with the
+ * response conj(FFT(pattern)), blocks of exactly Ne samples; mode 1: a FIR with the reversed conjugated
+ * pattern, any block length), |x|^2 through an M-tap moving average aligned with the correlator's delay,
+ * the normalised score sqrt(N/M) |c| / sqrt(e), and the peak search -- all on the device.  A peak is a
+ * score above the threshold that dominates the M-1 samples on either side; it is reported M samples
+ * late (possibly in the following block: index < 0 then), so block borders need no special case.
+ * peaks[k].index: position of the peak in the block's output vector; pattern start = index - delay.
+ * scores: the block's n scores (host or device vector; NULL: not wanted).  One small D2H per block.
+ * ------------------------------------------------------------------------------------ */
+typedef struct tsdgpu_detector tsdgpu_detector;
+typedef struct {
+  int32_t index;                       /* relative to the start of the block being processed */
+  float s_m1, s0, s_p1;                /* scores at index-1, index, index+1 */
+  float c_m1[2], c0[2], c_p1[2];       /* complex correlation values there */
+} tsdgpu_peak;
+int tsdgpu_detector_create(tsdgpu_detector **out, const void *pattern_host /* M complex, unit energy */, int M, int Ne,
+                           int mode, float threshold);
+int tsdgpu_detector_delay(const tsdgpu_detector *d);      /* correlator delay: Ne (mode 0) or M-1 (mode 1) */
+int tsdgpu_detector_fft_size(const tsdgpu_detector *d);   /* N of the OLA engine (1 in mode 1) */
+int tsdgpu_detector_step(tsdgpu_detector *d, const void *x, int64_t n, float *scores, tsdgpu_peak *peaks, int max_peaks,
+                         int *n_peaks, void *stream);
+int tsdgpu_detector_destroy(tsdgpu_detector *d);
+
+/* --------------------------------------------------------------------------------------
+ * Cross-correlation and delay estimate on the device: xcorrb / xcorr (src/fourier/fourier.cc:489-597:
+ * zero-padding to n + 2m, two forward FFTs in one batched call, correlation_freq = X0 conj(X1) sqrt(L)
+ * with the lags reordered, one inverse FFT, lags -(m-1)..(m-1) scaled by 1/n and, unbiased, by
+ * n / (n - |lag|)) and estimation_delais (src/fourier/estimation-delais.cc:9-14,100-118: |corr| over the
+ * product of the two RMS values, arg max, quadratic interpolation).  x, y: n complex samples, host or
+ * device (y NULL: autocorrelation); out: 2m-1 complex values.  tsdgpu_delay_estimate brings back two floats.
+ * ------------------------------------------------------------------------------------ */
+int tsdgpu_xcorr(const void *x, const void *y, int n, int m, int unbiased, void *out, void *stream);
+int tsdgpu_delay_estimate(const void *x, const void *y, int n, float *delay, float *score, void *stream);
+
+/* --------------------------------------------------------------------------------------
  * Several GPUs, ONE process: a long vector cut into contiguous chunks (shard g = samples
  * [n g / N, n (g+1) / N)), one operator handle per shard, and the one small left-neighbour halo each
  * operator needs -- FIR: K-1 input samples; SOS: the warm-up samples of tsdgpu_sos_halo; resampler:

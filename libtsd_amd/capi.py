@@ -93,6 +93,13 @@ def _declare(L):
     L.tsdgpu_sharded_step_parts.argtypes = [vp, C.POINTER(vp), C.POINTER(i64), C.POINTER(vp), C.POINTER(i64), C.POINTER(i64)]
     L.tsdgpu_sharded_reset.argtypes = [vp]
     L.tsdgpu_sharded_destroy.argtypes = [vp]
+    L.tsdgpu_xcorr.argtypes = [vp, vp, i32, i32, i32, vp, vp]
+    L.tsdgpu_delay_estimate.argtypes = [vp, vp, i32, C.POINTER(fl), C.POINTER(fl), vp]
+    L.tsdgpu_detector_create.argtypes = [C.POINTER(vp), vp, i32, i32, i32, fl]
+    L.tsdgpu_detector_delay.argtypes = [vp]
+    L.tsdgpu_detector_fft_size.argtypes = [vp]
+    L.tsdgpu_detector_step.argtypes = [vp, vp, i64, vp, vp, i32, C.POINTER(i32), vp]
+    L.tsdgpu_detector_destroy.argtypes = [vp]
     L.tsdgpu_malloc.argtypes = [C.POINTER(vp), C.c_size_t]
     L.tsdgpu_free.argtypes = [vp]
     L.tsdgpu_malloc_host.argtypes = [C.POINTER(vp), C.c_size_t]
@@ -644,5 +651,57 @@ class Sharded:
     def __del__(self):
         try:
             self.close()
+        except Exception:
+            pass
+
+
+def xcorr(x, y=None, m=-1, unbiased=True):
+    """xcorr / xcorrb (fourier.cc:534-597) on the device: -> the 2m-1 complex lags -(m-1) .. (m-1)."""
+    assert _dtype_code(x) == C64 and (y is None or _dtype_code(y) == C64)
+    n = int(x.shape[0])
+    if m < 0:
+        m = n
+    out = np.empty(2 * m - 1, np.complex64) if isinstance(x, np.ndarray) else x.new_empty(2 * m - 1)
+    _check(lib().tsdgpu_xcorr(_ptr(x), None if y is None else _ptr(y), n, m, 1 if unbiased else 0, _ptr(out), _stream_of(x, None)))
+    return out
+
+
+def delay_estimate(x, y):
+    """estimation_délais (estimation-delais.cc:100-118): -> (delay in samples, score)."""
+    assert _dtype_code(x) == C64 and _dtype_code(y) == C64 and x.shape[0] == y.shape[0]
+    d, s = C.c_float(0), C.c_float(0)
+    _check(lib().tsdgpu_delay_estimate(_ptr(x), _ptr(y), int(x.shape[0]), C.byref(d), C.byref(s), _stream_of(x, None)))
+    return d.value, s.value
+
+
+class Peak(C.Structure):
+    _fields_ = [("index", C.c_int32), ("s_m1", C.c_float), ("s0", C.c_float), ("s_p1", C.c_float),
+                ("c_m1", C.c_float * 2), ("c0", C.c_float * 2), ("c_p1", C.c_float * 2)]
+
+
+class Detector:
+    """Detecteur (detection.cc): score stream + peak records of a pattern detector; mode 0 = OLA engine, 1 = FIR."""
+
+    def __init__(self, pattern, Ne, mode=0, threshold=0.5):
+        p = np.ascontiguousarray(pattern, np.complex64)
+        p = (p / np.float32(np.sqrt(np.sum(np.abs(p.astype(np.complex128)) ** 2)))).astype(np.complex64)
+        self._h = C.c_void_p()
+        _check(lib().tsdgpu_detector_create(C.byref(self._h), p.ctypes.data, len(p), int(Ne), int(mode), float(threshold)))
+        self.delay = lib().tsdgpu_detector_delay(self._h)
+        self.N = lib().tsdgpu_detector_fft_size(self._h)
+
+    def step(self, x):
+        assert _dtype_code(x) == C64
+        n = int(x.shape[0])
+        sc = np.empty(n, np.float32) if isinstance(x, np.ndarray) else x.new_empty(n, dtype=__import__("torch").float32)
+        pk = (Peak * 256)()
+        npk = C.c_int(0)
+        _check(lib().tsdgpu_detector_step(self._h, _ptr(x), n, _ptr(sc), pk, 256, C.byref(npk), _stream_of(x, None)))
+        return sc, [pk[i] for i in range(npk.value)]
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().tsdgpu_detector_destroy(self._h)
         except Exception:
             pass

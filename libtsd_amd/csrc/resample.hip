@@ -630,6 +630,19 @@ int sync_table(tsdgpu_resampler *r, hipStream_t st)
 
 }  // namespace
 
+// LDS bytes per workgroup of the generic kernel for this handle (the arithmetic of tsdgpu_resampler_step):
+// checked at creation so that a configuration no step could launch -- a large ratio with wide complex
+// tiles -- is refused there instead of failing at every step
+static size_t rs_lds_need(const tsdgpu_resampler *r, int mode)
+{
+  const size_t sz = dtype_size(r->data_type);
+  const int rec_cap = ((int) ((double) RS_TI * (double) r->ratio * 1.0001) + 32 + 3) / 4 * 4;
+  const size_t wbytes = ((size_t) rs_tile_elems(r->K) * sz + (size_t) rec_cap * (mode ? 8 : 4) + 15) / 16 * 16;
+  const int lstride = r->K == 15 ? 20 : r->lstride;
+  const bool in_lds = (size_t) (r->nph + 1) * lstride * 4 <= (size_t) RS_LUT_LDS_BYTES;
+  return (size_t) (in_lds ? (r->nph + 1) * lstride + 4 : 8) * 4 + RS_WAVES * wbytes + 64;
+}
+
 extern "C" {
 
 int tsdgpu_resampler_create(tsdgpu_resampler **out, int data_type, float ratio, const float *lut_host, int K,
@@ -669,14 +682,7 @@ int tsdgpu_resampler_create(tsdgpu_resampler **out, int data_type, float ratio, 
     return rc;
   }
   {
-    // the generic kernel's LDS need (the same arithmetic as in tsdgpu_resampler_step): refuse here what no
-    // step could launch -- a large ratio with wide complex tiles -- instead of failing at every step
-    const size_t sz = dtype_size(data_type);
-    const int rec_cap = ((int) ((double) RS_TI * (double) ratio * 1.0001) + 32 + 3) / 4 * 4;
-    const size_t wbytes = ((size_t) rs_tile_elems(K) * sz + (size_t) rec_cap * 8 + 15) / 16 * 16;   // 8: the analytic mode's records
-    const int lstride = K == 15 ? 20 : r->lstride;
-    const bool in_lds = (size_t) (nphases + 1) * lstride * 4 <= (size_t) RS_LUT_LDS_BYTES;
-    const size_t lds = (size_t) (in_lds ? (nphases + 1) * lstride + 4 : 8) * 4 + RS_WAVES * wbytes + 64;
+    const size_t lds = rs_lds_need(r, 0);
     if (lds > 158 * 1024) {
       tsdgpu_resampler_destroy(r);
       return set_err(TSDGPU_ERR_UNSUPPORTED, "resampler_create: ratio %g with %d taps on %s data needs %zu bytes of LDS per workgroup (limit 158 KiB): "
@@ -703,6 +709,11 @@ int tsdgpu_resampler_create_analytic(tsdgpu_resampler **out, int data_type, floa
   int rc = tsdgpu_resampler_create(out, data_type, ratio, dummy.data(), K, 1);
   if (rc) return rc;
   (*out)->mode = kind;
+  if (rs_lds_need(*out, kind) > 158 * 1024) {
+    tsdgpu_resampler_destroy(*out);
+    *out = nullptr;
+    return set_err(TSDGPU_ERR_UNSUPPORTED, "resampler_create_analytic: ratio %g needs more LDS than a workgroup has: fold the ratio first", (double) ratio);
+  }
   for (int j = 0; j < K; j++) {
     double den = 1.0;
     for (int k = 0; k < K; k++)

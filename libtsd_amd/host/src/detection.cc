@@ -1,10 +1,14 @@
-// detection.cc -- pattern detector on the GPU correlators (libtsd core/src/fourier/detection.cc,
-// core/include/tsd/fourier.hpp:545-660).  Host side = the reference's peak logic; the two
-// per-sample streams it works on (correlation with the pattern, sliding energy) come from the
-// MI355X operators: filtre_fft (OLA engine, batched FFTs) or filtre_rif, and filtre_mg.
+// detection.cc -- mirror runtime: détecteur_création (libtsd core/src/fourier/detection.cc,
+// core/include/tsd/fourier.hpp:545-660) on the device-side detector of the C ABI (tsdgpu_detector_*,
+// csrc/detect.hip).  The GPU produces the score stream and, per block, the list of peaks with the three
+// scores and the three complex correlation values around each; what is left here is per DETECTION, not
+// per sample: sub-sample position, complex amplitude, and the noise estimate against the received
+// samples.  A peak is decided M samples after it occurred, so it may be reported with the block that
+// FOLLOWS the one it lies in; its position is always relative to the block being processed (negative
+// then), which is the convention of Detection::position.
 #include "tsd/fourier.hpp"
-#include "tsd_amd/extensions.hpp"
 #include "tsd/filtrage.hpp"
+#include "tsdgpu.h"
 #include <algorithm>
 #include <vector>
 
@@ -12,102 +16,37 @@ namespace tsd::fourier {
 
 namespace {
 
-// the last K input samples, whatever the block sizes (detection.cc:24-64)
-struct MemoireEntree {
-  entier K = 0;
-  Veccf mem;
-  void configure(entier K_)
-  {
-    K = K_;
-    mem = Veccf::zeros(K);
-  }
-  void step(const Veccf &x)
-  {
-    const entier n = x.rows();
-    if (n >= K) {
-      mem = x.tail(K).clone();
-    } else {
-      const Veccf vieux = mem.tail(K - n).clone();
-      mem.head(K - n) = vieux;
-      mem.tail(n) = x;
-    }
-  }
-  Veccf derniers(entier n) const { return mem.tail(n).clone(); }
-};
-
-// quadratic interpolation of a peak from three samples: position and value (detection.cc:9-21)
-float pic_position(float ym1, float y0, float yp1) { return (yp1 - ym1) / (2 * (2 * y0 - yp1 - ym1)); }
-cfloat pic_valeur(cfloat ym1, cfloat y0, cfloat yp1, float δ) { return y0 - (ym1 - yp1) * δ * 0.25f; }
-
 struct DetecteurGpu : Detecteur {
-  MemoireEntree entree;                         // input memory for the noise estimate
-  sptr<FiltreGen<float>> retard_energie;        // aligns the energy with the OLA correlator's delay
-  sptr<FiltreGen<cfloat>> correlateur;
-  sptr<FiltreGen<float>> filtre_energie;
-  entier itr = 0, dernier_n = 0, Ne = 0, N = 1, M = 0, delais_corr = 0;
-  Veccf T_motif, motif;                         // pattern normalised to unit energy, and its spectrum
-  float norme_motif = 1;
-  bouléen pic_final_a_traiter = false;
-  Detection pic_final;
-  cfloat lc = 0, lc0 = 0;                       // last two correlation samples of the previous block
-  float alc = 0, alc0 = 0;                      // ... and their normalised magnitudes
+  tsdgpu_detector *h = nullptr;
+  entier M = 0, N = 1, retard = 0;
+  float norme = 1;                       // sqrt of the pattern's energy
+  std::vector<cfloat> passé;             // the stream's most recent samples before the current block
 
   explicit DetecteurGpu(const DetecteurConfig &c) { configure(c); }
+  ~DetecteurGpu() override { tsdgpu_detector_destroy(h); }
 
   void configure_impl(const DetecteurConfig &c) override
   {
-    pic_final_a_traiter = false;
-    itr = 0;
-    double e = 0;
-    for (entier i = 0; i < c.motif.rows(); i++) e += std::norm(c.motif(i));
-    norme_motif = (float) std::sqrt(e);
+    tsdgpu_detector_destroy(h);
+    h = nullptr;
     M = c.motif.rows();
     if (M < 3) échec("détecteur: pattern of {} samples (need at least 3)", M);
-    motif = c.motif.clone();
-    motif /= cfloat(norme_motif, 0);
-    filtre_energie = tsd::filtrage::filtre_mg<float, double>(M);
-    Ne = (entier) c.Ne;
+    double énergie = 0;
+    for (entier i = 0; i < M; i++) énergie += std::norm(c.motif(i));
+    norme = (float) std::sqrt(énergie);
+    std::vector<cfloat> unitaire((size_t) M);
+    for (entier i = 0; i < M; i++) unitaire[(size_t) i] = c.motif(i) / norme;
+    entier Ne = (entier) c.Ne;
     if (Ne == 0) {
-      float C;
+      float coût;
       entier Nf, Nz;
-      ola_complexité_optimise(M, C, Nf, Nz, Ne);
+      ola_complexité_optimise(M, coût, Nf, Nz, Ne);
     }
-    if (c.mode == DetecteurConfig::MODE_OLA) {
-      FiltreFFTConfig oc;
-      oc.nb_zeros_min = M - 1;
-      oc.dim_blocs_temporel = Ne;
-      // the reference's callback X *= conj(T_motif) (detection.cc:166-169) as the engine's
-      // device-side response: the correlation never leaves the GPU between the two FFTs
-      N = prochaine_puissance_de_2(Ne + M - 1);
-      if (2 * M > N) échec("détecteur: pattern of {} samples does not fit the {}-point OLA blocks", M, N);
-      Veccf tmp = Veccf::zeros(N);
-      tmp.head(M) = motif;
-      T_motif = fft(tmp);
-      Veccf réponse(N);
-      for (entier i = 0; i < N; i++) réponse(i) = std::conj(T_motif(i));
-      auto [f, n_fft] = tsd_amd::filtre_fft_reponse(oc, réponse);
-      correlateur = f;
-      if (n_fft != N) échec("détecteur: OLA engine configured with N = {} instead of {}", n_fft, N);
-      delais_corr = Ne;
-      retard_energie = tsd::filtrage::ligne_a_retard<float>(delais_corr - M + 1);
-    } else {
-      N = 1;                                    // (the reference leaves N at its initial value in this mode)
-      double im = 0, tot = 0;
-      for (entier i = 0; i < M; i++) {
-        im += std::abs(motif(i).imag());
-        tot += std::abs(motif(i));
-      }
-      if (im / tot < 1e-7) {
-        correlateur = tsd::filtrage::filtre_rif<float, cfloat>(real(motif.reverse()));
-      } else {
-        Veccf h = motif.reverse();
-        for (entier i = 0; i < M; i++) h(i) = std::conj(h(i));
-        correlateur = tsd::filtrage::filtre_rif<cfloat, cfloat>(h);
-      }
-      retard_energie = nullptr;
-      delais_corr = M - 1;
-    }
-    entree.configure(delais_corr + 1);
+    if (tsdgpu_detector_create(&h, unitaire.data(), M, Ne, c.mode == DetecteurConfig::MODE_OLA ? 0 : 1, c.seuil))
+      échec("détecteur: {}", tsdgpu_last_error());
+    N = tsdgpu_detector_fft_size(h);
+    retard = tsdgpu_detector_delay(h);
+    passé.assign((size_t) (retard + 2 * M), cfloat(0));
   }
 
   void step(const Veccf &x, Vecf &y) override
@@ -115,111 +54,48 @@ struct DetecteurGpu : Detecteur {
     const DetecteurConfig &c = Configurable<DetecteurConfig>::config;
     const entier n = x.rows();
     if (n < 2) échec("détecteur: blocks of at least 2 samples expected (got {})", n);
-    Vecf en = filtre_energie->step(abs2(x));
-    if (retard_energie) en = retard_energie->step(en);
-    Veccf corr = correlateur->step(x);
-    if (corr.rows() != n) échec("Sortie OLA (corr) devrait faire {} échantillons, mais {}.", n, corr.rows());
-    const float ratio = std::sqrt(1.0f * N) / std::sqrt(1.0f * M);
     y.resize(n);
-    for (entier i = 0; i < n; i++) {
-      if (std::abs(corr(i)) <= std::sqrt(1e-12f)) corr(i) = 0;       // drop numerically empty values
-      y(i) = ratio * std::sqrt(std::norm(corr(i)) / (en(i) + 1e-20f));
-    }
-    // candidates: the largest value of every M-sample segment, above the threshold, not dominated
-    // by a larger candidate closer than M samples
-    std::vector<entier> cand, pics;
-    for (entier i = 0; i < n; i += M) {
-      const entier len = std::min(M, n - i);
-      entier im = i;
-      for (entier k = i; k < i + len; k++)
-        if (y(k) > y(im)) im = k;
-      if (y(im) > c.seuil) cand.push_back(im);
-    }
-    if (pic_final_a_traiter) {
-      pic_final_a_traiter = false;
-      pics.push_back(-1);
-    }
-    for (entier idx : cand) {
-      bool ok = true;
-      for (entier idx2 : cand)
-        if (y(idx2) > y(idx) && std::abs(idx - idx2) < M) {
-          ok = false;
-          break;
-        }
-      if (ok) pics.push_back(idx);
-    }
-    for (entier idx : pics) {
+    tsdgpu_peak pics[256];
+    int npics = 0;
+    if (tsdgpu_detector_step(h, x.data(), n, y.data(), pics, 256, &npics, nullptr)) échec("détecteur: {}", tsdgpu_last_error());
+    for (int k = 0; k < npics; k++) {
+      const tsdgpu_peak &p = pics[k];
       Detection det;
-      cfloat c0, c1, c2;
-      float ac0, ac1, ac2;
-      if (idx == -1) {
-        // the last sample of the previous block was a candidate: it needed this block's first sample
-        det = pic_final;
-        det.position -= dernier_n;
-        det.position_prec -= dernier_n;
-        ac0 = alc0; c0 = lc0;
-        ac1 = alc; c1 = lc;
-        ac2 = y(0); c2 = corr(0);
-        if (ac1 < ac2) break;                    // it was not the peak after all
-      } else {
-        det.score = y(idx);
-        det.position = idx - delais_corr;
-        det.θ = std::arg(corr(idx));
-        det.gain = std::abs(corr(idx)) / (norme_motif / std::sqrt((float) N));
-        det.position_prec = (float) det.position;
-        if (idx == 0) {
-          ac0 = alc; c0 = lc;
-          ac1 = y(0); c1 = corr(0);
-          ac2 = y(1); c2 = corr(1);
-          if (ac1 < ac0) break;                  // the previous block's last sample was larger
-        } else if (idx == n - 1) {
-          pic_final_a_traiter = true;            // handled at the start of the next block
-          pic_final = det;
-          break;
-        } else {
-          ac0 = y(idx - 1); c0 = corr(idx - 1);
-          ac1 = y(idx); c1 = corr(idx);
-          ac2 = y(idx + 1); c2 = corr(idx + 1);
-        }
-      }
-      float δ = pic_position(ac0, ac1, ac2);
+      det.score = p.s0;
+      det.position = p.index - retard;
+      // vertex of the parabola through the three scores; the complex amplitude read at the vertex
+      float δ = (p.s_p1 - p.s_m1) / (2 * (2 * p.s0 - p.s_p1 - p.s_m1));
       δ = std::clamp(δ, -0.5f, 0.5f);
-      det.position_prec += δ;
-      {
-        const cfloat g2 = pic_valeur(c0, c1, c2, δ) * (std::sqrt((float) N) / norme_motif);
-        det.gain = std::abs(g2);
-        det.θ = std::arg(g2);
+      det.position_prec = (float) det.position + δ;
+      const cfloat am1(p.c_m1[0], p.c_m1[1]), a0(p.c0[0], p.c0[1]), ap1(p.c_p1[0], p.c_p1[1]);
+      const cfloat amplitude = (a0 - (am1 - ap1) * (0.25f * δ)) * (std::sqrt((float) N) / norme);
+      det.gain = std::abs(amplitude);
+      det.θ = std::arg(amplitude);
+      // noise: the M received samples minus the pattern as estimated (gain, phase, fractional position)
+      Veccf modèle = c.motif.clone();
+      modèle *= amplitude;
+      modèle = délais(modèle, δ);
+      const int64_t début = (int64_t) passé.size() + det.position;        // in (passé ++ x)
+      double écart = 0;
+      entier compte = 0;
+      for (entier i = 1; i <= M - 2; i++) {
+        const int64_t q = début + i;
+        if (q < 0 || q >= (int64_t) passé.size() + n) continue;
+        const cfloat reçu = q < (int64_t) passé.size() ? passé[(size_t) q] : x.data()[q - (int64_t) passé.size()];
+        écart += std::norm(reçu - modèle(i));
+        compte++;
       }
-      // noise = what was received minus the pattern as estimated (gain, phase, fractional position)
-      Veccf recu_theo = c.motif.clone();
-      recu_theo *= std::polar(det.gain, det.θ);
-      recu_theo = délais(recu_theo, δ);
-      Veccf recu(M);
-      const entier id = idx - delais_corr;
-      entier dans_x = id >= 0 ? M : (id > -M ? M + id : 0);
-      const entier avant = M - dans_x;
-      if (dans_x > 0) recu.tail(dans_x) = x.segment(std::max(id, 0), dans_x);
-      if (avant > 0) {
-        if (avant < M)
-          recu.head(avant) = entree.derniers(avant);
-        else
-          recu.head(avant) = entree.mem.segment(std::clamp(id + entree.K, 0, entree.K - avant), avant);
-      }
-      double vb = 0;
-      for (entier i = 1; i <= M - 2; i++) vb += std::norm(recu(i) - recu_theo(i));
-      const float var_bruit = (float) (vb / (M - 2));
-      const float var_signal = std::pow(det.gain * norme_motif, 2.0f) / M;
+      const float var_bruit = compte > 0 ? (float) (écart / compte) : 0.f;
+      const float var_signal = det.gain * det.gain * norme * norme / M;
       det.σ_noise = std::sqrt(var_bruit);
       det.SNR_dB = 10 * std::log10(var_signal / var_bruit);
       if (c.gere_detection) c.gere_detection(det);
     }
-    entree.step(x);
-    alc0 = y(n - 2);
-    lc0 = corr(n - 2);
-    alc = y(n - 1);
-    lc = corr(n - 1);
-    itr++;
-    dernier_n = n;
+    // keep the tail of the stream for the detections the next block will report
+    const size_t garde = passé.size();
+    std::vector<cfloat> tout(passé);
+    tout.insert(tout.end(), x.data(), x.data() + n);
+    passé.assign(tout.end() - (std::ptrdiff_t) garde, tout.end());
   }
 };
 

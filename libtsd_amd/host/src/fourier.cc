@@ -62,34 +62,21 @@ std::tuple<Vecf, Veccf> ccorr(const Veccf &x0, const Veccf &x1)
   r /= cfloat((float) m, 0.f);
   return {linspace(0, (float) (m - 1), m), r};
 }
-std::tuple<Vecf, Veccf> xcorrb(const Veccf &x, const Veccf &y, entier m)
+// xcorrb / xcorr: zero-padding, the two forward transforms (one batched call), correlation_freq, the inverse
+// transform and the extraction / scaling of the lags all run on the device (tsdgpu_xcorr): the vectors go
+// up once, the 2m - 1 lags come back once
+static std::tuple<Vecf, Veccf> xcorr_gpu(const Veccf &x, const Veccf &y, entier m, bool non_biaisé)
 {
   const entier n = x.rows();
   if (m < 0) m = n;
-  const Veccf &yp = y.rows() == 0 ? x : y;
-  Veccf x2 = Veccf::zeros(m + n + m), y2 = Veccf::zeros(m + n + m);
-  x2.segment(m, n) = x;
-  y2.segment(m, n) = yp;
-  const Veccf r = correlateur_bloc(x2, y2);
+  if (y.rows() != 0 && y.rows() != n) échec("the two input vectors should have the dimension {} != {}.", n, y.rows());
   Veccf res(2 * m - 1);
-  for (entier i = 0; i < m; i++) res(m - 1 + i) = r(i) / (float) n;              // res.tail(m) = r.head(m) / n
-  for (entier i = 0; i < m - 1; i++) res(i) = r(r.rows() - (m - 1) + i) / (float) n;   // res.head(m-1) = r.tail(m-1) / n
+  if (tsdgpu_xcorr(x.data(), y.rows() == 0 ? nullptr : y.data(), n, m, non_biaisé ? 1 : 0, res.data(), nullptr))
+    échec("xcorr: {}", tsdgpu_last_error());
   return {linspace((float) -(m - 1), (float) (m - 1), 2 * m - 1), res};
 }
-std::tuple<Vecf, Veccf> xcorr(const Veccf &x, const Veccf &y, entier m)
-{
-  const entier n = x.rows();
-  if (m < 0) m = n;
-  auto [lags, zb] = xcorrb(x, y, m);
-  if (m > 1) {
-    const Vecf a = linspace((float) (n - (m - 1)), (float) (n - 1), m - 1), b = linspace((float) (n - 1), (float) (n - (m - 1)), m - 1);
-    for (entier i = 0; i < m - 1; i++) {
-      zb(i) /= cfloat(a(i) / n, 0.f);
-      zb(zb.rows() - (m - 1) + i) /= cfloat(b(i) / n, 0.f);
-    }
-  }
-  return {lags, zb};
-}
+std::tuple<Vecf, Veccf> xcorrb(const Veccf &x, const Veccf &y, entier m) { return xcorr_gpu(x, y, m, false); }
+std::tuple<Vecf, Veccf> xcorr(const Veccf &x, const Veccf &y, entier m) { return xcorr_gpu(x, y, m, true); }
 
 // ---- rééchan_freq (fourier.cc:1391-1419) -------------------------------------------------------
 Vecf rééchan_freq(const Vecf &x, float lom)
@@ -196,56 +183,26 @@ template Vecf délais<float>(const Vecf &, float);
 template Veccf délais<cfloat>(const Veccf &, float);
 
 // ---- estimation_délais, aligne_entier (estimation-delais.cc:9-170) ----------------------------
+// estimation_délais: the cross-correlation, the two energies, the arg max of the normalised magnitude and
+// its neighbours are computed on the device (tsdgpu_delay_estimate); two floats come back
 std::tuple<float, float> estimation_délais(const Veccf &x, const Veccf &y)
 {
   auto [xp, yp] = pad_zeros(x, y);
-  const entier N = xp.rows();
-  // biased version: the unbiased one amplifies large lags
-  auto [lags, corr] = xcorrb(xp, yp);
-  double s1 = 0, s2 = 0;
-  for (entier i = 0; i < N; i++) {
-    s1 += std::norm(xp(i));
-    s2 += std::norm(yp(i));
-  }
-  const float e1 = std::sqrt((float) (s1 / N)), e2 = std::sqrt((float) (s2 / N));
-  Vecf cn = abs(corr);
-  cn /= (e1 * e2 + 1e-50f);
-  const entier index = cn.index_max();
-  const float score = cn(index);
-  float δ = 0.0f;
-  if (index > 0 && index + 1 < cn.rows()) {
-    // quadratic interpolation of the peak (estimation-delais.cc:9-14)
-    const float ym1 = cn(index - 1), yp1 = cn(index + 1);
-    δ = (yp1 - ym1) / (2 * (2 * score - yp1 - ym1));
-    δ = std::clamp(δ, -0.5f, 0.5f);
-  }
-  return {lags(index) + δ, score};
+  float retard = 0, score = 0;
+  if (tsdgpu_delay_estimate(xp.data(), yp.data(), xp.rows(), &retard, &score, nullptr)) échec("estimation_délais: {}", tsdgpu_last_error());
+  return {retard, score};
 }
-template <typename T> std::tuple<Vecteur<T>, Vecteur<T>, entier, float> aligne_entier(const Vecteur<T> &x1, const Vecteur<T> &y1)
+// aligne_entier (estimation-delais.cc:120-170): the two vectors cut to their common support once the
+// integer part of the estimated delay is removed -- y late by d > 0 loses its first d samples, x late
+// loses its first |d|; the longer remainder is then cut at its end
+template <typename T> std::tuple<Vecteur<T>, Vecteur<T>, entier, float> aligne_entier(const Vecteur<T> &x, const Vecteur<T> &y)
 {
-  const Veccf x = x1.as_complex(), y = y1.as_complex();
-  auto [xp, yp] = pad_zeros(x, y, true);
-  auto [df, score] = estimation_délais(xp, yp);
-  const entier d = (entier) std::round(df);
-  Veccf xa, ya;
-  if (d == 0) {
-    xa = x.clone();
-    ya = y.clone();
-  } else if (d < 0) {
-    xa = x.tail(x.rows() + d).clone();
-    ya = y.clone();
-  } else {
-    xa = x.clone();
-    ya = y.tail(y.rows() - d).clone();
-  }
-  if (xa.rows() > ya.rows())
-    xa = xa.head(ya.rows()).clone();
-  else if (xa.rows() < ya.rows())
-    ya = ya.head(xa.rows()).clone();
-  if constexpr (est_complexe<T>())
-    return {xa, ya, d, score};
-  else
-    return {real(xa), real(ya), d, score};
+  auto [xp, yp] = pad_zeros(x.as_complex(), y.as_complex(), true);
+  auto [retard, score] = estimation_délais(xp, yp);
+  const entier d = (entier) std::round(retard);
+  const entier saut_x = d < 0 ? -d : 0, saut_y = d > 0 ? d : 0;
+  const entier commun = std::max(0, std::min(x.rows() - saut_x, y.rows() - saut_y));
+  return {x.segment(saut_x, commun).clone(), y.segment(saut_y, commun).clone(), d, score};
 }
 template std::tuple<Vecf, Vecf, entier, float> aligne_entier<float>(const Vecf &, const Vecf &);
 template std::tuple<Veccf, Veccf, entier, float> aligne_entier<cfloat>(const Veccf &, const Veccf &);

@@ -100,3 +100,66 @@ def psd_welch_sum(x, N, window):
         i += pas
         nseg += 1
     return S, nseg
+
+
+# ---- correlations and delay estimate: core/src/fourier/fourier.cc:489-597, estimation-delais.cc:9-14,100-118
+def correlation_freq(X0, X1):
+    """fourier.cc:489-503: Y(0) = X0(0) conj(X1(0)); Y.tail(n-1) = reversed tails multiplied; times sqrt(n)."""
+    n = len(X0)
+    Y = np.empty(n, c64)
+    Y[0] = X0[0] * np.conj(X1[0])
+    Y[1:] = (X0[1:][::-1] * np.conj(X1[1:][::-1])).astype(c64)
+    return (Y * c64(np.sqrt(f32(n)))).astype(c64)
+
+
+def correlateur_bloc(x0, x1):
+    """TFRCorrelateurBloc::step (fourier.cc:505-531): two forward plans, correlation_freq, inverse plan."""
+    return orc.fft(correlation_freq(orc.fft(x0), orc.fft(x1)), False)
+
+
+def xcorrb(x, y=None, m=-1):
+    """fourier.cc:534-560: biased cross-correlation, lags -(m-1) .. (m-1)."""
+    x = np.asarray(x, c64)
+    y = x if y is None else np.asarray(y, c64)
+    n = len(x)
+    if m < 0:
+        m = n
+    x2 = np.zeros(n + 2 * m, c64)
+    y2 = np.zeros(n + 2 * m, c64)
+    x2[m:m + n] = x
+    y2[m:m + n] = y
+    r = correlateur_bloc(x2, y2)
+    res = np.empty(2 * m - 1, c64)
+    res[m - 1:] = r[:m] / f32(n)
+    res[:m - 1] = r[len(r) - (m - 1):] / f32(n)
+    return np.linspace(-(m - 1), m - 1, 2 * m - 1).astype(f32), res
+
+
+def xcorr(x, y=None, m=-1):
+    """fourier.cc:562-597: unbiased version (the biased one divided by (n - |lag|) / n)."""
+    n = len(x)
+    if m < 0:
+        m = n
+    lags, zb = xcorrb(x, y, m)
+    if m > 1:
+        a = np.linspace(n - (m - 1), n - 1, m - 1).astype(f32) / f32(n)
+        zb[:m - 1] = (zb[:m - 1] / a.astype(c64)).astype(c64)
+        zb[len(zb) - (m - 1):] = (zb[len(zb) - (m - 1):] / a[::-1].astype(c64)).astype(c64)
+    return lags, zb
+
+
+def estimation_delais(x, y):
+    """estimation-delais.cc:100-118 (vectors of one length): peak of |xcorrb| / (rms x . rms y), quadratic
+    interpolation (:9-14) -> (delay, score)."""
+    x = np.asarray(x, c64)
+    y = np.asarray(y, c64)
+    lags, corr = xcorrb(x, y)
+    e1 = np.sqrt(f32(np.mean(np.abs(x.astype(np.complex128)) ** 2)))
+    e2 = np.sqrt(f32(np.mean(np.abs(y.astype(np.complex128)) ** 2)))
+    cn = (np.abs(corr) / (e1 * e2)).astype(f32)
+    k = int(np.argmax(cn))
+    d = 0.0
+    if 0 < k < len(cn) - 1:
+        d = float((cn[k + 1] - cn[k - 1]) / (2 * (2 * cn[k] - cn[k + 1] - cn[k - 1])))
+        d = min(0.5, max(-0.5, d))
+    return float(lags[k]) + d, float(cn[k])

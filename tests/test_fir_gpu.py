@@ -67,7 +67,8 @@ def test_fir_parity(tg, orc, method, cplx_data, cplx_taps, K):
 
 
 # long filters: the overlap-save plan on 4096..16384-point blocks (514..12289 taps), every block
-# size and both ends of its tap range; AUTO must pick it; beyond 12289 taps the direct kernel serves
+# size and both ends of its tap range; AUTO must pick it; beyond 12289 taps the partitioned plan (8192-tap
+# segments on the same engine) serves
 @pytest.mark.parametrize("cplx_data,cplx_taps", [(False, False), (True, False), (True, True)])
 @pytest.mark.parametrize("K", [514, 898, 1025, 2048, 2049, 4097, 4098, 8193, 12289, 12290])
 def test_fir_long_filters(tg, orc, cplx_data, cplx_taps, K):
@@ -76,7 +77,7 @@ def test_fir_long_filters(tg, orc, cplx_data, cplx_taps, K):
     x = rand(n, cplx_data, K + 1)
     ref = orc.fir(h, x)
     f = tg.Fir(h, tg.C64 if cplx_data else tg.F32, tg.FIR_AUTO)
-    assert f.method == (tg.FIR_OVERLAP_SAVE if K <= 12289 else tg.FIR_DIRECT)
+    assert f.method == tg.FIR_OVERLAP_SAVE
     # two ragged chunks: the second one starts from the carried history
     y = np.concatenate([f.step(x[:17001].copy()), f.step(x[17001:].copy())])
     assert relerr(y, ref) <= TOL
