@@ -91,6 +91,14 @@ int tsdgpu_fir_reset(tsdgpu_fir *f);                     /* history <- zeros */
  * caller exchanges between neighbouring chunks.  dst/src: host or device pointers.      */
 int tsdgpu_fir_get_history(tsdgpu_fir *f, void *dst, void *stream);
 int tsdgpu_fir_set_history(tsdgpu_fir *f, const void *src, void *stream);
+/* hipGraph capture of a streaming step.  By default a step alternates between two history buffers, so the
+ * launch arguments change from one step to the next and a captured step would replay ONE step, not the
+ * stream.  With capturable on, every step ends with the new history copied back to the first buffer (a
+ * ~1 KB device copy): all launches of a step of fixed (x, y, n, stream) are then identical from step to
+ * step, and the step can be captured once (hipStreamBeginCapture ... tsdgpu_fir_step ... EndCapture) and
+ * replayed per block -- a few microseconds per small block instead of several launches' worth.  Run one
+ * ordinary step of that size first (scratch buffers are allocated on first use, which capture forbids). */
+int tsdgpu_fir_set_capturable(tsdgpu_fir *f, int on);
 int tsdgpu_fir_method_used(const tsdgpu_fir *f);         /* DIRECT or OVERLAP_SAVE */
 int tsdgpu_fir_destroy(tsdgpu_fir *f);
 
@@ -175,7 +183,8 @@ int tsdgpu_sos_create(tsdgpu_sos **out, int data_type, const float *coefs_host, 
                       float gain, const float *rii1_host, int forme);
 int tsdgpu_sos_step(tsdgpu_sos *s, const void *x, void *y, int64_t n, void *stream);
 int tsdgpu_sos_reset(tsdgpu_sos *s);
-int tsdgpu_sos_reset_on(tsdgpu_sos *s, void *stream);   /* the same, ordered on `stream` (no host wait) */
+int tsdgpu_sos_reset_on(tsdgpu_sos *s, void *stream);
+int tsdgpu_sos_set_capturable(tsdgpu_sos *s, int on);   /* see tsdgpu_fir_set_capturable */   /* the same, ordered on `stream` (no host wait) */
 /* number of warm-up samples a chunk needs before its first output for the carried state
  * to be exact to 2^-30 (multi-GPU halo size); -1 if the filter decays too slowly.       */
 int64_t tsdgpu_sos_halo(const tsdgpu_sos *s);

@@ -283,6 +283,18 @@ int fir_partitioned_step(tsdgpu_fir *f, const void *dx, void *dy, int64_t n, hip
   return TSDGPU_OK;
 }
 
+// Capturable handles keep the stream's history in hist[0] at every step boundary: a step reads hist[0],
+// its kernels write the new history to hist[1] as always, and this copies it back (HL samples, ~1 KB).
+// Every launch of a step then has the same arguments as the previous one, so a step of fixed (x, y, n) can
+// be captured into a hipGraph and replayed as a stream.
+int fir_settle_history(tsdgpu_fir *f, hipStream_t st)
+{
+  if (!f->capturable || f->cur == 0) return TSDGPU_OK;
+  TSD_HIP(hipMemcpyAsync(f->hist[0], f->hist[1], (size_t) f->HL * dtype_size(f->data_type), hipMemcpyDeviceToDevice, st));
+  f->cur = 0;
+  return TSDGPU_OK;
+}
+
 }  // namespace tsdgpu
 
 using namespace tsdgpu;
@@ -379,6 +391,8 @@ int tsdgpu_fir_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, void *stre
   if (!f->parts.empty()) {
     rc = fir_partitioned_step(f, dx, dy, n, st);
     if (rc) return rc;
+    rc = fir_settle_history(f, st);
+    if (rc) return rc;
     return finish_out(y, bytes, dy, staged, st);
   }
   if (dx == dy) {
@@ -398,7 +412,24 @@ int tsdgpu_fir_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, void *stre
     if (!rc) rc = fir_update_history(f, dx, n, st);
   }
   if (rc) return rc;
+  rc = fir_settle_history(f, st);
+  if (rc) return rc;
   return finish_out(y, bytes, dy, staged, st);
+}
+
+int tsdgpu_fir_set_capturable(tsdgpu_fir *f, int on)
+{
+  TSD_CHECK(f != nullptr, "fir_set_capturable: NULL handle");
+  hipStream_t st = nullptr;
+  f->capturable = on != 0;
+  const int rc = fir_settle_history(f, st);
+  if (rc) return rc;
+  TSD_HIP(hipStreamSynchronize(st));
+  for (tsdgpu_fir *c : f->parts) {
+    const int rc2 = tsdgpu_fir_set_capturable(c, on);
+    if (rc2) return rc2;
+  }
+  return TSDGPU_OK;
 }
 
 int tsdgpu_fir_reset(tsdgpu_fir *f)

@@ -13,6 +13,7 @@ struct tsdgpu_fir {
   void *d_hrev = nullptr;   // reversed zero-padded taps, KP entries of tap_type
   void *hist[2] = {nullptr, nullptr};   // last HL input samples (double-buffered), newest last
   int cur = 0;
+  bool capturable = false;  // tsdgpu_fir_set_capturable: every step reads hist[0] and leaves the new history there
   std::vector<char> taps_host;
   tsdgpu::DevBuf in_stage, out_stage;
   // overlap-save plan (ols.hip)
@@ -31,6 +32,7 @@ struct tsdgpu_fir {
 namespace tsdgpu {
 int fir_direct_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, hipStream_t st);
 int fir_update_history(tsdgpu_fir *f, const void *x, int64_t n, hipStream_t st);
+int fir_settle_history(tsdgpu_fir *f, hipStream_t st);
 // overlap-save
 bool ols_preferred(const tsdgpu_fir *f);
 int ols_plan_create(tsdgpu_fir *f);

@@ -34,6 +34,8 @@ constexpr int SUB_FLOATS = 2048;      // floats per sub-tile (64 lanes x 32)
 constexpr int LANE_FLOATS = 32;
 constexpr int LDS_LANE_PITCH = 36;    // floats: 32 + 4 pad -> conflict-free b128 both ways
 
+constexpr int NARROW_FLOATS = 4;      // floats per lane of a warm-up step (one 16-B load, no transposition)
+
 struct SosSection {
   float b0, b1, b2, a1, a2;
   float seed;                 // 1: first-sample seed (SOIS), 0: zero start (RIIFoS)
@@ -42,6 +44,9 @@ struct SosSection {
   float A[6][4];              // (M^L)^(2^k), k = 0..5, row-major 2x2, M = [[-a1,-a2],[1,0]]
   float c1[LANE_FLOATS];      // output response to start state d1 (per in-lane sample index)
   float c2[LANE_FLOATS];      // output response to start state d2
+  // the same tables for the narrow warm-up steps (L = NARROW_FLOATS / channels samples per lane)
+  float An[6][4];
+  float c1n[NARROW_FLOATS], c2n[NARROW_FLOATS];
 };
 
 // state buffer layout (floats): [0] = seeded flag, then per (section, channel) four values:
@@ -56,14 +61,118 @@ __device__ __forceinline__ void wave_sync()
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// One cascade pass over the wave's samples held in registers: lane l owns LF consecutive floats
+// (LF / NCH samples per channel), v in, v out.  Per section: zero-state run, Kogge-Stone scan of the
+// end states over the 64 lanes, zero-input correction of every sample; the running state of every
+// (section, channel) lives in sst (LDS) and is advanced to the end of these 64 * LF floats.
+// NARROW selects the tables of the NARROW_FLOATS-per-lane warm-up steps.
+template <int NCH, int LF, bool NARROW>
+__device__ __forceinline__ void sos_cascade(float (&v)[LF], const SosSection *__restrict__ sec, int nsec, float *sst, int lane,
+                                            bool do_seed)
+{
+  constexpr int L = LF / NCH;
+#pragma unroll 1
+  for (int s = 0; s < nsec; s++) {
+    const SosSection &k = sec[s];
+    const float b0 = k.b0, b1 = k.b1, b2 = k.b2, a1 = k.a1, a2 = k.a2;
+    const float(*A)[4] = NARROW ? k.An : k.A;
+    const float *c1 = NARROW ? k.c1n : k.c1, *c2 = NARROW ? k.c2n : k.c2;
+#pragma unroll
+    for (int c = 0; c < NCH; c++) {
+      float *ss = &sst[(s * 2 + c) * 4];
+      float sin1 = ss[0], sin0 = ss[1];
+      float xin1 = ss[2], xin2 = ss[3];                      // DF1 only: previous two inputs
+      if (do_seed && k.seed != 0.f) {
+        // premier_appel: every memory of the section = its own first input (filtre-rt.cc:361-365)
+        const float x0 = __shfl(v[c], 0);
+        sin1 = sin0 = xin1 = xin2 = x0;
+      }
+      float d1 = 0.f, d2 = 0.f;
+      if (k.df1 == 0.f) {
+        // DF2 zero-state run over the lane's L samples (b0 = 1 -- what the pole / zero pairing of
+        // filtre_sois always produces -- saves the multiply; same value, 1.0f * d being exact)
+        if (b0 == 1.f) {
+#pragma unroll
+          for (int i = 0; i < L; i++) {
+            const float xin = v[i * NCH + c];
+            const float d = fmaf(-a2, d2, fmaf(-a1, d1, xin));
+            v[i * NCH + c] = fmaf(b2, d2, fmaf(b1, d1, d));
+            d2 = d1;
+            d1 = d;
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < L; i++) {
+            const float xin = v[i * NCH + c];
+            const float d = fmaf(-a2, d2, fmaf(-a1, d1, xin));
+            v[i * NCH + c] = fmaf(b2, d2, fmaf(b1, d1, b0 * d));
+            d2 = d1;
+            d1 = d;
+          }
+        }
+      } else {
+        // DF1: v = b0 x + b1 x[-1] + b2 x[-2] (previous lane's last two inputs for i < 2),
+        // then the all-pole recursion y = v - a1 y1 - a2 y2 from zero state
+        static_assert(L >= 2, "a lane holds at least two samples per channel");
+        const float my1 = v[(L - 1) * NCH + c], my2 = v[(L - 2) * NCH + c];
+        float xp1 = __shfl_up(my1, 1), xp2 = __shfl_up(my2, 1);
+        if (lane == 0) { xp1 = xin1; xp2 = xin2; }
+        if (lane == 63) { ss[2] = my1; ss[3] = my2; }
+#pragma unroll
+        for (int i = 0; i < L; i++) {
+          const float xin = v[i * NCH + c];
+          const float fir = fmaf(b2, xp2, fmaf(b1, xp1, b0 * xin));
+          const float yv = fmaf(-a2, d2, fmaf(-a1, d1, fir));
+          v[i * NCH + c] = yv;
+          xp2 = xp1;
+          xp1 = xin;
+          d2 = d1;
+          d1 = yv;
+        }
+      }
+      // lane 0 absorbs the start state: P = M^L * S_in + Z
+      float p1 = d1, p0 = d2;
+      if (lane == 0) {
+        p1 = fmaf(A[0][0], sin1, fmaf(A[0][1], sin0, p1));
+        p0 = fmaf(A[0][2], sin1, fmaf(A[0][3], sin0, p0));
+      }
+      // inclusive Kogge-Stone scan over the 64 lanes: P_l = sum_j (M^L)^(l-j) Z_j
+#pragma unroll
+      for (int kk = 0; kk < 6; kk++) {
+        const int dd = 1 << kk;
+        const float q1 = __shfl_up(p1, dd), q0 = __shfl_up(p0, dd);
+        if (lane >= dd) {
+          p1 = fmaf(A[kk][0], q1, fmaf(A[kk][1], q0, p1));
+          p0 = fmaf(A[kk][2], q1, fmaf(A[kk][3], q0, p0));
+        }
+      }
+      // true start state of this lane = end state of the previous lane
+      float s1 = __shfl_up(p1, 1), s0 = __shfl_up(p0, 1);
+      if (lane == 0) { s1 = sin1; s0 = sin0; }
+      // zero-input correction of every output of the lane
+#pragma unroll
+      for (int i = 0; i < L; i++) v[i * NCH + c] = fmaf(c1[i], s1, fmaf(c2[i], s0, v[i * NCH + c]));
+      // state after the last sample, carried on
+      if (lane == 63) {
+        ss[0] = p1;
+        ss[1] = p0;
+      }
+    }
+    wave_sync();
+  }
+}
+
 // NCH = 1: real samples; NCH = 2: interleaved complex (two real channels).
+// Chunk c owns sub-tiles [c spc, (c+1) spc).  Chunk 0 starts from the stream state; every other chunk
+// starts from zero state `warm_sub` whole sub-tiles plus `warm_nar` narrow steps (256 floats each, one
+// 16-B load per lane, a 4-float recurrence per lane and section: a fifth of a sub-tile's work) before
+// its first sample -- the host picks them so that the state transition over the warm-up is below 1e-9.
 template <int NCH>
 __global__ __launch_bounds__(64) void sos_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                  const SosSection *__restrict__ sec, int nsec, float gain,
                                                  const float *__restrict__ st_in, float *__restrict__ st_out,
-                                                 int64_t n_sub, int spc, int warm_sub)
+                                                 int64_t n_sub, int spc, int warm_sub, int warm_nar)
 {
-  constexpr int L = LANE_FLOATS / NCH;           // samples per lane
   __shared__ __attribute__((aligned(16))) float lds[64 * LDS_LANE_PITCH];
   __shared__ float sst[SOS_MAX_SEC * 8];          // running state per (section, channel): 4 floats
   const int lane = threadIdx.x;
@@ -71,13 +180,24 @@ __global__ __launch_bounds__(64) void sos_kernel(const float *__restrict__ x, fl
   const int64_t t_first = chunk * spc;                         // first sub-tile whose output we own
   const int64_t t_last = min(t_first + spc, n_sub);            // exclusive
   const bool first_chunk = chunk == 0;
-  int64_t t = first_chunk ? 0 : t_first - warm_sub;            // warm-up sub-tiles precede the chunk
   const bool seeded = st_in[0] != 0.f;
 
   // running state per section and channel: wave-uniform, kept in LDS (indexed by the
   // runtime section number; a register array would go to scratch)
   for (int i = lane; i < nsec * 8; i += 64) sst[i] = first_chunk ? st_in[1 + i] : 0.f;
   wave_sync();
+
+  int64_t t = t_first;
+  if (!first_chunk) {
+    t = t_first - warm_sub;
+    // narrow warm-up steps come first in time: they cover the floats just before sub-tile t
+    const float *xw = x + t * SUB_FLOATS - (int64_t) warm_nar * (64 * NARROW_FLOATS);
+    for (int w = 0; w < warm_nar; w++) {
+      const float4 q = *reinterpret_cast<const float4 *>(xw + (int64_t) w * (64 * NARROW_FLOATS) + 4 * lane);
+      float v4[NARROW_FLOATS] = {q.x, q.y, q.z, q.w};
+      sos_cascade<NCH, NARROW_FLOATS, true>(v4, sec, nsec, sst, lane, false);
+    }
+  }
 
   for (; t < t_last; t++) {
     const float *xt = x + t * SUB_FLOATS;
@@ -97,81 +217,7 @@ __global__ __launch_bounds__(64) void sos_kernel(const float *__restrict__ x, fl
     }
     wave_sync();
 
-    const bool do_seed = first_chunk && !seeded && t == 0;
-#pragma unroll 1
-    for (int s = 0; s < nsec; s++) {
-      const SosSection &k = sec[s];
-      const float b0 = k.b0, b1 = k.b1, b2 = k.b2, a1 = k.a1, a2 = k.a2;
-#pragma unroll
-      for (int c = 0; c < NCH; c++) {
-        float *ss = &sst[(s * 2 + c) * 4];
-        float sin1 = ss[0], sin0 = ss[1];
-        float xin1 = ss[2], xin2 = ss[3];                      // DF1 only: previous two inputs
-        if (do_seed && k.seed != 0.f) {
-          // premier_appel: every memory of the section = its own first input (filtre-rt.cc:361-365)
-          const float x0 = __shfl(v[c], 0);
-          sin1 = sin0 = xin1 = xin2 = x0;
-        }
-        float d1 = 0.f, d2 = 0.f;
-        if (k.df1 == 0.f) {
-          // DF2 zero-state run over the lane's L samples
-#pragma unroll
-          for (int i = 0; i < L; i++) {
-            const float xin = v[i * NCH + c];
-            const float d = fmaf(-a2, d2, fmaf(-a1, d1, xin));
-            v[i * NCH + c] = fmaf(b2, d2, fmaf(b1, d1, b0 * d));
-            d2 = d1;
-            d1 = d;
-          }
-        } else {
-          // DF1: v = b0 x + b1 x[-1] + b2 x[-2] (previous lane's last two inputs for i < 2),
-          // then the all-pole recursion y = v - a1 y1 - a2 y2 from zero state
-          const float my1 = v[(L - 1) * NCH + c], my2 = v[(L - 2) * NCH + c];
-          float xp1 = __shfl_up(my1, 1), xp2 = __shfl_up(my2, 1);
-          if (lane == 0) { xp1 = xin1; xp2 = xin2; }
-          if (lane == 63) { ss[2] = my1; ss[3] = my2; }
-#pragma unroll
-          for (int i = 0; i < L; i++) {
-            const float xin = v[i * NCH + c];
-            const float fir = fmaf(b2, xp2, fmaf(b1, xp1, b0 * xin));
-            const float yv = fmaf(-a2, d2, fmaf(-a1, d1, fir));
-            v[i * NCH + c] = yv;
-            xp2 = xp1;
-            xp1 = xin;
-            d2 = d1;
-            d1 = yv;
-          }
-        }
-        // lane 0 absorbs the sub-tile's start state: P = M^L * S_in + Z
-        float p1 = d1, p0 = d2;
-        if (lane == 0) {
-          p1 = fmaf(k.A[0][0], sin1, fmaf(k.A[0][1], sin0, p1));
-          p0 = fmaf(k.A[0][2], sin1, fmaf(k.A[0][3], sin0, p0));
-        }
-        // inclusive Kogge-Stone scan over the 64 lanes: P_l = sum_j (M^L)^(l-j) Z_j
-#pragma unroll
-        for (int kk = 0; kk < 6; kk++) {
-          const int dd = 1 << kk;
-          const float q1 = __shfl_up(p1, dd), q0 = __shfl_up(p0, dd);
-          if (lane >= dd) {
-            p1 = fmaf(k.A[kk][0], q1, fmaf(k.A[kk][1], q0, p1));
-            p0 = fmaf(k.A[kk][2], q1, fmaf(k.A[kk][3], q0, p0));
-          }
-        }
-        // true start state of this lane = end state of the previous lane
-        float s1 = __shfl_up(p1, 1), s0 = __shfl_up(p0, 1);
-        if (lane == 0) { s1 = sin1; s0 = sin0; }
-        // zero-input correction of every output of the lane
-#pragma unroll
-        for (int i = 0; i < L; i++) v[i * NCH + c] = fmaf(k.c1[i], s1, fmaf(k.c2[i], s0, v[i * NCH + c]));
-        // state after the sub-tile's last sample, carried to the next sub-tile
-        if (lane == 63) {
-          ss[0] = p1;
-          ss[1] = p0;
-        }
-      }
-      wave_sync();
-    }
+    sos_cascade<NCH, LANE_FLOATS, false>(v, sec, nsec, sst, lane, first_chunk && !seeded && t == 0);
 
     if (t >= t_first) {
       // ---- gain, transpose back, store 16 B per lane
@@ -253,6 +299,7 @@ struct tsdgpu_sos {
   SosSection *d_sec = nullptr;
   float *d_state[2] = {nullptr, nullptr};
   int cur = 0;
+  bool capturable = false;      // tsdgpu_sos_set_capturable: the state is back in d_state[0] after every step
   int64_t halo = 0;             // W: samples after which the state transition is below 1e-9
   DevBuf in_stage, out_stage;
 };
@@ -308,7 +355,14 @@ int64_t compute_halo(const std::vector<SosSection> &sec)
   return -1;   // does not decay (unstable or marginal filter)
 }
 
+void fill_tables_for(SosSection &k, int L, int NF, float *c1, float *c2, float (*Aout)[4]);
 void fill_tables(SosSection &k, int L)
+{
+  fill_tables_for(k, L, LANE_FLOATS, k.c1, k.c2, k.A);
+  // narrow warm-up steps: NARROW_FLOATS floats per lane = L * NARROW_FLOATS / LANE_FLOATS samples per channel
+  fill_tables_for(k, L * NARROW_FLOATS / LANE_FLOATS, NARROW_FLOATS, k.c1n, k.c2n, k.An);
+}
+void fill_tables_for(SosSection &k, int L, int NF, float *c1o, float *c2o, float (*Aout)[4])
 {
   const double a1 = k.a1, a2 = k.a2;
   // DF1 carries (y1, y2): the correction is the all-pole zero-input response itself
@@ -316,7 +370,7 @@ void fill_tables(SosSection &k, int L)
   // zero-input responses from unit start states (d1,d2) = (1,0) and (0,1)
   for (int which = 0; which < 2; which++) {
     double d1 = which == 0 ? 1.0 : 0.0, d2 = which == 0 ? 0.0 : 1.0;
-    for (int i = 0; i < LANE_FLOATS; i++) {
+    for (int i = 0; i < NF; i++) {
       double o = 0;
       if (i < L) {
         const double d = -a1 * d1 - a2 * d2;
@@ -324,7 +378,7 @@ void fill_tables(SosSection &k, int L)
         d2 = d1;
         d1 = d;
       }
-      (which == 0 ? k.c1 : k.c2)[i] = (float) o;
+      (which == 0 ? c1o : c2o)[i] = (float) o;
     }
   }
   // M^L by L-fold application, then repeated squaring for the scan
@@ -336,7 +390,7 @@ void fill_tables(SosSection &k, int L)
     for (int j = 0; j < 4; j++) A[j] = t[j];
   }
   for (int kk = 0; kk < 6; kk++) {
-    for (int j = 0; j < 4; j++) k.A[kk][j] = (float) A[j];
+    for (int j = 0; j < 4; j++) Aout[kk][j] = (float) A[j];
     const double t[4] = {A[0] * A[0] + A[1] * A[2], A[0] * A[1] + A[1] * A[3], A[2] * A[0] + A[3] * A[2],
                          A[2] * A[1] + A[3] * A[3]};
     for (int j = 0; j < 4; j++) A[j] = t[j];
@@ -477,25 +531,36 @@ int tsdgpu_sos_step(tsdgpu_sos *s, const void *x, void *y, int64_t n, void *stre
   float *st_in = s->d_state[s->cur], *st_out = s->d_state[s->cur ^ 1];
   if (n_sub > 0) {
     const int64_t sub_samples = SUB_FLOATS / nch;
-    int64_t warm_sub, spc;
+    int64_t warm_sub, warm_nar = 0, spc;
     if (s->halo < 0) {
       warm_sub = 0;
       spc = n_sub;                                          // no decay: one sequential chunk
     } else {
-      warm_sub = cdiv(s->halo, sub_samples);
-      // chunk length: enough chunks to fill the chip (~16 waves per CU), but never shorter
-      // than 4 warm-ups (<= 25 % redundant work) -- measured optimum 8 sub-tiles for 2^26
-      // samples and W = 256 (12.5 % overhead, 4096 waves)
-      spc = std::max<int64_t>({4, 4 * warm_sub, n_sub / 4096});
+      // warm-up of `halo` samples: whole sub-tiles for the bulk of a long halo, then narrow steps of
+      // 64 * NARROW_FLOATS floats (a fifth of a sub-tile's work each) for the rest
+      static const bool narrow = getenv("TSDGPU_SOS_WIDE_WARMUP") == nullptr;
+      const int64_t nar_samples = 64 * NARROW_FLOATS / nch;
+      if (narrow) {
+        warm_sub = s->halo / sub_samples;
+        warm_nar = cdiv(s->halo - warm_sub * sub_samples, nar_samples);
+        if (warm_nar * nar_samples >= sub_samples) { warm_sub++; warm_nar = 0; }
+      } else {
+        warm_sub = cdiv(s->halo, sub_samples);
+      }
+      // chunk length: enough chunks to fill the chip, but the warm-up never more than a quarter of the
+      // chunk's work (a narrow step counts as a fifth of a sub-tile)
+      static const int64_t TARGET = getenv("TSDGPU_SOS_CHUNKS") ? atoll(getenv("TSDGPU_SOS_CHUNKS")) : 4096;
+      const int64_t warm_cost = warm_sub + cdiv(warm_nar, 5);
+      spc = std::max<int64_t>({2, 4 * warm_cost, warm_sub + 1, n_sub / TARGET});
     }
     const int64_t nchunks = cdiv(n_sub, spc);
     TSD_CHECK(nchunks <= 0x7fffffff, "sos_step: too many chunks");
     if (nch == 1)
       hipLaunchKernelGGL(sos_kernel<1>, dim3((unsigned) nchunks), dim3(64), 0, st, (const float *) dx, (float *) dy,
-                         s->d_sec, s->nsec, s->gain, st_in, st_out, n_sub, (int) spc, (int) warm_sub);
+                         s->d_sec, s->nsec, s->gain, st_in, st_out, n_sub, (int) spc, (int) warm_sub, (int) warm_nar);
     else
       hipLaunchKernelGGL(sos_kernel<2>, dim3((unsigned) nchunks), dim3(64), 0, st, (const float *) dx, (float *) dy,
-                         s->d_sec, s->nsec, s->gain, st_in, st_out, n_sub, (int) spc, (int) warm_sub);
+                         s->d_sec, s->nsec, s->gain, st_in, st_out, n_sub, (int) spc, (int) warm_sub, (int) warm_nar);
     TSD_HIP(hipGetLastError());
     s->cur ^= 1;
   }
@@ -514,7 +579,24 @@ int tsdgpu_sos_step(tsdgpu_sos *s, const void *x, void *y, int64_t n, void *stre
     TSD_HIP(hipMemcpyAsync(dy_user, dy, bytes, hipMemcpyDeviceToDevice, st));
     dy = dy_user;
   }
+  if (s->capturable && s->cur == 1) {
+    // same launch arguments at every step (see tsdgpu_fir_set_capturable): the state goes back to buffer 0
+    TSD_HIP(hipMemcpyAsync(s->d_state[0], s->d_state[1], STATE_FLOATS * 4, hipMemcpyDeviceToDevice, st));
+    s->cur = 0;
+  }
   return finish_out(y, bytes, dy, staged, st);
+}
+
+int tsdgpu_sos_set_capturable(tsdgpu_sos *s, int on)
+{
+  TSD_CHECK(s != nullptr, "sos_set_capturable: NULL handle");
+  s->capturable = on != 0;
+  if (s->capturable && s->cur == 1) {
+    TSD_HIP(hipMemcpy(s->d_state[0], s->d_state[1], STATE_FLOATS * 4, hipMemcpyDeviceToDevice));
+    TSD_HIP(hipStreamSynchronize(nullptr));
+    s->cur = 0;
+  }
+  return TSDGPU_OK;
 }
 
 int tsdgpu_sos_reset(tsdgpu_sos *s)

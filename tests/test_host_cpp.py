@@ -43,3 +43,14 @@ def test_host_layer_gpu_suite():
     r = subprocess.run([BIN], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
     assert "ALL C++ HOST TESTS OK" in r.stdout
+
+
+@pytest.mark.gpu
+def test_graph_capture_of_streaming_steps():
+    """tests/cpp/test_graph_capture.hip: a FIR / SOS step captured once into a hipGraph and replayed per block
+    reproduces the stream of ordinary steps bit for bit (tsdgpu_*_set_capturable)."""
+    exe = os.path.join(ROOT, "tests", "cpp", "build", "test_graph_capture")
+    if not os.path.exists(exe):
+        build()
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "GRAPH CAPTURE OK" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
