@@ -1102,6 +1102,9 @@ struct tsdgpu_fft {
   cpx *d_chirp = nullptr, *d_xc = nullptr;   // Bluestein chirp (2n-1) and FFT of its conjugate (n2)
   DevBuf work, work2, in_stage, out_stage;
   StepOrder order;            // top-level plans only (sub-plans run under their owner's)
+  // grouped schedule of the 2^20 plan (TSDGPU_FFT_GROUP): two side streams and their events
+  hipStream_t gs[2] = {nullptr, nullptr};
+  hipEvent_t ge[2] = {nullptr, nullptr}, ge_in = nullptr;
 };
 
 namespace {
@@ -1365,6 +1368,11 @@ void plan_destroy(tsdgpu_fft *p)
 {
   if (!p) return;
   if (p->sub) plan_destroy(p->sub);
+  for (int i = 0; i < 2; i++) {
+    if (p->gs[i]) (void) hipStreamDestroy(p->gs[i]);
+    if (p->ge[i]) (void) hipEventDestroy(p->ge[i]);
+  }
+  if (p->ge_in) (void) hipEventDestroy(p->ge_in);
   for (cpx *q : {p->d_tw, p->d_tw1, p->d_tw2, p->d_thi, p->d_tlo, p->d_rot, p->d_chirp, p->d_xc, p->d_w1, p->d_w2, p->d_ta, p->d_td, p->d_wm})
     if (q) (void) hipFree(q);
   p->work.release();
@@ -1478,6 +1486,39 @@ int step_device(tsdgpu_fft *p, const cpx *x, cpx *y, int batch, int forward, hip
         return n > 0 ? n : 256;
       }();
       static const int GRID = getenv("TSDGPU_FFT_GRID") ? atoi(getenv("TSDGPU_FFT_GRID")) : NCU;
+      // Grouped schedule (experiment, off by default: DESIGN.md section 3.3): the batch is cut in groups of G
+      // transforms whose intermediate (G x 8 MiB) is small enough to stay in the 256 MiB Infinity Cache between
+      // its pass 1 and its pass 2; consecutive groups alternate between two side streams with a slot of the
+      // intermediate buffer each, so that the head of one group's launch fills the tail of the previous one's.
+      static const int GROUP = getenv("TSDGPU_FFT_GROUP") ? atoi(getenv("TSDGPU_FFT_GROUP")) : 0;
+      if (GROUP > 0 && batch > GROUP && x != y) {
+        if (!p->gs[0]) {
+          for (int i = 0; i < 2; i++) {
+            TSD_HIP(hipStreamCreateWithFlags(&p->gs[i], hipStreamNonBlocking));
+            TSD_HIP(hipEventCreateWithFlags(&p->ge[i], hipEventDisableTiming));
+          }
+          TSD_HIP(hipEventCreateWithFlags(&p->ge_in, hipEventDisableTiming));
+        }
+        const size_t slot = (size_t) GROUP * 1024 * ZP;           // elements of z per stream
+        TSD_HIP(hipEventRecord(p->ge_in, st));
+        for (int i = 0; i < 2; i++) TSD_HIP(hipStreamWaitEvent(p->gs[i], p->ge_in, 0));
+        int gi = 0;
+        for (int b0 = 0; b0 < batch; b0 += GROUP, gi++) {
+          const int nb = std::min(GROUP, batch - b0), nt = 64 * nb, grd = std::min(nt, GRID);
+          hipStream_t s2 = p->gs[gi & 1];
+          cpx *zz = z + (size_t) (gi & 1) * slot;
+          hipLaunchKernelGGL((fft1m_cols_kernel<1>), dim3(grd), dim3(1024), F1M_LDS, s2, x + (size_t) b0 * n, zz, p->d_w1, p->d_w2, p->d_ta,
+                             p->d_td, inverse, 1.0f, ZP, nt);
+          hipLaunchKernelGGL((fft1m_cols_kernel<2>), dim3(grd), dim3(1024), F1M_LDS, s2, zz, y + (size_t) b0 * n, p->d_w1, p->d_w2, p->d_ta,
+                             p->d_td, inverse, 1.0f / 1024.0f, ZP, nt);
+        }
+        TSD_HIP(hipGetLastError());
+        for (int i = 0; i < 2; i++) {
+          TSD_HIP(hipEventRecord(p->ge[i], p->gs[i]));
+          TSD_HIP(hipStreamWaitEvent(st, p->ge[i], 0));
+        }
+        return TSDGPU_OK;
+      }
       const int grid = std::min(ntiles, GRID);
       hipLaunchKernelGGL((fft1m_cols_kernel<1>), dim3(grid), dim3(1024), F1M_LDS, st, x, z, p->d_w1, p->d_w2, p->d_ta,
                          p->d_td, inverse, 1.0f, ZP, ntiles);

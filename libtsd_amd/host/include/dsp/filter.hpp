@@ -19,6 +19,10 @@ inline Vecf design_fir_wnd(int n, const std::string &type, float fc, const std::
 { return tsd::filtrage::design_rif_fen(n, type, fc, wnd, fc2); }
 inline FRat<cfloat> design_iira(int n, const std::string &type, const std::string &prototype, float fc, float δ_bp = 0.1f, float δ_bc = 60)
 { return tsd::filtrage::design_riia(n, type, prototype, fc, δ_bp, δ_bc); }
+// dsp/filter.hpp:497-543
+using BiquadSpec = tsd::filtrage::BiquadSpec;
+inline FRat<float> design_biquad(const std::string &type, float f, float Q, float gain_dB = 0) { return tsd::filtrage::design_biquad(type, f, Q, gain_dB); }
+inline FRat<float> design_biquad(const BiquadSpec &spec) { return tsd::filtrage::design_biquad(spec); }
 template <typename Tc, typename T = Tc> sptr<FilterGen<T>> filter_fir(const Vector<Tc> &h) { return tsd::filtrage::filtre_rif<Tc, T>(h); }
 template <typename T> sptr<FilterGen<T>> filter_fir_fft(const Vecf &h) { return tsd::filtrage::filtre_rif_fft<T>(h); }
 template <typename T> sptr<FilterGen<T>> filter_sois(const FRat<cfloat> &h, RIIStructure s = FormeDirecte2) { return tsd::filtrage::filtre_sois<T>(h, s); }

@@ -34,6 +34,16 @@ Vecf design_rif_fen(entier n, cstring type, float fc, cstring fen = "hn", float 
 Vecf design_rif_prod(const Vecf &h1, const Vecf &h2);
 FRat<cfloat> design_riia(entier n, cstring type, cstring prototype, float fc, float δ_bp = 0.1f, float δ_bc = 60);
 float sinc(float T, float f);
+// design_biquad (filtrage.hpp:565-652; rii.cc:489-667): second-order sections from the Audio-EQ-Cookbook
+// prototypes; type strings "lp"/"pb", "hp"/"ph", "bp"/"passe-bande", "cb"/"notch"/"sb", "plateau-bf",
+// "plateau-hf", "res".  The result is a coefficient-form FRat<float>: filtrer() factorises it (parity of that
+// factorisation is unpinned -- Eigen's solver in the reference).
+struct BiquadSpec {
+  enum Type { PASSE_BAS = 0, PASSE_HAUT, PASSE_BANDE, COUPE_BANDE, RESONATEUR, PLATEAU_BF, PLATEAU_HF } type = PASSE_BAS;
+  float f = 0.25f, Q = 0.707f, gain_dB = 1;
+};
+FRat<float> design_biquad(cstring type, float f, float Q, float gain_dB = 0);
+FRat<float> design_biquad(const BiquadSpec &spec);
 
 // ---- stateful operators (factories) ------------------------------------------------------------
 template <typename Tc, typename T = Tc> sptr<FiltreGen<T>> filtre_rif(const Vecteur<Tc> &h);

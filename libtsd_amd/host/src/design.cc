@@ -117,6 +117,49 @@ FRat<cfloat> design_riia(entier n, cstring type, cstring prototype, float fc, fl
   return h;
 }
 
+// ---- design: biquads of the Audio-EQ-Cookbook (the source rii.cc:576 names; rii.cc:489-507,577-667) ----
+// H(z^-1) = (b0 + b1 z^-1 + b2 z^-2) / (a0 + a1 z^-1 + a2 z^-2), normalised by a0.  With A = 10^(gain/40),
+// w = 2 pi f, alpha = sin w / (2 Q), beta = sqrt(2 A) (the shelf slope the reference fixes):
+FRat<float> design_biquad(const BiquadSpec &sp)
+{
+  const float A = std::sqrt(std::pow(10.0f, sp.gain_dB / 20)), w = (float) (2 * π * sp.f);
+  const float c = std::cos(w), sn = std::sin(w), al = sn / (2 * sp.Q), be = std::sqrt(2 * A);
+  struct { float b[3], a[3]; } k{};
+  auto pose = [&](float b0, float b1, float b2, float a0, float a1, float a2) { k = {{b0, b1, b2}, {a0, a1, a2}}; };
+  const float ap = A + 1, am = A - 1;
+  switch (sp.type) {
+    case BiquadSpec::PASSE_BAS: pose((1 - c) / 2, 1 - c, (1 - c) / 2, 1 + al, -2 * c, 1 - al); break;
+    case BiquadSpec::PASSE_HAUT: pose((1 + c) / 2, -(1 + c), (1 + c) / 2, 1 + al, -2 * c, 1 - al); break;
+    case BiquadSpec::PASSE_BANDE: pose(al, 0, -al, 1 + al, -2 * c, 1 - al); break;
+    case BiquadSpec::COUPE_BANDE: pose(1, -2 * c, 1, 1 + al, -2 * c, 1 - al); break;
+    case BiquadSpec::RESONATEUR: pose(1 + al * A, -2 * c, 1 - al * A, 1 + al / A, -2 * c, 1 - al / A); break;
+    case BiquadSpec::PLATEAU_BF:
+      pose(A * (ap - am * c + be * sn), 2 * A * (am - ap * c), A * (ap - am * c - be * sn), ap + am * c + be * sn, -2 * (am + ap * c), ap + am * c - be * sn);
+      break;
+    case BiquadSpec::PLATEAU_HF:
+      pose(A * (ap + am * c + be * sn), -2 * A * (am + ap * c), A * (ap + am * c - be * sn), ap - am * c + be * sn, 2 * (am - ap * c), ap - am * c - be * sn);
+      break;
+    default: échec("Type de biquad invalide ({}).", (int) sp.type);
+  }
+  const float a0 = k.a[0];
+  return FRat<float>::rii(Vecf::valeurs({k.b[0] / a0, k.b[1] / a0, k.b[2] / a0}), Vecf::valeurs({1.0f, k.a[1] / a0, k.a[2] / a0}));
+}
+FRat<float> design_biquad(cstring type, float f, float Q, float gain_dB)
+{
+  static const struct { const char *nom; BiquadSpec::Type t; } noms[] = {
+      {"lp", BiquadSpec::PASSE_BAS}, {"pb", BiquadSpec::PASSE_BAS}, {"hp", BiquadSpec::PASSE_HAUT}, {"ph", BiquadSpec::PASSE_HAUT},
+      {"bp", BiquadSpec::PASSE_BANDE}, {"passe-bande", BiquadSpec::PASSE_BANDE}, {"cb", BiquadSpec::COUPE_BANDE},
+      {"notch", BiquadSpec::COUPE_BANDE}, {"sb", BiquadSpec::COUPE_BANDE}, {"plateau-bf", BiquadSpec::PLATEAU_BF},
+      {"plateau-hf", BiquadSpec::PLATEAU_HF}, {"res", BiquadSpec::RESONATEUR}};
+  BiquadSpec sp;
+  sp.f = f;
+  sp.Q = Q;
+  sp.gain_dB = gain_dB;
+  for (const auto &e : noms)
+    if (type == e.nom) sp.type = e.t;          // (an unknown name leaves the low-pass default, like the reference)
+  return design_biquad(sp);
+}
+
 // ---- polynomial roots -----------------------------------------------------------------------
 }  // namespace filtrage
 

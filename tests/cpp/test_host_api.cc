@@ -157,6 +157,30 @@ static void test_fragments()
   CHECK(r3.rows() == r1.rows() && ecart_rel(r3, r1) == 0.f, "sharded rééchan must be bit-exact: %d vs %d outputs, %g", r3.rows(), r1.rows(), ecart_rel(r3, r1));
 }
 
+// design_biquad (test-filtres.cc:296-314 only plots): every type through filtrer() -- coefficient form,
+// factorised, two-pole section on the GPU -- against the biquad's own frequency response
+static void test_design_biquad()
+{
+  const int n = 1 << 15;
+  for (const char *type : {"lp", "hp", "bp", "notch", "res", "plateau-bf", "plateau-hf"}) {
+    const FRat<float> h = design_biquad(type, 0.1f, 0.9f, 6.0f);
+    const FRat<float> hz = h.eval_inv_z();                       // powers of z^-1
+    const Vecf b = hz.numer.coefs, a = hz.denom.coefs;
+    CHECK(b.rows() == 3 && a.rows() == 3 && std::abs(a(0) - 1) < 1e-6f, "design_biquad(%s): %d / %d coefficients", type, b.rows(), a.rows());
+    for (float f : {0.02f, 0.1f, 0.3f}) {
+      Veccf x(n);
+      for (int i = 0; i < n; i++) x(i) = std::polar(1.0f, (float) (2 * π * f * i));
+      const Veccf y = filtrer<cfloat>(Design(h), x);
+      const cfloat w = std::polar(1.0f, (float) (-2 * π * f));
+      const cfloat H = (b(0) + b(1) * w + b(2) * w * w) / (a(0) + a(1) * w + a(2) * w * w);
+      double m = 0;
+      for (int i = n / 2; i < n; i++) m += std::abs(y(i));
+      m /= n / 2;
+      CHECK(std::abs((float) m - std::abs(H)) <= 2e-4f * std::max(1.0f, std::abs(H)), "design_biquad(%s) at f = %g: gain %g, H = %g", type, f, m, std::abs(H));
+    }
+  }
+}
+
 static void test_tab()   // test-tab.cc:53-137 semantics
 {
   Vecf a = linspace(0, 9, 10);
@@ -1231,6 +1255,7 @@ int main(int argc, char **argv)
   test_rif_vs_rif_fft();
   test_fir_vs_oracle();
   test_sois();
+  test_design_biquad();
   for (int n : {16, 1, 2, 3, 4, 5, 8, 10, 17, 128, 129, 1024}) { test_fft_valide(n, false); test_fft_valide(n, true); }
   test_fft_misc();
   test_reechan();
