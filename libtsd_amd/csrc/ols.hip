@@ -213,6 +213,56 @@ __device__ __forceinline__ void ols_body(cv *lds, const void *__restrict__ xv, c
     process(A, B, b);   // edge launches: one block per wave, no prefetch
     return;
   }
+#ifndef OLS_DEPTH   // blocks of prefetch in flight per wave (1: two register sets; 2: three)
+#define OLS_DEPTH 1
+#endif
+#if OLS_DEPTH == 2
+  // Three register sets: while block b is transformed, block b+G is landing (issued a whole block
+  // earlier) and block b+2G has just been requested -- 16 KiB per wave in flight instead of 8.  The wait
+  // forced before the stores names the NEAR set only (vmcnt(30): the far loads stay in flight).
+  cv C[16];
+  auto fetch_into = [&](cv (&dst)[16], int64_t blk) {
+    if (REAL) ols_fetch_real<false>(dst, xr, histr, histlen, Km1, L, n, blk, lane);
+    else ols_fetch<false>(dst, x, hist, histlen, Km1, L, n, blk, lane);
+  };
+  auto process3 = [&](cv (&cur)[16], cv (&far)[16], cv (&near)[16], int64_t blk) {
+    if (blk + 2 * G < b_hi) fetch_into(far, blk + 2 * G);
+    forward(cur, lds, lane, tw1, tw2, sync);
+#pragma unroll
+    for (int r = 0; r < 16; r++) cur[r] = cmul(cur[r], H[r]);
+    inverse(cur, lds, lane, tw1, tw2, sync);
+    sync();
+    if (blk + G < b_hi) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) asm volatile("" ::"v"(near[r]));
+    }
+    const int r0 = Km1 >> 6;
+    if (!REAL) {
+      cv *yb = y + (blk * (int64_t) L - Km1);
+#pragma unroll
+      for (int r = 0; r < 16; r++)
+        if (r >= r0) yb[64 * r + lane] = cur[r];
+    } else {
+      const int64_t oa = 2 * blk * (int64_t) L, ob = oa + L;
+      float *ya = yr + (oa - Km1), *yb = yr + (ob - Km1);
+#pragma unroll
+      for (int r = 0; r < 16; r++)
+        if (r >= r0) { ya[64 * r + lane] = cur[r].x; yb[64 * r + lane] = cur[r].y; }
+    }
+  };
+  if (b + G < b_hi) fetch_into(B, b + G);
+  for (;;) {
+    process3(A, C, B, b);
+    b += G;
+    if (b >= b_hi) break;
+    process3(B, A, C, b);
+    b += G;
+    if (b >= b_hi) break;
+    process3(C, B, A, b);
+    b += G;
+    if (b >= b_hi) break;
+  }
+#else
   for (;;) {
     process(A, B, b);
     b += G;
@@ -221,6 +271,7 @@ __device__ __forceinline__ void ols_body(cv *lds, const void *__restrict__ xv, c
     b += G;
     if (b >= b_hi) break;
   }
+#endif
 }
 
 // One launch per step: workgroups [0, G) walk the interior blocks, the next `ne` workgroups
