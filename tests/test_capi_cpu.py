@@ -75,3 +75,25 @@ def test_plain_c_example_runs(tmp_path):
     import subprocess
     r = subprocess.run([_build_c_example(tmp_path)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "C ABI example OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_binding_refuses_wrong_dtypes_and_strided_views():
+    """the C ABI reads packed float32 / complex64; the binding must refuse anything else instead of
+    reinterpreting it (float64, integers, complex128, strided views)."""
+    import numpy as np
+    from libtsd_amd import capi
+    assert capi._dtype_code(np.zeros(4, np.float32)) == capi.F32
+    assert capi._dtype_code(np.zeros(4, np.complex64)) == capi.C64
+    for bad in (np.zeros(4, np.float64), np.zeros(4, np.complex128), np.zeros(4, np.int32), np.zeros(4, np.float16)):
+        with pytest.raises(capi.TsdGpuError):
+            capi._dtype_code(bad)
+        with pytest.raises(capi.TsdGpuError):
+            capi._ptr(bad)
+    with pytest.raises(capi.TsdGpuError):
+        capi._ptr(np.zeros(8, np.float32)[::2])
+    import torch
+    with pytest.raises(capi.TsdGpuError):
+        capi._ptr(torch.zeros(4, dtype=torch.float64))
+    with pytest.raises(capi.TsdGpuError):
+        capi._ptr(torch.zeros(8)[::2])
+    assert capi._ptr(torch.zeros(8)) != 0
