@@ -30,9 +30,13 @@
 namespace tsdgpu {
 
 constexpr int SOS_MAX_SEC = 32;
-constexpr int SUB_FLOATS = 2048;      // floats per sub-tile (64 lanes x 32)
-constexpr int LANE_FLOATS = 32;
-constexpr int LDS_LANE_PITCH = 36;    // floats: 32 + 4 pad -> conflict-free b128 both ways
+#ifndef SOS_LANE_FLOATS               // floats a lane holds per sub-tile: 32 (default), 16 (build option: half the LDS and VGPRs per wave)
+#define SOS_LANE_FLOATS 32
+#endif
+constexpr int LANE_FLOATS = SOS_LANE_FLOATS;
+constexpr int SUB_FLOATS = 64 * LANE_FLOATS;      // floats per sub-tile (2048)
+constexpr int LDS_LANE_PITCH = LANE_FLOATS + 4;   // floats: + 4 pad -> conflict-free b128 both ways (36: 9 x 16 B, odd; 20: 5 x 16 B, odd)
+constexpr int LANE_QUADS = LANE_FLOATS / 4;
 
 constexpr int NARROW_FLOATS = 4;      // floats per lane of a warm-up step (one 16-B load, no transposition)
 
@@ -204,14 +208,14 @@ __global__ __launch_bounds__(64) void sos_kernel(const float *__restrict__ x, fl
     // ---- load 16 B per lane, transpose through LDS: lane gets floats [32*lane, 32*lane+32)
     float v[LANE_FLOATS];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < LANE_QUADS; i++) {
       const int p = 4 * (i * 64 + lane);                       // float index in the sub-tile
       const float4 q = *reinterpret_cast<const float4 *>(xt + p);
-      *reinterpret_cast<float4 *>(&lds[(p >> 5) * LDS_LANE_PITCH + (p & 31)]) = q;
+      *reinterpret_cast<float4 *>(&lds[(p / LANE_FLOATS) * LDS_LANE_PITCH + (p % LANE_FLOATS)]) = q;
     }
     wave_sync();
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < LANE_QUADS; i++) {
       const float4 q = *reinterpret_cast<const float4 *>(&lds[lane * LDS_LANE_PITCH + 4 * i]);
       v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w;
     }
@@ -222,16 +226,16 @@ __global__ __launch_bounds__(64) void sos_kernel(const float *__restrict__ x, fl
     if (t >= t_first) {
       // ---- gain, transpose back, store 16 B per lane
 #pragma unroll
-      for (int i = 0; i < 8; i++) {
+      for (int i = 0; i < LANE_QUADS; i++) {
         const float4 q = make_float4(v[4 * i] * gain, v[4 * i + 1] * gain, v[4 * i + 2] * gain, v[4 * i + 3] * gain);
         *reinterpret_cast<float4 *>(&lds[lane * LDS_LANE_PITCH + 4 * i]) = q;
       }
       wave_sync();
       float *yt = y + t * SUB_FLOATS;
 #pragma unroll
-      for (int i = 0; i < 8; i++) {
+      for (int i = 0; i < LANE_QUADS; i++) {
         const int p = 4 * (i * 64 + lane);
-        *reinterpret_cast<float4 *>(yt + p) = *reinterpret_cast<const float4 *>(&lds[(p >> 5) * LDS_LANE_PITCH + (p & 31)]);
+        *reinterpret_cast<float4 *>(yt + p) = *reinterpret_cast<const float4 *>(&lds[(p / LANE_FLOATS) * LDS_LANE_PITCH + (p % LANE_FLOATS)]);
       }
       wave_sync();
     }
