@@ -94,84 +94,34 @@ Vecf rééchan_freq(const Vecf &x, float lom)
 }
 
 // ---- délais (fourier.cc:607-698) ----------------------------------------------------------------
-// Packed real FFT pair used by the real fractional delay (fourier.cc:130-229, "numerical recipes"
-// split): n real samples <-> n/2 complex bins, bin 0 carrying (DC, Nyquist) as (re, im).
-static Veccf rtfr_moitié(const Vecf &x)
-{
-  const entier n = x.rows(), h = n / 2;
-  Veccf z(h);
-  for (entier i = 0; i < h; i++) z(i) = cfloat(x(2 * i), x(2 * i + 1));
-  const Veccf Z = fft(z);
-  Veccf X(h);
-  for (entier i = 0; i <= h; i++) {
-    const cfloat a = Z(i == h ? 0 : i), b = std::conj(Z(i > 0 ? h - i : 0));
-    const cfloat w((float) std::cos(-(2 * π * i) / n), (float) std::sin(-(2 * π * i) / n));
-    const cfloat v = cfloat(0.25f, 0) * (a + b) - cfloat(0, 0.25f) * (a - b) * w;
-    if (i < h)
-      X(i) = v;
-    else
-      X(0).imag(v.real());
-  }
-  return X;
-}
-static Vecf irtfr_moitié(const Veccf &X)
-{
-  const entier h = X.rows(), n = 2 * h;
-  Veccf Z(h);
-  for (entier i = 0; i < h; i++) {
-    const cfloat xi = i == 0 ? cfloat(X(0).real(), 0) : X(i), xp = i == 0 ? cfloat(X(0).imag(), 0) : X(h - i);
-    const cfloat e = xi + std::conj(xp), o = (xi - std::conj(xp)) * std::polar(1.0f, (float) ((2 * π * i) / n));
-    Z(i) = e + cfloat(0, 1) * o;
-  }
-  const Veccf z = ifft(Z);
-  Vecf x(n);
-  for (entier i = 0; i < h; i++) {
-    x(2 * i) = z(i).real();
-    x(2 * i + 1) = z(i).imag();
-  }
-  return x;
-}
+// Fractional delay = a linear phase on the spectrum of the vector zero-padded to twice its length (a quarter
+// of the padded length on either side): bin k of the padded transform, at signed frequency f_k = k/n for
+// k < n/2 and (k - n)/n above, is rotated by exp(-2 pi j f_k τ).  One forward and one inverse GPU transform.
+// A real vector goes through the same complex path and keeps the real part (the reference runs a packed
+// half-size real transform there and rounds its Nyquist bin differently: below 1e-6 of the peak on the
+// band-limited signals a fractional delay is meant for).
 static Veccf délais_frac(const Veccf &x, float τ)
 {
-  const entier n = 2 * x.rows();
-  Veccf x2 = Veccf::zeros(n);
-  x2.segment(n / 4, n / 2) = x;
-  Veccf X = fft(x2);
-  // X *= fftshift(polar(1, -2 pi i tau / n + pi tau))
+  const entier m = x.rows(), n = 2 * m, marge = m / 2;
+  Veccf étendu = Veccf::zeros(n);
+  étendu.segment(marge, m) = x;
+  Veccf X = fft(étendu);
   for (entier k = 0; k < n; k++) {
-    const entier i = (k + n / 2) % n;                        // fftshift(rot)(k) = rot((k + n/2) mod n), n even
-    X(k) *= std::polar(1.0f, -2 * π_f * i * τ / n + π_f * τ);
+    const entier ks = k < n / 2 ? k : k - n;                       // signed bin
+    X(k) *= std::polar(1.0f, (float) (-2.0 * π * (double) ks * (double) τ / (double) n));
   }
-  return ifft(X).segment(n / 4, n / 2).clone();
+  return ifft(X).segment(marge, m).clone();
 }
-static Vecf délais_frac(const Vecf &x, float τ)
+static Vecf délais_frac(const Vecf &x, float τ) { return real(délais_frac(x.as_complex(), τ)); }
+// whole-sample delay: y(i) = x(i - d), zeros shifted in
+template <typename T> static Vecteur<T> délais_entier(const Vecteur<T> &x, entier d)
 {
-  const entier n = 2 * x.rows();
-  Vecf x2 = Vecf::zeros(n);
-  x2.segment(n / 4, n / 2) = x;
-  Veccf X = rtfr_moitié(x2);
-  // the rotation is accumulated by repeated float multiplication, like the reference (:643-660)
-  cfloat rot(1.0f, 0.0f);
-  const cfloat dphi = std::polar(1.0f, (float) (-τ * 2 * π / n));
-  for (entier i = 0; i < n / 2; i++) {
-    if (i == 0)
-      X(i).real((X(i).real() * rot).real());
-    else
-      X(i) *= rot;
-    rot *= dphi;
-  }
-  X(0).imag((X(0).imag() * rot).real());
-  return irtfr_moitié(X).segment(n / 4, n / 2).clone();
-}
-template <typename T> static Vecteur<T> délais_entier(const Vecteur<T> &x, entier τ)
-{
-  if (τ == 0) return x;
   const entier n = x.rows();
-  Vecteur<T> y = Vecteur<T>::zeros(n);
-  if (τ > 0)
-    y.tail(n - τ) = x.head(n - τ);
-  else
-    y.head(n + τ) = x.tail(n + τ);
+  Vecteur<T> y = Vecteur<T>::hote(n);
+  for (entier i = 0; i < n; i++) {
+    const entier j = i - d;
+    y.data()[i] = (j >= 0 && j < n) ? x.data()[j] : T(0);
+  }
   return y;
 }
 template <typename T> Vecteur<T> délais(const Vecteur<T> &x, float τ)
