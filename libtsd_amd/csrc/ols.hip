@@ -400,6 +400,7 @@ int ols_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, hipStream_t st)
       grid = cdiv(cdiv(nint, rounds), 8) * 8;
     }
   }
+  const int64_t b_lo_w = b_lo;
   // edge items, one wave each: [0, b_lo) read the history halo, [b_hi, nblocks) are ragged
   const int64_t n_lo = b_lo, b_tail = b_hi;
   const int ne = (int) (n_lo + (nblocks - b_tail));
@@ -407,7 +408,7 @@ int ols_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, hipStream_t st)
   const int nxt = f->cur ^ 1;
 #define OLS_LAUNCH(REAL)                                                                                                       \
   hipLaunchKernelGGL((ols_kernel<REAL>), dim3((unsigned) (grid + ne + 1)), dim3(64), 0, st, x, (const void *) f->hist[f->cur], \
-                     f->hist[nxt], y, d, d + OLS_N, d + 2 * OLS_N, OLS_N - L, f->HL, L, n, b_lo, b_hi, nblocks, (int) grid, ne,   \
+                     f->hist[nxt], y, d, d + OLS_N, d + 2 * OLS_N, OLS_N - L, f->HL, L, n, b_lo_w, b_hi, nblocks, (int) grid, ne,   \
                      e[0], e[1])
   if (real) OLS_LAUNCH(true);
   else OLS_LAUNCH(false);
