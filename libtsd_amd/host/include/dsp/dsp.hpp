@@ -15,6 +15,11 @@ using Veccf = tsd::Veccf;
 template <typename Te, typename Ts = Te> using FilterGen = tsd::FiltreGen<Te, Ts>;   // dsp/dsp.hpp:462-472
 template <typename Te, typename Ts = Te, typename Tc = tsd::Void> using Filter = tsd::Filtre<Te, Ts, Tc>;
 using tsd::linspace;
+using tsd::randn;
+using tsd::randcn;
+using tsd::sigcos;
+using tsd::sigsin;
+using tsd::sigexp;
 // dsp::resample (dsp/dsp.hpp:499-503)
 template <typename T> Vector<T> resample(const Vector<T> &x, float ratio) { return tsd::rééchan(x, ratio); }
 }  // namespace dsp

@@ -461,6 +461,11 @@ template <typename T> Vecteur<T> surech(const Vecteur<T> &x, entier R)
   for (entier i = 0; i < n; i++) y(i * R) = x(i);
   return y;
 }
+// sigexp / sigcos / sigsin (core/src/tsd.cc:217-245): the phasor advanced by repeated multiplication in double, its
+// modulus renormalised every 1000 samples; cos / sin = its real / imaginary part
+Vecteur<cfloat> sigexp(float f, entier n);
+Vecteur<float> sigcos(float f, entier n);
+Vecteur<float> sigsin(float f, entier n);
 // randn / randcn on a default-seeded engine (core/src/tsd.cc:173,410-483)
 std::default_random_engine &generateur_aleatoire();
 Vecf randn(entier n);

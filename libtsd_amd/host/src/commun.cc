@@ -150,6 +150,21 @@ Veccf randcn(entier n)
   }
   return x;
 }
+Veccf sigexp(float f, entier n)
+{
+  Veccf x = Veccf::hote(n);
+  const cdouble pas = std::polar(1.0, (double) f * 2 * π);
+  cdouble r = 1;
+  for (entier i = 0; i < n; i++) {
+    if (i > 0 && i % 1000 == 0) r /= std::abs(r);          // the modulus is brought back to 1 every 1000 samples
+    x(i) = cfloat(r);
+    r *= pas;
+  }
+  return x;
+}
+Vecf sigcos(float f, entier n) { return real(sigexp(f, n)); }
+Vecf sigsin(float f, entier n) { return imag(sigexp(f, n)); }
+
 entier prochaine_puissance_de_2(entier i)
 {
   const entier lg2 = (entier) std::ceil(std::log((float) i) / std::log(2.0f));

@@ -54,3 +54,26 @@ def test_graph_capture_of_streaming_steps():
         build()
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "GRAPH CAPTURE OK" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def _build_readme_example(tmp_path):
+    exe = str(tmp_path / "readme_call_sites")
+    libdir = os.path.join(ROOT, "libtsd_amd", "lib")
+    subprocess.run(["g++", "-std=c++20", "-O1", "-I" + os.path.join(ROOT, "libtsd_amd", "host", "include"),
+                    os.path.join(ROOT, "examples", "readme_call_sites.cc"), "-L" + libdir, "-ltsd_host", "-ltsdgpu",
+                    "-Wl,-rpath," + libdir, "-o", exe], check=True, capture_output=True)
+    return exe
+
+
+def test_reference_readme_call_sites_compile(tmp_path):
+    """examples/readme_call_sites.cc: the filtering statements of libtsd's README (both APIs, `let` / `soit` spellings,
+    umbrella headers) compile against the mirror as they stand."""
+    build()
+    _build_readme_example(tmp_path)
+
+
+@pytest.mark.gpu
+def test_reference_readme_call_sites_run(tmp_path):
+    build()
+    r = subprocess.run([_build_readme_example(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "README CALL SITES OK" in r.stdout, r.stdout + r.stderr
