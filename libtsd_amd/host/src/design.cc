@@ -91,12 +91,164 @@ Vecf design_rif_prod(const Vecf &h1, const Vecf &h2)
 
 // ---- design: Butterworth low-pass through the bilinear transform (rii.cc:20-23,41-73,
 //      173-187,195-215,405-452) --------------------------------------------------------------
-FRat<cfloat> design_riia(entier n, cstring type, cstring prototype, float fc, float, float)
+// Analog prototypes with cut-off 1 rad/s as zeros / poles / gain, H(s) = k prod(s - z) / prod(s - p), DC gain 1 like the
+// reference's (rii.cc:195-404 forces it through numer.mlt).  Textbook forms: Butterworth and Chebyshev poles on the circle /
+// ellipse; inverse Chebyshev = the reciprocal pole set with zeros at j / cos θ; elliptic through Landen sequences
+// (S. Orfanidis, "Lecture notes on elliptic filter design": degree equation, cd / sn / asn by descending / ascending
+// Landen transformations).  All in double; rounded to float once, at the end of design_riia.
+namespace {
+typedef std::complex<double> cd_t;
+struct Proto {
+  std::vector<cd_t> z, p;
+  double k = 1;
+};
+void gain_dc_unitaire(Proto &h)
 {
-  if (!(type == "lp" || type == "pb") || prototype.substr(0, 1) != "b")
-    échec("design_riia: only the Butterworth low-pass (\"lp\", \"butt\") is built in this hot-path mirror "
-          "(got type '{}', prototype '{}'); other prototypes are design-time code outside the path",
-          type, prototype);
+  cd_t g = 1;
+  for (const cd_t &p : h.p) g *= -p;
+  for (const cd_t &z : h.z) g /= -z;
+  h.k = g.real();
+}
+Proto proto_butterworth(int n)
+{
+  Proto h;
+  for (int k = 1; k <= n; k++) h.p.push_back(std::polar(1.0, π * (2.0 * k + n - 1) / (2.0 * n)));
+  gain_dc_unitaire(h);
+  return h;
+}
+Proto proto_tchebychev(int n, double ondulation_dB, bool inverse)
+{
+  Proto h;
+  const double e2 = std::pow(10.0, ondulation_dB / 10) - 1;
+  const double eps = inverse ? 1 / std::sqrt(e2) : std::sqrt(e2), a = std::asinh(1 / eps) / n;
+  for (int k = 1; k <= n; k++) {
+    const double th = (2.0 * k - 1) * π / (2.0 * n);
+    const cd_t q(-std::sinh(a) * std::sin(th), std::cosh(a) * std::cos(th));
+    h.p.push_back(inverse ? 1.0 / q : q);
+    if (inverse && std::fabs(std::cos(th)) > 1e-12) h.z.push_back(cd_t(0, 1 / std::cos(th)));   // (odd n: the middle zero is at infinity)
+  }
+  gain_dc_unitaire(h);
+  return h;
+}
+// Landen sequence of a modulus: v_{i+1} = (v_i / (1 + sqrt(1 - v_i^2)))^2
+std::vector<double> landen(double k)
+{
+  std::vector<double> v;
+  for (int i = 0; i < 12 && k > 1e-18; i++) {
+    const double kp = std::sqrt((1 - k) * (1 + k));
+    k = (k / (1 + kp)) * (k / (1 + kp));
+    v.push_back(k);
+  }
+  return v;
+}
+cd_t jacobi_cd(cd_t u, double k)     // cd(u K, k), u in units of the quarter period
+{
+  const std::vector<double> v = landen(k);
+  cd_t w = std::cos(u * (π / 2));
+  for (int i = (int) v.size() - 1; i >= 0; i--) w = (1 + v[i]) * w / (1.0 + v[i] * w * w);
+  return w;
+}
+cd_t jacobi_sn(cd_t u, double k)
+{
+  const std::vector<double> v = landen(k);
+  cd_t w = std::sin(u * (π / 2));
+  for (int i = (int) v.size() - 1; i >= 0; i--) w = (1 + v[i]) * w / (1.0 + v[i] * w * w);
+  return w;
+}
+cd_t jacobi_asn(cd_t w, double k)    // inverse of sn, in units of the quarter period
+{
+  std::vector<double> v = landen(k);
+  double avant = k;
+  for (size_t i = 0; i < v.size(); i++) {
+    w = 2.0 * w / ((1 + v[i]) * (1.0 + std::sqrt(1.0 - avant * avant * w * w)));
+    avant = v[i];
+  }
+  return (2 / π) * std::asin(w);
+}
+Proto proto_elliptique(int n, double rp_dB, double rs_dB)
+{
+  Proto h;
+  const double ep = std::sqrt(std::pow(10.0, rp_dB / 10) - 1), es = std::sqrt(std::pow(10.0, rs_dB / 10) - 1);
+  const double k1 = ep / es, k1p = std::sqrt((1 - k1) * (1 + k1));
+  const int L = n / 2;
+  // degree equation: k' = k1'^n prod sn(u_i K1', k1')^4, k = sqrt(1 - k'^2)
+  double kp = std::pow(k1p, n);
+  for (int i = 1; i <= L; i++) kp *= std::pow(std::abs(jacobi_sn((2.0 * i - 1) / n, k1p)), 4);
+  const double k = std::sqrt((1 - kp) * (1 + kp));
+  const cd_t v0 = cd_t(0, -1) * jacobi_asn(cd_t(0, 1) / ep, k1) / (double) n;
+  for (int i = 1; i <= L; i++) {
+    const double u = (2.0 * i - 1) / n;
+    const cd_t zeta = jacobi_cd(u, k);
+    const cd_t z = cd_t(0, 1) / (k * zeta), pl = cd_t(0, 1) * jacobi_cd(cd_t(u, 0) - cd_t(0, 1) * v0, k);
+    h.z.push_back(z);
+    h.z.push_back(std::conj(z));
+    h.p.push_back(pl);
+    h.p.push_back(std::conj(pl));
+  }
+  if (n & 1) h.p.push_back(cd_t(0, 1) * jacobi_sn(cd_t(0, 1) * v0, k));
+  gain_dc_unitaire(h);
+  return h;
+}
+}  // namespace
+
+// design_riia (filtrage.hpp:666-701; rii.cc:405-487): analog prototype -> low-pass / high-pass at the pre-warped
+// frequency -> bilinear transform (fe = 1), the result in pole / zero form.  "butt" + "lp" keeps the reference's own
+// float operation order (configs[3]'s design, compared with the oracle's restatement); the other prototypes and the
+// high-pass go through the double-precision pipeline above.
+static FRat<cfloat> design_riia_generique(entier n, bool passe_haut, const Proto &proto, float fc)
+{
+  const double wa = 2 * std::tan(π * (double) fc);                   // pre-warping, fe = 1
+  std::vector<cd_t> z, p;
+  double k = proto.k;
+  const int np = (int) proto.p.size(), nz = (int) proto.z.size();
+  if (!passe_haut) {                                                  // s -> s / wa
+    for (const cd_t &r : proto.z) z.push_back(r * wa);
+    for (const cd_t &r : proto.p) p.push_back(r * wa);
+    k *= std::pow(wa, np - nz);
+  } else {                                                            // s -> wa / s
+    cd_t g = k;
+    for (const cd_t &r : proto.z) { z.push_back(wa / r); g *= -r; }
+    for (const cd_t &r : proto.p) { p.push_back(wa / r); g /= -r; }
+    for (int i = nz; i < np; i++) z.push_back(0.0);
+    k = g.real();
+  }
+  // bilinear: s = 2 (z - 1) / (z + 1); zeros at infinity land on z = -1
+  Veccf zd((entier) p.size()), pd((entier) p.size());
+  cd_t g = k;
+  for (size_t i = 0; i < p.size(); i++) {
+    pd((entier) i) = cfloat((2.0 + p[i]) / (2.0 - p[i]));
+    g /= (2.0 - p[i]);
+    if (i < z.size()) {
+      zd((entier) i) = cfloat((2.0 + z[i]) / (2.0 - z[i]));
+      g *= (2.0 - z[i]);
+    } else {
+      zd((entier) i) = cfloat(-1.f, 0.f);
+    }
+  }
+  (void) n;
+  FRat<cfloat> h;
+  h.numer = Poly<cfloat>::from_roots(zd);
+  h.denom = Poly<cfloat>::from_roots(pd);
+  h.numer.mlt = cfloat((float) g.real(), 0.f);
+  h.denom.mlt = cfloat(1.f, 0.f);
+  return h;
+}
+
+FRat<cfloat> design_riia(entier n, cstring type, cstring prototype, float fc, float δ_bp, float δ_bc)
+{
+  if (n < 1) échec("design_riia: order {}", n);
+  const bool lp = type == "lp" || type == "pb", hp = type == "hp" || type == "ph";
+  if (!lp && !hp) échec("design_riia: type '{}' is not built (have lp / pb, hp / ph; the reference has no band types either, rii.cc:438-441)", type);
+  const bool butt = prototype.substr(0, 1) == "b";
+  if (!butt || hp) {
+    Proto proto;
+    if (butt) proto = proto_butterworth(n);
+    else if (prototype == "cheb1") proto = proto_tchebychev(n, δ_bp, false);
+    else if (prototype == "cheb2") proto = proto_tchebychev(n, δ_bc, true);
+    else if (prototype.substr(0, 5) == "ellip") proto = proto_elliptique(n, δ_bp, δ_bc);
+    else échec("design_riia: unknown analog prototype '{}' (butt, cheb1, cheb2, ellip)", prototype);
+    return design_riia_generique(n, hp, proto, fc);
+  }
   const float wd = (float) (2 * π * fc);
   const float wa = 2 * 1.0f * std::tan(wd / (2 * 1.0f));
   Veccf z(n), p(n);

@@ -157,6 +157,56 @@ static void test_fragments()
   CHECK(r3.rows() == r1.rows() && ecart_rel(r3, r1) == 0.f, "sharded rééchan must be bit-exact: %d vs %d outputs, %g", r3.rows(), r1.rows(), ecart_rel(r3, r1));
 }
 
+// test_riia (test-filtres.cc:668-679 -> test_design :327-404): the four analog prototypes at order 12, fc = 0.25, 0.1 dB /
+// 60 dB: the magnitude at 2048 frequencies of [0, 0.5) stays within 0.1 of 1 over the first 800 bins and within 0.1 of 0
+// over the last 800 (mirrored for the high-pass).  Evaluated from the poles and zeros, and -- the data path -- measured
+// through filtrer() on the GPU at bins of both bands.
+static void test_riia()
+{
+  auto gain_at = [](const FRat<cfloat> &h, double f) {
+    const cdouble w = std::polar(1.0, 2 * π * f);
+    cdouble H = cdouble(h.numer.mlt) / cdouble(h.denom.mlt);
+    for (int i = 0; i < h.numer.coefs.rows(); i++) H *= (w - cdouble(h.numer.coefs(i)));
+    for (int i = 0; i < h.denom.coefs.rows(); i++) H /= (w - cdouble(h.denom.coefs(i)));
+    return std::abs(H);
+  };
+  const int npts = 2048;
+  for (const char *type : {"lp", "hp"})
+    for (const char *proto : {"ellip", "butt", "cheb1", "cheb2"}) {
+      const bool hp = type[0] == 'h';
+      const FRat<cfloat> h = design_riia(12, type, proto, 0.25f, 0.1f, 60);
+      CHECK(h.numer.mode_racines && h.denom.mode_racines && h.numer.coefs.rows() == 12 && h.denom.coefs.rows() == 12, "design_riia(%s, %s): 12 zeros and poles", type, proto);
+      double emax_bp = 0, emax_bc = 0, rmax = 0;
+      for (int i = 0; i < 12; i++) rmax = std::max(rmax, (double) std::abs(h.denom.coefs(i)));
+      for (int k = 0; k < npts; k++) {
+        const double g = gain_at(h, 0.5 * k / npts);
+        const bool bande_passante = hp ? k >= npts - 800 : k < 800, bande_coupee = hp ? k < 800 : k >= npts - 800;
+        if (bande_passante) emax_bp = std::max(emax_bp, std::abs(g - 1));
+        if (bande_coupee) emax_bc = std::max(emax_bc, g);
+      }
+      CHECK(rmax < 1 && emax_bp <= 0.1 && emax_bc <= 0.1, "design_riia(12, %s, %s): template missed (pass band %g, stop band %g, pole radius %g)", type, proto, emax_bp, emax_bc, rmax);
+      // through the GPU cascade: one bin of each band
+      const int n = 1 << 15;
+      for (double f : {hp ? 0.45 : 0.05, hp ? 0.05 : 0.45}) {
+        Veccf x(n);
+        for (int i = 0; i < n; i++) x(i) = std::polar(1.0f, (float) (2 * π * f * i));
+        const Veccf y = filtrer<cfloat>(Design(h), x);
+        double m = 0;
+        for (int i = n / 2; i < n; i++) m += std::abs(y(i));
+        m /= n / 2;
+        CHECK(std::abs(m - gain_at(h, f)) <= 2e-3, "design_riia(%s, %s) through filtrer at f = %g: %g vs %g", type, proto, f, m, gain_at(h, f));
+      }
+    }
+  // orders around the odd / even cases of every prototype stay stable and keep a unit DC gain
+  for (int n : {1, 2, 3, 5, 8})
+    for (const char *proto : {"ellip", "butt", "cheb1", "cheb2"}) {
+      const FRat<cfloat> h = design_riia(n, "lp", proto, 0.2f, 0.5f, 40);
+      double rmax = 0;
+      for (int i = 0; i < h.denom.coefs.rows(); i++) rmax = std::max(rmax, (double) std::abs(h.denom.coefs(i)));
+      CHECK(rmax < 1 && std::abs(gain_at(h, 0) - 1) < 1e-3, "design_riia(%d, lp, %s): DC gain %g, pole radius %g", n, proto, gain_at(h, 0), rmax);
+    }
+}
+
 // design_biquad (test-filtres.cc:296-314 only plots): every type through filtrer() -- coefficient form,
 // factorised, two-pole section on the GPU -- against the biquad's own frequency response
 static void test_design_biquad()
@@ -1257,6 +1307,7 @@ int main(int argc, char **argv)
   test_fir_vs_oracle();
   test_sois();
   test_design_biquad();
+  test_riia();
   for (int n : {16, 1, 2, 3, 4, 5, 8, 10, 17, 128, 129, 1024}) { test_fft_valide(n, false); test_fft_valide(n, true); }
   test_fft_misc();
   test_reechan();
