@@ -41,6 +41,8 @@ typedef enum { TSDGPU_F32 = 0, TSDGPU_C64 = 1 } tsdgpu_dtype;
 const char *tsdgpu_last_error(void);
 /* number of visible HIP devices (0 on a CPU-only host; never fails) */
 int tsdgpu_device_count(void);
+/* the calling thread's current HIP device (what allocations and handle creations land on); -1 without a device */
+int tsdgpu_current_device(void);
 /* "libtsd_amd x.y (gfx950)" */
 const char *tsdgpu_version(void);
 

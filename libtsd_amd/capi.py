@@ -46,6 +46,7 @@ def _declare(L):
     L.tsdgpu_last_error.restype = C.c_char_p
     L.tsdgpu_version.restype = C.c_char_p
     L.tsdgpu_device_count.restype = i32
+    L.tsdgpu_current_device.restype = i32
     L.tsdgpu_fir_create.argtypes = [C.POINTER(vp), i32, i32, vp, i32, i32]
     L.tsdgpu_fir_step.argtypes = [vp, vp, vp, i64, vp]
     L.tsdgpu_fir_reset.argtypes = [vp]

@@ -215,6 +215,16 @@ int tsdgpu_device_count(void)
   return n;
 }
 
+int tsdgpu_current_device(void)
+{
+  int d = -1;
+  if (hipGetDevice(&d) != hipSuccess) {
+    (void) hipGetLastError();
+    return -1;
+  }
+  return d;
+}
+
 const char *tsdgpu_version(void) { return "libtsd_amd 0.2 (gfx950)"; }
 
 int tsdgpu_malloc(void **out, size_t bytes)

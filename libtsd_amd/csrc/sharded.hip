@@ -334,7 +334,8 @@ int tsdgpu_sharded_step_host(tsdgpu_sharded *h, const void *x, int64_t n, void *
       if (!rc && ocap > 0) rc = h->out[g].reserve((size_t) ocap * esz);
       if (!rc && cnt > 0 && hipMemcpyAsync(h->in[g].p, xs + (size_t) lo * esz, (size_t) cnt * esz, hipMemcpyHostToDevice, st) != hipSuccess)
         rc = set_err(TSDGPU_ERR_HIP, "chunk upload failed: %s", hipGetErrorString(hipGetLastError()));
-      if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = set_err(TSDGPU_ERR_HIP, "upload sync failed");
+      // unconditional: `hal` must outlive its copy whatever failed above
+      if (hipStreamSynchronize(st) != hipSuccess && !rc) rc = set_err(TSDGPU_ERR_HIP, "upload sync failed");
     } while (0);
     rdv.wait();                                         // every shard holds its inputs: y may now be written
     if (!rc) {
@@ -363,7 +364,10 @@ int tsdgpu_sharded_step_host(tsdgpu_sharded *h, const void *x, int64_t n, void *
   (void) hipSetDevice(prev);
   int64_t total = 0;
   for (int g = 0; g < N; g++) {
-    if (rcs[(size_t) g]) return set_err(rcs[(size_t) g], "shard %d: %s", g, msgs[(size_t) g].c_str());
+    if (rcs[(size_t) g]) {
+      h->carry = carry_avant;       // a failed call consumes nothing: the stream position and its tail stay as they were
+      return set_err(rcs[(size_t) g], "shard %d: %s", g, msgs[(size_t) g].c_str());
+    }
     total += outs[(size_t) g];
   }
   h->seen += n;
@@ -409,8 +413,8 @@ int tsdgpu_sharded_step_parts(tsdgpu_sharded *h, const void *const *x_parts, con
     if (need > 0) TSD_HIP(hipMemcpyAsync(dst, h->carry.data() + (size_t) (H - need) * esz, (size_t) need * esz, hipMemcpyHostToDevice, h->stream[g]));
   }
   // the new carry: the tail of this call, gathered to the host (small) before any shard writes in place
+  std::vector<char> nc = h->carry;
   {
-    std::vector<char> nc = h->carry;
     int64_t need = std::min(H, n), kept = H - need;
     if (kept > 0 && need > 0) std::memmove(nc.data(), nc.data() + (size_t) need * esz, (size_t) kept * esz);
     int64_t fill = H;
@@ -428,7 +432,6 @@ int tsdgpu_sharded_step_parts(tsdgpu_sharded *h, const void *const *x_parts, con
       TSD_HIP(hipSetDevice(h->dev[g]));
       TSD_HIP(hipStreamSynchronize(h->stream[g]));     // halos landed: in-place shards may start
     }
-    h->carry.swap(nc);
   }
   // (2) the shards, concurrently (one stream each; the enqueue itself is cheap)
   std::vector<int64_t> got((size_t) N, 0);
@@ -450,6 +453,7 @@ int tsdgpu_sharded_step_parts(tsdgpu_sharded *h, const void *const *x_parts, con
     if (out_counts) out_counts[g] = got[(size_t) g];
     total += got[(size_t) g];
   }
+  h->carry.swap(nc);                // committed with the position: a failed call consumes nothing
   h->seen += n;
   h->out_total += total;
   return TSDGPU_OK;

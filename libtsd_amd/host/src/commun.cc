@@ -17,25 +17,27 @@ namespace detail {
 // blocks are kept and handed out again (best fit within 25 %, at most `limite` bytes kept per kind).
 namespace {
 struct CacheBlocs {
+  // a block belongs to the device that was current when it was allocated (-1: page-locked host memory)
+  typedef std::pair<int, size_t> Cle;
   std::mutex m;
-  std::multimap<size_t, void *> libres;
-  std::unordered_map<void *, size_t> tailles;     // capacity of every live block of this kind
+  std::multimap<Cle, void *> libres;
+  std::unordered_map<void *, Cle> tailles;        // (device, capacity) of every live block of this kind
   size_t garde = 0, limite;
   explicit CacheBlocs(size_t lim) : limite(lim) {}
-  void *prend(size_t octets)
+  void *prend(size_t octets, int dev)
   {
     std::lock_guard<std::mutex> l(m);
-    auto it = libres.lower_bound(octets);
-    if (it == libres.end() || it->first > octets + octets / 4) return nullptr;
+    auto it = libres.lower_bound(Cle(dev, octets));
+    if (it == libres.end() || it->first.first != dev || it->first.second > octets + octets / 4) return nullptr;
     void *p = it->second;
-    garde -= it->first;
+    garde -= it->first.second;
     libres.erase(it);
     return p;
   }
-  void note(void *p, size_t octets)
+  void note(void *p, size_t octets, int dev)
   {
     std::lock_guard<std::mutex> l(m);
-    tailles[p] = octets;
+    tailles[p] = Cle(dev, octets);
   }
   // true: kept for reuse; false: the caller frees it
   bool rend(void *p)
@@ -43,11 +45,11 @@ struct CacheBlocs {
     std::lock_guard<std::mutex> l(m);
     auto it = tailles.find(p);
     if (it == tailles.end()) return false;
-    if (garde + it->second > limite) {
+    if (garde + it->second.second > limite) {
       tailles.erase(it);
       return false;
     }
-    garde += it->second;
+    garde += it->second.second;
     libres.emplace(it->second, p);
     return true;
   }
@@ -71,10 +73,11 @@ CacheBlocs &cache_hote()
 
 void *gpu_alloc(size_t octets)
 {
-  if (void *q = cache_gpu().prend(octets)) return q;
+  const int dev = tsdgpu_current_device();
+  if (void *q = cache_gpu().prend(octets, dev)) return q;
   void *p = nullptr;
   if (tsdgpu_malloc(&p, octets)) échec("Vecteur (device): {}", tsdgpu_last_error());
-  cache_gpu().note(p, octets);
+  cache_gpu().note(p, octets, dev);
   return p;
 }
 void gpu_free(void *p)
@@ -87,9 +90,9 @@ void *hote_alloc(size_t octets, bool *verrouillée)
   static const bool gpu = tsdgpu_device_count() > 0 && std::getenv("TSD_AMD_NO_PINNED") == nullptr;
   if (gpu) {
     *verrouillée = true;
-    if (void *q = cache_hote().prend(octets)) return q;
+    if (void *q = cache_hote().prend(octets, -1)) return q;
     if (tsdgpu_malloc_host(&p, octets) == 0 && p) {
-      cache_hote().note(p, octets);
+      cache_hote().note(p, octets, -1);
       return p;
     }
   }
