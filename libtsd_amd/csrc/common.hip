@@ -1,5 +1,11 @@
 // common.hip -- error reporting and host/device staging for the C-ABI shim.
 #include "common.hpp"
+#include <map>
+#include <string>
+#include <mutex>
+#include <thread>
+#include <deque>
+#include <condition_variable>
 #include <algorithm>
 #include <cstdlib>
 
@@ -147,23 +153,66 @@ struct HostPipe {
 };
 HostPipe &host_pipe()
 {
-  static thread_local HostPipe p;     // one per calling thread: handles are not shared between threads mid-step
-  return p;
+  // one per calling thread (handles are not shared between threads mid-step) and per device (streams belong to
+  // the device that was current when they were created)
+  static thread_local std::map<int, HostPipe> pipes;
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess) (void) hipGetLastError();
+  return pipes[d];
 }
 }  // namespace
 
+static int hip_rc(hipError_t e, const char *what)
+{
+  if (e == hipSuccess) return TSDGPU_OK;
+  (void) hipGetLastError();
+  return set_err(TSDGPU_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+
+// true for plain (malloc'd, not registered) host memory: copies from / to it block the calling thread
+static bool is_pageable_host(const void *p)
+{
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+    (void) hipGetLastError();
+    return true;
+  }
+  return attr.type == hipMemoryTypeUnregistered;
+}
+
 int pipelined_host_step(const void *x, void *y, int64_t n, size_t esz, hipStream_t user,
                         const std::function<int(const void *, void *, int64_t, hipStream_t)> &step)
+{
+  // same-length operator: every chunk produces what it consumed (y may be x: a chunk is written after it was read)
+  return pipelined_host_step_var(
+      x, n, esz, y, esz, nullptr, 1, user, [](int64_t c) { return c; },
+      [&step](const void *cx, void *cy, int64_t cnt, int64_t, int64_t *got, hipStream_t q) {
+        *got = cnt;
+        return step(cx, cy, cnt, q);
+      });
+}
+
+// One pipeline for both kinds of operator.  `step(in, out, cnt, cap, &got, stream)` enqueues the operator on device
+// pointers and reports the chunk's output count on the host; the chunks' outputs are laid one behind the other.
+//  * page-locked host memory: the copies are asynchronous, one thread enqueues everything on three streams;
+//  * pageable host memory (what a libtsd Tab holds): a copy blocks its caller until the runtime has staged it, so the
+//    copies OUT run on a second host thread -- PCIe then carries both directions at once here too.
+int pipelined_host_step_var(const void *x, int64_t n, size_t esz_in, void *y, size_t esz_out, int64_t *n_out, int64_t chunk_align,
+                            hipStream_t user, const std::function<int64_t(int64_t)> &out_cap,
+                            const std::function<int(const void *, void *, int64_t, int64_t, int64_t *, hipStream_t)> &step)
 {
   HostPipe &P = host_pipe();
   int rc = P.init();
   if (rc) return rc;
   static const size_t CHUNK = getenv("TSDGPU_PIPE_CHUNK_MB") ? (size_t) atoi(getenv("TSDGPU_PIPE_CHUNK_MB")) << 20 : PIPE_CHUNK_BYTES;
-  const int64_t per = std::max<int64_t>(1024, (int64_t) (CHUNK / esz));
+  static const bool one_thread = getenv("TSDGPU_PIPE_ONE_THREAD") != nullptr;
+  const int64_t al = std::max<int64_t>(1, chunk_align);
+  const int64_t per = std::max<int64_t>(al, std::max<int64_t>(1024, (int64_t) (CHUNK / esz_in)) / al * al);
   const int64_t nchunks = (n + per - 1) / per;
+  const int64_t cap = std::max<int64_t>(out_cap(std::min(per, n)), 1);
   for (int b = 0; b < 2; b++) {
-    rc = P.bin[b].reserve((size_t) std::min(per, n) * esz);
-    if (!rc) rc = P.bout[b].reserve((size_t) std::min(per, n) * esz);
+    rc = P.bin[b].reserve((size_t) std::min(per, n) * esz_in);
+    if (!rc) rc = P.bout[b].reserve((size_t) cap * esz_out);
     if (rc) return rc;
   }
   // work already queued on the caller's stream (e.g. a history upload) comes first
@@ -172,31 +221,119 @@ int pipelined_host_step(const void *x, void *y, int64_t n, size_t esz, hipStream
   TSD_HIP(hipStreamWaitEvent(P.s_k, P.e_user, 0));
   const char *xs = (const char *) x;
   char *ys = (char *) y;
-  for (int64_t c = 0; c < nchunks; c++) {
+  const bool two_threads = !one_thread && nchunks >= 2 && (is_pageable_host(x) || is_pageable_host(y));
+
+  // ---- the copies out, on their own thread when they block -------------------------------------------------------
+  struct Sortie { int b; int64_t off, got; };
+  std::mutex m;
+  std::condition_variable cv;
+  std::deque<Sortie> file;
+  int64_t sorties_faites = 0;          // chunks whose outputs are on the host
+  bool fini = false;
+  int rc_out = TSDGPU_OK;
+  std::string msg_out;
+  int dev = 0;
+  (void) hipGetDevice(&dev);
+  auto copie_sortie = [&](const Sortie &o) -> int {
+    TSD_HIP(hipStreamWaitEvent(P.s_out, P.e_k[o.b], 0));
+    if (o.got > 0) TSD_HIP(hipMemcpyAsync(ys + (size_t) o.off * esz_out, P.bout[o.b].p, (size_t) o.got * esz_out, hipMemcpyDeviceToHost, P.s_out));
+    TSD_HIP(hipEventRecord(P.e_out[o.b], P.s_out));
+    return TSDGPU_OK;
+  };
+  std::thread fil;
+  if (two_threads)
+    fil = std::thread([&] {
+      (void) hipSetDevice(dev);
+      for (;;) {
+        Sortie o;
+        {
+          std::unique_lock<std::mutex> l(m);
+          cv.wait(l, [&] { return fini || !file.empty(); });
+          if (file.empty()) return;
+          o = file.front();
+          file.pop_front();
+        }
+        int r = copie_sortie(o);
+        if (!r && hipStreamSynchronize(P.s_out) != hipSuccess) r = set_err(TSDGPU_ERR_HIP, "host pipeline: copy out failed");
+        std::lock_guard<std::mutex> l(m);
+        if (r && !rc_out) {
+          rc_out = r;
+          msg_out = last_error_ref();
+        }
+        sorties_faites++;
+        cv.notify_all();
+      }
+    });
+  auto arrete_fil = [&] {
+    if (!two_threads) return;
+    {
+      std::lock_guard<std::mutex> l(m);
+      fini = true;
+    }
+    cv.notify_all();
+    fil.join();
+  };
+
+  int64_t produced = 0;
+  for (int64_t c = 0; c < nchunks && !rc; c++) {
     const int b = (int) (c & 1);
     const int64_t off = c * per, cnt = std::min(per, n - off);
-    if (c >= 2) TSD_HIP(hipStreamWaitEvent(P.s_in, P.e_k[b], 0));          // chunk c-2's kernels have read bin[b]
-    TSD_HIP(hipMemcpyAsync(P.bin[b].p, xs + (size_t) off * esz, (size_t) cnt * esz, hipMemcpyHostToDevice, P.s_in));
-    TSD_HIP(hipEventRecord(P.e_in[b], P.s_in));
-    TSD_HIP(hipStreamWaitEvent(P.s_k, P.e_in[b], 0));
-    if (c >= 2) TSD_HIP(hipStreamWaitEvent(P.s_k, P.e_out[b], 0));         // chunk c-2's D2H has read bout[b]
-    rc = step(P.bin[b].p, P.bout[b].p, cnt, P.s_k);
-    if (rc) {
-      (void) hipStreamSynchronize(P.s_k);
-      (void) hipStreamSynchronize(P.s_out);
-      return rc;
+    if (two_threads) {
+      if (c >= 2) {
+        // chunk c-2 is on the host: its kernels have read bin[b] and its copy has read bout[b]
+        std::unique_lock<std::mutex> l(m);
+        cv.wait(l, [&] { return sorties_faites >= c - 1 || rc_out; });
+        if (rc_out) break;
+      }
+    } else if (c >= 2) {
+      rc = hip_rc(hipStreamWaitEvent(P.s_in, P.e_k[b], 0), "host pipeline");          // chunk c-2's kernels have read bin[b]
+      if (!rc) rc = hip_rc(hipStreamWaitEvent(P.s_k, P.e_out[b], 0), "host pipeline");  // chunk c-2's D2H has read bout[b]
+      if (rc) break;
     }
-    TSD_HIP(hipEventRecord(P.e_k[b], P.s_k));
-    TSD_HIP(hipStreamWaitEvent(P.s_out, P.e_k[b], 0));
-    TSD_HIP(hipMemcpyAsync(ys + (size_t) off * esz, P.bout[b].p, (size_t) cnt * esz, hipMemcpyDeviceToHost, P.s_out));
-    TSD_HIP(hipEventRecord(P.e_out[b], P.s_out));
+    rc = hip_rc(hipMemcpyAsync(P.bin[b].p, xs + (size_t) off * esz_in, (size_t) cnt * esz_in, hipMemcpyHostToDevice, P.s_in), "host pipeline: copy in");
+    if (!rc) rc = hip_rc(hipEventRecord(P.e_in[b], P.s_in), "host pipeline");
+    if (!rc) rc = hip_rc(hipStreamWaitEvent(P.s_k, P.e_in[b], 0), "host pipeline");
+    if (rc) break;
+    int64_t got = 0;
+    rc = step(P.bin[b].p, P.bout[b].p, cnt, cap, &got, P.s_k);
+    if (rc) break;
+    rc = hip_rc(hipEventRecord(P.e_k[b], P.s_k), "host pipeline");
+    if (rc) break;
+    const Sortie o{b, produced, got};
+    if (two_threads) {
+      {
+        std::lock_guard<std::mutex> l(m);
+        file.push_back(o);
+      }
+      cv.notify_all();
+    } else {
+      rc = copie_sortie(o);
+    }
+    produced += got;
   }
-  TSD_HIP(hipStreamSynchronize(P.s_out));
-  TSD_HIP(hipStreamSynchronize(P.s_k));
+  arrete_fil();        // (drains its queue first)
+  const std::string msg = rc ? last_error_ref() : std::string();
+  (void) hipStreamSynchronize(P.s_out);
+  (void) hipStreamSynchronize(P.s_k);
+  if (rc) return set_err(rc, "%s", msg.c_str());
+  if (rc_out) return set_err(rc_out, "%s", msg_out.c_str());
   // later work on the caller's stream sees the operator's new state
   TSD_HIP(hipEventRecord(P.e_user, P.s_k));
   TSD_HIP(hipStreamWaitEvent(user, P.e_user, 0));
+  if (n_out) *n_out = produced;
   return TSDGPU_OK;
+}
+
+bool host_pipe_enabled()
+{
+  static const bool on = getenv("TSDGPU_NO_PIPE") == nullptr;
+  return on;
+}
+
+bool host_ranges_overlap(const void *a, size_t na, const void *b, size_t nb)
+{
+  const char *pa = (const char *) a, *pb = (const char *) b;
+  return pa < pb + nb && pb < pa + na;
 }
 
 }  // namespace tsdgpu

@@ -63,6 +63,13 @@ constexpr size_t PIPE_MIN_BYTES = (size_t) 8 << 20;      // below this one H2D /
 constexpr size_t PIPE_CHUNK_BYTES = (size_t) 16 << 20;
 int pipelined_host_step(const void *x, void *y, int64_t n, size_t elem_bytes, hipStream_t user_stream,
                         const std::function<int(const void *, void *, int64_t, hipStream_t)> &step);
+// variable output length (resampler, integer-rate stages): `step(in, out, cnt, cap, &got, stream)` reports the chunk's
+// output count on the host; chunk lengths are multiples of chunk_align; out_cap(cnt) bounds the outputs of cnt inputs
+int pipelined_host_step_var(const void *x, int64_t n, size_t esz_in, void *y, size_t esz_out, int64_t *n_out, int64_t chunk_align,
+                            hipStream_t user_stream, const std::function<int64_t(int64_t)> &out_cap,
+                            const std::function<int(const void *, void *, int64_t, int64_t, int64_t *, hipStream_t)> &step);
+bool host_ranges_overlap(const void *a, size_t na, const void *b, size_t nb);
+bool host_pipe_enabled();     // false with TSDGPU_NO_PIPE=1 (A/B switch: whole-vector staging instead)
 
 // Serialises use of a handle's scratch buffers: host threads through the mutex, streams through
 // an event (a step on another stream waits for the previous step's work).  libtsd's Spectrum calls

@@ -375,7 +375,7 @@ int tsdgpu_fir_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, void *stre
   TSD_CHECK(x != nullptr && y != nullptr, "fir_step: NULL buffer");
   hipStream_t st = (hipStream_t) stream;
   const size_t bytes = (size_t) n * dtype_size(f->data_type);
-  if (bytes >= PIPE_MIN_BYTES && !is_device_ptr(x) && !is_device_ptr(y)) {
+  if (bytes >= PIPE_MIN_BYTES && host_pipe_enabled() && !is_device_ptr(x) && !is_device_ptr(y)) {
     // large host vectors: chunked H2D / kernel / D2H pipeline (the history carries from chunk to chunk)
     return pipelined_host_step(x, y, n, dtype_size(f->data_type), st,
                                [f](const void *cx, void *cy, int64_t cnt, hipStream_t s) { return tsdgpu_fir_step(f, cx, cy, cnt, s); });

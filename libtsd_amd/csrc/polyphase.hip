@@ -398,6 +398,18 @@ int tsdgpu_polyfir_step(tsdgpu_polyfir *p, const void *x, int64_t n, void *y, in
             (long long) y_capacity);
   TSD_CHECK(x != nullptr && (nout == 0 || y != nullptr), "polyfir_step: NULL buffer");
   const size_t sz = dtype_size(p->data_type);
+  // large HOST vectors: chunked H2D / kernel / D2H pipeline (chunks are whole multiples of the rate, so a chunk of a
+  // decimating stage never leaves a partial group to the next one beyond what the stage's own counter carries)
+  if ((size_t) n * sz >= PIPE_MIN_BYTES && host_pipe_enabled() && y != nullptr && !is_device_ptr(x) && !is_device_ptr(y) &&
+      !host_ranges_overlap(x, (size_t) n * sz, y, (size_t) nout * sz)) {
+    const bool up = p->kind == TSDGPU_POLY_UPS;
+    const int R = std::max(p->R, 1);
+    return pipelined_host_step_var(
+        x, n, sz, y, sz, n_out, R, st, [up, R](int64_t c) { return up ? c * R : c / R + 2; },
+        [p](const void *cx, void *cy, int64_t cnt, int64_t cap, int64_t *got, hipStream_t q) {
+          return tsdgpu_polyfir_step(p, cx, cnt, cy, cap, got, q);
+        });
+  }
   const void *dx = nullptr;
   void *dy = nullptr;
   bool staged = false;
@@ -723,7 +735,7 @@ int tsdgpu_rii_step(tsdgpu_rii *r, const void *x, void *y, int64_t n, void *stre
   if (r->path == 0) return tsdgpu_sos_step(r->sos, x, y, n, stream);
   hipStream_t st = (hipStream_t) stream;
   const size_t bytes = (size_t) n * dtype_size(r->data_type);
-  if (bytes >= PIPE_MIN_BYTES && !is_device_ptr(x) && !is_device_ptr(y))
+  if (bytes >= PIPE_MIN_BYTES && host_pipe_enabled() && !is_device_ptr(x) && !is_device_ptr(y))
     return pipelined_host_step(x, y, n, dtype_size(r->data_type), st,
                                [r](const void *cx, void *cy, int64_t cnt, hipStream_t q) { return tsdgpu_rii_step(r, cx, cy, cnt, q); });
   const void *dx = nullptr;

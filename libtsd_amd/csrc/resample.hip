@@ -746,6 +746,22 @@ int tsdgpu_resampler_step(tsdgpu_resampler *r, const void *x, int64_t n, void *y
   if (n == 0) return TSDGPU_OK;
   TSD_CHECK(x != nullptr, "resampler_step: NULL input");
   hipStream_t st = (hipStream_t) stream;
+  // a large HOST vector goes through in chunks: H2D of chunk i+1, the kernel of chunk i and D2H of chunk i-1 overlap
+  // (position, window and output offset are carried from chunk to chunk exactly as between two calls)
+  if ((size_t) n * dtype_size(r->data_type) >= PIPE_MIN_BYTES && host_pipe_enabled() && y != nullptr && !is_device_ptr(x) && !is_device_ptr(y)) {
+    const size_t esz = dtype_size(r->data_type);
+    const int64_t total = tsdgpu_resampler_out_count(r, n);
+    if (total < 0) return TSDGPU_ERR_INVALID;
+    TSD_CHECK(total <= y_capacity, "resampler_step: output needs %lld samples, capacity is %lld", (long long) total, (long long) y_capacity);
+    if (!host_ranges_overlap(x, (size_t) n * esz, y, (size_t) total * esz)) {
+      const double ratio = (double) r->ratio;
+      return pipelined_host_step_var(
+          x, n, esz, y, esz, n_out, 1, st, [ratio](int64_t c) { return (int64_t) ((double) c * ratio * 1.0001) + 64; },
+          [r](const void *cx, void *cy, int64_t cnt, int64_t cap, int64_t *got, hipStream_t q) {
+            return tsdgpu_resampler_step(r, cx, cnt, cy, cap, got, q);
+          });
+    }
+  }
   float ph_end;
   int64_t cum_end;
   // (the schedule is shared between the handles of a ratio: held while this call reads or extends it)

@@ -45,6 +45,20 @@ int main(int argc, char **argv)
     best = std::min(best, ms_since(t0));
   }
   printf("{\"case\": \"filtrer() one-shot, host pinned Veccf (allocates its output)\", \"log2n\": %d, \"ms\": %.3f, \"Msamples_s\": %.0f}\n", log2n, best, gs / best * 1e3);
+  // rééchan-style step on host vectors: variable output length through the same chunked pipeline
+  {
+    auto r = filtre_reechan<cfloat>(160.f / 147);
+    Veccf yr;
+    r->step(x, yr);
+    best = 1e30;
+    for (int it = 0; it < 3; it++) {
+      auto t0 = std::chrono::steady_clock::now();
+      r->step(x, yr);
+      best = std::min(best, ms_since(t0));
+    }
+    printf("{\"case\": \"filtre_reechan(160/147) step, host pinned Veccf\", \"log2n\": %d, \"ms\": %.3f, \"Msamples_s\": %.0f, \"outputs\": %d}\n", log2n, best,
+           gs / best * 1e3, yr.rows());
+  }
   // pageable host memory (malloc): what a libtsd Tab holds
   {
     cfloat *px = (cfloat *) malloc((size_t) n * sizeof(cfloat)), *py = (cfloat *) malloc((size_t) n * sizeof(cfloat));

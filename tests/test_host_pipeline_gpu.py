@@ -61,3 +61,67 @@ def test_sos_and_rii_host_pipeline(tg, orc):
     m = 4000
     ref = orc.Rii(nu, de).step(x[:m])
     assert np.abs(yh[:m] - ref).max() <= 1e-5 * np.abs(ref).max()
+
+
+# variable output length: the resampler and the integer-rate stages report each chunk's output count on the host and
+# the chunks' outputs are laid one behind the other (pipelined_host_step_var)
+def test_resampler_host_pipeline_matches_resident(tg, orc):
+    import torch
+    n = (5 << 20) + 4321                       # 40 MiB of complex samples: three chunks
+    x = crand(n, 3)
+    for ratio in (160.0 / 147, 0.7311):
+        yh = tg.Resampler(ratio, tg.C64).step(x)
+        yd = tg.Resampler(ratio, tg.C64).step(torch.from_numpy(x).cuda()).cpu().numpy()
+        assert yh.shape == yd.shape
+        assert np.array_equal(yh, yd)          # the schedule and the per-output arithmetic do not depend on the cut
+        # two calls (the second one short: plain staging), then the oracle across the first chunk border
+        r = tg.Resampler(ratio, tg.C64)
+        y2 = np.concatenate([r.step(x[: 4 << 20]), r.step(x[4 << 20:])])
+        assert np.array_equal(y2, yd)
+    # the oracle on the head of the stream (the resident run above was compared whole)
+    ref = orc.Resampler(160.0 / 147).step(x[: 40000])
+    yy = tg.Resampler(160.0 / 147, tg.C64).step(x)
+    assert np.abs(yy[: ref.shape[0]] - ref).max() <= 1e-5 * np.abs(ref).max()
+    # capacity is checked before anything is written
+    r = tg.Resampler(160.0 / 147, tg.C64)
+    small = np.empty(n, np.complex64)
+    with pytest.raises(tg.TsdGpuError):
+        r.step(x, small)
+    assert r.out_offset == 0
+
+
+@pytest.mark.parametrize("kind,R", [("decim", 3), ("decim", 8), ("halfband", 2), ("ups", 3), ("pick", 5)])
+def test_polyfir_host_pipeline_matches_resident(tg, orc, kind, R):
+    import torch
+    n = (3 << 20) + 1001                       # 24 MiB of complex samples
+    x = crand(n, 4)
+    h = orc.design_rif_fen(31 if kind != "halfband" else 31, "lp", 0.4 / R).astype(np.float32)
+    code = {"decim": tg.POLY_DECIM, "halfband": tg.POLY_HALFBAND, "ups": tg.POLY_UPS, "pick": tg.POLY_PICK}[kind]
+    mk = lambda: tg.PolyFir(code, tg.C64, None if kind == "pick" else h, R)
+    yh = mk().step(x)
+    yd = mk().step(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert yh.shape == yd.shape
+    assert np.array_equal(yh, yd)
+    f = mk()
+    y2 = np.concatenate([f.step(x[: (2 << 20) + 1]), f.step(x[(2 << 20) + 1:])])
+    assert np.array_equal(y2, yd)
+
+
+# page-locked host memory (what the C++ mirror's Vecteur holds from 1 MiB): asynchronous copies, one enqueueing thread;
+# numpy arrays above are pageable and take the two-thread flavour
+def test_pinned_host_memory_pipeline(tg, orc):
+    import torch
+    n = (5 << 20) + 99
+    x = crand(n, 5)
+    xp = torch.from_numpy(x).pin_memory()
+    h = orc.design_rif_fen(63, "lp", 0.1)
+    yp = torch.empty(n, dtype=torch.complex64).pin_memory()
+    tg.Fir(h, tg.C64, tg.FIR_DIRECT).step(xp, yp)
+    yd = tg.Fir(h, tg.C64, tg.FIR_DIRECT).step(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert np.array_equal(yp.numpy(), yd)
+    r = tg.Resampler(160.0 / 147, tg.C64)
+    yo = torch.empty(r.out_count(n), dtype=torch.complex64).pin_memory()
+    got = r.step(xp, yo)
+    yd = tg.Resampler(160.0 / 147, tg.C64).step(torch.from_numpy(x).cuda()).cpu().numpy()
+    assert got.shape[0] == yd.shape[0]
+    assert np.array_equal(got.numpy(), yd)
