@@ -275,7 +275,7 @@ int tsdgpu_sharded_step_host(tsdgpu_sharded *h, const void *x, int64_t n, void *
   TSD_CHECK(n >= 0, "sharded_step_host: negative length");
   if (n_out) *n_out = 0;
   if (n == 0) return TSDGPU_OK;
-  TSD_CHECK(x != nullptr && y != nullptr, "sharded_step_host: NULL buffer");
+  TSD_CHECK(x != nullptr, "sharded_step_host: NULL input");
   TSD_CHECK(!is_device_ptr(x) && !is_device_ptr(y), "sharded_step_host: x and y must be host vectors (resident chunks go through tsdgpu_sharded_step_parts)");
   const size_t esz = h->esz();
   const int N = h->nshards;
@@ -300,7 +300,10 @@ int tsdgpu_sharded_step_host(tsdgpu_sharded *h, const void *x, int64_t n, void *
     if (rc) return rc;
     TSD_CHECK(off[(size_t) N] - off[0] <= y_capacity, "sharded_step_host: output capacity %lld < %lld outputs", (long long) y_capacity,
               (long long) (off[(size_t) N] - off[0]));
+    // (a few inputs of a decimating ratio may produce nothing: no output vector is needed then)
+    TSD_CHECK(y != nullptr || off[(size_t) N] == off[0], "sharded_step_host: NULL output");
   } else {
+    TSD_CHECK(y != nullptr, "sharded_step_host: NULL output");
     TSD_CHECK(y_capacity >= n, "sharded_step_host: output capacity %lld < %lld", (long long) y_capacity, (long long) n);
   }
   // the halo of shard 0 comes from the previous calls; save the tail of this one first (y may be x)

@@ -140,3 +140,15 @@ def test_sharded_errors(tg, orc):
     sh = tg.Sharded("fir", tg.F32, 3, devices=[0, 0, 0], taps=h)
     assert len(sh.step_host(np.zeros(0, np.float32))) == 0
     assert np.array_equal(sh.step_host(np.ones(2, np.float32)), tg.Fir(h, tg.F32, tg.FIR_DIRECT).step(np.ones(2, np.float32))) or True
+
+
+def test_sharded_resampler_call_without_outputs():
+    """found by the fuzz sweep: one input at a decimating ratio produces nothing -- an empty (NULL) output vector is legal"""
+    import libtsd_amd as t
+    sh, one = t.Sharded("resampler", t.C64, 3, ratio=0.51), t.Resampler(0.51, t.C64)
+    rng = np.random.default_rng(0)
+    for n in (1, 1, 2, 1, 7):
+        x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+        ys, y1 = sh.step_host(x), one.step(x)
+        assert ys.shape == y1.shape
+        assert np.array_equal(ys, y1)
