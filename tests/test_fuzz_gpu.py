@@ -252,3 +252,58 @@ def test_fuzz_sharded(tg, orc, seed):
             assert np.array_equal(ys, y1), (seed, kind, N, n)
         else:
             assert np.abs(ys - y1).max() <= 2e-6 * max(np.abs(y1).max(), 1e-3), (seed, kind, N, n)
+
+
+@pytest.mark.parametrize("seed", range(8 * SCALE))
+def test_fuzz_resampler_wide(tg, orc, seed):
+    """the whole accepted ratio range (1/64 .. 8), short and long tables, the analytic interpolators; a configuration the
+    kernel cannot hold must be refused at CREATE time"""
+    rng = np.random.default_rng(3500 + seed)
+    cplx = bool(rng.integers(2))
+    ratio = float(np.float32(np.exp(rng.uniform(np.log(1 / 64), np.log(8.0)))))
+    n = int(rng.choice([1, 64, 511, 513, 4097, 33333]))
+    x = rand(rng, n, cplx)
+    dt = tg.C64 if cplx else tg.F32
+    flavour = int(rng.integers(4))
+    try:
+        if flavour == 0:
+            ref, g = orc.Resampler(ratio, analytic=("lin", 0)), tg.Resampler(ratio, dt, analytic=("lin", 0))
+        elif flavour == 1:
+            d = int(rng.choice([1, 2, 3, 5, 7]))
+            ref, g = orc.Resampler(ratio, analytic=("lagrange", d)), tg.Resampler(ratio, dt, analytic=("lagrange", d))
+        else:
+            K, nph = [(2, 16), (7, 64), (15, 256), (31, 256), (24, 1000)][int(rng.integers(5))]
+            ref = orc.Resampler(ratio, K=K, nphases=nph, fcut=float(min(0.4, ratio / 2)))
+            g = tg.Resampler(ratio, dt, K=K, nphases=nph, lut=ref.lut)
+    except tg.TsdGpuError as e:
+        assert "LDS" in str(e) or "UNSUPPORTED" in str(e) or "needs" in str(e), str(e)
+        return
+    yref = ref.step(x)
+    parts = [g.step(x[a:b].copy()) for a, b in random_chunks(rng, n)]
+    y = np.concatenate(parts) if parts else np.zeros(0, x.dtype)
+    assert len(y) == len(yref), (seed, ratio, flavour)
+    if len(y):
+        assert relerr(y, yref) <= (TOL if flavour != 1 else 5e-5), (seed, ratio, cplx, flavour)
+
+
+@pytest.mark.parametrize("seed", range(3 * SCALE))
+def test_fuzz_detector(tg, orc, seed):
+    """patterns planted at random places (block borders included) are all found, once, at their place"""
+    rng = np.random.default_rng(9800 + seed)
+    M = int(rng.choice([31, 64, 127, 200]))
+    Ne = int(rng.choice([512, 1024, 4096]))
+    mode = int(rng.integers(2))
+    nblk = 8
+    pat = rand(rng, M, True)
+    x = (0.01 * rand(rng, Ne * nblk, True)).astype(np.complex64)
+    starts, s = [], int(rng.integers(0, Ne))
+    while s + 3 * M < Ne * (nblk - 2):
+        starts.append(s)
+        x[s:s + M] += np.complex64((0.5 + rng.uniform(0, 1)) * np.exp(1j * rng.uniform(0, 6.28))) * pat
+        s += int(rng.integers(2 * M + 1, 2 * Ne))
+    det = tg.Detector(pat, Ne, mode, threshold=0.8)
+    found = []
+    for b in range(nblk):
+        _, pk = det.step(x[b * Ne:(b + 1) * Ne].copy())
+        found += [b * Ne + p.index - det.delay for p in pk]
+    assert found == starts, (seed, M, Ne, mode)
