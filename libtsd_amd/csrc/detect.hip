@@ -274,7 +274,7 @@ int tsdgpu_detector_create(tsdgpu_detector **out, const void *motif_host, int M,
     if (rc) break;
     const size_t eb = (size_t) std::max(d->D, 1) * sizeof(float);
     if (hipMalloc((void **) &d->ehist[0], eb) != hipSuccess || hipMalloc((void **) &d->ehist[1], eb) != hipSuccess ||
-        hipMemset(d->ehist[0], 0, eb) != hipSuccess || hipMemset(d->ehist[1], 0, eb) != hipSuccess) {
+        hipMemset(d->ehist[0], 0, eb) != hipSuccess || hipMemset(d->ehist[1], 0, eb) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
       rc = set_err(TSDGPU_ERR_HIP, "detector_create: allocation failed: %s", hipGetErrorString(hipGetLastError()));
       break;
     }

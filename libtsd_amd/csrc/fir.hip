@@ -339,7 +339,7 @@ int tsdgpu_fir_create(tsdgpu_fir **out, int data_type, int tap_type, const void 
       break;
     }
     if (hipMemcpy(f->d_hrev, hrev.data(), hrev.size(), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemset(f->hist[0], 0, hbytes) != hipSuccess || hipMemset(f->hist[1], 0, hbytes) != hipSuccess) {
+        hipMemset(f->hist[0], 0, hbytes) != hipSuccess || hipMemset(f->hist[1], 0, hbytes) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {   // (a device memset may return before it ran: settled here, steps may come on any stream)
       rc = set_err(TSDGPU_ERR_HIP, "fir_create: upload failed: %s", hipGetErrorString(hipGetLastError()));
       break;
     }

@@ -292,6 +292,7 @@ int ola_alloc(cpx **p, size_t count)
 {
   TSD_HIP(hipMalloc((void **) p, std::max<size_t>(count, 1) * sizeof(cpx)));
   TSD_HIP(hipMemset(*p, 0, std::max<size_t>(count, 1) * sizeof(cpx)));
+  TSD_HIP(hipStreamSynchronize(nullptr));   // the memset is not ordered with the caller's non-blocking streams
   return TSDGPU_OK;
 }
 

@@ -288,7 +288,7 @@ int fused_setup(tsdgpu_polyfir *p, const std::vector<float> &g, int NPH, int W, 
       hipMalloc(&p->d_hist[1], hb) != hipSuccess)
     return set_err(TSDGPU_ERR_HIP, "polyfir_create: hipMalloc failed: %s", hipGetErrorString(hipGetLastError()));
   if (hipMemcpy(p->d_g, g.data(), g.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemset(p->d_hist[0], 0, hb) != hipSuccess || hipMemset(p->d_hist[1], 0, hb) != hipSuccess)
+      hipMemset(p->d_hist[0], 0, hb) != hipSuccess || hipMemset(p->d_hist[1], 0, hb) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess)
     return set_err(TSDGPU_ERR_HIP, "polyfir_create: upload failed: %s", hipGetErrorString(hipGetLastError()));
   (void) hipFuncSetAttribute((const void *) polyfir_fused_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void) hipFuncSetAttribute((const void *) polyfir_fused_kernel<float2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -709,7 +709,7 @@ int tsdgpu_rii_create2(tsdgpu_rii **out, int data_type, int coef_type, const voi
   if (!rc && (hipMalloc((void **) &r->d_denom, (size_t) Kd * cw) != hipSuccess || hipMalloc((void **) &r->d_hist, hb) != hipSuccess))
     rc = set_err(TSDGPU_ERR_HIP, "rii_create: hipMalloc failed: %s", hipGetErrorString(hipGetLastError()));
   if (!rc && (hipMemcpy(r->d_denom, reel ? (const void *) dr.data() : denom_host, (size_t) Kd * cw, hipMemcpyHostToDevice) != hipSuccess ||
-              hipMemset(r->d_hist, 0, hb) != hipSuccess))
+              hipMemset(r->d_hist, 0, hb) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess))
     rc = set_err(TSDGPU_ERR_HIP, "rii_create: upload failed: %s", hipGetErrorString(hipGetLastError()));
   if (rc) {
     tsdgpu_rii_destroy(r);

@@ -675,7 +675,7 @@ int tsdgpu_resampler_create(tsdgpu_resampler **out, int data_type, float ratio, 
   else if (hipMemset(r->d_lut, 0, lut_bytes) != hipSuccess ||
            hipMemcpy2D(r->d_lut, (size_t) r->gl * sizeof(float), lut_host, (size_t) K * sizeof(float), (size_t) K * sizeof(float),
                        (size_t) nphases + 1, hipMemcpyHostToDevice) != hipSuccess ||
-           hipMemset(r->d_hist[0], 0, hb) != hipSuccess || hipMemset(r->d_hist[1], 0, hb) != hipSuccess)
+           hipMemset(r->d_hist[0], 0, hb) != hipSuccess || hipMemset(r->d_hist[1], 0, hb) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess)
     rc = set_err(TSDGPU_ERR_HIP, "resampler_create: upload failed: %s", hipGetErrorString(hipGetLastError()));
   if (rc) {
     tsdgpu_resampler_destroy(r);

@@ -471,7 +471,7 @@ int tsdgpu::sos_create_ex(tsdgpu_sos **out, int data_type, const float *coefs_ho
       break;
     }
     if ((!sec.empty() && hipMemcpy(s->d_sec, sec.data(), sec.size() * sizeof(SosSection), hipMemcpyHostToDevice) != hipSuccess) ||
-        hipMemset(s->d_state[0], 0, STATE_FLOATS * 4) != hipSuccess || hipMemset(s->d_state[1], 0, STATE_FLOATS * 4) != hipSuccess) {
+        hipMemset(s->d_state[0], 0, STATE_FLOATS * 4) != hipSuccess || hipMemset(s->d_state[1], 0, STATE_FLOATS * 4) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
       rc = set_err(TSDGPU_ERR_HIP, "sos_create: upload failed: %s", hipGetErrorString(hipGetLastError()));
       break;
     }
