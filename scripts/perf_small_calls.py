@@ -37,6 +37,14 @@ def main():
     def create():
         t.Fir(h, t.F32).close()
 
+    # host-block size sweep (float32 samples)
+    sweep = {}
+    for n in (512, 4096, 16384, 65536, 262144):
+        xs = np.random.default_rng(1).standard_normal(n).astype(np.float32)
+        ys = np.empty_like(xs)
+        f.step(xs, ys)
+        sweep[str(n)] = round(med(lambda: f.step(xs, ys)), 1)
+    print(json.dumps({"fir31_step_host_us_by_block": sweep}))
     xc = x.astype(np.complex64)
     p = t.Fft(4096)
     p.step(xc)
