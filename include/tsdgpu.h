@@ -66,7 +66,8 @@ int tsdgpu_synchronize(void *stream);
 /* y[i] <- (Re y[i], 0) for n complex samples, device or host memory (what FiltreFFTRIF<cfloat> does to its
  * output, src/fourier/fourier.cc:976) */
 int tsdgpu_zero_imag(void *y, int64_t n, void *stream);
-/* 1 when p is memory a kernel can dereference (device, managed or registered host memory) */
+/* 1 when p is device or managed memory -- what every entry point treats as RESIDENT (no staging, asynchronous on the
+ * caller's stream); page-locked / registered host memory counts as host memory (staged, but with asynchronous copies) */
 int tsdgpu_is_device_pointer(const void *p);
 
 /* --------------------------------------------------------------------------------------

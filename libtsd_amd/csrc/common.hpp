@@ -32,8 +32,8 @@ int set_err(int code, const char *fmt, ...);
 
 inline size_t dtype_size(int dt) { return dt == TSDGPU_C64 ? 8 : 4; }
 
-// true when p is memory the device can dereference in a kernel (hipMalloc'd, managed or
-// registered host memory)
+// true when p is device or managed memory (treated as resident); page-locked / registered host
+// memory is host memory here: it is staged, its copies being asynchronous
 bool is_device_ptr(const void *p);
 
 // Grow-only device scratch buffer owned by a handle.
