@@ -288,6 +288,9 @@ __global__ __launch_bounds__(RS_THREADS) void resample_kernel(const T *__restric
 #ifndef RS15_NW
 #define RS15_NW 12
 #endif
+#ifndef RS15_LATE_STORE
+#define RS15_LATE_STORE 1
+#endif
 constexpr int RS15_WAVES = RS15_NW;
 constexpr int RS15_TILE_PAD = (RS_TI + 16) + (RS_TI + 16) / 8 + 2;      // padded sample slots per wave
 template <typename T>
@@ -300,14 +303,24 @@ __global__ __launch_bounds__(64 * RS15_WAVES) void resample15_kernel(const T *__
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float *lut_s = reinterpret_cast<float *>(smem_raw);
   char *wbase = reinterpret_cast<char *>(lut_s + ((P.nph + 1) * LS + 3) / 4 * 4);
+#if RS15_LATE_STORE
+  // The outputs of a tile are stored at the START of the next iteration, right after that tile's samples have gone
+  // to LDS and BEFORE its own prefetch is issued.  vmcnt retires in issue order: stored at the end of their own
+  // iteration, the stores sat between the prefetch and its consumer, and the wait for the prefetch at the loop
+  // top (`s_waitcnt vmcnt(0)` at the latch in the ISA) waited for the stores' acknowledgement as well -- every tile
+  // paid a full store round trip.  Stored here, they are a whole evaluation old when that wait comes.  The staging
+  // buffer therefore keeps its contents across the loop top and has its own room beside the sample image.
+  const size_t wbytes = ((size_t) (RS15_TILE_PAD + P.rec_cap) * sizeof(T) + 15) / 16 * 16;
+  T *tile = reinterpret_cast<T *>(wbase + wv * wbytes);      // padded: sample s at s + (s >> 3)
+  T *obuf = tile + RS15_TILE_PAD;                            // outputs of the tile, in order
+#else
   // The output staging buffer ALIASES the sample image: every lane has its 22-sample window in
   // registers before the first output of the wave is written (one wave: program order is LDS
-  // order), and the image is only rewritten after the outputs have been flushed.  (It halves the
-  // per-wave LDS; 16 waves per CU then fit but need 128 VGPRs -- 60 B of spills -- and measured
-  // 0.531 ms against 0.538 ms for 12 waves: not worth it.)
+  // order), and the image is only rewritten after the outputs have been flushed.
   const size_t wbytes = ((size_t) max(RS15_TILE_PAD, P.rec_cap) * sizeof(T) + 15) / 16 * 16;
   T *tile = reinterpret_cast<T *>(wbase + wv * wbytes);      // padded: sample s at s + (s >> 3)
   T *obuf = tile;                                            // outputs of the tile, in order
+#endif
 
   for (int i = threadIdx.x; i < (P.nph + 1) * K; i += 64 * RS15_WAVES) {
     const int c = i / K, k = i - c * K;
@@ -368,6 +381,14 @@ __global__ __launch_bounds__(64 * RS15_WAVES) void resample15_kernel(const T *__
   };
 
   if (wtile0 < ntiles) fetch(wtile0, icT);
+#if RS15_LATE_STORE
+  int pend_begin = 0, pend_last = 0;       // outputs [pend_begin, pend_last) of the previous tile wait in obuf
+  T *pend_y = y;
+  auto flush = [&]() {
+    for (int oo = pend_begin + lane; oo < pend_last; oo += 64) pend_y[oo] = obuf[oo];
+    pend_last = 0;
+  };
+#endif
   for (int tix = wtile0; tix < ntiles; tix += wstep) {
     const int64_t T0 = P.tile0 + (int64_t) tix * RS_TI;
 #pragma unroll
@@ -375,6 +396,9 @@ __global__ __launch_bounds__(64 * RS15_WAVES) void resample15_kernel(const T *__
       const int s_ = lane + j * 64;
       if (s_ < RS_TI + K) tile[s_ + (s_ >> 3)] = pf[j];
     }
+#if RS15_LATE_STORE
+    flush();                               // the previous tile's outputs (see above)
+#endif
     const int64_t i_abs = T0 + (int64_t) lane * RS_SEG;
     int64_t ic = icT + lane * RS_SEG, q = qT;
     if (P.lambda > 0)
@@ -439,9 +463,18 @@ __global__ __launch_bounds__(64 * RS15_WAVES) void resample15_kernel(const T *__
     wave_sync();
     const int o_begin = (int) max((int64_t) 0, P.cum_pos - cum_t0);
     T *yt = y + (cum_t0 - P.cum_pos);
+#if RS15_LATE_STORE
+    pend_begin = o_begin;
+    pend_last = last;
+    pend_y = yt;
+#else
     for (int oo = o_begin + lane; oo < last; oo += 64) yt[oo] = obuf[oo];
     wave_sync();
+#endif
   }
+#if RS15_LATE_STORE
+  flush();
+#endif
 }
 
 // new_hist = last H samples of (old_hist ++ x[0..n))
@@ -814,7 +847,7 @@ int tsdgpu_resampler_step(tsdgpu_resampler *r, const void *x, int64_t n, void *y
   static const int PG = getenv("TSDGPU_RS_WG_PER_CU") ? atoi(getenv("TSDGPU_RS_WG_PER_CU")) : 0;
   int per_cu = PG > 0 ? PG : (int) std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (lds + 1024)));
   const int64_t pgrid = std::min<int64_t>(cdiv(tiles, RS_WAVES), (int64_t) 256 * per_cu);
-  const size_t wb15 = ((size_t) std::max(RS15_TILE_PAD, P.rec_cap) * sz + 15) / 16 * 16;
+  const size_t wb15 = ((size_t) (RS15_LATE_STORE ? RS15_TILE_PAD + P.rec_cap : std::max(RS15_TILE_PAD, P.rec_cap)) * sz + 15) / 16 * 16;
   const size_t lds15 = (size_t) ((r->nph + 1) * 20 + 4) * 4 + RS15_WAVES * wb15 + 64;
   if (r->K == 15 && r->mode == 0 && lds15 <= 158 * 1024) {     // fused kernel; larger ratios fall back to the generic one
     const int64_t g15 = std::min<int64_t>(cdiv(tiles, RS15_WAVES), 256);

