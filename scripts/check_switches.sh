@@ -1,0 +1,29 @@
+#!/bin/bash
+# The tuning / debugging switches of DESIGN section 5b select alternative code paths that must stay parity-green:
+# runs the test files that exercise each path with the switch set.  usage (GPU box, repo root): scripts/check_switches.sh
+set -u
+run() {   # run "ENV=1 [ENV2=..]" files...
+  local envs=$1; shift
+  local out
+  out=$(env $envs python3 -m pytest "$@" -x -q -m gpu -p no:cacheprovider 2>&1 | tail -1)
+  echo "[$envs] $* -> $out"
+  case "$out" in *failed*|*error*) FAILED=1;; esac
+}
+FAILED=0
+run TSDGPU_FFT_GENERIC=1 tests/test_fft_gpu.py tests/test_ola_gpu.py
+run TSDGPU_FFT_W1024=1 tests/test_fft_gpu.py
+run TSDGPU_FFT_NO_SMOOTH=1 tests/test_fft_gpu.py
+run TSDGPU_FFT_GROUP=8 tests/test_fft_gpu.py
+run TSDGPU_OLA_UNFUSED=1 tests/test_ola_gpu.py tests/test_detect_gpu.py
+run TSDGPU_RFFT_TWO_PASS=1 tests/test_fft_gpu.py
+run TSDGPU_POLY_COMPOSED=1 tests/test_polyphase_gpu.py
+run TSDGPU_SOS_WIDE_WARMUP=1 tests/test_sos_gpu.py tests/test_sharded_gpu.py
+run TSDGPU_SOS_CHUNKS=16384 tests/test_sos_gpu.py
+# (the tests that assert WHICH path serves a filter, or its speed, are about the default choice)
+run TSDGPU_RII_LITERAL=1 tests/test_polyphase_gpu.py -k "not block_parallel and not under_2ms and not cliff and not literal_fallback and not complex_coefficients"
+run TSDGPU_NO_PIPE=1 tests/test_host_pipeline_gpu.py
+run TSDGPU_PIPE_ONE_THREAD=1 tests/test_host_pipeline_gpu.py
+run TSDGPU_PIPE_CHUNK_MB=1 tests/test_host_pipeline_gpu.py
+run TSDGPU_OLS_LONG_MIN=200 tests/test_fir_gpu.py
+run TSDGPU_RS_WG_PER_CU=2 tests/test_resample_gpu.py
+exit $FAILED
