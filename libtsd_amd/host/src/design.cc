@@ -66,16 +66,27 @@ static Vecf coefs_filtre_sinc(entier n, float fc)
 
 Vecf design_rif_fen(entier n, cstring type, float fc, cstring fen, float fc2)
 {
-  (void) fc2;
   const Vecf f = fenêtre(fen, n, true);
   Vecf h;
+  const entier no2 = (n - 1) / 2;
   if (type == "lp" || type == "pb") {
     h = coefs_filtre_sinc(n, fc);
   } else if (type == "hp" || type == "ph") {
     h = -coefs_filtre_sinc(n, fc);
-    h((n - 1) / 2) += 1.0f;
+    h(no2) += 1.0f;
+  } else if (type == "bp" || type == "pm" || type == "sb") {
+    // rif-fen.cc:61-78: the low-pass of half the band width, moved to the band centre by 2 cos(ωc k), k = -no2 .. no2
+    // (n samples only when n is odd: the reference's element-wise product refuses an even n); stop-band = delta - band-pass
+    if (n % 2 == 0) échec("design_rif_fen: type '{}' needs an odd number of coefficients (n = {})", type, n);
+    const float ωc = (float) (π * (double) (fc2 + fc)), δf = (fc2 - fc) / 2;
+    h = coefs_filtre_sinc(n, δf);
+    for (entier i = 0; i < n; i++) h(i) *= 2.0f * std::cos(ωc * (float) (i - no2));
+    if (type == "sb") {
+      h = -h;
+      h(no2) += 1.0f;
+    }
   } else {
-    échec("design_rif_fen: type '{}' is not built in this hot-path mirror (have lp/pb, hp/ph)", type);
+    échec("design_rif_fen: invalid type '{}' (lp/pb, hp/ph, bp/pm, sb)", type);
   }
   Vecf h2 = h * f;
   if (type == "lp") h2 /= h2.somme();     // only the literal "lp" is normalised (rif-fen.cc:96-98)

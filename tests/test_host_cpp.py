@@ -23,6 +23,17 @@ def test_host_layer_builds_and_refuses_cpu():
         assert "OK" in r.stdout
 
 
+def test_design_layer_under_sanitizers():
+    """the GPU-free part of the mirror (array type, windows, FIR / IIR designs incl. the elliptic prototype, polynomial roots,
+    interpolator tables) built with -fsanitize=address,undefined: values against closed forms, no memory error, no UB"""
+    build()
+    exe = os.path.join(ROOT, "tests", "cpp", "build", "test_design_cpu")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")      # (the mirror keeps its allocation caches for the process lifetime)
+    r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "DESIGN LAYER OK" in r.stdout
+
+
 def test_host_library_exports_factories():
     build()
     out = subprocess.run(["nm", "-DC", os.path.join(ROOT, "libtsd_amd", "lib", "libtsd_host.so")],
