@@ -66,6 +66,18 @@ int tsdgpu_synchronize(void *stream);
 /* y[i] <- (Re y[i], 0) for n complex samples, device or host memory (what FiltreFFTRIF<cfloat> does to its
  * output, src/fourier/fourier.cc:976) */
 int tsdgpu_zero_imag(void *y, int64_t n, void *stream);
+/* Element-wise operations on RESIDENT vectors (device pointers only; n elements of data_type; dst may be a or b except
+ * for REVERSE): what libtsd call sites put between two operators of the path -- Tab::reverse, *=, /=, + - *, abs, abs2,
+ * real, imag, as_complex (include/tsd/tableau.hpp:883-901,1141-1257; src/tableau.cc:582-592,822-854,1243-1533).  Same IEEE
+ * operations as the host loops (no contraction; complex quotients in double like libgcc).
+ *   REVERSE dst[i] = a[n-1-i] | SCALE a*s | DIV_SCALAR a/s (s = s_re + i s_im, s_im ignored for F32) | ADD SUB MUL with b |
+ *   NEG | ABS, ABS2 (dst float) | REAL, IMAG (C64 -> float) | TO_COMPLEX (F32 -> C64) | CONJ                                 */
+typedef enum {
+  TSDGPU_VEC_REVERSE = 0, TSDGPU_VEC_SCALE = 1, TSDGPU_VEC_DIV_SCALAR = 2, TSDGPU_VEC_ADD = 3, TSDGPU_VEC_SUB = 4, TSDGPU_VEC_MUL = 5,
+  TSDGPU_VEC_NEG = 6, TSDGPU_VEC_ABS = 7, TSDGPU_VEC_ABS2 = 8, TSDGPU_VEC_REAL = 9, TSDGPU_VEC_IMAG = 10, TSDGPU_VEC_TO_COMPLEX = 11,
+  TSDGPU_VEC_CONJ = 12
+} tsdgpu_vec_opcode;
+int tsdgpu_vec_op(int op, int data_type, void *dst, const void *a, const void *b, float s_re, float s_im, int64_t n, void *stream);
 /* 1 when p is device or managed memory -- what every entry point treats as RESIDENT (no staging, asynchronous on the
  * caller's stream); page-locked / registered host memory counts as host memory (staged, but with asynchronous copies) */
 int tsdgpu_is_device_pointer(const void *p);

@@ -113,6 +113,10 @@ void gpu_copie(void *dst, const void *src, size_t octets);   // host<->device, d
 void gpu_zero(void *p, size_t octets);
 bool est_ptr_gpu(const void *p);
 bool &residence_active();
+// element-wise operation on resident vectors (tsdgpu_vec_op; `op` is a tsdgpu_vec_opcode, complexe: cfloat elements)
+enum OpVec { OP_REVERSE = 0, OP_SCALE = 1, OP_DIV_SCALAIRE = 2, OP_ADD = 3, OP_SUB = 4, OP_MUL = 5, OP_NEG = 6, OP_ABS = 7, OP_ABS2 = 8,
+             OP_REAL = 9, OP_IMAG = 10, OP_VERS_COMPLEXE = 11, OP_CONJ = 12 };
+void gpu_op_vec(int op, bool complexe, void *dst, const void *a, const void *b, float s_re, float s_im, size_t n);
 }  // namespace detail
 struct ResidenceGpu {
   bool avant;
@@ -294,16 +298,43 @@ template <typename T> class Vecteur {
   }
   Vecteur head(entier n) const { return segment(0, n); }
   Vecteur tail(entier n) const { return segment(n_ - n, n); }
+  // Resident float / cfloat vectors run their element-wise arithmetic on the device (tsdgpu_vec_op): what call sites put
+  // between two operators of the path -- filtfilt's reverse, y = fft(x) * H, x / s -- then stays in HBM.  Other element
+  // types, reductions and element access remain host-only and refuse a resident vector loudly.
+  static constexpr bool op_gpu_possible() { return std::is_same_v<T, float> || std::is_same_v<T, cfloat>; }
+  static float re_de(T s) { if constexpr (est_complexe<T>()) return s.real(); else return (float) s; }
+  static float im_de(T s) { if constexpr (est_complexe<T>()) return s.imag(); else { (void) s; return 0.f; } }
+  void op_gpu(int op, Vecteur &dst, const Vecteur *b, T s, const char *quoi) const
+  {
+    if constexpr (op_gpu_possible()) {
+      if (b && (!b->gpu_ || b->n_ != n_)) échec("Vecteur: {} between a resident vector and a host vector or one of another size", quoi);
+      detail::gpu_op_vec(op, est_complexe<T>(), dst.p_, p_, b ? b->p_ : nullptr, re_de(s), im_de(s), (size_t) n_);
+    } else {
+      exige_hote(quoi);
+    }
+  }
   Vecteur reverse() const
   {
-    exige_hote("reverse");
     Vecteur v;
+    if (gpu_ && op_gpu_possible()) {
+      v.alloc(n_, true);
+      op_gpu(detail::OP_REVERSE, v, nullptr, T(), "reverse");
+      return v;
+    }
+    exige_hote("reverse");
     v.alloc(n_, false);
     for (entier i = 0; i < n_; i++) v.p_[i] = p_[n_ - 1 - i];
     return v;
   }
   Vecteur<cfloat> as_complex() const
   {
+    if constexpr (std::is_same_v<T, float>) {
+      if (gpu_) {
+        Vecteur<cfloat> v = Vecteur<cfloat>::sur_gpu(n_);
+        detail::gpu_op_vec(detail::OP_VERS_COMPLEXE, false, v.data(), p_, nullptr, 0.f, 0.f, (size_t) n_);
+        return v;
+      }
+    }
     exige_hote("as_complex");
     Vecteur<cfloat> v = Vecteur<cfloat>::hote(n_);
     for (entier i = 0; i < n_; i++) v.data()[i] = cfloat(p_[i]);
@@ -318,12 +349,36 @@ template <typename T> class Vecteur {
   }
 
   // element-wise arithmetic used around the hot path
-  Vecteur &operator*=(T s) { exige_hote("arithmetic"); for (entier i = 0; i < n_; i++) p_[i] *= s; return *this; }
-  Vecteur &operator/=(T s) { exige_hote("arithmetic"); for (entier i = 0; i < n_; i++) p_[i] /= s; return *this; }
-  Vecteur &operator+=(const Vecteur &o) { chk(o); for (entier i = 0; i < n_; i++) p_[i] += o.p_[i]; return *this; }
-  Vecteur &operator-=(const Vecteur &o) { chk(o); for (entier i = 0; i < n_; i++) p_[i] -= o.p_[i]; return *this; }
-  Vecteur &operator*=(const Vecteur &o) { chk(o); for (entier i = 0; i < n_; i++) p_[i] *= o.p_[i]; return *this; }
-  Vecteur operator-() const { exige_hote("arithmetic"); Vecteur v(*this); for (entier i = 0; i < n_; i++) v.p_[i] = -v.p_[i]; return v; }
+  Vecteur &operator*=(T s)
+  {
+    if (gpu_ && op_gpu_possible()) { op_gpu(detail::OP_SCALE, *this, nullptr, s, "arithmetic"); return *this; }
+    exige_hote("arithmetic"); for (entier i = 0; i < n_; i++) p_[i] *= s; return *this;
+  }
+  Vecteur &operator/=(T s)
+  {
+    if (gpu_ && op_gpu_possible()) { op_gpu(detail::OP_DIV_SCALAIRE, *this, nullptr, s, "arithmetic"); return *this; }
+    exige_hote("arithmetic"); for (entier i = 0; i < n_; i++) p_[i] /= s; return *this;
+  }
+  Vecteur &operator+=(const Vecteur &o)
+  {
+    if (gpu_ && op_gpu_possible()) { op_gpu(detail::OP_ADD, *this, &o, T(), "arithmetic"); return *this; }
+    chk(o); for (entier i = 0; i < n_; i++) p_[i] += o.p_[i]; return *this;
+  }
+  Vecteur &operator-=(const Vecteur &o)
+  {
+    if (gpu_ && op_gpu_possible()) { op_gpu(detail::OP_SUB, *this, &o, T(), "arithmetic"); return *this; }
+    chk(o); for (entier i = 0; i < n_; i++) p_[i] -= o.p_[i]; return *this;
+  }
+  Vecteur &operator*=(const Vecteur &o)
+  {
+    if (gpu_ && op_gpu_possible()) { op_gpu(detail::OP_MUL, *this, &o, T(), "arithmetic"); return *this; }
+    chk(o); for (entier i = 0; i < n_; i++) p_[i] *= o.p_[i]; return *this;
+  }
+  Vecteur operator-() const
+  {
+    if (gpu_ && op_gpu_possible()) { Vecteur v; v.alloc(n_, true); op_gpu(detail::OP_NEG, v, nullptr, T(), "arithmetic"); return v; }
+    exige_hote("arithmetic"); Vecteur v(*this); for (entier i = 0; i < n_; i++) v.p_[i] = -v.p_[i]; return v;
+  }
   friend Vecteur operator+(const Vecteur &a, const Vecteur &b) { Vecteur v(a); v += b; return v; }
   friend Vecteur operator-(const Vecteur &a, const Vecteur &b) { Vecteur v(a); v -= b; return v; }
   friend Vecteur operator*(const Vecteur &a, const Vecteur &b) { Vecteur v(a); v *= b; return v; }
@@ -398,6 +453,12 @@ using Veci = Vecteur<int32_t>;
 
 template <typename T> Vecteur<float> abs(const Vecteur<T> &x)
 {
+  if constexpr (std::is_same_v<T, float> || std::is_same_v<T, cfloat>)
+    if (x.est_sur_gpu()) {
+      Vecteur<float> y = Vecteur<float>::sur_gpu(x.rows());
+      detail::gpu_op_vec(detail::OP_ABS, est_complexe<T>(), y.data(), x.data(), nullptr, 0.f, 0.f, (size_t) x.rows());
+      return y;
+    }
   x.exige_hote("abs");
   Vecteur<float> y = Vecteur<float>::hote(x.rows());
   for (entier i = 0; i < x.rows(); i++) y.data()[i] = std::abs(x.data()[i]);
@@ -406,6 +467,12 @@ template <typename T> Vecteur<float> abs(const Vecteur<T> &x)
 // |x|^2 element-wise and power -> dB (core/include/tsd/tsd.hpp:414-421, tableau.hpp abs2)
 template <typename T> Vecteur<float> abs2(const Vecteur<T> &x)
 {
+  if constexpr (std::is_same_v<T, float> || std::is_same_v<T, cfloat>)
+    if (x.est_sur_gpu()) {
+      Vecteur<float> y = Vecteur<float>::sur_gpu(x.rows());
+      detail::gpu_op_vec(detail::OP_ABS2, est_complexe<T>(), y.data(), x.data(), nullptr, 0.f, 0.f, (size_t) x.rows());
+      return y;
+    }
   x.exige_hote("abs2");
   Vecteur<float> y = Vecteur<float>::hote(x.rows());
   for (entier i = 0; i < x.rows(); i++) y(i) = std::norm(x.data()[i]);
@@ -417,8 +484,24 @@ inline Vecf pow2db(const Vecf &x)
   for (entier i = 0; i < x.rows(); i++) y(i) = 10 * std::log10(x(i));
   return y;
 }
-inline Vecf real(const Veccf &x) { x.exige_hote("real"); return Vecf::int_expr(x.rows(), [&](entier i) { return x.data()[i].real(); }); }
-inline Vecf imag(const Veccf &x) { x.exige_hote("imag"); return Vecf::int_expr(x.rows(), [&](entier i) { return x.data()[i].imag(); }); }
+inline Vecf real(const Veccf &x)
+{
+  if (x.est_sur_gpu()) {
+    Vecf y = Vecf::sur_gpu(x.rows());
+    detail::gpu_op_vec(detail::OP_REAL, true, y.data(), x.data(), nullptr, 0.f, 0.f, (size_t) x.rows());
+    return y;
+  }
+  return Vecf::int_expr(x.rows(), [&](entier i) { return x.data()[i].real(); });
+}
+inline Vecf imag(const Veccf &x)
+{
+  if (x.est_sur_gpu()) {
+    Vecf y = Vecf::sur_gpu(x.rows());
+    detail::gpu_op_vec(detail::OP_IMAG, true, y.data(), x.data(), nullptr, 0.f, 0.f, (size_t) x.rows());
+    return y;
+  }
+  return Vecf::int_expr(x.rows(), [&](entier i) { return x.data()[i].imag(); });
+}
 template <typename T> Vecteur<T> vconcat(const Vecteur<T> &a, const Vecteur<T> &b)
 {
   Vecteur<T> v(a.rows() + b.rows());      // follows the residency guard; the two halves are views

@@ -116,6 +116,11 @@ void gpu_zero(void *p, size_t octets)
   if (tsdgpu_memset(p, 0, octets, nullptr)) échec("Vecteur (device setZero): {}", tsdgpu_last_error());
 }
 bool est_ptr_gpu(const void *p) { return tsdgpu_is_device_pointer(p) != 0; }
+void gpu_op_vec(int op, bool complexe, void *dst, const void *a, const void *b, float s_re, float s_im, size_t n)
+{
+  if (tsdgpu_vec_op(op, complexe ? TSDGPU_C64 : TSDGPU_F32, dst, a, b, s_re, s_im, (int64_t) n, nullptr))
+    échec("Vecteur (device arithmetic): {}", tsdgpu_last_error());
+}
 bool &residence_active()
 {
   static thread_local bool actif = false;

@@ -11,7 +11,7 @@ base="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result -ffp-c
 case $unit in ols.hip|fft.hip|ols_long.hip) base="$base -fno-slp-vectorize -ffp-contract=fast";; esac
 /opt/rocm/bin/hipcc $base $flags -c $unit -o build/variants/${name}.o
 objs=""
-for f in common fir ols ols_long fft sos resample polyphase ola sharded detect; do
+for f in common fir ols ols_long fft sos resample polyphase ola sharded detect vecops; do
   if [ "$f.hip" == "$unit" ]; then objs="$objs build/variants/${name}.o"; else objs="$objs build/$f.o"; fi
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../lib/variants/libtsdgpu_${name}.so $objs

@@ -68,6 +68,84 @@ template <typename T> static float ecart_rel(const Vecteur<T> &a, const Vecteur<
   }
   return e / std::max(m, 1e-30f);
 }
+// element-wise arithmetic of RESIDENT float / cfloat vectors runs on the device (tsdgpu_vec_op) and gives what the host
+// loops give: bit for bit for reverse, + - *, scalar products, abs2, real, imag, as_complex, negation; to an ulp for the
+// complex quotient (evaluated in double like libgcc) and for abs (hypotf of two libraries); filtfilt stays resident
+static void test_residence_ops()
+{
+  const int n = 100003;
+  const Veccf x = randcn(n), z = randcn(n);
+  const Vecf u = randn(n), w = randn(n);
+  const Veccf xg = x.vers_gpu(), zg = z.vers_gpu();
+  const Vecf ug = u.vers_gpu(), wg = w.vers_gpu();
+  auto pareil = [](const auto &a_gpu, const auto &b_hote, const char *quoi, float tol) {
+    CHECK(a_gpu.est_sur_gpu(), "%s: the result left the GPU", quoi);
+    const auto a = a_gpu.vers_hote();
+    CHECK(a.rows() == b_hote.rows(), "%s: %d vs %d elements", quoi, (int) a.rows(), (int) b_hote.rows());
+    float e = 0, m = 0;
+    for (int i = 0; i < a.rows(); i++) {
+      e = std::max(e, (float) std::abs(a.data()[i] - b_hote.data()[i]));
+      m = std::max(m, (float) std::abs(b_hote.data()[i]));
+    }
+    CHECK(e <= tol * m, "%s: device %s host (max deviation %g of %g)", quoi, tol == 0 ? "!=" : "too far from", e, m);
+  };
+  pareil(xg.reverse(), x.reverse(), "reverse (complex)", 0);
+  pareil(ug.reverse(), u.reverse(), "reverse (real)", 0);
+  pareil(xg + zg, x + z, "+", 0);
+  pareil(xg - zg, x - z, "-", 0);
+  pareil(xg * zg, x * z, "* (complex)", 0);
+  pareil(ug * wg, u * w, "* (real)", 0);
+  pareil(xg * cfloat(0.3f, -1.7f), x * cfloat(0.3f, -1.7f), "* complex scalar", 0);
+  pareil(ug * 2.5f, u * 2.5f, "* real scalar", 0);
+  pareil(ug / 3.0f, u / 3.0f, "/ real scalar", 0);
+  pareil(xg / cfloat(1024.f, 0.f), x / cfloat(1024.f, 0.f), "/ real-valued complex scalar", 1.2e-7f);
+  pareil(xg / cfloat(0.3f, -1.7f), x / cfloat(0.3f, -1.7f), "/ complex scalar", 1.2e-7f);
+  pareil(-xg, -x, "negation", 0);
+  pareil(abs2(xg), abs2(x), "abs2", 0);
+  pareil(abs(xg), abs(x), "abs", 1.2e-7f);
+  pareil(abs(ug), abs(u), "abs (real)", 0);
+  pareil(real(xg), real(x), "real", 0);
+  pareil(imag(xg), imag(x), "imag", 0);
+  pareil(ug.as_complex(), u.as_complex(), "as_complex", 0);
+  {
+    Veccf a = xg.clone();
+    a *= zg;
+    a += xg;
+    a /= cfloat(2.f, 0.f);
+    Veccf b = x.clone();
+    b *= z;
+    b += x;
+    b /= cfloat(2.f, 0.f);
+    pareil(a, b, "in-place chain", 1.2e-7f);
+  }
+  // mixed residency and unsupported cases are refused, not silently staged
+  bool threw = false;
+  try { (void) (xg + z); } catch (const std::runtime_error &) { threw = true; }
+  CHECK(threw, "resident + host must be refused");
+  threw = false;
+  try { (void) xg.somme(); } catch (const std::runtime_error &) { threw = true; }
+  CHECK(threw, "reductions on a resident vector must be refused");
+  // filtfilt = filter, reverse, filter, reverse (filtrage.hpp:1761-1765): now entirely on the device
+  const Vecf h = design_rif_fen(63, "lp", 0.1f);
+  const Veccf y_h = filtfilt<cfloat>(Design(h), x);
+  Veccf y_g;
+  {
+    ResidenceGpu garde;
+    y_g = filtfilt<cfloat>(Design(h), xg);
+  }
+  CHECK(y_g.est_sur_gpu(), "resident filtfilt left the GPU");
+  CHECK(ecart_rel(y_g.vers_hote(), y_h) <= 2e-6f, "resident filtfilt: %g", ecart_rel(y_g.vers_hote(), y_h));
+  // y = ifft(fft(x) * H) as a user writes it, resident
+  const Veccf H = randcn(4096);
+  const Veccf ref = ifft(fft(x.head(4096).clone()) * H);
+  Veccf res;
+  {
+    ResidenceGpu garde;
+    res = ifft(fft(xg.head(4096).clone()) * H.vers_gpu());
+  }
+  CHECK(res.est_sur_gpu() && ecart_rel(res.vers_hote(), ref) <= 2e-6f, "resident spectral product: %g", ecart_rel(res.vers_hote(), ref));
+}
+
 static void test_residence_gpu()
 {
   const int n = 1 << 18;
@@ -1372,6 +1450,7 @@ int main(int argc, char **argv)
   // (last: they draw from the shared random generator, and the statistical tests above are ported with
   // the noise realisations the default seed gives them)
   test_residence_gpu();
+  test_residence_ops();
   test_fragments();
   printf(nfail ? "FAILED (%d)\n" : "ALL C++ HOST TESTS OK\n", nfail);
   return nfail ? 1 : 0;
