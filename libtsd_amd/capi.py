@@ -95,6 +95,8 @@ def _declare(L):
     L.tsdgpu_sharded_reset.argtypes = [vp]
     L.tsdgpu_sharded_destroy.argtypes = [vp]
     L.tsdgpu_xcorr.argtypes = [vp, vp, i32, i32, i32, vp, vp]
+    L.tsdgpu_vec_op.argtypes = [i32, i32, vp, vp, vp, C.c_float, C.c_float, C.c_int64, vp]
+    L.tsdgpu_vec_op.restype = i32
     L.tsdgpu_delay_estimate.argtypes = [vp, vp, i32, C.POINTER(fl), C.POINTER(fl), vp]
     L.tsdgpu_detector_create.argtypes = [C.POINTER(vp), vp, i32, i32, i32, fl]
     L.tsdgpu_detector_delay.argtypes = [vp]
@@ -664,6 +666,25 @@ def xcorr(x, y=None, m=-1, unbiased=True):
         m = n
     out = np.empty(2 * m - 1, np.complex64) if isinstance(x, np.ndarray) else x.new_empty(2 * m - 1)
     _check(lib().tsdgpu_xcorr(_ptr(x), None if y is None else _ptr(y), n, m, 1 if unbiased else 0, _ptr(out), _stream_of(x, None)))
+    return out
+
+
+VEC_OPS = {"reverse": 0, "scale": 1, "div": 2, "add": 3, "sub": 4, "mul": 5, "neg": 6, "abs": 7, "abs2": 8, "real": 9, "imag": 10,
+           "to_complex": 11, "conj": 12}
+
+
+def vec_op(op, a, b=None, scalar=0.0, out=None):
+    """Element-wise arithmetic on RESIDENT torch tensors (tsdgpu_vec_op): reverse / scale / div / add / sub / mul / neg keep
+    the element type, abs / abs2 / real / imag give float32, to_complex gives complex64."""
+    import torch
+    dt = _dtype_code(a)
+    code = VEC_OPS[op]
+    if out is None:
+        odt = torch.float32 if code in (7, 8, 9, 10) else (torch.complex64 if code == 11 else a.dtype)
+        out = torch.empty(a.shape[0], dtype=odt, device=a.device) if not isinstance(a, np.ndarray) else np.empty(a.shape[0])
+    s = complex(scalar)
+    _check(lib().tsdgpu_vec_op(code, dt, _ptr(out), _ptr(a), None if b is None else _ptr(b), s.real, s.imag, int(a.shape[0]),
+                               _stream_of(a, None)))
     return out
 
 
