@@ -78,6 +78,11 @@ typedef enum {
   TSDGPU_VEC_CONJ = 12
 } tsdgpu_vec_opcode;
 int tsdgpu_vec_op(int op, int data_type, void *dst, const void *a, const void *b, float s_re, float s_im, int64_t n, void *stream);
+/* Reductions of a RESIDENT vector, returned to the host (one small copy): the sum (real and imaginary parts, accumulated in
+ * double like Tab::somme, tableau.hpp:656-717) and, for F32 data, the largest / smallest value and the index of the first
+ * largest one (valeur_max / valeur_min / index_max).  Any output pointer may be NULL.                                     */
+int tsdgpu_vec_reduce(int data_type, const void *a, int64_t n, double *sum_re_im /* [2] */, float *max_min /* [2] */,
+                      int64_t *arg_max, void *stream);
 /* 1 when p is device or managed memory -- what every entry point treats as RESIDENT (no staging, asynchronous on the
  * caller's stream); page-locked / registered host memory counts as host memory (staged, but with asynchronous copies) */
 int tsdgpu_is_device_pointer(const void *p);

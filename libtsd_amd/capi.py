@@ -97,6 +97,8 @@ def _declare(L):
     L.tsdgpu_xcorr.argtypes = [vp, vp, i32, i32, i32, vp, vp]
     L.tsdgpu_vec_op.argtypes = [i32, i32, vp, vp, vp, C.c_float, C.c_float, C.c_int64, vp]
     L.tsdgpu_vec_op.restype = i32
+    L.tsdgpu_vec_reduce.argtypes = [i32, vp, C.c_int64, vp, vp, vp, vp]
+    L.tsdgpu_vec_reduce.restype = i32
     L.tsdgpu_delay_estimate.argtypes = [vp, vp, i32, C.POINTER(fl), C.POINTER(fl), vp]
     L.tsdgpu_detector_create.argtypes = [C.POINTER(vp), vp, i32, i32, i32, fl]
     L.tsdgpu_detector_delay.argtypes = [vp]
@@ -686,6 +688,15 @@ def vec_op(op, a, b=None, scalar=0.0, out=None):
     _check(lib().tsdgpu_vec_op(code, dt, _ptr(out), _ptr(a), None if b is None else _ptr(b), s.real, s.imag, int(a.shape[0]),
                                _stream_of(a, None)))
     return out
+
+
+def vec_reduce(a):
+    """Reductions of a RESIDENT tensor (tsdgpu_vec_reduce): -> (sum as complex, max, min, index of the first max)."""
+    s = (C.c_double * 2)()
+    mm = (C.c_float * 2)()
+    im = C.c_int64(-1)
+    _check(lib().tsdgpu_vec_reduce(_dtype_code(a), _ptr(a), int(a.shape[0]), s, mm, C.byref(im), _stream_of(a, None)))
+    return complex(s[0], s[1]), mm[0], mm[1], im.value
 
 
 def delay_estimate(x, y):

@@ -6,6 +6,9 @@
 // loops of the mirror: no contraction (this file is built with -ffp-contract=off), complex products as ac - bd / ad + bc,
 // complex quotients evaluated in double like libgcc's __divsc3.
 #include "common.hpp"
+#include <algorithm>
+#include <cmath>
+#include <vector>
 
 namespace tsdgpu {
 namespace {
@@ -81,10 +84,80 @@ __global__ __launch_bounds__(256) void vec_conj_kernel(float2 *__restrict__ dst,
   if (i < n) dst[i] = make_float2(a[i].x, -a[i].y);
 }
 
+// ---- reductions: sum in double (the host loops accumulate in double too: tableau.hpp:656-717), max / min / first arg max
+struct RedPart { double s_re, s_im; float vmax, vmin; long long imax; };
+
+template <bool CPLX>
+__global__ __launch_bounds__(256) void vec_reduce_kernel(const float *__restrict__ a, int64_t n, RedPart *__restrict__ part)
+{
+  __shared__ RedPart sh[256];
+  RedPart r{0.0, 0.0, -INFINITY, INFINITY, -1};
+  for (int64_t i = (int64_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t) gridDim.x * 256) {
+    if (CPLX) {
+      r.s_re += (double) a[2 * i];
+      r.s_im += (double) a[2 * i + 1];
+    } else {
+      const float v = a[i];
+      r.s_re += (double) v;
+      if (v > r.vmax) { r.vmax = v; r.imax = i; }      // strictly greater: the FIRST maximum of the thread's ascending indices
+      if (v < r.vmin) r.vmin = v;
+    }
+  }
+  sh[threadIdx.x] = r;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) {
+    if ((int) threadIdx.x < d) {
+      RedPart &x = sh[threadIdx.x];
+      const RedPart y = sh[threadIdx.x + d];
+      x.s_re += y.s_re;
+      x.s_im += y.s_im;
+      if (y.vmax > x.vmax || (y.vmax == x.vmax && y.imax >= 0 && (x.imax < 0 || y.imax < x.imax))) { x.vmax = y.vmax; x.imax = y.imax; }
+      if (y.vmin < x.vmin) x.vmin = y.vmin;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+
 }  // namespace
 }  // namespace tsdgpu
 
 using namespace tsdgpu;
+
+extern "C" int tsdgpu_vec_reduce(int data_type, const void *a, int64_t n, double *sum_re_im, float *max_min, int64_t *arg_max,
+                                 void *stream)
+{
+  TSD_CHECK(n >= 0, "vec_reduce: negative length");
+  TSD_CHECK(data_type == TSDGPU_F32 || data_type == TSDGPU_C64, "vec_reduce: bad data_type %d", data_type);
+  if (sum_re_im) sum_re_im[0] = sum_re_im[1] = 0.0;
+  if (arg_max) *arg_max = -1;
+  if (n == 0) return TSDGPU_OK;
+  TSD_CHECK(a != nullptr && is_device_ptr(a), "vec_reduce: a resident vector is expected");
+  hipStream_t st = (hipStream_t) stream;
+  const int nb = (int) std::min<int64_t>(cdiv(n, 256), 1024);
+  static thread_local DevBuf parts;       // (one per calling thread; a few tens of KB)
+  int rc = parts.reserve((size_t) nb * sizeof(RedPart));
+  if (rc) return rc;
+  if (data_type == TSDGPU_C64) hipLaunchKernelGGL(vec_reduce_kernel<true>, dim3(nb), dim3(256), 0, st, (const float *) a, n, (RedPart *) parts.p);
+  else hipLaunchKernelGGL(vec_reduce_kernel<false>, dim3(nb), dim3(256), 0, st, (const float *) a, n, (RedPart *) parts.p);
+  TSD_HIP(hipGetLastError());
+  std::vector<RedPart> h((size_t) nb);
+  TSD_HIP(hipMemcpyAsync(h.data(), parts.p, (size_t) nb * sizeof(RedPart), hipMemcpyDeviceToHost, st));
+  TSD_HIP(hipStreamSynchronize(st));
+  // the block partials are folded on the host in block order: deterministic, and a few KB
+  RedPart t{0.0, 0.0, -INFINITY, INFINITY, -1};
+  for (const RedPart &p : h) {
+    t.s_re += p.s_re;
+    t.s_im += p.s_im;
+    if (p.vmax > t.vmax || (p.vmax == t.vmax && p.imax >= 0 && (t.imax < 0 || p.imax < t.imax))) { t.vmax = p.vmax; t.imax = p.imax; }
+    if (p.vmin < t.vmin) t.vmin = p.vmin;
+  }
+  if (sum_re_im) { sum_re_im[0] = t.s_re; sum_re_im[1] = t.s_im; }
+  if (max_min) { max_min[0] = t.vmax; max_min[1] = t.vmin; }
+  if (arg_max) *arg_max = t.imax;
+  return TSDGPU_OK;
+}
+
 
 extern "C" int tsdgpu_vec_op(int op, int data_type, void *dst, const void *a, const void *b, float s_re, float s_im, int64_t n,
                              void *stream)

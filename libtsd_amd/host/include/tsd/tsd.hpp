@@ -117,6 +117,8 @@ bool &residence_active();
 enum OpVec { OP_REVERSE = 0, OP_SCALE = 1, OP_DIV_SCALAIRE = 2, OP_ADD = 3, OP_SUB = 4, OP_MUL = 5, OP_NEG = 6, OP_ABS = 7, OP_ABS2 = 8,
              OP_REAL = 9, OP_IMAG = 10, OP_VERS_COMPLEXE = 11, OP_CONJ = 12 };
 void gpu_op_vec(int op, bool complexe, void *dst, const void *a, const void *b, float s_re, float s_im, size_t n);
+// sum (re, im; accumulated in double), max / min and index of the first max of a resident float / cfloat vector (tsdgpu_vec_reduce)
+void gpu_reduction(bool complexe, const void *a, size_t n, double *somme2, float *maxmin2, long long *imax);
 }  // namespace detail
 struct ResidenceGpu {
   bool avant;
@@ -389,6 +391,13 @@ template <typename T> class Vecteur {
   // reductions accumulate in double (tableau.hpp:656-717)
   T somme() const
   {
+    if constexpr (op_gpu_possible())
+      if (gpu_) {
+        double s2[2];
+        detail::gpu_reduction(est_complexe<T>(), p_, (size_t) n_, s2, nullptr, nullptr);
+        if constexpr (est_complexe<T>()) return T((float) s2[0], (float) s2[1]);
+        else return (T) s2[0];
+      }
     exige_hote("somme");
     if constexpr (est_complexe<T>()) {
       cdouble s = 0;
@@ -401,9 +410,24 @@ template <typename T> class Vecteur {
     }
   }
   T moyenne() const { return n_ ? somme() / (T) n_ : T(); }
-  T valeur_max() const { exige_hote("valeur_max"); tsd_assertion(n_ > 0); return *std::max_element(p_, p_ + n_); }
-  T valeur_min() const { exige_hote("valeur_min"); tsd_assertion(n_ > 0); return *std::min_element(p_, p_ + n_); }
-  entier index_max() const { exige_hote("index_max"); return n_ ? (entier) (std::max_element(p_, p_ + n_) - p_) : -1; }
+  T valeur_max() const
+  {
+    if constexpr (std::is_same_v<T, float>)
+      if (gpu_) { tsd_assertion(n_ > 0); float mm[2]; detail::gpu_reduction(false, p_, (size_t) n_, nullptr, mm, nullptr); return mm[0]; }
+    exige_hote("valeur_max"); tsd_assertion(n_ > 0); return *std::max_element(p_, p_ + n_);
+  }
+  T valeur_min() const
+  {
+    if constexpr (std::is_same_v<T, float>)
+      if (gpu_) { tsd_assertion(n_ > 0); float mm[2]; detail::gpu_reduction(false, p_, (size_t) n_, nullptr, mm, nullptr); return mm[1]; }
+    exige_hote("valeur_min"); tsd_assertion(n_ > 0); return *std::min_element(p_, p_ + n_);
+  }
+  entier index_max() const
+  {
+    if constexpr (std::is_same_v<T, float>)
+      if (gpu_) { long long i = -1; detail::gpu_reduction(false, p_, (size_t) n_, nullptr, nullptr, &i); return (entier) i; }
+    exige_hote("index_max"); return n_ ? (entier) (std::max_element(p_, p_ + n_) - p_) : -1;
+  }
 
  private:
   explicit Vecteur(entier n, bool sur_gpu_) { alloc(n, sur_gpu_); }

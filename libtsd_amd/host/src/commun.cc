@@ -121,6 +121,13 @@ void gpu_op_vec(int op, bool complexe, void *dst, const void *a, const void *b, 
   if (tsdgpu_vec_op(op, complexe ? TSDGPU_C64 : TSDGPU_F32, dst, a, b, s_re, s_im, (int64_t) n, nullptr))
     échec("Vecteur (device arithmetic): {}", tsdgpu_last_error());
 }
+void gpu_reduction(bool complexe, const void *a, size_t n, double *somme2, float *maxmin2, long long *imax)
+{
+  int64_t im = -1;
+  if (tsdgpu_vec_reduce(complexe ? TSDGPU_C64 : TSDGPU_F32, a, (int64_t) n, somme2, maxmin2, &im, nullptr))
+    échec("Vecteur (device reduction): {}", tsdgpu_last_error());
+  if (imax) *imax = (long long) im;
+}
 bool &residence_active()
 {
   static thread_local bool actif = false;

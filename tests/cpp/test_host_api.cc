@@ -122,9 +122,22 @@ static void test_residence_ops()
   bool threw = false;
   try { (void) (xg + z); } catch (const std::runtime_error &) { threw = true; }
   CHECK(threw, "resident + host must be refused");
+  // reductions: the sum is accumulated in double on both sides (the orders differ: the float results agree to an ulp)
+  {
+    const cfloat sg = xg.somme(), sh = x.somme();
+    CHECK(std::abs(sg - sh) <= 2e-7f * std::max(1.0f, std::abs(sh)), "somme (complex): %g%+gi vs %g%+gi", sg.real(), sg.imag(), sh.real(), sh.imag());
+    CHECK(std::abs(ug.somme() - u.somme()) <= 2e-7f * std::max(1.0f, std::abs(u.somme())), "somme (real): %g vs %g", ug.somme(), u.somme());
+    CHECK(std::abs(ug.moyenne() - u.moyenne()) <= 1e-9f + 2e-7f * std::abs(u.moyenne()), "moyenne");
+    CHECK(ug.valeur_max() == u.valeur_max() && ug.valeur_min() == u.valeur_min(), "valeur_max / valeur_min");
+    CHECK(ug.index_max() == u.index_max(), "index_max: %d vs %d", (int) ug.index_max(), (int) u.index_max());
+    Vecf plat = Vecf::zeros(5000);                       // ties: the FIRST maximum, like std::max_element
+    plat(1234) = 2.0f;
+    plat(4321) = 2.0f;
+    CHECK(plat.vers_gpu().index_max() == 1234, "index_max with ties: %d", (int) plat.vers_gpu().index_max());
+  }
   threw = false;
-  try { (void) xg.somme(); } catch (const std::runtime_error &) { threw = true; }
-  CHECK(threw, "reductions on a resident vector must be refused");
+  try { (void) xg(0); } catch (const std::runtime_error &) { threw = true; }
+  CHECK(threw, "element access on a resident vector must be refused");
   // filtfilt = filter, reverse, filter, reverse (filtrage.hpp:1761-1765): now entirely on the device
   const Vecf h = design_rif_fen(63, "lp", 0.1f);
   const Veccf y_h = filtfilt<cfloat>(Design(h), x);

@@ -61,3 +61,20 @@ def test_vec_op_refusals(tg):
         tg.vec_op("real", torch.zeros(16, device="cuda"))      # real() of a real vector
     with pytest.raises(tg.TsdGpuError):
         tg.vec_op("add", x, torch.zeros(16, dtype=torch.complex64), out=x)   # host operand: resident vectors only
+
+
+@pytest.mark.parametrize("n", [1, 255, 70000, (1 << 22) + 3])
+def test_vec_reduce(tg, n):
+    import torch
+    rng = np.random.default_rng(n)
+    xr = rng.standard_normal(n).astype(np.float32)
+    xc = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)
+    s, mx, mn, im = tg.vec_reduce(torch.from_numpy(xr).cuda())
+    assert abs(s.real - xr.astype(np.float64).sum()) <= 1e-9 * max(1.0, np.abs(xr).sum())
+    assert mx == xr.max() and mn == xr.min() and im == int(np.argmax(xr))
+    s, _, _, _ = tg.vec_reduce(torch.from_numpy(xc).cuda())
+    ref = xc.astype(np.complex128).sum()
+    assert abs(s - ref) <= 1e-9 * max(1.0, np.abs(xc).sum())
+    flat = np.zeros(5000, np.float32)
+    flat[[1234, 4321]] = 2.0
+    assert tg.vec_reduce(torch.from_numpy(flat).cuda())[3] == 1234          # ties: the first one
