@@ -9,9 +9,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BIN = os.path.join(ROOT, "tests", "cpp", "build", "test_host_api")
 
 
-def build():
+def build(*cibles):
+    """the host library and the named targets of tests/cpp (default: the GPU test binaries; the sanitizer build of the design
+    test is only made where it is run, in the CPU tier)"""
     subprocess.run(["make", "-C", os.path.join(ROOT, "libtsd_amd", "host")], check=True, capture_output=True)
-    subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "cpp")], check=True, capture_output=True)
+    cibles = cibles or ("build/test_host_api", "build/perf_host_api", "build/test_graph_capture")
+    subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "cpp"), *cibles], check=True, capture_output=True)
 
 
 def test_host_layer_builds_and_refuses_cpu():
@@ -26,7 +29,7 @@ def test_host_layer_builds_and_refuses_cpu():
 def test_design_layer_under_sanitizers():
     """the GPU-free part of the mirror (array type, windows, FIR / IIR designs incl. the elliptic prototype, polynomial roots,
     interpolator tables) built with -fsanitize=address,undefined: values against closed forms, no memory error, no UB"""
-    build()
+    build("build/test_design_cpu")
     exe = os.path.join(ROOT, "tests", "cpp", "build", "test_design_cpu")
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")      # (the mirror keeps its allocation caches for the process lifetime)
     r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=600)
