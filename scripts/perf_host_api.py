@@ -9,5 +9,5 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 subprocess.run(["make", "-C", os.path.join(ROOT, "libtsd_amd", "csrc"), "-s"], check=True)
 subprocess.run(["make", "-C", os.path.join(ROOT, "libtsd_amd", "host"), "-s"], check=True)
-subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "-s"], check=True)
+subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "cpp"), "-s", "build/perf_host_api"], check=True)
 sys.exit(subprocess.run([os.path.join(ROOT, "tests", "cpp", "build", "perf_host_api")] + sys.argv[1:]).returncode)
