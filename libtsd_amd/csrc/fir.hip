@@ -51,9 +51,18 @@ __device__ __forceinline__ float2 mac(float2 acc, float2 x, float2 h)
 template <typename T, typename TC, int R, int THREADS, bool FAST>
 __global__ __launch_bounds__(THREADS) void fir_direct_kernel(
     const T *__restrict__ x, const T *__restrict__ hist, T *__restrict__ y,
-    const TC *__restrict__ hrev, int KP, int64_t n)
+    const TC *__restrict__ hrev, int KP, int64_t n, const T *__restrict__ old_hist, T *__restrict__ new_hist, int HL)
 {
   constexpr int TILE = THREADS * R;
+  // the workgroup after the last tile writes the stream's new history (the last HL samples of old history ++ x) into the
+  // handle's OTHER history buffer: one launch per step instead of two (small blocks are launch-bound)
+  if (blockIdx.x == gridDim.x - 1) {
+    for (int i = threadIdx.x; i < HL; i += THREADS) {
+      const int64_t g = n - HL + i;
+      new_hist[i] = g < 0 ? old_hist[HL + g] : x[g];
+    }
+    return;
+  }
   constexpr int VEC = 16 / (int) sizeof(T);          // samples per 16 B
   constexpr int P = VEC;                             // pad samples per segment
   constexpr int SP = R + P;                          // segment pitch in samples (80 B)
@@ -197,21 +206,27 @@ static int launch_direct(const tsdgpu_fir *f, const void *x, void *y, int64_t n,
   // 16-byte global accesses need 16-byte aligned buffers (tile starts are multiples of 64 B)
   const bool fast = (((uintptr_t) x | (uintptr_t) y) & 15) == 0;
   const T *hp = (const T *) f->hist[f->cur] + (f->HL - KP);
+  const T *oldh = (const T *) f->hist[f->cur];
+  T *newh = (T *) f->hist[f->cur ^ 1];
   if (fast)
-    hipLaunchKernelGGL((fir_direct_kernel<T, TC, R, THREADS, true>), dim3((unsigned) tiles), dim3(THREADS), lds, st,
-                       (const T *) x, hp, (T *) y, (const TC *) f->d_hrev, KP, n);
+    hipLaunchKernelGGL((fir_direct_kernel<T, TC, R, THREADS, true>), dim3((unsigned) tiles + 1), dim3(THREADS), lds, st,
+                       (const T *) x, hp, (T *) y, (const TC *) f->d_hrev, KP, n, oldh, newh, f->HL);
   else
-    hipLaunchKernelGGL((fir_direct_kernel<T, TC, R, THREADS, false>), dim3((unsigned) tiles), dim3(THREADS), lds, st,
-                       (const T *) x, hp, (T *) y, (const TC *) f->d_hrev, KP, n);
+    hipLaunchKernelGGL((fir_direct_kernel<T, TC, R, THREADS, false>), dim3((unsigned) tiles + 1), dim3(THREADS), lds, st,
+                       (const T *) x, hp, (T *) y, (const TC *) f->d_hrev, KP, n, oldh, newh, f->HL);
   TSD_HIP(hipGetLastError());
   return TSDGPU_OK;
 }
 
+// (the launch also writes the new history into the other buffer: the caller flips f->cur)
 int fir_direct_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, hipStream_t st)
 {
-  if (f->data_type == TSDGPU_F32) return launch_direct<float, float, 16>(f, x, y, n, st);
-  if (f->tap_type == TSDGPU_F32) return launch_direct<float2, float, 8>(f, x, y, n, st);
-  return launch_direct<float2, float2, 8>(f, x, y, n, st);
+  int rc;
+  if (f->data_type == TSDGPU_F32) rc = launch_direct<float, float, 16>(f, x, y, n, st);
+  else if (f->tap_type == TSDGPU_F32) rc = launch_direct<float2, float, 8>(f, x, y, n, st);
+  else rc = launch_direct<float2, float2, 8>(f, x, y, n, st);
+  if (!rc) f->cur ^= 1;
+  return rc;
 }
 
 int fir_update_history(tsdgpu_fir *f, const void *x, int64_t n, hipStream_t st)
@@ -408,8 +423,7 @@ int tsdgpu_fir_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, void *stre
   } else if (f->method == TSDGPU_FIR_OVERLAP_SAVE) {
     rc = ols_step(f, dx, dy, n, st);             // history update folded into the launch
   } else {
-    rc = fir_direct_step(f, dx, dy, n, st);
-    if (!rc) rc = fir_update_history(f, dx, n, st);
+    rc = fir_direct_step(f, dx, dy, n, st);      // history update folded into the launch
   }
   if (rc) return rc;
   rc = fir_settle_history(f, st);
