@@ -1,6 +1,7 @@
 // common.hip -- error reporting and host/device staging for the C-ABI shim.
 #include "common.hpp"
 #include <map>
+#include <vector>
 #include <string>
 #include <mutex>
 #include <thread>
@@ -101,32 +102,69 @@ struct Bounce {
   hipStream_t st[BOUNCE_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
   bool pending[BOUNCE_SLOTS] = {false, false, false, false};
   int next = 0;
-  bool ok = false, failed = false;
-  bool init()
+};
+// Blocks are never given back to the runtime: a thread borrows one for its lifetime and returns it to this list when it
+// ends (no HIP call at thread or process exit; the next borrower waits on whatever the previous one left pending), so the
+// page-locked memory held is 100 KiB x the largest number of threads that ever staged small buffers at the same time.
+struct BouncePool {
+  std::mutex m;
+  std::vector<Bounce *> libres;
+  Bounce *prend()
   {
-    if (ok || failed) return ok;
+    {
+      std::lock_guard<std::mutex> l(m);
+      if (!libres.empty()) {
+        Bounce *b = libres.back();
+        libres.pop_back();
+        return b;
+      }
+    }
     static const bool off = getenv("TSDGPU_NO_BOUNCE") != nullptr;
-    failed = off;
-    if (failed) return false;
+    if (off) return nullptr;
     char *blk = nullptr;
     if (hipHostMalloc((void **) &blk, BOUNCE_MAX * (BOUNCE_SLOTS + 1), hipHostMallocDefault) != hipSuccess) {
       (void) hipGetLastError();
-      failed = true;
-      return false;
+      return nullptr;
     }
+    Bounce *b = new Bounce();
     for (int i = 0; i < BOUNCE_SLOTS; i++) {
-      in[i] = blk + (size_t) i * BOUNCE_MAX;
-      if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) { failed = true; return false; }
+      b->in[i] = blk + (size_t) i * BOUNCE_MAX;
+      if (hipEventCreateWithFlags(&b->ev[i], hipEventDisableTiming) != hipSuccess) {
+        (void) hipGetLastError();
+        return nullptr;       // (a box that cannot create an event has bigger problems: the block is abandoned)
+      }
     }
-    out = blk + (size_t) BOUNCE_SLOTS * BOUNCE_MAX;
-    ok = true;
-    return true;      // (kept for the life of the thread: 320 KiB)
+    b->out = blk + (size_t) BOUNCE_SLOTS * BOUNCE_MAX;
+    return b;
+  }
+  void rend(Bounce *b)
+  {
+    std::lock_guard<std::mutex> l(m);
+    libres.push_back(b);
   }
 };
-Bounce &bounce()
+BouncePool &bounce_pool()
 {
-  static thread_local Bounce b;
-  return b;
+  static BouncePool *p = new BouncePool();      // never destroyed: threads may end after main() has returned
+  return *p;
+}
+struct BounceRef {
+  Bounce *b = nullptr;
+  bool tried = false;
+  ~BounceRef() { if (b) bounce_pool().rend(b); }
+  Bounce *get()
+  {
+    if (!tried) {
+      tried = true;
+      b = bounce_pool().prend();
+    }
+    return b;
+  }
+};
+Bounce *bounce()
+{
+  static thread_local BounceRef r;
+  return r.get();
 }
 }  // namespace
 
@@ -138,8 +176,9 @@ int stage_in(const void *src, size_t bytes, DevBuf &buf, hipStream_t st, const v
   }
   int rc = buf.reserve(bytes);
   if (rc) return rc;
-  Bounce &B = bounce();
-  if (bytes <= BOUNCE_MAX && B.init()) {
+  Bounce *Bp = bytes <= BOUNCE_MAX ? bounce() : nullptr;
+  if (Bp) {
+    Bounce &B = *Bp;
     const int k = B.next;
     B.next = (k + 1) % BOUNCE_SLOTS;
     if (B.pending[k]) TSD_HIP(hipEventSynchronize(B.ev[k]));     // the DMA engine has read the slot (immediate after a synchronised call)
@@ -173,8 +212,9 @@ int stage_out(void *dst, size_t bytes, DevBuf &buf, void **dev, bool *staged)
 int finish_out(void *dst, size_t bytes, const void *dev, bool staged, hipStream_t st)
 {
   if (!staged || bytes == 0) return TSDGPU_OK;
-  Bounce &B = bounce();
-  if (bytes <= BOUNCE_MAX && B.init()) {
+  Bounce *Bp = bytes <= BOUNCE_MAX ? bounce() : nullptr;
+  if (Bp) {
+    Bounce &B = *Bp;
     TSD_HIP(hipMemcpyAsync(B.out, dev, bytes, hipMemcpyDeviceToHost, st));
     TSD_HIP(hipStreamSynchronize(st));
     for (int k = 0; k < BOUNCE_SLOTS; k++)
