@@ -255,15 +255,47 @@ struct HostPipe {
     return TSDGPU_OK;
   }
 };
-HostPipe &host_pipe()
+// Pipes are borrowed for the duration of ONE call (a pipelined step returns only when everything has run) and go back to
+// a per-device free list: concurrent calls get a pipe each, a thread that ends leaves nothing behind.  Never freed.
+struct HostPipePool {
+  std::mutex m;
+  std::map<int, std::vector<HostPipe *>> libres;
+  HostPipe *prend(int dev)
+  {
+    {
+      std::lock_guard<std::mutex> l(m);
+      auto &v = libres[dev];
+      if (!v.empty()) {
+        HostPipe *p = v.back();
+        v.pop_back();
+        return p;
+      }
+    }
+    return new HostPipe();
+  }
+  void rend(int dev, HostPipe *p)
+  {
+    std::lock_guard<std::mutex> l(m);
+    libres[dev].push_back(p);
+  }
+};
+HostPipePool &host_pipe_pool()
 {
-  // one per calling thread (handles are not shared between threads mid-step) and per device (streams belong to
-  // the device that was current when they were created)
-  static thread_local std::map<int, HostPipe> pipes;
-  int d = 0;
-  if (hipGetDevice(&d) != hipSuccess) (void) hipGetLastError();
-  return pipes[d];
+  static HostPipePool *pool = new HostPipePool();
+  return *pool;
 }
+struct HostPipeRef {
+  int dev = 0;
+  HostPipe *p = nullptr;
+  HostPipeRef()
+  {
+    if (hipGetDevice(&dev) != hipSuccess) (void) hipGetLastError();
+    p = host_pipe_pool().prend(dev);      // (streams belong to the device that is current when they are created)
+  }
+  ~HostPipeRef() { host_pipe_pool().rend(dev, p); }
+  HostPipeRef(const HostPipeRef &) = delete;
+  HostPipeRef &operator=(const HostPipeRef &) = delete;
+};
 }  // namespace
 
 static int hip_rc(hipError_t e, const char *what)
@@ -305,7 +337,8 @@ int pipelined_host_step_var(const void *x, int64_t n, size_t esz_in, void *y, si
                             hipStream_t user, const std::function<int64_t(int64_t)> &out_cap,
                             const std::function<int(const void *, void *, int64_t, int64_t, int64_t *, hipStream_t)> &step)
 {
-  HostPipe &P = host_pipe();
+  HostPipeRef ref;
+  HostPipe &P = *ref.p;
   int rc = P.init();
   if (rc) return rc;
   static const size_t CHUNK = getenv("TSDGPU_PIPE_CHUNK_MB") ? (size_t) atoi(getenv("TSDGPU_PIPE_CHUNK_MB")) << 20 : PIPE_CHUNK_BYTES;
