@@ -8,6 +8,7 @@
 #include "common.hpp"
 #include <algorithm>
 #include <cmath>
+#include <mutex>
 #include <vector>
 
 namespace tsdgpu {
@@ -135,8 +136,33 @@ extern "C" int tsdgpu_vec_reduce(int data_type, const void *a, int64_t n, double
   TSD_CHECK(a != nullptr && is_device_ptr(a), "vec_reduce: a resident vector is expected");
   hipStream_t st = (hipStream_t) stream;
   const int nb = (int) std::min<int64_t>(cdiv(n, 256), 1024);
-  static thread_local DevBuf parts;       // (one per calling thread; a few tens of KB)
-  int rc = parts.reserve((size_t) nb * sizeof(RedPart));
+  // partial results: a 48-KiB device block borrowed for the call from a per-device free list (never freed; as many
+  // blocks as calls ever ran at once)
+  struct Bloc { int dev; DevBuf buf; };
+  static std::mutex m;
+  static std::vector<Bloc *> *libres = new std::vector<Bloc *>();
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) (void) hipGetLastError();
+  Bloc *bl = nullptr;
+  {
+    std::lock_guard<std::mutex> l(m);
+    for (size_t i = 0; i < libres->size(); i++)
+      if ((*libres)[i]->dev == dev) {
+        bl = (*libres)[i];
+        libres->erase(libres->begin() + (long) i);
+        break;
+      }
+  }
+  if (!bl) {
+    bl = new Bloc();
+    bl->dev = dev;
+  }
+  struct Rend {
+    Bloc *b;
+    ~Rend() { std::lock_guard<std::mutex> l(m); libres->push_back(b); }
+  } rend{bl};
+  DevBuf &parts = bl->buf;
+  int rc = parts.reserve((size_t) 1024 * sizeof(RedPart));
   if (rc) return rc;
   if (data_type == TSDGPU_C64) hipLaunchKernelGGL(vec_reduce_kernel<true>, dim3(nb), dim3(256), 0, st, (const float *) a, n, (RedPart *) parts.p);
   else hipLaunchKernelGGL(vec_reduce_kernel<false>, dim3(nb), dim3(256), 0, st, (const float *) a, n, (RedPart *) parts.p);
