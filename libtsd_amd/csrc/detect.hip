@@ -351,8 +351,10 @@ int tsdgpu_detector_step(tsdgpu_detector *d, const void *x, int64_t n, float *sc
     TSD_HIP(hipMemcpyAsync(scores, d->sbuf[cur] + d->P, (size_t) n * sizeof(float), dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
   }
   std::vector<char> host(sizeof(DetHeader) + (size_t) d->max_recs * sizeof(tsdgpu_peak));
-  TSD_HIP(hipMemcpyAsync(host.data(), d->recs.p, host.size(), hipMemcpyDeviceToHost, st));
-  TSD_HIP(hipStreamSynchronize(st));
+  {
+    const int rc2 = finish_out(host.data(), host.size(), d->recs.p, true, st);     // (page-locked bounce + synchronisation)
+    if (rc2) return rc2;
+  }
   const DetHeader *hh = (const DetHeader *) host.data();
   const tsdgpu_peak *hr = (const tsdgpu_peak *) (host.data() + sizeof(DetHeader));
   TSD_CHECK(hh->count <= d->max_recs, "detector_step: %d peaks in one block (limit %d): raise the threshold", hh->count, d->max_recs);
