@@ -58,4 +58,6 @@ def test_concurrent_threads_small_and_large_host_calls(orc):
     torch.cuda.synchronize()
     free2 = torch.cuda.mem_get_info()[0]
     assert not errs, errs
-    assert free1 - free2 <= (64 << 20), f"device memory kept growing: {free0 >> 20} -> {free1 >> 20} -> {free2 >> 20} MiB"
+    # 25 threads have come and gone.  What stays is bounded by the CONCURRENCY (at most 5 calls at once: 5 host pipes of
+    # 4 x 16 MiB, 5 reduction blocks), not by the number of threads: a per-thread leak of one pipe would be 1.6 GiB here
+    assert free0 - free2 <= (600 << 20), f"device memory kept growing: {free0 >> 20} -> {free1 >> 20} -> {free2 >> 20} MiB"
