@@ -342,6 +342,26 @@ template <typename T> class Vecteur {
     for (entier i = 0; i < n_; i++) v.data()[i] = cfloat(p_[i]);
     return v;
   }
+  Vecteur conjugate() const
+  {
+    if constexpr (std::is_same_v<T, cfloat>) {
+      Vecteur v;
+      v.alloc(n_, gpu_);
+      if (gpu_) detail::gpu_op_vec(detail::OP_CONJ, true, v.p_, p_, nullptr, 0.f, 0.f, (size_t) n_);
+      else for (entier i = 0; i < n_; i++) v.p_[i] = std::conj(p_[i]);
+      return v;
+    } else {
+      return clone();
+    }
+  }
+  // a vector of n zeros on the side (host / device) this one lives on
+  Vecteur zeros_du_meme_cote(entier n) const
+  {
+    Vecteur v;
+    v.alloc(n, gpu_);
+    v.setZero();
+    return v;
+  }
   template <typename U> Vecteur<U> as() const
   {
     exige_hote("as");

@@ -36,14 +36,18 @@ void csym_forçage_impl(Veccf &X)
 }
 
 // ---- correlations (fourier.cc:489-597) --------------------------------------------------------
+// The element-wise steps are written with the array operators, which run where the vectors live; the entry points bring
+// host vectors to the device once and the result back once, so nothing but the transforms' inputs / outputs crosses PCIe
+// and no step runs on the host (a resident caller gets a resident result).
 static Veccf correlation_freq(const Veccf &X0, const Veccf &X1)
 {
   const entier n = X0.rows();
   if (n != X1.rows()) échec("correlation_freq: dimensions {} != {}", n, X1.rows());
-  Veccf Y(n);
-  Y(0) = X0(0) * std::conj(X1(0));
-  // Y.tail(n-1) = X0.tail(n-1).reverse() * X1.tail(n-1).reverse().conjugate()
-  for (entier i = 1; i < n; i++) Y(i) = X0(n - i) * std::conj(X1(n - i));
+  // Y(0) = X0(0) conj(X1(0));  Y.tail(n-1) = X0.tail(n-1).reverse() * X1.tail(n-1).reverse().conjugate()   (fourier.cc:489-505)
+  const Veccf P = X0 * X1.conjugate();
+  Veccf Y = X0.zeros_du_meme_cote(n);
+  if (n > 0) Y.head(1) = P.head(1);
+  if (n > 1) Y.tail(n - 1) = P.tail(n - 1).reverse();
   Y *= cfloat(std::sqrt((float) n), 0.f);
   return Y;
 }
@@ -58,9 +62,15 @@ static Veccf correlateur_bloc(const Veccf &x0, const Veccf &x1)
 std::tuple<Vecf, Veccf> ccorr(const Veccf &x0, const Veccf &x1)
 {
   const entier m = x0.rows();
-  Veccf r = correlateur_bloc(x0, x1);
-  r /= cfloat((float) m, 0.f);
-  return {linspace(0, (float) (m - 1), m), r};
+  const bool hote = !x0.est_sur_gpu();
+  if (m == 0) return {Vecf(), Veccf()};
+  Veccf r;
+  {
+    ResidenceGpu garde;        // the transforms' outputs stay on the device
+    r = hote ? correlateur_bloc(x0.vers_gpu(), x1.rows() ? x1.vers_gpu() : Veccf()) : correlateur_bloc(x0, x1);
+    r /= cfloat((float) m, 0.f);
+  }
+  return {linspace(0, (float) (m - 1), m), hote ? r.vers_hote() : r};
 }
 // xcorrb / xcorr: zero-padding, the two forward transforms (one batched call), correlation_freq, the inverse
 // transform and the extraction / scaling of the lags all run on the device (tsdgpu_xcorr): the vectors go
@@ -83,14 +93,20 @@ Vecf rééchan_freq(const Vecf &x, float lom)
 {
   if (lom == 1) return x;
   const entier n = x.rows(), n2 = (entier) std::round(n * lom);
-  const Veccf X = fft(x);
-  Veccf X2 = Veccf::zeros(n2);
-  const entier h = (lom > 1 ? n : n2) / 2;
-  X2.head(h) = X.head(h);
-  X2.tail(h) = X.tail(h);
-  Veccf xi = ifft(X2);
-  xi *= cfloat(std::sqrt(lom), 0.f);
-  return real(xi);
+  const bool hote = !x.est_sur_gpu();
+  Vecf y;
+  {
+    ResidenceGpu garde;        // the transforms' outputs stay on the device
+    const Veccf X = fft(hote ? x.vers_gpu() : x);
+    Veccf X2 = X.zeros_du_meme_cote(n2);
+    const entier h = (lom > 1 ? n : n2) / 2;
+    X2.head(h) = X.head(h);
+    X2.tail(h) = X.tail(h);
+    Veccf xi = ifft(X2);
+    xi *= cfloat(std::sqrt(lom), 0.f);
+    y = real(xi);
+  }
+  return hote ? y.vers_hote() : y;
 }
 
 // ---- délais (fourier.cc:607-698) ----------------------------------------------------------------
@@ -103,14 +119,24 @@ Vecf rééchan_freq(const Vecf &x, float lom)
 static Veccf délais_frac(const Veccf &x, float τ)
 {
   const entier m = x.rows(), n = 2 * m, marge = m / 2;
-  Veccf étendu = Veccf::zeros(n);
-  étendu.segment(marge, m) = x;
-  Veccf X = fft(étendu);
+  const bool hote = !x.est_sur_gpu();
+  // the linear phase, tabulated on the host (n phasors) and multiplied in where the spectrum lives
+  Veccf phase = Veccf::hote(n);
   for (entier k = 0; k < n; k++) {
     const entier ks = k < n / 2 ? k : k - n;                       // signed bin
-    X(k) *= std::polar(1.0f, (float) (-2.0 * π * (double) ks * (double) τ / (double) n));
+    phase.data()[k] = std::polar(1.0f, (float) (-2.0 * π * (double) ks * (double) τ / (double) n));
   }
-  return ifft(X).segment(marge, m).clone();
+  Veccf y;
+  {
+    ResidenceGpu garde;        // the transforms' outputs stay on the device
+    const Veccf xg = hote ? x.vers_gpu() : x;
+    Veccf étendu = xg.zeros_du_meme_cote(n);
+    étendu.segment(marge, m) = xg;
+    Veccf X = fft(étendu);
+    X *= phase.vers_gpu();
+    y = ifft(X).segment(marge, m).clone();
+  }
+  return hote ? y.vers_hote() : y;
 }
 static Vecf délais_frac(const Vecf &x, float τ) { return real(délais_frac(x.as_complex(), τ)); }
 // whole-sample delay: y(i) = x(i - d), zeros shifted in

@@ -157,6 +157,17 @@ static void test_residence_ops()
     res = ifft(fft(xg.head(4096).clone()) * H.vers_gpu());
   }
   CHECK(res.est_sur_gpu() && ecart_rel(res.vers_hote(), ref) <= 2e-6f, "resident spectral product: %g", ecart_rel(res.vers_hote(), ref));
+  // the correlation / delay compositions run on the device whatever the caller holds: resident in -> resident out, same values
+  {
+    const Veccf a = x.head(4096).clone(), b = z.head(4096).clone();
+    const auto [lh, ch] = ccorr(a, b);
+    const auto [lg, cg] = ccorr(a.vers_gpu(), b.vers_gpu());
+    CHECK(!ch.est_sur_gpu() && cg.est_sur_gpu() && ecart_rel(cg.vers_hote(), ch) <= 1e-6f, "ccorr resident vs host: %g", ecart_rel(cg.vers_hote(), ch));
+    const Veccf dh = délais(a, 2.5f), dg = délais(a.vers_gpu(), 2.5f);
+    CHECK(!dh.est_sur_gpu() && dg.est_sur_gpu() && ecart_rel(dg.vers_hote(), dh) <= 1e-6f, "délais resident vs host: %g", ecart_rel(dg.vers_hote(), dh));
+    const Vecf rh = rééchan_freq(u.head(4096).clone(), 2), rg = rééchan_freq(u.head(4096).clone().vers_gpu(), 2);
+    CHECK(!rh.est_sur_gpu() && rg.est_sur_gpu() && rg.rows() == 8192 && ecart_rel(rg.vers_hote(), rh) <= 1e-6f, "rééchan_freq resident vs host");
+  }
 }
 
 static void test_residence_gpu()
