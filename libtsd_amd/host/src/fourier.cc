@@ -143,11 +143,9 @@ static Vecf délais_frac(const Vecf &x, float τ) { return real(délais_frac(x.a
 template <typename T> static Vecteur<T> délais_entier(const Vecteur<T> &x, entier d)
 {
   const entier n = x.rows();
-  Vecteur<T> y = Vecteur<T>::hote(n);
-  for (entier i = 0; i < n; i++) {
-    const entier j = i - d;
-    y.data()[i] = (j >= 0 && j < n) ? x.data()[j] : T(0);
-  }
+  Vecteur<T> y = x.zeros_du_meme_cote(n);          // (two views and a copy: runs where x lives)
+  if (d >= 0 && d < n) y.segment(d, n - d) = x.segment(0, n - d);
+  else if (d < 0 && -d < n) y.segment(0, n + d) = x.segment(-d, n + d);
   return y;
 }
 template <typename T> Vecteur<T> délais(const Vecteur<T> &x, float τ)
