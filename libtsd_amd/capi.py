@@ -323,10 +323,11 @@ class Ola:
     def _out(self, x, n):
         return np.empty(n, np.complex64) if isinstance(x, np.ndarray) else x.new_empty(n)
 
-    def step(self, x, stream=None):
+    def step(self, x, y=None, stream=None):
         assert _dtype_code(x) == C64
         n = int(x.shape[0])
-        y = self._out(x, max(1, lib().tsdgpu_ola_max_out(self._h, n)))
+        if y is None:
+            y = self._out(x, max(1, lib().tsdgpu_ola_max_out(self._h, n)))
         nout = C.c_int64(0)
         _check(lib().tsdgpu_ola_step(self._h, _ptr(x) if n else None, n, _ptr(y), C.byref(nout), _stream_of(x, stream)))
         return y[:nout.value]

@@ -38,6 +38,9 @@ bool ols_preferred(const tsdgpu_fir *f);
 int ols_plan_create(tsdgpu_fir *f);
 void ols_plan_destroy(tsdgpu_fir *f);
 int ols_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, hipStream_t st);
+// overlap-ADD fast path (Ne = 512, N = 1024, no window, device response) on the in-wave 1024-point transform: ols.hip
+void ola1024_tables(const float2 *H_host, float2 *out3);
+int ola1024_launch(const float2 *x, float2 *y, const float2 *tables3, const float2 *svg_in, float2 *svg_out, int64_t B, hipStream_t st);
 // overlap-save for long filters (514..12289 taps), radix-16 Stockham blocks
 bool ols_long_supported(const tsdgpu_fir *f);
 int ols_long_plan_create(tsdgpu_fir *f);

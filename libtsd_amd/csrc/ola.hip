@@ -6,6 +6,8 @@
 #include "common.hpp"
 #include "fft1024_wave.hpp"
 #include "stockham16.hpp"
+#include "fir_internal.hpp"
+#include <vector>
 #include <algorithm>
 #include <cmath>
 
@@ -22,6 +24,8 @@ struct tsdgpu_ola {
   bool fuse_response = false;              // set by tsdgpu_ola_step: the forward transform applies H itself
   bool response_applied = false;
   tsdgpu::DevBuf frames, spectra, in_stage, out_stage;
+  tsdgpu::cpx *d_fast = nullptr;           // fast path (Ne = 512, N = 1024, no window): response in register order / N + twiddles (3 x 1024)
+  tsdgpu::cpx *d_svg_tmp = nullptr;        // Ne: the new tail, written by the last wave while the first one may still read d_svg
 };
 
 namespace tsdgpu {
@@ -349,10 +353,22 @@ int tsdgpu_ola_set_response(tsdgpu_ola *h, const void *H)
   if (!H) {
     if (h->d_H) (void) hipFree(h->d_H);
     h->d_H = nullptr;
+    if (h->d_fast) (void) hipFree(h->d_fast);
+    h->d_fast = nullptr;
     return TSDGPU_OK;
   }
   if (!h->d_H) TSD_HIP(hipMalloc((void **) &h->d_H, (size_t) h->N * sizeof(cpx)));
   TSD_HIP(hipMemcpy(h->d_H, H, (size_t) h->N * sizeof(cpx), hipMemcpyDefault));
+  // the reference's default geometry without window: one fused kernel (ols.hip, ola1024_kernel) serves whole-block calls
+  static const bool unfused = getenv("TSDGPU_OLA_UNFUSED") != nullptr;
+  if (!unfused && !h->windowed && h->N == 1024 && h->Ne == 512) {
+    std::vector<cpx> Hh(1024), t3(3 * 1024);
+    TSD_HIP(hipMemcpy(Hh.data(), h->d_H, 1024 * sizeof(cpx), hipMemcpyDeviceToHost));
+    ola1024_tables(Hh.data(), t3.data());
+    if (!h->d_fast) TSD_HIP(hipMalloc((void **) &h->d_fast, t3.size() * sizeof(cpx)));
+    if (!h->d_svg_tmp) TSD_HIP(hipMalloc((void **) &h->d_svg_tmp, 512 * sizeof(cpx)));
+    TSD_HIP(hipMemcpy(h->d_fast, t3.data(), t3.size() * sizeof(cpx), hipMemcpyHostToDevice));
+  }
   return TSDGPU_OK;
 }
 
@@ -498,6 +514,35 @@ int tsdgpu_ola_write_spectra(tsdgpu_ola *h, const void *host_src, void *stream)
 int tsdgpu_ola_step(tsdgpu_ola *h, const void *x, int64_t n, void *y, int64_t *n_out, void *stream)
 {
   TSD_CHECK(h != nullptr, "ola_step: NULL handle");
+  if (h->d_fast && h->nrest == 0 && n >= h->Ne && h->pending_blocks < 0 && x != nullptr && y != nullptr) {
+    // fast path: B whole blocks through ONE kernel, 16 B of HBM traffic per sample (see ols.hip)
+    hipStream_t st = (hipStream_t) stream;
+    const int Ne = h->Ne;
+    const int64_t B = n / Ne, nout = B * Ne, left = n - nout;
+    if (n_out) *n_out = 0;
+    const void *dxv = nullptr;
+    void *dyv = nullptr;
+    bool staged = false;
+    int rc = stage_in(x, (size_t) n * sizeof(cpx), h->in_stage, st, &dxv);
+    if (rc) return rc;
+    if ((rc = stage_out(y, (size_t) nout * sizeof(cpx), h->out_stage, &dyv, &staged))) return rc;
+    if (dxv == dyv) {
+      // in place on the device: a run re-reads the block before it, which the run before may already have overwritten
+      if ((rc = h->in_stage.reserve((size_t) n * sizeof(cpx)))) return rc;
+      TSD_HIP(hipMemcpyAsync(h->in_stage.p, dxv, (size_t) n * sizeof(cpx), hipMemcpyDeviceToDevice, st));
+      dxv = h->in_stage.p;
+    }
+    const cpx *dx = (const cpx *) dxv;
+    if (left > 0) TSD_HIP(hipMemcpyAsync(h->d_rest, dx + nout, (size_t) left * sizeof(cpx), hipMemcpyDeviceToDevice, st));
+    if ((rc = ola1024_launch(dx, (cpx *) dyv, h->d_fast, h->d_svg, h->d_svg_tmp, B, st))) return rc;
+    TSD_HIP(hipMemcpyAsync(h->d_svg, h->d_svg_tmp, (size_t) Ne * sizeof(cpx), hipMemcpyDeviceToDevice, st));
+    if ((rc = finish_out(y, (size_t) nout * sizeof(cpx), dyv, staged, st))) return rc;
+    if (dxv != x && !staged) TSD_HIP(hipStreamSynchronize(st));    // (a staged input must outlive its kernels)
+    h->nrest = (int) left;
+    h->cnt_ech += nout;
+    if (n_out) *n_out = nout;
+    return TSDGPU_OK;
+  }
   void *sp = nullptr;
   int nf = 0;
   h->fuse_response = true;
@@ -572,7 +617,7 @@ int tsdgpu_ola_destroy(tsdgpu_ola *h)
 {
   if (!h) return TSDGPU_OK;
   if (h->plan) tsdgpu_fft_destroy(h->plan);
-  for (void *q : {(void *) h->d_fen, (void *) h->d_H, (void *) h->d_svg, (void *) h->d_last, (void *) h->d_prev_half, (void *) h->d_rest})
+  for (void *q : {(void *) h->d_fen, (void *) h->d_H, (void *) h->d_svg, (void *) h->d_last, (void *) h->d_prev_half, (void *) h->d_rest, (void *) h->d_fast, (void *) h->d_svg_tmp})
     if (q) (void) hipFree(q);
   h->frames.release();
   h->spectra.release();

@@ -418,4 +418,105 @@ int ols_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, hipStream_t st)
   return TSDGPU_OK;
 }
 
+// ---- overlap-ADD on the same in-wave transform: the fast path of the OLA engine (ola.hip) ----------------------------
+// OLA<cfloat>::step_interne without window (fourier.cc:846-872) in its default geometry Ne = 512, N = 1024 (= Nz = Ne):
+//   frame = [512 zeros | block b]  ->  X = FFT(frame)  ->  X *= H (the caller's response)  ->  x2 = IFFT(X)
+//   y_b = x2_{b-1}[512..1023] + x2_b[0..511]          (svg.tail(Nz) += x2.head(Nz); y = svg; svg = x2.tail(Ne))
+// The multi-kernel engine moves 80 B per sample through HBM for that (frames, spectra, inverse frames); here a wave keeps
+// a RUN of consecutive blocks in registers end to end: 16 B per sample.  The tail of the block before the run is needed to
+// start it: the first wave takes it from the handle's state (svg), the others recompute that one block (1 / per more work).
+__global__ __launch_bounds__(64, 2) void ola1024_kernel(const cpx *__restrict__ x, cpx *__restrict__ y, const cpx *__restrict__ Hreg,
+                                                        const cpx *__restrict__ TW1, const cpx *__restrict__ TW2,
+                                                        const cpx *__restrict__ svg_in, cpx *__restrict__ svg_out, int64_t B, int per)
+{
+  __shared__ cv lds[LDS_ELEMS];
+  const int lane = threadIdx.x;
+  const int64_t b_lo = (int64_t) blockIdx.x * per, b_hi = min(B, b_lo + (int64_t) per);
+  if (b_lo >= B) return;
+  cv tw1[16], tw2[16], H[16];
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    tw1[r] = ((const cv *) TW1)[r * 64 + lane];
+    tw2[r] = ((const cv *) TW2)[r * 64 + lane];
+    H[r] = ((const cv *) Hreg)[r * 64 + lane];
+  }
+  auto sync = []() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  const cv *xs = (const cv *) x;
+  cv *ys = (cv *) y;
+  cv cur[16], carry[8], nxt[8];
+  auto transform = [&](cv (&v)[16]) {
+    forward(v, lds, lane, tw1, tw2, sync);
+#pragma unroll
+    for (int r = 0; r < 16; r++) v[r] = cmul(v[r], H[r]);
+    inverse(v, lds, lane, tw1, tw2, sync);
+    sync();
+  };
+  if (b_lo == 0) {
+#pragma unroll
+    for (int r = 0; r < 8; r++) carry[r] = ((const cv *) svg_in)[64 * r + lane];
+  } else {
+#pragma unroll
+    for (int r = 0; r < 8; r++) { cur[r] = mkv(0.f, 0.f); cur[8 + r] = xs[(b_lo - 1) * 512 + 64 * r + lane]; }
+    transform(cur);
+#pragma unroll
+    for (int r = 0; r < 8; r++) carry[r] = cur[8 + r];
+  }
+#pragma unroll
+  for (int r = 0; r < 8; r++) nxt[r] = xs[b_lo * 512 + 64 * r + lane];
+  for (int64_t b = b_lo; b < b_hi; b++) {
+#pragma unroll
+    for (int r = 0; r < 8; r++) { cur[r] = mkv(0.f, 0.f); cur[8 + r] = nxt[r]; }
+    const bool more = b + 1 < b_hi;
+    if (more) {
+#pragma unroll
+      for (int r = 0; r < 8; r++) nxt[r] = xs[(b + 1) * 512 + 64 * r + lane];
+    }
+    transform(cur);
+    if (more) {
+      // (vmcnt retires in order: wait for the prefetch, a whole transform old, BEFORE the stores are queued behind it)
+#pragma unroll
+      for (int r = 0; r < 8; r++) asm volatile("" ::"v"(nxt[r]));
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+      ys[b * 512 + 64 * r + lane] = mkv(cur[r].x + carry[r].x, cur[r].y + carry[r].y);
+      carry[r] = cur[8 + r];
+    }
+  }
+  if (b_hi == B) {
+#pragma unroll
+    for (int r = 0; r < 8; r++) ((cv *) svg_out)[64 * r + lane] = carry[r];
+  }
+}
+
+// tables of the fast path: the response in the transform's register order, scaled by 1/N (the engine's transforms are
+// unitary each way, the in-wave ones are not scaled), and the two twiddle sets -> 3 x 1024 complex values
+void ola1024_tables(const cpx *H_host, cpx *out3)
+{
+  for (int lane = 0; lane < 64; lane++)
+    for (int r = 0; r < 16; r++) {
+      const cpx h = H_host[freq_index(lane, r)];
+      out3[r * 64 + lane] = mk(h.x / 1024.f, h.y / 1024.f);
+    }
+  fill_twiddles(out3 + 1024, out3 + 2048);
+}
+
+// B whole blocks of 512 samples: x, y, svg device pointers (y may not alias x: blocks are re-read by the next run)
+int ola1024_launch(const cpx *x, cpx *y, const cpx *tables3, const cpx *svg_in, cpx *svg_out, int64_t B, hipStream_t st)
+{
+  if (B <= 0) return TSDGPU_OK;
+  // blocks per wave: short calls spread one block per wave (each recomputes its predecessor: twice the arithmetic, all of it
+  // parallel); long ones amortise the recomputed block over a run of up to 16
+  const int per = (int) std::min<int64_t>(16, std::max<int64_t>(1, B / 2048));
+  const int64_t grid = cdiv(B, per);
+  if (grid > 0x7fffffff) return set_err(TSDGPU_ERR_UNSUPPORTED, "ola: too many blocks in one call");
+  hipLaunchKernelGGL(ola1024_kernel, dim3((unsigned) grid), dim3(64), 0, st, x, y, tables3, tables3 + 1024, tables3 + 2048, svg_in, svg_out, B, per);
+  TSD_HIP(hipGetLastError());
+  return TSDGPU_OK;
+}
+
 }  // namespace tsdgpu

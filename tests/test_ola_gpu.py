@@ -164,3 +164,44 @@ def test_welch_long_device_input():
     ref, _ = ola_oracle.psd_welch_sum(x[:50 * N + 1].cpu().numpy(), N, w)
     S2, _ = t.welch(x[:50 * N + 1], N, w)
     assert np.max(np.abs(S2 - ref)) <= TOL * np.max(ref)
+
+
+def test_fused_default_geometry_long_runs():
+    """Ne = 512 / N = 1024 without window runs as ONE kernel (ols.hip, ola1024_kernel): a wave keeps a run of up to 16
+    consecutive blocks in registers and starts it by recomputing the block before.  Long calls (runs of 1, 4 and 16 blocks
+    per wave), two calls in a row (the tail carried by the handle), in place, host arrays: against the device FIR that the
+    product with H = FFT([0 .. 0 | h]) * sqrt(N) must equal, Ne - K later (fourier.cc:946-990)."""
+    import torch
+    rng = np.random.default_rng(11)
+    K, Ne = 127, 512
+    g = t.Ola(Ne, K, None)
+    assert (g.N, g.Ne) == (1024, 512)
+    H, h = response(g.N, rng, K)
+    d = Ne - K
+    for B in (3, 700, 9000, 40000):
+        n = B * Ne
+        x = torch.view_as_complex(torch.randn(n, 2, device="cuda", generator=torch.Generator(device="cuda").manual_seed(B)))
+        ref = t.Fir(h, t.C64, t.FIR_DIRECT).step(x)
+        g = t.Ola(Ne, K, None)
+        g.set_response(H)
+        y = g.step(x)
+        assert y.shape[0] == n
+        e = float((y[d:] - ref[:n - d]).abs().max() / ref.abs().max())
+        assert e <= 2e-5, (B, e)
+        # the same stream in two calls (the second one ragged: 100 samples wait for a next call), then in place
+        g2 = t.Ola(Ne, K, None)
+        g2.set_response(H)
+        cut = (B // 2) * Ne
+        y2 = torch.cat([g2.step(x[:cut]), g2.step(x[cut:n - Ne + 100])])
+        assert torch.equal(y2, y[:y2.shape[0]])
+        g3 = t.Ola(Ne, K, None)
+        g3.set_response(H)
+        xi = x.clone()
+        assert torch.equal(g3.step(xi, xi), y)
+    # host arrays through the same path
+    xh = randc(rng, 64 * Ne)
+    g = t.Ola(Ne, K, None)
+    g.set_response(H)
+    yh = g.step(xh)
+    yr = orc.fir(h, xh)
+    assert relerr(yh[d:], yr[:len(yh) - d]) <= 2e-5
