@@ -35,9 +35,24 @@ __global__ void det_abs2_kernel(const cpx *__restrict__ x, float *__restrict__ e
 
 // score of the block's n correlation outputs into the rolling buffers at [P, P + n); the energy of output i
 // is the moving average D samples earlier (D = correlator delay - (M - 1)): from this block or the history
+struct DetHeader { int count, pad[3]; };
+
+// (small blocks are launch-bound: the workgroups after the n / 256 scoring ones write the next energy history, and the very
+// first thread clears the peak counter of the search that follows)
 __global__ void det_score_kernel(const cpx *__restrict__ corr, const float *__restrict__ en, const float *__restrict__ ehist, int D,
-                                 float ratio, float *__restrict__ sbuf, cpx *__restrict__ cbuf, int P, int64_t n)
+                                 float ratio, float *__restrict__ sbuf, cpx *__restrict__ cbuf, int P, int64_t n,
+                                 float *__restrict__ ehist_next, DetHeader *__restrict__ hdr, unsigned nb_score)
 {
+  if (blockIdx.x == 0 && threadIdx.x == 0) hdr->count = 0;
+  if (blockIdx.x >= nb_score) {
+    // next history: the last D moving-average values of (ehist ++ en)
+    const int k = (int) (blockIdx.x - nb_score) * blockDim.x + threadIdx.x;
+    if (k < D) {
+      const int64_t src = n - D + k;
+      ehist_next[k] = src >= 0 ? en[src] : ehist[D + src];
+    }
+    return;
+  }
   const int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   cpx c = corr[i];
@@ -51,22 +66,22 @@ __global__ void det_score_kernel(const cpx *__restrict__ corr, const float *__re
   cbuf[P + i] = c;
 }
 
-// next history: the last D moving-average values of (ehist ++ en)
-__global__ void det_ehist_kernel(const float *__restrict__ ehist, const float *__restrict__ en, float *__restrict__ next, int D, int64_t n)
-{
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= D) return;
-  const int64_t src = n - D + i;
-  next[i] = src >= 0 ? en[src] : ehist[D + src];
-}
-
-struct DetHeader { int count, pad[3]; };
 
 // peaks among buffer positions j in [M + 1, M + n]: above the threshold, larger than the M - 1 later
 // samples and not smaller than the M - 1 earlier ones.  One record per peak (unordered; sorted by the host).
+// (the workgroups after the n / 256 searching ones move the last P samples of the rolling buffers to the front of the other pair)
 __global__ void det_peak_kernel(const float *__restrict__ sbuf, const cpx *__restrict__ cbuf, int M, int P, int64_t n, float seuil,
-                                DetHeader *__restrict__ hdr, tsdgpu_peak *__restrict__ recs, int max_recs)
+                                DetHeader *__restrict__ hdr, tsdgpu_peak *__restrict__ recs, int max_recs, float *__restrict__ s_nxt,
+                                cpx *__restrict__ c_nxt, unsigned nb_peak)
 {
+  if (blockIdx.x >= nb_peak) {
+    const int i = (int) (blockIdx.x - nb_peak) * blockDim.x + threadIdx.x;
+    if (i < P) {
+      s_nxt[i] = sbuf[n + i];
+      c_nxt[i] = cbuf[n + i];
+    }
+    return;
+  }
   const int64_t k = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= n) return;
   const int64_t j = M + 1 + k;
@@ -85,15 +100,6 @@ __global__ void det_peak_kernel(const float *__restrict__ sbuf, const cpx *__res
   recs[slot] = r;
 }
 
-// the last P samples of the rolling buffers move to the front of the other pair
-__global__ void det_roll_kernel(const float *__restrict__ s_cur, const cpx *__restrict__ c_cur, float *__restrict__ s_nxt,
-                                cpx *__restrict__ c_nxt, int P, int64_t n)
-{
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= P) return;
-  s_nxt[i] = s_cur[n + i];
-  c_nxt[i] = c_cur[n + i];
-}
 
 // ---- correlations ----------------------------------------------------------------------------------
 // Y(0) = X0(0) conj(X1(0)), Y(i) = X0(n - i) conj(X1(n - i)), all times sqrt(n)   (fourier.cc:489-503)
@@ -316,33 +322,27 @@ int tsdgpu_detector_step(tsdgpu_detector *d, const void *x, int64_t n, float *sc
   if (d->mode == 0) {
     int64_t got = 0;
     TSD_CHECK(tsdgpu_ola_max_out(d->ola, n) <= n + d->Ne, "detector_step: unexpected OLA output bound");
-    rc = d->sc_stage.reserve((size_t) (n + d->Ne) * sizeof(cpx));
+    rc = d->corr.reserve((size_t) (n + d->Ne) * sizeof(cpx));          // (the engine may hand out up to one more block)
     if (rc) return rc;
-    rc = tsdgpu_ola_step(d->ola, dx, n, d->sc_stage.p, &got, st);
+    rc = tsdgpu_ola_step(d->ola, dx, n, d->corr.p, &got, st);
     if (rc) return rc;
     if (got != n)
       return set_err(TSDGPU_ERR_INVALID, "detector_step: the OLA correlator returned %lld samples for %lld inputs (feed whole blocks of %d samples)",
                      (long long) got, (long long) n, d->Ne);
-    TSD_HIP(hipMemcpyAsync(d->corr.p, d->sc_stage.p, (size_t) n * sizeof(cpx), hipMemcpyDeviceToDevice, st));
   } else {
     rc = tsdgpu_fir_step(d->fir_corr, dx, d->corr.p, n, st);
     if (rc) return rc;
   }
   const int cur = d->cur, nxt = cur ^ 1;
-  hipLaunchKernelGGL(det_score_kernel, dim3(nb(n)), dim3(256), 0, st, d->corr.as<cpx>(), d->en.as<float>(), d->ehist[d->ecur], d->D, d->ratio,
-                     d->sbuf[cur], d->cbuf[cur], d->P, n);
-  TSD_HIP(hipGetLastError());
-  if (d->D > 0) {
-    hipLaunchKernelGGL(det_ehist_kernel, dim3(nb(d->D)), dim3(256), 0, st, d->ehist[d->ecur], d->en.as<float>(), d->ehist[d->ecur ^ 1], d->D, n);
-    TSD_HIP(hipGetLastError());
-    d->ecur ^= 1;
-  }
   DetHeader *hdr = (DetHeader *) d->recs.p;
   tsdgpu_peak *recs = (tsdgpu_peak *) ((char *) d->recs.p + sizeof(DetHeader));
-  TSD_HIP(hipMemsetAsync(hdr, 0, sizeof(DetHeader), st));
-  hipLaunchKernelGGL(det_peak_kernel, dim3(nb(n)), dim3(256), 0, st, d->sbuf[cur], d->cbuf[cur], d->M, d->P, n, d->seuil, hdr, recs, d->max_recs);
+  const unsigned nbn = nb(n);
+  hipLaunchKernelGGL(det_score_kernel, dim3(nbn + (d->D > 0 ? nb(d->D) : 0)), dim3(256), 0, st, d->corr.as<cpx>(), d->en.as<float>(),
+                     d->ehist[d->ecur], d->D, d->ratio, d->sbuf[cur], d->cbuf[cur], d->P, n, d->ehist[d->ecur ^ 1], hdr, nbn);
   TSD_HIP(hipGetLastError());
-  hipLaunchKernelGGL(det_roll_kernel, dim3(nb(d->P)), dim3(256), 0, st, d->sbuf[cur], d->cbuf[cur], d->sbuf[nxt], d->cbuf[nxt], d->P, n);
+  if (d->D > 0) d->ecur ^= 1;
+  hipLaunchKernelGGL(det_peak_kernel, dim3(nbn + nb(d->P)), dim3(256), 0, st, d->sbuf[cur], d->cbuf[cur], d->M, d->P, n, d->seuil, hdr, recs,
+                     d->max_recs, d->sbuf[nxt], d->cbuf[nxt], nbn);
   TSD_HIP(hipGetLastError());
   d->cur = nxt;
   // results: the score vector (if asked for) and ONE small copy of the peak records
