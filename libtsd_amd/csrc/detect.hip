@@ -257,18 +257,20 @@ int tsdgpu_detector_create(tsdgpu_detector **out, const void *motif_host, int M,
       if (rc) break;
       d->delais = Ne;
     } else {
-      // correlation as a FIR with the reversed conjugated pattern (real taps when the pattern is real)
+      // correlation as a FIR with the reversed conjugated pattern (real taps when the pattern is real): the reference's MODE_RIF
+      // is a time-domain filter -- exact zeros in, exact zeros out -- so moderate patterns stay on the direct kernel
+      const int methode_exacte = M <= 1024 ? TSDGPU_FIR_DIRECT : TSDGPU_FIR_AUTO;
       double im = 0, tot = 0;
       for (int i = 0; i < M; i++) { im += std::fabs(mo[i].imag()); tot += std::abs(mo[i]); }
       d->N = 1;
       if (im / std::max(tot, 1e-300) < 1e-7) {
         std::vector<float> h((size_t) M);
         for (int i = 0; i < M; i++) h[i] = mo[M - 1 - i].real();
-        rc = tsdgpu_fir_create(&d->fir_corr, TSDGPU_C64, TSDGPU_F32, h.data(), M, TSDGPU_FIR_AUTO);
+        rc = tsdgpu_fir_create(&d->fir_corr, TSDGPU_C64, TSDGPU_F32, h.data(), M, methode_exacte);
       } else {
         std::vector<std::complex<float>> h((size_t) M);
         for (int i = 0; i < M; i++) h[i] = std::conj(mo[M - 1 - i]);
-        rc = tsdgpu_fir_create(&d->fir_corr, TSDGPU_C64, TSDGPU_C64, h.data(), M, TSDGPU_FIR_AUTO);
+        rc = tsdgpu_fir_create(&d->fir_corr, TSDGPU_C64, TSDGPU_C64, h.data(), M, methode_exacte);
       }
       if (rc) break;
       d->delais = M - 1;
@@ -276,7 +278,10 @@ int tsdgpu_detector_create(tsdgpu_detector **out, const void *motif_host, int M,
     d->ratio = std::sqrt((float) d->N) / std::sqrt((float) M);
     d->D = d->delais - (M - 1);
     std::vector<float> mg((size_t) M, (float) (1.0 / (double) M));
-    rc = tsdgpu_fir_create(&d->fir_en, TSDGPU_F32, TSDGPU_F32, mg.data(), M, TSDGPU_FIR_AUTO);
+    // the energy average in the TIME domain: a score divides by it, and where the stream is quiet (its start, a pause) an
+    // FFT convolution leaves rounding noise of the block's loudest samples in place of a tiny positive average -- scores
+    // of 3e5 at the first sample of a stream were found by the fuzz sweep.  A direct sum of non-negative terms cannot.
+    rc = tsdgpu_fir_create(&d->fir_en, TSDGPU_F32, TSDGPU_F32, mg.data(), M, M <= 8192 ? TSDGPU_FIR_DIRECT : TSDGPU_FIR_AUTO);
     if (rc) break;
     const size_t eb = (size_t) std::max(d->D, 1) * sizeof(float);
     if (hipMalloc((void **) &d->ehist[0], eb) != hipSuccess || hipMalloc((void **) &d->ehist[1], eb) != hipSuccess ||

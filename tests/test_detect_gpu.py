@@ -83,3 +83,31 @@ def test_detector_scores_and_peaks(tg, mode):
     assert [f[0] for f in found] == [s for s in starts if s + det.delay + M < Ne * nblk]
     for pos, p in found:
         assert p.s0 >= p.s_m1 and p.s0 >= p.s_p1 and p.s0 > 0.8
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_detector_quiet_stream_start_and_pauses(tg, mode):
+    """found by the fuzz sweep: where the stream is quiet -- its first samples (one tiny sample in the energy window), a pause
+    of exact zeros -- the score divides by a near-zero energy average; with that average taken from an FFT convolution the
+    rounding noise of the block's loud samples stood in its place and scores of 3e5 came out.  The average (and, in FIR
+    mode, the correlation) now come from time-domain sums: the scores there stay small and no peak is reported."""
+    rng = np.random.default_rng(9907)
+    M, Ne, nblk = 200, 1024, 6
+    pat = crand(M, 31)
+    x = np.zeros(Ne * nblk, np.complex64)
+    x[0] = 1e-4 + 2e-5j                                    # a nearly empty first window
+    x[1:300] = (0.01 * crand(299, 32)).astype(np.complex64)
+    starts = [700, 2 * Ne + 50, 4 * Ne - 30]               # patterns with pauses of exact zeros between them
+    for s in starts:
+        x[s:s + M] += pat
+    det = tg.Detector(pat, Ne, mode, threshold=0.8)
+    found, scores = [], []
+    for b in range(nblk):
+        sc, pk = det.step(x[b * Ne:(b + 1) * Ne].copy())
+        scores.append(sc)
+        found += [b * Ne + p.index - det.delay for p in pk]
+    sc = np.concatenate(scores)
+    assert np.isfinite(sc).all()
+    assert found == starts, (found, starts)
+    assert sc[det.delay - (M - 1): det.delay - (M - 1) + 250].max() < 0.8      # the first windows of the stream
+    del rng
