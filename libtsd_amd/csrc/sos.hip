@@ -248,44 +248,78 @@ __global__ __launch_bounds__(64) void sos_kernel(const float *__restrict__ x, fl
   }
 }
 
-// Sequential tail (fewer samples than one sub-tile, or a ragged end): one lane per channel
-// applies the reference recurrence literally from the carried state and updates it.
+// Ragged end (the samples after the last whole sub-tile; a whole call of fewer than 2048 floats): ONE wave.
+//  (1) every whole group of 256 floats runs as a narrow step of the block-parallel cascade -- the steps of a chunk's
+//      warm-up, this time with their outputs stored;
+//  (2) the last < 256 floats go through the sections as a systolic pipeline: lane (section, channel) applies the reference
+//      recurrence literally to sample t - section at step t and hands its output to the next section's lane by a shuffle,
+//      the samples sitting in LDS -- m + nsec steps of a few tens of cycles.
+// (The first version walked the samples section after section from global memory, one dependent load per sample: 0.9 us per
+// sample of a 6-section chain -- 466 us for a 512-sample block, up to 1.8 ms added to ANY call whose length is not a multiple
+// of 2048 floats.)  x must be 16-B aligned at float f0 (it is: f0 is a multiple of 2048 floats of an aligned buffer).
 template <int NCH>
-__global__ void sos_tail_kernel(const float *__restrict__ x, float *__restrict__ y, const SosSection *__restrict__ sec,
-                                int nsec, float gain, float *__restrict__ st, int64_t n0, int64_t n1)
+__global__ __launch_bounds__(64) void sos_tail_kernel(const float *__restrict__ x, float *__restrict__ y, const SosSection *__restrict__ sec,
+                                                      int nsec, float gain, float *__restrict__ st, int64_t f0, int64_t f1)
 {
-  const int c = threadIdx.x;
-  if (c >= NCH) return;
+  __shared__ float sst[SOS_MAX_SEC * 8];
+  __shared__ float buf[64 * NARROW_FLOATS];
+  const int lane = threadIdx.x;
   const bool seeded = st[0] != 0.f;
-  for (int s = 0; s < nsec; s++) {
-    const SosSection k = sec[s];
-    float d1 = st[state_index(s, c)], d2 = st[state_index(s, c) + 1];
-    float x1 = st[state_index(s, c) + 2], x2 = st[state_index(s, c) + 3];
-    for (int64_t i = n0; i < n1; i++) {
-      const float xin = (s == 0 ? x : y)[i * NCH + c];
-      if (i == n0 && !seeded && k.seed != 0.f) d1 = d2 = x1 = x2 = xin;
-      float o;
-      if (k.df1 == 0.f) {
-        const float d = fmaf(-k.a2, d2, fmaf(-k.a1, d1, xin));
-        o = fmaf(k.b2, d2, fmaf(k.b1, d1, k.b0 * d));
-        d2 = d1;
-        d1 = d;
-      } else {
-        o = fmaf(-k.a2, d2, fmaf(-k.a1, d1, fmaf(k.b2, x2, fmaf(k.b1, x1, k.b0 * xin))));
-        x2 = x1;
-        x1 = xin;
-        d2 = d1;
-        d1 = o;
-      }
-      y[i * NCH + c] = (s == nsec - 1) ? o * gain : o;
-    }
-    st[state_index(s, c)] = d1;
-    st[state_index(s, c) + 1] = d2;
-    st[state_index(s, c) + 2] = x1;
-    st[state_index(s, c) + 3] = x2;
+  for (int i = lane; i < nsec * 8; i += 64) sst[i] = st[1 + i];
+  wave_sync();
+  int64_t f = f0;
+  // (1) narrow steps
+  for (; f + 64 * NARROW_FLOATS <= f1; f += 64 * NARROW_FLOATS) {
+    const float4 q = *reinterpret_cast<const float4 *>(x + f + 4 * lane);
+    float v4[NARROW_FLOATS] = {q.x, q.y, q.z, q.w};
+    sos_cascade<NCH, NARROW_FLOATS, true>(v4, sec, nsec, sst, lane, !seeded && f == 0);
+    *reinterpret_cast<float4 *>(y + f + 4 * lane) = make_float4(v4[0] * gain, v4[1] * gain, v4[2] * gain, v4[3] * gain);
   }
-  __syncthreads();
-  if (c == 0 && n1 > n0) st[0] = 1.f;
+  // (2) systolic tail over the m = f1 - f < 256 floats left
+  const int m = (int) (f1 - f), ms = m / NCH;
+  if (ms > 0) {
+    for (int i = lane; i < m; i += 64) buf[i] = x[f + i];
+    wave_sync();
+    const int sidx = lane / NCH, c = lane - sidx * NCH;
+    const bool actif = sidx < nsec;
+    const SosSection &k = sec[actif ? sidx : 0];
+    const float b0 = k.b0, b1 = k.b1, b2 = k.b2, a1 = k.a1, a2 = k.a2;
+    const bool df1 = k.df1 != 0.f, graine = k.seed != 0.f && !seeded && f == 0;    // first sample of the stream: seeded sections
+    float *ss = &sst[(sidx * 2 + c) * 4];
+    float d1 = 0.f, d2 = 0.f, x1 = 0.f, x2 = 0.f, out = 0.f;
+    if (actif) { d1 = ss[0]; d2 = ss[1]; x1 = ss[2]; x2 = ss[3]; }
+    for (int t = 0; t < ms + nsec - 1; t++) {
+      const float amont = __shfl_up(out, NCH);             // what the previous section produced at the previous step
+      const int i = t - sidx;
+      if (actif && i >= 0 && i < ms) {
+        const float xin = sidx == 0 ? buf[i * NCH + c] : amont;
+        if (i == 0 && graine) d1 = d2 = x1 = x2 = xin;     // filtre-rt.cc:361-365
+        float o;
+        if (!df1) {
+          const float d = fmaf(-a2, d2, fmaf(-a1, d1, xin));
+          o = fmaf(b2, d2, fmaf(b1, d1, b0 * d));
+          d2 = d1;
+          d1 = d;
+        } else {
+          o = fmaf(-a2, d2, fmaf(-a1, d1, fmaf(b2, x2, fmaf(b1, x1, b0 * xin))));
+          x2 = x1;
+          x1 = xin;
+          d2 = d1;
+          d1 = o;
+        }
+        out = o;
+        if (sidx == nsec - 1) buf[i * NCH + c] = o * gain;  // (index i <= t: section 0 has read it already)
+      }
+    }
+    wave_sync();
+    for (int i = lane; i < m; i += 64) y[f + i] = buf[i];
+    if (actif) { ss[0] = d1; ss[1] = d2; ss[2] = x1; ss[3] = x2; }
+    wave_sync();
+  }
+  if (f1 > f0) {
+    if (lane == 0) st[0] = 1.f;
+    for (int i = lane; i < nsec * 8; i += 64) st[1 + i] = sst[i];
+  }
 }
 
 }  // namespace tsdgpu
@@ -570,13 +604,14 @@ int tsdgpu_sos_step(tsdgpu_sos *s, const void *x, void *y, int64_t n, void *stre
   }
   const int64_t n0 = n_sub * (SUB_FLOATS / nch);
   if (n0 < n) {
+    // the ragged end: narrow parallel steps + a systolic pipeline over the last < 256 floats, one wave (float indices)
     float *stc = s->d_state[s->cur];
     if (nch == 1)
       hipLaunchKernelGGL(sos_tail_kernel<1>, dim3(1), dim3(64), 0, st, (const float *) dx, (float *) dy, s->d_sec, s->nsec,
-                         s->gain, stc, n0, n);
+                         s->gain, stc, n_sub * SUB_FLOATS, nfl);
     else
       hipLaunchKernelGGL(sos_tail_kernel<2>, dim3(1), dim3(64), 0, st, (const float *) dx, (float *) dy, s->d_sec, s->nsec,
-                         s->gain, stc, n0, n);
+                         s->gain, stc, n_sub * SUB_FLOATS, nfl);
     TSD_HIP(hipGetLastError());
   }
   if (dy_user) {
