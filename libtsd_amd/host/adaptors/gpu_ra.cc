@@ -58,13 +58,20 @@ template <typename T> static SondeItrp sonde_interpolateur(const sptr<Interpolat
       const std::vector<float> r = coefs(j < np ? ((float) j + 0.5f) / (float) np : 1.0f);
       std::copy(r.begin(), r.end(), s.lut.begin() + (size_t) j * K);
     }
+    // the hypothesis coefs(τ) == row[(int) (τ np)], checked at both ends of every row's interval and at 256 scattered
+    // phases (a probe per one-shot rééchan(): 4096 scattered phases cost 0.2 ms of allocations)
     bool ok = true;
-    for (int i = 0; i < 4096 && ok; i++) {
-      const float τ = phase(i);
+    auto verifie = [&](float τ) {
+      if (!(τ >= 0.f && τ < 1.f)) return;
       const entier idx = (entier) (τ * np);
-      const std::vector<float> r = coefs(τ);
-      ok = std::equal(r.begin(), r.end(), s.lut.begin() + (size_t) idx * K);
+      const Vecteur<float> r = rif->coefs(τ);
+      ok = ok && r.rows() == K && std::equal(r.data(), r.data() + K, s.lut.begin() + (size_t) idx * K);
+    };
+    for (entier j = 0; j < np && ok; j++) {
+      verifie(std::nextafter((float) j / (float) np, 2.0f));
+      verifie(std::nextafter((float) (j + 1) / (float) np, -1.0f));
     }
+    for (int i = 0; i < 256 && ok; i++) verifie(phase(i));
     if (ok) {
       s.genre = SondeItrp::TABLE;
       s.nphases = np;
@@ -207,6 +214,9 @@ template <typename T> struct AdaptationRythmeArbitraireGpu : Filtre<T, T, float>
         f->step(*src, y);
       } else {
         Vecteur<T> &dst = (src == &a) ? b : a;
+#ifdef TSD_AMD_MIRROR
+        ResidenceGpu garde;        // the mirror's vectors can live on the device: the intermediate stays there (one
+#endif                             // upload of x, one download of y for the whole chain); libtsd's Tab cannot
         f->step(*src, dst);
         src = &dst;
       }
