@@ -5,6 +5,9 @@
 // tsdgpu_fft and the function that installs it; it defines no libtsd symbol, so it links beside an
 // unmodified fourier.cc.
 #include "gpu_commun.hpp"
+#include <vector>
+#include <mutex>
+#include <map>
 #include "tsd_amd/extensions.hpp"
 
 namespace tsd_amd {
@@ -15,20 +18,59 @@ using tsd::fourier::FFTPlan;
 // TFRPlanDefaut's contract (fourier.cc:360-467): (re)configures itself when the input size changes;
 // unitary scaling 1/sqrt(n) in BOTH directions whatever `normalize` says (the reference never stores
 // it, fourier.cc:362,372-376); natural order.
+// libtsd's fft() / ifft() make a plan per CALL (fourier.hpp:163-205).  A device plan costs 30 us (n = 4096) to 1.1 ms (2^20) to
+// build -- its twiddle tables -- so finished plans go to a small per-size reserve instead of being destroyed, and the next
+// plan of that size takes one from there (a handle serves one caller at a time: it leaves the reserve while in use).
+struct ReservePlans {
+  std::mutex m;
+  std::map<entier, std::vector<tsdgpu_fft *>> libres;
+  size_t total = 0;
+  tsdgpu_fft *prend(entier n)
+  {
+    std::lock_guard<std::mutex> l(m);
+    auto it = libres.find(n);
+    if (it == libres.end() || it->second.empty()) return nullptr;
+    tsdgpu_fft *h = it->second.back();
+    it->second.pop_back();
+    total--;
+    return h;
+  }
+  void rend(entier n, tsdgpu_fft *h)
+  {
+    if (!h) return;
+    {
+      std::lock_guard<std::mutex> l(m);
+      auto &v = libres[n];
+      if (v.size() < 4 && total < 64) {        // a few plans per size, a few dozen sizes
+        v.push_back(h);
+        total++;
+        return;
+      }
+    }
+    tsdgpu_fft_destroy(h);
+  }
+};
+static ReservePlans &reserve_plans()
+{
+  static ReservePlans *r = new ReservePlans();      // never destroyed: plans may be returned during static destruction
+  return *r;
+}
+
 struct FFTPlanGpu : FFTPlan {
   tsdgpu_fft *h = nullptr;
   entier n = -1;
   bouléen avant_defaut = true;
-  virtual ~FFTPlanGpu() { tsdgpu_fft_destroy(h); }     // FFTPlan has no virtual destructor: make_shared's deleter knows the type
+  virtual ~FFTPlanGpu() { reserve_plans().rend(n, h); }     // FFTPlan has no virtual destructor: make_shared's deleter knows the type
   void configure(entier n_, bouléen avant, bouléen)
   {
     avant_defaut = avant;
     if (n_ == n) return;
-    tsdgpu_fft_destroy(h);
+    reserve_plans().rend(n, h);
     h = nullptr;
     n = n_;
     if (n < 1) return;
-    if (tsdgpu_fft_create(&h, n, 1)) gpu_fail("FFTPlan::configure");
+    h = reserve_plans().prend(n);
+    if (!h && tsdgpu_fft_create(&h, n, 1)) gpu_fail("FFTPlan::configure");
   }
   void step(const Veccf &x, Veccf &y, bouléen avant)
   {
