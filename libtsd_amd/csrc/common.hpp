@@ -71,6 +71,46 @@ int pipelined_host_step_var(const void *x, int64_t n, size_t esz_in, void *y, si
 bool host_ranges_overlap(const void *a, size_t na, const void *b, size_t nb);
 bool host_pipe_enabled();     // false with TSDGPU_NO_PIPE=1 (A/B switch: whole-vector staging instead)
 
+// Scratch of a STATELESS entry point (xcorr, welch, delay estimate ...): buffers and plans are borrowed for the call from a
+// small free list and go back to it, instead of a hipMalloc / plan construction / hipFree per call (a hipFree also
+// synchronises the device).  Ctx needs `int dev` and `void libere()`; prefere(ctx) picks a context that already fits.
+template <typename Ctx> struct CtxReserve {
+  std::mutex m;
+  std::vector<Ctx *> libres;
+  size_t garde;
+  explicit CtxReserve(size_t g = 8) : garde(g) {}
+  template <typename Pref> Ctx *prend(Pref prefere)
+  {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) (void) hipGetLastError();
+    {
+      std::lock_guard<std::mutex> l(m);
+      for (int pass = 0; pass < 2; pass++)
+        for (size_t i = 0; i < libres.size(); i++)
+          if (libres[i]->dev == dev && (pass == 1 || prefere(*libres[i]))) {
+            Ctx *c = libres[i];
+            libres.erase(libres.begin() + (long) i);
+            return c;
+          }
+    }
+    Ctx *c = new Ctx();
+    c->dev = dev;
+    return c;
+  }
+  void rend(Ctx *c)
+  {
+    {
+      std::lock_guard<std::mutex> l(m);
+      if (libres.size() < garde) {
+        libres.push_back(c);
+        return;
+      }
+    }
+    c->libere();
+    delete c;
+  }
+};
+
 // Serialises use of a handle's scratch buffers: host threads through the mutex, streams through
 // an event (a step on another stream waits for the previous step's work).  libtsd's Spectrum calls
 // plan->step from OpenMP threads on one plan (fourier.cc:1244-1252), so plans must tolerate it.

@@ -19,6 +19,8 @@
 // cross-correlation around it, and the peak of |corr| / (e1 e2) with its two neighbours: one pass each,
 // on the device; estimation_délais returns after one small D2H.
 #include "common.hpp"
+#include <vector>
+#include <mutex>
 #include <algorithm>
 #include <cmath>
 #include <complex>
@@ -398,18 +400,34 @@ int tsdgpu_xcorr(const void *x, const void *y, int n, int m, int unbiased, void 
   TSD_CHECK(m >= 1 && m <= n, "xcorr: m = %d outside [1, n = %d]", m, n);
   hipStream_t st = (hipStream_t) stream;
   const int L = n + 2 * m;
-  DevBuf pad, spec, res;
+  // the plan of this length and the scratch buffers are borrowed from a small reserve for the call (a one-shot xcorr() of
+  // 4096 samples spent 0.2 of its 0.3 ms building a 4224-point plan and in hipMalloc / hipFree)
+  struct Ctx {
+    int dev = 0, L = 0;
+    tsdgpu_fft *p = nullptr;
+    DevBuf pad, spec, res;
+    void libere() { tsdgpu_fft_destroy(p); pad.release(); spec.release(); res.release(); }
+  };
+  static CtxReserve<Ctx> *reserve = new CtxReserve<Ctx>();
+  Ctx *c = reserve->prend([L](const Ctx &k) { return k.L == L; });
+  auto rend = [&]() { reserve->rend(c); };
+  DevBuf &pad = c->pad, &spec = c->spec, &res = c->res;
   int rc = pad.reserve((size_t) 2 * L * sizeof(cpx));
   if (!rc) rc = spec.reserve((size_t) 2 * L * sizeof(cpx));
   if (!rc) rc = res.reserve((size_t) (2 * m - 1) * sizeof(cpx));
-  tsdgpu_fft *p = nullptr;
-  if (!rc) rc = tsdgpu_fft_create(&p, L, 2);
-  if (rc) { pad.release(); spec.release(); res.release(); tsdgpu_fft_destroy(p); return rc; }
+  if (!rc && c->L != L) {
+    tsdgpu_fft_destroy(c->p);
+    c->p = nullptr;
+    c->L = 0;
+    rc = tsdgpu_fft_create(&c->p, L, 2);
+    if (!rc) c->L = L;
+  }
+  if (rc) { rend(); return rc; }
+  tsdgpu_fft *p = c->p;
   cpx *px = pad.as<cpx>(), *py = px + L;
   auto fin = [&](int code) {
     (void) hipStreamSynchronize(st);
-    tsdgpu_fft_destroy(p);
-    pad.release(); spec.release(); res.release();
+    rend();
     return code;
   };
   if (hipMemsetAsync(px, 0, (size_t) 2 * L * sizeof(cpx), st) != hipSuccess ||
@@ -421,11 +439,11 @@ int tsdgpu_xcorr(const void *x, const void *y, int n, int m, int unbiased, void 
   hipLaunchKernelGGL(corr_freq_kernel, dim3(nb(L)), dim3(256), 0, st, spec.as<cpx>(), spec.as<cpx>() + L, px, L, std::sqrt((float) L));
   rc = tsdgpu_fft_step(p, px, py, 1, 0, st);
   if (rc) return fin(rc);
-  const bool dev = is_device_ptr(out);
-  cpx *dst = dev ? (cpx *) out : res.as<cpx>();
+  const bool out_dev = is_device_ptr(out);
+  cpx *dst = out_dev ? (cpx *) out : res.as<cpx>();
   hipLaunchKernelGGL(xcorr_extract_kernel, dim3(nb(2 * m - 1)), dim3(256), 0, st, py, dst, L, n, m, unbiased ? 1 : 0);
   if (hipGetLastError() != hipSuccess) return fin(set_err(TSDGPU_ERR_HIP, "xcorr: launch failed"));
-  if (!dev && hipMemcpyAsync(out, dst, (size_t) (2 * m - 1) * sizeof(cpx), hipMemcpyDeviceToHost, st) != hipSuccess)
+  if (!out_dev && hipMemcpyAsync(out, dst, (size_t) (2 * m - 1) * sizeof(cpx), hipMemcpyDeviceToHost, st) != hipSuccess)
     return fin(set_err(TSDGPU_ERR_HIP, "xcorr: download failed"));
   return fin(TSDGPU_OK);
 }
@@ -437,7 +455,14 @@ int tsdgpu_delay_estimate(const void *x, const void *y, int n, float *delay, flo
 {
   TSD_CHECK(x != nullptr && y != nullptr && delay != nullptr && score != nullptr && n >= 1, "delay_estimate: bad argument");
   hipStream_t st = (hipStream_t) stream;
-  DevBuf xs, ys, cr, sm;
+  struct Ctx {
+    int dev = 0;
+    DevBuf xs, ys, cr, sm;
+    void libere() { xs.release(); ys.release(); cr.release(); sm.release(); }
+  };
+  static CtxReserve<Ctx> *reserve = new CtxReserve<Ctx>();
+  Ctx *c = reserve->prend([](const Ctx &) { return true; });
+  DevBuf &xs = c->xs, &ys = c->ys, &cr = c->cr, &sm = c->sm;
   int rc = cr.reserve((size_t) (2 * n - 1) * sizeof(cpx));
   if (!rc) rc = sm.reserve(2 * sizeof(double) + sizeof(PeakOut));
   const void *dx = nullptr, *dy = nullptr;
@@ -445,7 +470,7 @@ int tsdgpu_delay_estimate(const void *x, const void *y, int n, float *delay, flo
   if (!rc) rc = stage_in(y, (size_t) n * sizeof(cpx), ys, st, &dy);
   auto fin = [&](int code) {
     (void) hipStreamSynchronize(st);
-    xs.release(); ys.release(); cr.release(); sm.release();
+    reserve->rend(c);
     return code;
   };
   if (rc) return fin(rc);

@@ -564,7 +564,17 @@ int tsdgpu_welch(const void *x, int64_t n, int N, const float *window, float *S,
   if (n > N) nseg = (n - N - 1) / pas + 1;                         // i = 0, pas, ... while i + N < n  (:13)
   if (n_segments) *n_segments = nseg;
   TSD_CHECK(nseg <= 0x7fffffff, "welch: %lld segments in one call", (long long) nseg);
-  DevBuf xin, seg, part, wbuf, sout;
+  // scratch and plan borrowed for the call (the one-shot API used to spend most of its time in hipMalloc / hipFree and in
+  // building the plan)
+  struct Ctx {
+    int dev = 0, N = 0, lots = 0;
+    tsdgpu_fft *plan = nullptr;
+    DevBuf xin, seg, part, wbuf, sout;
+    void libere() { if (plan) tsdgpu_fft_destroy(plan); xin.release(); seg.release(); part.release(); wbuf.release(); sout.release(); }
+  };
+  static CtxReserve<Ctx> *reserve = new CtxReserve<Ctx>(4);
+  Ctx *c = reserve->prend([N](const Ctx &k) { return k.N == N; });
+  DevBuf &xin = c->xin, &seg = c->seg, &part = c->part, &wbuf = c->wbuf, &sout = c->sout;
   const void *dxv = nullptr, *dwv = nullptr;
   void *dS = nullptr;
   bool staged = false;
@@ -572,6 +582,14 @@ int tsdgpu_welch(const void *x, int64_t n, int N, const float *window, float *S,
   if (!rc) rc = stage_in(window, (size_t) N * sizeof(float), wbuf, st, &dwv);
   if (!rc) rc = stage_out(S, (size_t) N * sizeof(float), sout, &dS, &staged);
   tsdgpu_fft *plan = nullptr;
+  if (!rc && nseg > 0 && !(c->plan && c->N == N)) {        // (the batch count given at creation is only a hint)
+    if (c->plan) tsdgpu_fft_destroy(c->plan);
+    c->plan = nullptr;
+    c->N = c->lots = 0;
+    rc = tsdgpu_fft_create(&c->plan, N, (int) nseg);
+    if (!rc) { c->N = N; c->lots = (int) nseg; }
+  }
+  plan = c->plan;
   if (!rc && nseg == 0) {
     if (hipMemsetAsync(dS, 0, (size_t) N * sizeof(float), st) != hipSuccess) rc = set_err(TSDGPU_ERR_HIP, "welch: memset failed");
   } else if (!rc) {
@@ -581,7 +599,6 @@ int tsdgpu_welch(const void *x, int64_t n, int N, const float *window, float *S,
     const int64_t per_group = cdiv(nseg, groups);
     rc = seg.reserve((size_t) total * sizeof(cpx));
     if (!rc) rc = part.reserve((size_t) groups * N * sizeof(float));
-    if (!rc) rc = tsdgpu_fft_create(&plan, N, (int) nseg);
     bool fused = false;
     if (!rc) {
       // fused: segments gathered and windowed by the transform itself, which stores |X|^2 only
@@ -608,8 +625,7 @@ int tsdgpu_welch(const void *x, int64_t n, int N, const float *window, float *S,
   if (!rc) rc = finish_out(S, (size_t) N * sizeof(float), dS, staged, st);
   // the scratch buffers die with the call: wait for the work that uses them
   (void) hipStreamSynchronize(st);
-  if (plan) tsdgpu_fft_destroy(plan);
-  xin.release(); seg.release(); part.release(); wbuf.release(); sout.release();
+  reserve->rend(c);
   return rc;
 }
 
