@@ -73,7 +73,7 @@ bool host_pipe_enabled();     // false with TSDGPU_NO_PIPE=1 (A/B switch: whole-
 
 // Scratch of a STATELESS entry point (xcorr, welch, delay estimate ...): buffers and plans are borrowed for the call from a
 // small free list and go back to it, instead of a hipMalloc / plan construction / hipFree per call (a hipFree also
-// synchronises the device).  Ctx needs `int dev` and `void libere()`; prefere(ctx) picks a context that already fits.
+// synchronises the device).  Ctx needs `int dev`, `size_t octets()` and `void libere()`; prefere(ctx) picks a context that already fits.
 template <typename Ctx> struct CtxReserve {
   std::mutex m;
   std::vector<Ctx *> libres;
@@ -99,7 +99,8 @@ template <typename Ctx> struct CtxReserve {
   }
   void rend(Ctx *c)
   {
-    {
+    // (a context grown by one very large call is not kept: the reserve is for the many ordinary ones)
+    if (c->octets() <= ((size_t) 512 << 20)) {
       std::lock_guard<std::mutex> l(m);
       if (libres.size() < garde) {
         libres.push_back(c);

@@ -407,6 +407,7 @@ int tsdgpu_xcorr(const void *x, const void *y, int n, int m, int unbiased, void 
     tsdgpu_fft *p = nullptr;
     DevBuf pad, spec, res;
     void libere() { tsdgpu_fft_destroy(p); pad.release(); spec.release(); res.release(); }
+    size_t octets() const { return pad.cap + spec.cap + res.cap; }
   };
   static CtxReserve<Ctx> *reserve = new CtxReserve<Ctx>();
   Ctx *c = reserve->prend([L](const Ctx &k) { return k.L == L; });
@@ -459,6 +460,7 @@ int tsdgpu_delay_estimate(const void *x, const void *y, int n, float *delay, flo
     int dev = 0;
     DevBuf xs, ys, cr, sm;
     void libere() { xs.release(); ys.release(); cr.release(); sm.release(); }
+    size_t octets() const { return xs.cap + ys.cap + cr.cap + sm.cap; }
   };
   static CtxReserve<Ctx> *reserve = new CtxReserve<Ctx>();
   Ctx *c = reserve->prend([](const Ctx &) { return true; });

@@ -571,6 +571,7 @@ int tsdgpu_welch(const void *x, int64_t n, int N, const float *window, float *S,
     tsdgpu_fft *plan = nullptr;
     DevBuf xin, seg, part, wbuf, sout;
     void libere() { if (plan) tsdgpu_fft_destroy(plan); xin.release(); seg.release(); part.release(); wbuf.release(); sout.release(); }
+    size_t octets() const { return xin.cap + seg.cap + part.cap + wbuf.cap + sout.cap; }
   };
   static CtxReserve<Ctx> *reserve = new CtxReserve<Ctx>(4);
   Ctx *c = reserve->prend([N](const Ctx &k) { return k.N == N; });
