@@ -80,6 +80,25 @@ __device__ __forceinline__ float2 tap_mac(float2 acc, float h, float2 x)
   return make_float2(fmaf(h, x.x, acc.x), fmaf(h, x.y, acc.y));
 }
 
+// canonical index of the periodic phase sequence: ic -> mu + (ic - mu) mod lambda, q += the number of periods removed.
+// A few subtractions when the index is a few periods out (the usual case: lambda in the millions, 160/147: 3.85 M); a
+// division otherwise -- ratios whose float recurrence has a SHORT period (1: lambda = 1, 0.5: 2, 2.5: 5 ...) put millions
+// of periods between the table and a stream position, and the subtraction loop they used to go through cost
+// 178 ms per 4 M samples at ratio 1.
+__device__ __forceinline__ void rs_wrap(int64_t &ic, int64_t &q, int64_t mu, int64_t lambda)
+{
+  if (lambda <= 0) return;
+  const int64_t lim = mu + lambda;
+  if (ic < lim) return;
+  if (ic - lim < 4 * lambda) {
+    do { ic -= lambda; q++; } while (ic >= lim);
+  } else {
+    const int64_t d = ic - mu, k = d / lambda;
+    q += k;
+    ic = mu + (d - k * lambda);
+  }
+}
+
 // KT = 15: the filtre_reechan interpolator -- taps padded to 16 and read as four ds_read_b128
 // from LUT rows of pitch 20 floats (80 B: 16-B aligned, and 5 mod 16 in 16-B units, so the
 // rows selected by 16 lanes whose columns step regularly fall on distinct bank groups).
@@ -165,8 +184,10 @@ __global__ __launch_bounds__(RS_THREADS) void resample_kernel(const T *__restric
       }
     }
     int64_t ic_ = icT_ + lane * RS_SEG;
-    if (P.lambda > 0)
-      while (ic_ >= P.mu + P.lambda) ic_ -= P.lambda;
+    {
+      int64_t q_ = 0;
+      rs_wrap(ic_, q_, P.mu, P.lambda);
+    }
     cpf.phase_bits = 0x40000000u;                                   // 2.0f: "emit nothing"
     cpf.cum = 0;
     if (T0_ + (int64_t) lane * RS_SEG < P.pos + P.n) cpf = ck[ic_ / RS_CK];
@@ -183,16 +204,14 @@ __global__ __launch_bounds__(RS_THREADS) void resample_kernel(const T *__restric
     }
     const int64_t i_abs = T0 + (int64_t) lane * RS_SEG;
     int64_t ic = icT + lane * RS_SEG, q = qT;
-    if (P.lambda > 0)
-      while (ic >= P.mu + P.lambda) { ic -= P.lambda; q++; }
+    rs_wrap(ic, q, P.mu, P.lambda);
     const bool in_call = i_abs < P.pos + P.n;              // lanes past the end of the call do nothing
     const float inc = P.inc;
     float phase = bits2f(cpf.phase_bits);
     int64_t cum = (int64_t) cpf.cum + q * P.opp;
     // ---- issue the next tile's loads
     icT += icStep;
-    if (P.lambda > 0)
-      while (icT >= P.mu + P.lambda) { icT -= P.lambda; qT++; }
+    rs_wrap(icT, qT, P.mu, P.lambda);
     if (tix + wstep < ntiles) fetch(tix + wstep, icT);
 
     if (in_call) {
@@ -373,8 +392,10 @@ __global__ __launch_bounds__(64 * RS15_WAVES) void resample15_kernel(const T *__
       }
     }
     int64_t ic_ = icT_ + lane * RS_SEG;
-    if (P.lambda > 0)
-      while (ic_ >= P.mu + P.lambda) ic_ -= P.lambda;
+    {
+      int64_t q_ = 0;
+      rs_wrap(ic_, q_, P.mu, P.lambda);
+    }
     cpf.phase_bits = 0x40000000u;
     cpf.cum = 0;
     if (T0_ + (int64_t) lane * RS_SEG < P.pos + P.n) cpf = ck[ic_ / RS_CK];
@@ -401,15 +422,13 @@ __global__ __launch_bounds__(64 * RS15_WAVES) void resample15_kernel(const T *__
 #endif
     const int64_t i_abs = T0 + (int64_t) lane * RS_SEG;
     int64_t ic = icT + lane * RS_SEG, q = qT;
-    if (P.lambda > 0)
-      while (ic >= P.mu + P.lambda) { ic -= P.lambda; q++; }
+    rs_wrap(ic, q, P.mu, P.lambda);
     const bool in_call = i_abs < P.pos + P.n;
     const float inc = P.inc;
     float phase = bits2f(cpf.phase_bits);
     int64_t cum = (int64_t) cpf.cum + q * P.opp;
     icT += icStep;
-    if (P.lambda > 0)
-      while (icT >= P.mu + P.lambda) { icT -= P.lambda; qT++; }
+    rs_wrap(icT, qT, P.mu, P.lambda);
     if (tix + wstep < ntiles) fetch(tix + wstep, icT);
 
     if (in_call) {

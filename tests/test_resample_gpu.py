@@ -208,3 +208,31 @@ def test_resampler_create_refuses_what_no_step_can_launch(tg):
     r = tg.Resampler(5.0, tg.F32, lut=lut)          # a large ratio that does fit keeps working
     x = np.ones(1000, np.float32)
     assert abs(len(r.step(x)) - 5000) <= 2
+
+
+@pytest.mark.parametrize("ratio", [1.0, 0.5, 1.25, 1.5, 2.5])
+def test_short_period_ratios_far_into_a_stream(tg, orc, ratio):
+    """Ratios whose float32 phase recurrence has a SHORT period (1.0: one input, 0.5: two, 1.25: five ...) put millions of
+    periods between the schedule table and a position far into a stream; the kernels used to fold the index back by
+    repeated subtraction -- 178 ms per 4 M samples at ratio 1 (found by scripts/perf_resample_ratios.py).  Values against
+    the oracle past 2^22 inputs, and a loose bound on the time."""
+    import time
+    import torch
+    n1, n2 = (1 << 22) + 12345, 200000
+    x = rand(n1 + n2, True, 77)
+    ref = orc.Resampler(ratio, K=15, nphases=256, fcut=float(min(0.4, ratio / 2)))
+    yref = ref.step(x)
+    g = tg.Resampler(ratio, tg.C64, K=15, nphases=256, lut=ref.lut)
+    xd = torch.from_numpy(x).cuda()
+    y1 = g.step(xd[:n1])
+    y2 = g.step(xd[n1:])
+    torch.cuda.synchronize()
+    assert y1.shape[0] + y2.shape[0] == yref.shape[0]
+    tail = yref[y1.shape[0]:]
+    assert relerr(y2.cpu().numpy(), tail) <= TOL
+    t0 = time.perf_counter()
+    for _ in range(5):
+        g.step(xd[:n1])
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 5 * 1e3
+    assert ms < 5.0, f"ratio {ratio}: {ms:.1f} ms per 4 M inputs far into the stream"
