@@ -86,18 +86,56 @@ void installe_fftplan_gpu() { tsd::fourier::fftplan_defaut = fftplan_gpu; }
 
 // RTFRPlan (fourier.cc:280-355) on tsdgpu_rfft: packed n/2-point complex FFT, untangling with the
 // 0.5/sqrt(2) factors and the forced conjugate symmetry all run on the device.
+// (the same reserve for the real-input plans: rfft() / fft(Vecf) make one per call too)
+struct ReservePlansReels {
+  std::mutex m;
+  std::map<entier, std::vector<tsdgpu_rfft *>> libres;
+  size_t total = 0;
+  tsdgpu_rfft *prend(entier n)
+  {
+    std::lock_guard<std::mutex> l(m);
+    auto it = libres.find(n);
+    if (it == libres.end() || it->second.empty()) return nullptr;
+    tsdgpu_rfft *h = it->second.back();
+    it->second.pop_back();
+    total--;
+    return h;
+  }
+  void rend(entier n, tsdgpu_rfft *h)
+  {
+    if (!h) return;
+    {
+      std::lock_guard<std::mutex> l(m);
+      auto &v = libres[n];
+      if (v.size() < 4 && total < 64) {
+        v.push_back(h);
+        total++;
+        return;
+      }
+    }
+    tsdgpu_rfft_destroy(h);
+  }
+};
+static ReservePlansReels &reserve_plans_reels()
+{
+  static ReservePlansReels *r = new ReservePlansReels();
+  return *r;
+}
+
 struct RTFRPlanGpu : FiltreGen<float, cfloat> {
   entier n = -1;
   tsdgpu_rfft *h = nullptr;
   explicit RTFRPlanGpu(entier n_) { configure(n_); }
-  ~RTFRPlanGpu() { tsdgpu_rfft_destroy(h); }
+  ~RTFRPlanGpu() { reserve_plans_reels().rend(n, h); }
   void configure(entier n_)
   {
     if (n_ == n) return;
-    tsdgpu_rfft_destroy(h);
+    reserve_plans_reels().rend(n, h);
     h = nullptr;
     n = n_;
-    if (n > 0 && tsdgpu_rfft_create(&h, n)) gpu_fail("rtfrplan_création");
+    if (n <= 0) return;
+    h = reserve_plans_reels().prend(n);
+    if (!h && tsdgpu_rfft_create(&h, n)) gpu_fail("rtfrplan_création");
   }
   void step(const Vecf &x, Veccf &y)
   {
