@@ -185,7 +185,7 @@ struct tsdgpu_detector {
   float seuil = 0.5f, ratio = 1.f;
   tsdgpu_ola *ola = nullptr;
   tsdgpu_fir *fir_corr = nullptr, *fir_en = nullptr;
-  DevBuf x_stage, corr, e2, en, recs, sc_stage;
+  DevBuf x_stage, corr, e2, en, recs;
   float *ehist[2] = {nullptr, nullptr};
   float *sbuf[2] = {nullptr, nullptr};
   cpx *cbuf[2] = {nullptr, nullptr};
@@ -384,7 +384,7 @@ int tsdgpu_detector_destroy(tsdgpu_detector *d)
     if (d->sbuf[b]) (void) hipFree(d->sbuf[b]);
     if (d->cbuf[b]) (void) hipFree(d->cbuf[b]);
   }
-  d->x_stage.release(); d->corr.release(); d->e2.release(); d->en.release(); d->recs.release(); d->sc_stage.release();
+  d->x_stage.release(); d->corr.release(); d->e2.release(); d->en.release(); d->recs.release();
   delete d;
   return TSDGPU_OK;
 }
