@@ -111,8 +111,19 @@ __device__ __forceinline__ void rs_wrap(int64_t &ic, int64_t &q, int64_t mu, int
 template <typename T, int KT>
 __global__ __launch_bounds__(RS_THREADS) void resample_kernel(const T *__restrict__ x, const T *__restrict__ hist,
                                                               T *__restrict__ y, const float *__restrict__ lut,
-                                                              const RsCk *__restrict__ ck, RsParams P, int ntiles)
+                                                              const RsCk *__restrict__ ck, RsParams P, int ntiles,
+                                                              T *__restrict__ hist_next)
 {
+  // the workgroup after the persistent ones writes the stream's next window history (the last K - 1 inputs of
+  // history ++ x) into the handle's other buffer: one launch per step
+  if (blockIdx.x == gridDim.x - 1) {
+    const int H = P.K - 1;
+    for (int i = threadIdx.x; i < H; i += RS_THREADS) {
+      const int64_t g = P.n - H + i;
+      hist_next[i] = g < 0 ? hist[H + g] : x[g];
+    }
+    return;
+  }
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int K = KT > 0 ? KT : P.K;
   const int lstride = KT == 15 ? 20 : P.lstride;
@@ -146,7 +157,7 @@ __global__ __launch_bounds__(RS_THREADS) void resample_kernel(const T *__restric
   // canonical (cycle-folded) index of this wave's first tile: ONE 64-bit division per wave;
   // afterwards the index advances by a constant and is folded by subtraction
   const int wtile0 = blockIdx.x * RS_WAVES + wv;
-  const int wstep = gridDim.x * RS_WAVES;
+  const int wstep = (gridDim.x - 1) * RS_WAVES;
   int64_t icT = P.tile0 + (int64_t) wtile0 * RS_TI, qT = 0;
   if (P.lambda > 0 && icT >= P.mu + P.lambda) {
     const int64_t d = icT - P.mu;
@@ -315,8 +326,16 @@ constexpr int RS15_TILE_PAD = (RS_TI + 16) + (RS_TI + 16) / 8 + 2;      // padde
 template <typename T>
 __global__ __launch_bounds__(64 * RS15_WAVES) void resample15_kernel(const T *__restrict__ x, const T *__restrict__ hist,
                                                                      T *__restrict__ y, const float *__restrict__ lut,
-                                                                     const RsCk *__restrict__ ck, RsParams P, int ntiles)
+                                                                     const RsCk *__restrict__ ck, RsParams P, int ntiles,
+                                                                     T *__restrict__ hist_next)
 {
+  if (blockIdx.x == gridDim.x - 1) {      // (see resample_kernel: the next window history rides in this launch)
+    for (int i = threadIdx.x; i < 14; i += 64 * RS15_WAVES) {
+      const int64_t g = P.n - 14 + i;
+      hist_next[i] = g < 0 ? hist[14 + g] : x[g];
+    }
+    return;
+  }
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int K = 15, LS = 20;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -354,7 +373,7 @@ __global__ __launch_bounds__(64 * RS15_WAVES) void resample15_kernel(const T *__
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
   const int wtile0 = blockIdx.x * RS15_WAVES + wv;
-  const int wstep = gridDim.x * RS15_WAVES;
+  const int wstep = (gridDim.x - 1) * RS15_WAVES;
   int64_t icT = P.tile0 + (int64_t) wtile0 * RS_TI, qT = 0;
   if (P.lambda > 0 && icT >= P.mu + P.lambda) {
     const int64_t d = icT - P.mu;
@@ -496,16 +515,6 @@ __global__ __launch_bounds__(64 * RS15_WAVES) void resample15_kernel(const T *__
 #endif
 }
 
-// new_hist = last H samples of (old_hist ++ x[0..n))
-template <typename T>
-__global__ void rs_hist_update_kernel(const T *__restrict__ x, const T *__restrict__ old_hist, T *__restrict__ new_hist,
-                                      int H, int64_t n)
-{
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= H) return;
-  const int64_t g = n - H + i;
-  new_hist[i] = g < 0 ? old_hist[H + g] : x[g];
-}
 
 }  // namespace tsdgpu
 
@@ -871,30 +880,20 @@ int tsdgpu_resampler_step(tsdgpu_resampler *r, const void *x, int64_t n, void *y
   if (r->K == 15 && r->mode == 0 && lds15 <= 158 * 1024) {     // fused kernel; larger ratios fall back to the generic one
     const int64_t g15 = std::min<int64_t>(cdiv(tiles, RS15_WAVES), 256);
     if (r->data_type == TSDGPU_C64)
-      hipLaunchKernelGGL(resample15_kernel<float2>, dim3((unsigned) g15), dim3(64 * RS15_WAVES), lds15, st, (const float2 *) dx,
-                         (const float2 *) r->d_hist[r->cur], (float2 *) dy, r->d_lut, r->d_ck, P, (int) tiles);
+      hipLaunchKernelGGL(resample15_kernel<float2>, dim3((unsigned) g15 + 1), dim3(64 * RS15_WAVES), lds15, st, (const float2 *) dx,
+                         (const float2 *) r->d_hist[r->cur], (float2 *) dy, r->d_lut, r->d_ck, P, (int) tiles, (float2 *) r->d_hist[r->cur ^ 1]);
     else
-      hipLaunchKernelGGL(resample15_kernel<float>, dim3((unsigned) g15), dim3(64 * RS15_WAVES), lds15, st, (const float *) dx,
-                         (const float *) r->d_hist[r->cur], (float *) dy, r->d_lut, r->d_ck, P, (int) tiles);
+      hipLaunchKernelGGL(resample15_kernel<float>, dim3((unsigned) g15 + 1), dim3(64 * RS15_WAVES), lds15, st, (const float *) dx,
+                         (const float *) r->d_hist[r->cur], (float *) dy, r->d_lut, r->d_ck, P, (int) tiles, (float *) r->d_hist[r->cur ^ 1]);
   } else {
 #define RS_LAUNCH(T, KT)                                                                                            \
-  hipLaunchKernelGGL((resample_kernel<T, KT>), dim3((unsigned) pgrid), dim3(RS_THREADS), lds, st, (const T *) dx, \
-                     (const T *) r->d_hist[r->cur], (T *) dy, r->d_lut, r->d_ck, P, (int) tiles)
+  hipLaunchKernelGGL((resample_kernel<T, KT>), dim3((unsigned) pgrid + 1), dim3(RS_THREADS), lds, st, (const T *) dx, \
+                     (const T *) r->d_hist[r->cur], (T *) dy, r->d_lut, r->d_ck, P, (int) tiles, (T *) r->d_hist[r->cur ^ 1])
   if (r->data_type == TSDGPU_C64) RS_LAUNCH(float2, 0); else RS_LAUNCH(float, 0);
 #undef RS_LAUNCH
   }
   TSD_HIP(hipGetLastError());
-  if (r->K > 1) {
-    const int H = r->K - 1, nxt = r->cur ^ 1;
-    if (r->data_type == TSDGPU_C64)
-      hipLaunchKernelGGL(rs_hist_update_kernel<float2>, dim3((unsigned) cdiv(H, 64)), dim3(64), 0, st, (const float2 *) dx,
-                         (const float2 *) r->d_hist[r->cur], (float2 *) r->d_hist[nxt], H, n);
-    else
-      hipLaunchKernelGGL(rs_hist_update_kernel<float>, dim3((unsigned) cdiv(H, 64)), dim3(64), 0, st, (const float *) dx,
-                         (const float *) r->d_hist[r->cur], (float *) r->d_hist[nxt], H, n);
-    TSD_HIP(hipGetLastError());
-    r->cur = nxt;
-  }
+  if (r->K > 1) r->cur ^= 1;      // (the launch wrote the next window history into the other buffer)
   r->pos += n;
   r->cum_pos = cum_end;
   if (n_out) *n_out = nout;
