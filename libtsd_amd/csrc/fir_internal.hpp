@@ -40,6 +40,9 @@ void ols_plan_destroy(tsdgpu_fir *f);
 int ols_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, hipStream_t st);
 // overlap-ADD fast path (Ne = 512, N = 1024, no window, device response) on the in-wave 1024-point transform: ols.hip
 void ola1024_tables(const float2 *H_host, float2 *out3);
+// Welch sums for N = 1024 on the in-wave transform (ols.hip): part[grid][1024], grid = ceil(nseg / per)
+int welch1024_launch(const float2 *x, const float *w, const float2 *tw2x1024, float *part, int64_t nseg, int per, hipStream_t st);
+void welch1024_tables(float2 *out2);
 int ola1024_launch(const float2 *x, float2 *y, const float2 *tables3, const float2 *svg_in, float2 *svg_out, int64_t B, hipStream_t st);
 // overlap-save for long filters (514..12289 taps), radix-16 Stockham blocks
 bool ols_long_supported(const tsdgpu_fir *f);

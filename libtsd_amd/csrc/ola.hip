@@ -281,6 +281,16 @@ __global__ void welch_power_kernel(const cpx *__restrict__ X, float *__restrict_
   }
   part[(size_t) blockIdx.y * N + i] = acc;
 }
+// first stage of a two-stage sum over many partial rows: out[y][i] = sum of the rows of group y (rows_per_group each)
+__global__ void welch_sum_groups_kernel(const float *__restrict__ part, float *__restrict__ out, int N, int rows, int rows_per_group)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int g0 = blockIdx.y * rows_per_group, g1 = min(g0 + rows_per_group, rows);
+  float acc = 0.f;
+  for (int g = g0; g < g1; g++) acc += part[(size_t) g * N + i];
+  out[(size_t) blockIdx.y * N + i] = acc;
+}
 __global__ void welch_sum_kernel(const float *__restrict__ part, float *__restrict__ S, int N, int groups)
 {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -569,8 +579,9 @@ int tsdgpu_welch(const void *x, int64_t n, int N, const float *window, float *S,
   struct Ctx {
     int dev = 0, N = 0, lots = 0;
     tsdgpu_fft *plan = nullptr;
-    DevBuf xin, seg, part, wbuf, sout;
-    void libere() { if (plan) tsdgpu_fft_destroy(plan); xin.release(); seg.release(); part.release(); wbuf.release(); sout.release(); }
+    DevBuf xin, seg, part, wbuf, sout, tw;
+    bool tw_pret = false;
+    void libere() { if (plan) tsdgpu_fft_destroy(plan); xin.release(); seg.release(); part.release(); wbuf.release(); sout.release(); tw.release(); }
     size_t octets() const { return xin.cap + seg.cap + part.cap + wbuf.cap + sout.cap; }
   };
   static CtxReserve<Ctx> *reserve = new CtxReserve<Ctx>(4);
@@ -583,6 +594,35 @@ int tsdgpu_welch(const void *x, int64_t n, int N, const float *window, float *S,
   if (!rc) rc = stage_in(window, (size_t) N * sizeof(float), wbuf, st, &dwv);
   if (!rc) rc = stage_out(S, (size_t) N * sizeof(float), sout, &dS, &staged);
   tsdgpu_fft *plan = nullptr;
+  static const bool multi = getenv("TSDGPU_OLA_UNFUSED") != nullptr;
+  if (!rc && nseg > 0 && N == 1024 && !multi) {
+    // N = 1024: ONE kernel on the in-wave transform keeps the running sums in registers (ols.hip, welch1024_kernel)
+    if (!c->tw_pret) {
+      std::vector<cpx> t2(2048);
+      welch1024_tables(t2.data());
+      rc = c->tw.reserve(t2.size() * sizeof(cpx));
+      if (!rc && hipMemcpy(c->tw.p, t2.data(), t2.size() * sizeof(cpx), hipMemcpyHostToDevice) != hipSuccess)
+        rc = set_err(TSDGPU_ERR_HIP, "welch: table upload failed");
+      c->tw_pret = rc == TSDGPU_OK;
+    }
+    const int per = (int) std::min<int64_t>(64, std::max<int64_t>(1, nseg / 2048));
+    const int64_t rows = cdiv(nseg, per);
+    // the rows of the waves are summed in two deterministic stages (a single stage would walk thousands of rows from
+    // four workgroups)
+    const int rpg = (int) std::max<int64_t>(1, cdiv(rows, 64)), ngr = (int) cdiv(rows, rpg);
+    if (!rc) rc = part.reserve((size_t) (rows + ngr) * N * sizeof(float));
+    float *p1 = part.as<float>(), *p2 = p1 + (size_t) rows * N;
+    if (!rc) rc = welch1024_launch((const cpx *) dxv, (const float *) dwv, c->tw.as<cpx>(), p1, nseg, per, st);
+    if (!rc) {
+      hipLaunchKernelGGL(welch_sum_groups_kernel, dim3(nblk(N), (unsigned) ngr), dim3(256), 0, st, p1, p2, N, (int) rows, rpg);
+      hipLaunchKernelGGL(welch_sum_kernel, dim3(nblk(N)), dim3(256), 0, st, p2, (float *) dS, N, ngr);
+      if (hipGetLastError() != hipSuccess) rc = set_err(TSDGPU_ERR_HIP, "welch: launch failed");
+    }
+    if (!rc) rc = finish_out(S, (size_t) N * sizeof(float), dS, staged, st);
+    (void) hipStreamSynchronize(st);
+    reserve->rend(c);
+    return rc;
+  }
   if (!rc && nseg > 0 && !(c->plan && c->N == N)) {        // (the batch count given at creation is only a hint)
     if (c->plan) tsdgpu_fft_destroy(c->plan);
     c->plan = nullptr;
@@ -599,7 +639,7 @@ int tsdgpu_welch(const void *x, int64_t n, int N, const float *window, float *S,
     const int groups = (int) std::max<int64_t>(1, std::min<int64_t>(512, std::min<int64_t>(cdiv(nseg, 16), cdiv(262144, N))));
     const int64_t per_group = cdiv(nseg, groups);
     rc = seg.reserve((size_t) total * sizeof(cpx));
-    if (!rc) rc = part.reserve((size_t) groups * N * sizeof(float));
+    if (!rc) rc = part.reserve((size_t) (groups + 64) * N * sizeof(float));       // + the rows of the second summation stage
     bool fused = false;
     if (!rc) {
       // fused: segments gathered and windowed by the transform itself, which stores |X|^2 only
@@ -619,7 +659,15 @@ int tsdgpu_welch(const void *x, int64_t n, int N, const float *window, float *S,
       else
         hipLaunchKernelGGL(welch_power_kernel, dim3(nblk(N), (unsigned) groups), dim3(256), 0, st, seg.as<cpx>(), part.as<float>(), N,
                            nseg, per_group);
-      hipLaunchKernelGGL(welch_sum_kernel, dim3(nblk(N)), dim3(256), 0, st, part.as<float>(), (float *) dS, N, groups);
+      if (groups > 64) {
+        // (two deterministic stages: one stage would walk hundreds of rows from N / 256 workgroups)
+        const int rpg = (int) cdiv(groups, 64), ngr = (int) cdiv(groups, rpg);
+        float *p2 = part.as<float>() + (size_t) groups * N;
+        hipLaunchKernelGGL(welch_sum_groups_kernel, dim3(nblk(N), (unsigned) ngr), dim3(256), 0, st, part.as<float>(), p2, N, groups, rpg);
+        hipLaunchKernelGGL(welch_sum_kernel, dim3(nblk(N)), dim3(256), 0, st, p2, (float *) dS, N, ngr);
+      } else {
+        hipLaunchKernelGGL(welch_sum_kernel, dim3(nblk(N)), dim3(256), 0, st, part.as<float>(), (float *) dS, N, groups);
+      }
       if (hipGetLastError() != hipSuccess) rc = set_err(TSDGPU_ERR_HIP, "welch: launch failed");
     }
   }

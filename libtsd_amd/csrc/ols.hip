@@ -519,4 +519,63 @@ int ola1024_launch(const cpx *x, cpx *y, const cpx *tables3, const cpx *svg_in, 
   return TSDGPU_OK;
 }
 
+// ---- Welch periodogram sums, N = 1024, on the same in-wave transform (ola.hip: tsdgpu_welch's fast path) -------------
+// psd_welch (freqestim.cc:7-20): segments of N samples every N/2, windowed, |FFT|^2 summed.  A wave runs through `per`
+// consecutive segments: loads (each sample is read by two segments: 16 B of HBM traffic per sample, against the 50 B of
+// the framing / transform / power passes), window, transform, and the 1024 running sums stay in registers until the
+// end of the run; part[wave][i] gets them in fftshift order (the reduction over the waves is welch_sum_kernel's).
+__global__ __launch_bounds__(64, 2) void welch1024_kernel(const cpx *__restrict__ x, const float *__restrict__ w,
+                                                          const cpx *__restrict__ TW1, const cpx *__restrict__ TW2,
+                                                          float *__restrict__ part, int64_t nseg, int per)
+{
+  __shared__ cv lds[LDS_ELEMS];
+  const int lane = threadIdx.x;
+  const int64_t k_lo = (int64_t) blockIdx.x * per, k_hi = min(nseg, k_lo + (int64_t) per);
+  cv tw1[16], tw2[16];
+  float win[16], acc[16];
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    tw1[r] = ((const cv *) TW1)[r * 64 + lane];
+    tw2[r] = ((const cv *) TW2)[r * 64 + lane];
+    win[r] = w[64 * r + lane];
+    acc[r] = 0.f;
+  }
+  auto sync = []() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  const cv *xs = (const cv *) x;
+  cv cur[16], nxt[16];
+  if (k_lo < k_hi) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) nxt[r] = xs[k_lo * 512 + 64 * r + lane];
+  }
+  for (int64_t k = k_lo; k < k_hi; k++) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) cur[r] = mkv(nxt[r].x * win[r], nxt[r].y * win[r]);      // x.segment(i, N) * f  (:15)
+    if (k + 1 < k_hi) {
+#pragma unroll
+      for (int r = 0; r < 16; r++) nxt[r] = xs[(k + 1) * 512 + 64 * r + lane];
+    }
+    forward(cur, lds, lane, tw1, tw2, sync);
+    sync();
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] += cur[r].x * cur[r].x + cur[r].y * cur[r].y;     // abs2 (:16)
+  }
+  // the engine's transform is unitary (1 / sqrt(N)): |X|^2 / N
+#pragma unroll
+  for (int r = 0; r < 16; r++) part[(size_t) blockIdx.x * 1024 + ((freq_index(lane, r) + 512) & 1023)] = acc[r] * (1.0f / 1024.0f);
+}
+
+int welch1024_launch(const cpx *x, const float *w, const cpx *tw2x1024, float *part, int64_t nseg, int per, hipStream_t st)
+{
+  const int64_t grid = cdiv(nseg, per);
+  hipLaunchKernelGGL(welch1024_kernel, dim3((unsigned) grid), dim3(64), 0, st, x, w, tw2x1024, tw2x1024 + 1024, part, nseg, per);
+  TSD_HIP(hipGetLastError());
+  return TSDGPU_OK;
+}
+
+void welch1024_tables(cpx *out2) { fill_twiddles(out2, out2 + 1024); }
+
 }  // namespace tsdgpu

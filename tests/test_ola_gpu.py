@@ -135,7 +135,7 @@ def test_errors():
 
 
 # psd_welch (freqestim.cc:7-20) on the device: framing, one batched FFT, sum of the periodograms
-@pytest.mark.parametrize("N", [1, 2, 64, 256, 1000, 1001, 4096])
+@pytest.mark.parametrize("N", [1, 2, 64, 256, 1000, 1001, 1024, 4096])      # (1024: one fused kernel on the in-wave transform)
 def test_welch_matches_oracle(N):
     rng = np.random.default_rng(N)
     w = ola_oracle.fen_hann_periodique(N) if N > 2 else np.ones(N, np.float32)
