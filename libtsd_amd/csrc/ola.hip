@@ -26,6 +26,7 @@ struct tsdgpu_ola {
   tsdgpu::DevBuf frames, spectra, in_stage, out_stage;
   tsdgpu::cpx *d_fast = nullptr;           // fast path (Ne = 512, N = 1024, no window): response in register order / N + twiddles (3 x 1024)
   tsdgpu::cpx *d_svg_tmp = nullptr;        // Ne: the new tail, written by the last wave while the first one may still read d_svg
+  tsdgpu::cpx *d_run = nullptr;            // any other geometry without window: response / N (N values), then W_N^i, i < N/16
 };
 
 namespace tsdgpu {
@@ -149,6 +150,177 @@ bool framed_fft_launch(const tsdgpu_fft *plan, const FrameSrc &S, int64_t nfr, c
   if (r0 == 16) FR_LAUNCH(16); else if (r0 == 8) FR_LAUNCH(8); else if (r0 == 4) FR_LAUNCH(4); else FR_LAUNCH(2);
 #undef FR_LAUNCH
   return true;
+}
+
+// ---- OLA without window as ONE kernel, any geometry whose frame fits the LDS ------------------------------------------
+// OLA<cfloat>::step_interne (fourier.cc:846-872):  frame_b = [Nz zeros | block b] -> FFT -> * H -> IFFT = x2_b;
+//   y_b = x2_{b-1}[Nz ..] with its last Nz samples += x2_b[0 .. Nz);   svg <- x2_b[Nz ..]
+// The separate passes (framed transform, inverse transform, addition) move 80 B per sample through HBM.  Here tpt = N/16
+// threads own a RUN of `per` consecutive blocks: both transforms in the LDS image of the frame (stockham16.hpp), the
+// Ne carried samples in LDS beside it, 16 B of HBM traffic per sample.  A run starts from the block before it, which it
+// recomputes (the first one takes the handle's svg).  Hs = H / N: the engine's transforms are unitary each way, the
+// ones here are not scaled; the inverse is the conjugate of the forward transform of the conjugate.
+// Every thread of the workgroup passes every barrier: runs past the end carry zeros.
+template <int R0, int THREADS, bool HALF>
+__global__ __launch_bounds__(THREADS, THREADS == 256 ? 3 : 2) void ola_run_kernel(const cpx *__restrict__ blk0, int nrest, const cpx *__restrict__ x,
+                                                       cpx *__restrict__ y, const cpx *__restrict__ Hs, const cpx *__restrict__ TW,
+                                                       const cpx *__restrict__ svg_in, cpx *__restrict__ svg_out, int Ne, int N, int tpt,
+                                                       int64_t B, int per)
+{
+  extern __shared__ __attribute__((aligned(16))) char run_raw[];
+  const int Nz = N - Ne, t = threadIdx.x, T = THREADS / tpt;
+  const int tl = t / tpt, j0 = t - tl * tpt;
+  // HALF (Ne = Nz = 8 tpt): registers 8..15 of a thread are the carried samples of its registers 0..7 -- no LDS copy
+  cpx *s = reinterpret_cast<cpx *>(run_raw) + (size_t) tl * (N + (N >> 4) + (HALF ? 0 : Ne));
+  cpx *tail = s + N + (N >> 4);
+  const int64_t b_lo = ((int64_t) blockIdx.x * T + tl) * per, b_hi = min(B, b_lo + (int64_t) per);
+  auto sync = []() { __syncthreads(); };
+  cpx v[16], carry[HALF ? 8 : 1];
+  for (int it = -1; it < per; it++) {
+    const int64_t b = b_lo + it;
+    // (opaque copy: keeps the compiler from carrying every address derived from the thread index across the loop --
+    // 240 VGPRs and scratch otherwise)
+    int j = j0;
+    asm volatile("" : "+v"(j));
+    {
+      // block 0 = [rest ++ head of x] was made contiguous by the host (blk0); block b > 0 starts at x[b Ne - nrest]
+      const bool live = b >= 0 && b < b_hi;
+      const cpx *src = (b == 0 ? blk0 : x + (b * Ne - nrest)) - Nz;
+#pragma unroll
+      for (int m = 0; m < 16; m++) {
+        const int p = j + m * tpt;
+        v[m] = (live && (HALF ? m >= 8 : p >= Nz)) ? src[p] : make_float2(0.f, 0.f);
+      }
+    }
+    if (it >= 0) sync();                            // the image is still being read by the last pass of the block before
+    s16::transform<R0>(v, s, TW, N, j, tpt, sync);
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      const cpx h = Hs[j + q * tpt];
+      v[q] = make_float2(v[q].x * h.x - v[q].y * h.y, -(v[q].x * h.y + v[q].y * h.x));
+    }
+    sync();
+    asm volatile("" : "+v"(j));
+    s16::transform<R0>(v, s, TW, N, j, tpt, sync);
+    asm volatile("" : "+v"(j));
+    // v[q] = conj(x2[j + q tpt])
+    const bool keep = it < 0 || b < b_hi;           // (a run cut short by the end keeps its last carried block)
+    if (HALF) {
+      if (it >= 0 && b < b_hi) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) y[b * Ne + j + q * tpt] = make_float2(carry[q].x + v[q].x, carry[q].y - v[q].y);
+      }
+      if (it < 0 && b_lo == 0) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) carry[q] = svg_in[j + q * tpt];
+      } else if (keep) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) carry[q] = make_float2(v[q + 8].x, -v[q + 8].y);
+      }
+    } else {
+      if (it >= 0) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+          const int p = j + q * tpt;
+          if (p < Nz) {
+            const cpx a = tail[Ne - Nz + p];
+            tail[Ne - Nz + p] = make_float2(a.x + v[q].x, a.y - v[q].y);
+          }
+        }
+        sync();
+        if (b < b_hi)
+          for (int i = j; i < Ne; i += tpt) y[b * Ne + i] = tail[i];
+        sync();
+      }
+      if (it < 0 && b_lo == 0) {
+        for (int i = j; i < Ne; i += tpt) tail[i] = svg_in[i];
+      } else if (keep) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+          const int p = j + q * tpt;
+          if (p >= Nz) tail[p - Nz] = make_float2(v[q].x, -v[q].y);
+        }
+      }
+    }
+  }
+  if (b_lo < B && b_hi == B) {
+    if (HALF) {
+#pragma unroll
+      for (int q = 0; q < 8; q++) svg_out[j0 + q * tpt] = carry[q];
+    }
+  }
+  if (!HALF) {
+    sync();
+    if (b_lo < B && b_hi == B)
+      for (int i = j0; i < Ne; i += tpt) svg_out[i] = tail[i];
+  }
+}
+
+struct OlaRunGeom {
+  int tpt, threads, T;
+  bool half;
+  size_t lds;
+};
+OlaRunGeom ola_run_geom(int N, int Ne)
+{
+  OlaRunGeom g;
+  g.tpt = std::max(N / 16, 1);
+  g.threads = std::max(256, g.tpt);
+  g.T = g.threads / g.tpt;
+  g.half = 2 * Ne == N;
+  g.lds = (size_t) g.T * (N + N / 16 + (g.half ? 0 : Ne)) * sizeof(cpx);
+  return g;
+}
+// the fused kernel serves the frames that fit the LDS with at most 512 threads per transform
+bool ola_run_fits(int N, int Ne)
+{
+  const OlaRunGeom g = ola_run_geom(N, Ne);
+  return N >= 16 && g.threads <= 512 && g.lds <= 160 * 1024;
+}
+
+// B >= 1 whole blocks of [rest ++ x] -> y; tables = Hs (N), TW (N/16).  y may not alias x (runs re-read their predecessor).
+int ola_run_launch(const cpx *blk0, int nrest, const cpx *x, cpx *y, const cpx *tables, const cpx *svg_in, cpx *svg_out, int Ne, int N,
+                   int64_t B, hipStream_t st)
+{
+  const OlaRunGeom g = ola_run_geom(N, Ne);
+  const int tpt = g.tpt, T = g.T;
+  int logn = 0;
+  while ((1 << logn) < N) logn++;
+  const int r0 = 1 << ((logn & 3) == 0 ? 4 : (logn & 3));
+  // blocks per run: every run recomputes the block before it, so a run costs per + 1 blocks, and the workgroups pass over
+  // the chip in rounds of (CUs x resident workgroups): the cheapest (rounds x (per + 1)) wins
+  static const int cus = []() {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  const int64_t slots = (int64_t) cus * std::max<int64_t>(1, std::min<int64_t>(g.threads == 256 ? 3 : 1, (160 * 1024) / g.lds));   // (registers: 3 waves per SIMD)
+  int per = 1;
+  int64_t best = -1;
+  for (int c = 1; c <= 32; c++) {
+    const int64_t wgs = cdiv(cdiv(B, c), T), cost = cdiv(wgs, slots) * (c + 1);
+    if (best < 0 || cost < best) best = cost, per = c;
+  }
+  const int64_t runs = cdiv(B, per), grid = cdiv(runs, T);
+  if (grid > 0x7fffffff) return set_err(TSDGPU_ERR_UNSUPPORTED, "ola: too many blocks in one call");
+#define RUN_LAUNCH(R, TH, HF)                                                                                            \
+  do {                                                                                                                   \
+    (void) hipFuncSetAttribute((const void *) ola_run_kernel<R, TH, HF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    hipLaunchKernelGGL((ola_run_kernel<R, TH, HF>), dim3((unsigned) grid), dim3(TH), g.lds, st, blk0, nrest, x, y, tables, tables + N, svg_in, svg_out, Ne, N, tpt, B, per); \
+  } while (0)
+#define RUN_PICK(TH, HF)                                                                                                 \
+  do {                                                                                                                   \
+    if (r0 == 16) RUN_LAUNCH(16, TH, HF); else if (r0 == 8) RUN_LAUNCH(8, TH, HF); else if (r0 == 4) RUN_LAUNCH(4, TH, HF); else RUN_LAUNCH(2, TH, HF); \
+  } while (0)
+  if (g.threads == 256 && g.half) RUN_PICK(256, true);
+  else if (g.threads == 256) RUN_PICK(256, false);
+  else if (g.threads == 512 && g.half) RUN_PICK(512, true);
+  else if (g.threads == 512) RUN_PICK(512, false);
+  else return set_err(TSDGPU_ERR_UNSUPPORTED, "ola: frame of %d points does not fit the fused kernel", N);   // (set_response does not select it)
+#undef RUN_PICK
+#undef RUN_LAUNCH
+  TSD_HIP(hipGetLastError());
+  return TSDGPU_OK;
 }
 
 // dst[i] = sample (p0 + i) of [rest ++ x]   (new prev_half / new rest)
@@ -365,6 +537,8 @@ int tsdgpu_ola_set_response(tsdgpu_ola *h, const void *H)
     h->d_H = nullptr;
     if (h->d_fast) (void) hipFree(h->d_fast);
     h->d_fast = nullptr;
+    if (h->d_run) (void) hipFree(h->d_run);
+    h->d_run = nullptr;
     return TSDGPU_OK;
   }
   if (!h->d_H) TSD_HIP(hipMalloc((void **) &h->d_H, (size_t) h->N * sizeof(cpx)));
@@ -378,6 +552,20 @@ int tsdgpu_ola_set_response(tsdgpu_ola *h, const void *H)
     if (!h->d_fast) TSD_HIP(hipMalloc((void **) &h->d_fast, t3.size() * sizeof(cpx)));
     if (!h->d_svg_tmp) TSD_HIP(hipMalloc((void **) &h->d_svg_tmp, 512 * sizeof(cpx)));
     TSD_HIP(hipMemcpy(h->d_fast, t3.data(), t3.size() * sizeof(cpx), hipMemcpyHostToDevice));
+  } else if (!unfused && !h->windowed && ola_run_fits(h->N, h->Ne)) {
+    // the other geometries whose frame and carried block fit the LDS: one kernel too (ola_run_kernel)
+    const int N = h->N;
+    std::vector<cpx> tb((size_t) N + N / 16);
+    TSD_HIP(hipMemcpy(tb.data(), h->d_H, (size_t) N * sizeof(cpx), hipMemcpyDeviceToHost));
+    for (int i = 0; i < N; i++) tb[i] = make_float2(tb[i].x / (float) N, tb[i].y / (float) N);
+    const double PI = 3.14159265358979323846;
+    for (int i = 0; i < N / 16; i++) {
+      const double a = -2.0 * PI * (double) i / (double) N;
+      tb[(size_t) N + i] = make_float2((float) std::cos(a), (float) std::sin(a));
+    }
+    if (!h->d_run) TSD_HIP(hipMalloc((void **) &h->d_run, tb.size() * sizeof(cpx)));
+    if (!h->d_svg_tmp) TSD_HIP(hipMalloc((void **) &h->d_svg_tmp, (size_t) h->Ne * sizeof(cpx)));
+    TSD_HIP(hipMemcpy(h->d_run, tb.data(), tb.size() * sizeof(cpx), hipMemcpyHostToDevice));
   }
   return TSDGPU_OK;
 }
@@ -553,6 +741,42 @@ int tsdgpu_ola_step(tsdgpu_ola *h, const void *x, int64_t n, void *y, int64_t *n
     if (n_out) *n_out = nout;
     return TSDGPU_OK;
   }
+  if (h->d_run && h->pending_blocks < 0 && n >= 0 && (n == 0 || x != nullptr) && ((int64_t) h->nrest + n) / h->Ne >= 1 && y != nullptr) {
+    // any other geometry without window: B whole blocks of [rest ++ x] through ONE kernel (ola_run_kernel)
+    hipStream_t st = (hipStream_t) stream;
+    const int Ne = h->Ne;
+    const int64_t tot = (int64_t) h->nrest + n, B = tot / Ne, nout = B * Ne, left = tot - nout;
+    if (n_out) *n_out = 0;
+    TSD_CHECK(B <= (1 << 24), "ola_step: %lld blocks in one call", (long long) B);
+    const void *dxv = nullptr;
+    void *dyv = nullptr;
+    bool staged = false;
+    int rc = stage_in(x, (size_t) n * sizeof(cpx), h->in_stage, st, &dxv);
+    if (rc) return rc;
+    if ((rc = stage_out(y, (size_t) nout * sizeof(cpx), h->out_stage, &dyv, &staged))) return rc;
+    if (host_ranges_overlap(dxv, (size_t) n * sizeof(cpx), dyv, (size_t) nout * sizeof(cpx))) {
+      // in place on the device: a run re-reads the block before it, which the run before may already have overwritten
+      if ((rc = h->in_stage.reserve((size_t) n * sizeof(cpx)))) return rc;
+      TSD_HIP(hipMemcpyAsync(h->in_stage.p, dxv, (size_t) n * sizeof(cpx), hipMemcpyDeviceToDevice, st));
+      dxv = h->in_stage.p;
+    }
+    const cpx *dx = (const cpx *) dxv;
+    // block 0 made contiguous: the waiting samples, then the head of x (rest has room for a whole block)
+    if (h->nrest > 0) TSD_HIP(hipMemcpyAsync(h->d_rest + h->nrest, dx, (size_t) (Ne - h->nrest) * sizeof(cpx), hipMemcpyDeviceToDevice, st));
+    if ((rc = ola_run_launch(h->nrest > 0 ? h->d_rest : dx, h->nrest, dx, (cpx *) dyv, h->d_run, h->d_svg, h->d_svg_tmp, Ne, h->N, B, st))) return rc;
+    TSD_HIP(hipMemcpyAsync(h->d_svg, h->d_svg_tmp, (size_t) Ne * sizeof(cpx), hipMemcpyDeviceToDevice, st));
+    if (left > 0) {
+      // the samples after the last whole block lie inside x (B >= 1): rest is only written
+      hipLaunchKernelGGL(ola_gather_kernel, dim3(nblk(left)), dim3(256), 0, st, h->d_rest, 0, dx, nout - h->nrest, h->d_rest, (int) left);
+      TSD_HIP(hipGetLastError());
+    }
+    if ((rc = finish_out(y, (size_t) nout * sizeof(cpx), dyv, staged, st))) return rc;
+    if (dxv != x && !staged) TSD_HIP(hipStreamSynchronize(st));    // (a staged input must outlive its kernels)
+    h->nrest = (int) left;
+    h->cnt_ech += nout;
+    if (n_out) *n_out = nout;
+    return TSDGPU_OK;
+  }
   void *sp = nullptr;
   int nf = 0;
   h->fuse_response = true;
@@ -682,7 +906,7 @@ int tsdgpu_ola_destroy(tsdgpu_ola *h)
 {
   if (!h) return TSDGPU_OK;
   if (h->plan) tsdgpu_fft_destroy(h->plan);
-  for (void *q : {(void *) h->d_fen, (void *) h->d_H, (void *) h->d_svg, (void *) h->d_last, (void *) h->d_prev_half, (void *) h->d_rest, (void *) h->d_fast, (void *) h->d_svg_tmp})
+  for (void *q : {(void *) h->d_fen, (void *) h->d_H, (void *) h->d_svg, (void *) h->d_last, (void *) h->d_prev_half, (void *) h->d_rest, (void *) h->d_fast, (void *) h->d_svg_tmp, (void *) h->d_run})
     if (q) (void) hipFree(q);
   h->frames.release();
   h->spectra.release();

@@ -205,3 +205,36 @@ def test_fused_default_geometry_long_runs():
     yh = g.step(xh)
     yr = orc.fir(h, xh)
     assert relerr(yh[d:], yr[:len(yh) - d]) <= 2e-5
+
+
+@pytest.mark.parametrize("Ne,K", [(2048, 127), (3000, 500), (4096, 1025), (6000, 2000), (64, 33), (100, 20), (16, 15), (900, 100)])
+def test_fused_other_geometries_long_runs(Ne, K):
+    """Every other geometry without window whose frame fits the LDS runs as ONE kernel too (ola.hip, ola_run_kernel):
+    N/16 threads own a run of consecutive blocks, the carried block in registers (Ne = N/2) or in LDS.  Long calls
+    (several blocks per run, the last run cut short), the stream in two ragged calls (waiting samples: block 0 is made
+    contiguous on the host side), in place: against the device FIR, Ne - K later (fourier.cc:946-990)."""
+    import torch
+    rng = np.random.default_rng(12)
+    g = t.Ola(Ne, K, None)
+    H, h = response(g.N, rng, K)
+    d = Ne - K
+    for n in (3 * Ne, (1 << 22) // Ne * Ne + Ne, (13 << 20) // Ne * Ne):
+        x = torch.view_as_complex(torch.randn(n, 2, device="cuda", generator=torch.Generator(device="cuda").manual_seed(n)))
+        ref = t.Fir(h, t.C64, t.FIR_DIRECT).step(x)
+        g = t.Ola(Ne, K, None)
+        g.set_response(H)
+        y = g.step(x)
+        assert y.shape[0] == n
+        e = float((y[d:] - ref[:n - d]).abs().max() / ref.abs().max())
+        assert e <= 2e-5, (n, e)
+        g2 = t.Ola(Ne, K, None)
+        g2.set_response(H)
+        cut = (n // Ne // 2) * Ne + Ne // 3
+        y2 = torch.cat([g2.step(x[:cut]), g2.step(x[cut:n - Ne + 7]), g2.step(x[n - Ne + 7:])])
+        assert y2.shape[0] == n
+        # (the runs fall elsewhere: same sums, another order inside the transforms' last bits only where a run starts)
+        assert float((y2 - y).abs().max() / ref.abs().max()) <= 1e-6
+        g3 = t.Ola(Ne, K, None)
+        g3.set_response(H)
+        xi = x.clone()
+        assert torch.equal(g3.step(xi, xi), y)
