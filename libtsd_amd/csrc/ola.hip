@@ -323,6 +323,79 @@ int ola_run_launch(const cpx *blk0, int nrest, const cpx *x, cpx *y, const cpx *
   return TSDGPU_OK;
 }
 
+// ---- Welch sums as ONE kernel, 16 <= N <= 8192 (N = 1024 has its in-wave flavour in ols.hip) -------------------------
+// psd_welch (freqestim.cc:7-20): segments of N samples every N/2, windowed, |FFT|^2 summed.  N/16 threads walk a run of
+// `per` consecutive segments: window, transform in the LDS image, the 16 running sums of a thread in registers; the run's
+// row part[run][.] gets them in fftshift order, scaled to the engine's unitary transform (|X|^2 / N).  8 B of HBM
+// traffic per sample and a row per run, against the |X|^2 plane (4 B per segment sample written, then read) of the
+// framed transform + summation passes.
+template <int R0, int THREADS>
+__global__ __launch_bounds__(THREADS, THREADS == 256 ? 3 : 2) void welch_run_kernel(const cpx *__restrict__ x, const float *__restrict__ w,
+                                                                                    const cpx *__restrict__ TW, float *__restrict__ part,
+                                                                                    int N, int tpt, int64_t nseg, int per)
+{
+  extern __shared__ __attribute__((aligned(16))) char wr_raw[];
+  const int t = threadIdx.x, T = THREADS / tpt, pas = N / 2;
+  const int tl = t / tpt, j0 = t - tl * tpt;
+  cpx *s = reinterpret_cast<cpx *>(wr_raw) + (size_t) tl * (N + (N >> 4));
+  const int64_t run = (int64_t) blockIdx.x * T + tl, k_lo = run * per, k_hi = min(nseg, k_lo + (int64_t) per);
+  auto sync = []() { __syncthreads(); };
+  float win[16], acc[16];
+#pragma unroll
+  for (int m = 0; m < 16; m++) {
+    win[m] = w[j0 + m * tpt];
+    acc[m] = 0.f;
+  }
+  cpx v[16];
+  for (int it = 0; it < per; it++) {
+    const int64_t k = k_lo + it;
+    int j = j0;
+    asm volatile("" : "+v"(j));        // (see ola_run_kernel: no addresses carried across the loop)
+    const bool live = k < k_hi;
+    const cpx *src = x + k * pas;
+#pragma unroll
+    for (int m = 0; m < 16; m++) {
+      const cpx a = live ? src[j + m * tpt] : make_float2(0.f, 0.f);
+      v[m] = make_float2(a.x * win[m], a.y * win[m]);                          // x.segment(i, N) * f  (:15)
+    }
+    if (it > 0) sync();                // the image is still being read by the last pass of the segment before
+    s16::transform<R0>(v, s, TW, N, j, tpt, sync);
+#pragma unroll
+    for (int q = 0; q < 16; q++) acc[q] += v[q].x * v[q].x + v[q].y * v[q].y;    // abs2 (:16)
+  }
+  if (k_lo < nseg) {
+    const float g = 1.0f / (float) N;
+#pragma unroll
+    for (int q = 0; q < 16; q++) part[(size_t) run * N + ((j0 + q * tpt + pas) & (N - 1))] = acc[q] * g;
+  }
+}
+
+// rows of partial sums written: part must hold *rows x N floats
+int welch_run_launch(const cpx *x, const float *w, const cpx *TW, float *part, int N, int64_t nseg, int per, hipStream_t st)
+{
+  const OlaRunGeom g = ola_run_geom(N, N / 2);
+  int logn = 0;
+  while ((1 << logn) < N) logn++;
+  const int r0 = 1 << ((logn & 3) == 0 ? 4 : (logn & 3));
+  const int64_t grid = cdiv(cdiv(nseg, per), g.T);
+#define WR_LAUNCH(R, TH)                                                                                                 \
+  do {                                                                                                                   \
+    (void) hipFuncSetAttribute((const void *) welch_run_kernel<R, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    hipLaunchKernelGGL((welch_run_kernel<R, TH>), dim3((unsigned) grid), dim3(TH), g.lds, st, x, w, TW, part, N, g.tpt, nseg, per); \
+  } while (0)
+#define WR_PICK(TH)                                                                                                      \
+  do {                                                                                                                   \
+    if (r0 == 16) WR_LAUNCH(16, TH); else if (r0 == 8) WR_LAUNCH(8, TH); else if (r0 == 4) WR_LAUNCH(4, TH); else WR_LAUNCH(2, TH); \
+  } while (0)
+  if (g.threads == 256) WR_PICK(256);
+  else if (g.threads == 512) WR_PICK(512);
+  else return set_err(TSDGPU_ERR_UNSUPPORTED, "welch: N = %d does not fit the fused kernel", N);
+#undef WR_PICK
+#undef WR_LAUNCH
+  TSD_HIP(hipGetLastError());
+  return TSDGPU_OK;
+}
+
 // dst[i] = sample (p0 + i) of [rest ++ x]   (new prev_half / new rest)
 __global__ void ola_gather_kernel(const cpx *__restrict__ rest, int nrest, const cpx *__restrict__ x, int64_t p0,
                                   cpx *__restrict__ dst, int count)
@@ -804,12 +877,12 @@ int tsdgpu_welch(const void *x, int64_t n, int N, const float *window, float *S,
     int dev = 0, N = 0, lots = 0;
     tsdgpu_fft *plan = nullptr;
     DevBuf xin, seg, part, wbuf, sout, tw;
-    bool tw_pret = false;
+    int tw_N = 0;                     // the size the transform tables in tw were made for (0: none)
     void libere() { if (plan) tsdgpu_fft_destroy(plan); xin.release(); seg.release(); part.release(); wbuf.release(); sout.release(); tw.release(); }
     size_t octets() const { return xin.cap + seg.cap + part.cap + wbuf.cap + sout.cap; }
   };
   static CtxReserve<Ctx> *reserve = new CtxReserve<Ctx>(4);
-  Ctx *c = reserve->prend([N](const Ctx &k) { return k.N == N; });
+  Ctx *c = reserve->prend([N](const Ctx &k) { return k.N == N || k.tw_N == N; });
   DevBuf &xin = c->xin, &seg = c->seg, &part = c->part, &wbuf = c->wbuf, &sout = c->sout;
   const void *dxv = nullptr, *dwv = nullptr;
   void *dS = nullptr;
@@ -821,13 +894,14 @@ int tsdgpu_welch(const void *x, int64_t n, int N, const float *window, float *S,
   static const bool multi = getenv("TSDGPU_OLA_UNFUSED") != nullptr;
   if (!rc && nseg > 0 && N == 1024 && !multi) {
     // N = 1024: ONE kernel on the in-wave transform keeps the running sums in registers (ols.hip, welch1024_kernel)
-    if (!c->tw_pret) {
+    if (c->tw_N != 1024) {
       std::vector<cpx> t2(2048);
       welch1024_tables(t2.data());
+      c->tw_N = 0;
       rc = c->tw.reserve(t2.size() * sizeof(cpx));
       if (!rc && hipMemcpy(c->tw.p, t2.data(), t2.size() * sizeof(cpx), hipMemcpyHostToDevice) != hipSuccess)
         rc = set_err(TSDGPU_ERR_HIP, "welch: table upload failed");
-      c->tw_pret = rc == TSDGPU_OK;
+      if (!rc) c->tw_N = 1024;
     }
     const int per = (int) std::min<int64_t>(64, std::max<int64_t>(1, nseg / 2048));
     const int64_t rows = cdiv(nseg, per);
@@ -837,6 +911,45 @@ int tsdgpu_welch(const void *x, int64_t n, int N, const float *window, float *S,
     if (!rc) rc = part.reserve((size_t) (rows + ngr) * N * sizeof(float));
     float *p1 = part.as<float>(), *p2 = p1 + (size_t) rows * N;
     if (!rc) rc = welch1024_launch((const cpx *) dxv, (const float *) dwv, c->tw.as<cpx>(), p1, nseg, per, st);
+    if (!rc) {
+      hipLaunchKernelGGL(welch_sum_groups_kernel, dim3(nblk(N), (unsigned) ngr), dim3(256), 0, st, p1, p2, N, (int) rows, rpg);
+      hipLaunchKernelGGL(welch_sum_kernel, dim3(nblk(N)), dim3(256), 0, st, p2, (float *) dS, N, ngr);
+      if (hipGetLastError() != hipSuccess) rc = set_err(TSDGPU_ERR_HIP, "welch: launch failed");
+    }
+    if (!rc) rc = finish_out(S, (size_t) N * sizeof(float), dS, staged, st);
+    (void) hipStreamSynchronize(st);
+    reserve->rend(c);
+    return rc;
+  }
+  if (!rc && nseg > 0 && !multi && N >= 16 && (N & (N - 1)) == 0 && ola_run_fits(N, N / 2)) {
+    // the other powers of two up to 8192: ONE kernel on the LDS transform keeps the running sums in registers (welch_run_kernel)
+    if (c->tw_N != N) {
+      std::vector<cpx> tw((size_t) N / 16);
+      const double PI = 3.14159265358979323846;
+      for (int i = 0; i < N / 16; i++) {
+        const double a = -2.0 * PI * (double) i / (double) N;
+        tw[i] = make_float2((float) std::cos(a), (float) std::sin(a));
+      }
+      c->tw_N = 0;
+      rc = c->tw.reserve(tw.size() * sizeof(cpx));
+      if (!rc && hipMemcpy(c->tw.p, tw.data(), tw.size() * sizeof(cpx), hipMemcpyHostToDevice) != hipSuccess)
+        rc = set_err(TSDGPU_ERR_HIP, "welch: table upload failed");
+      if (!rc) c->tw_N = N;
+    }
+    const OlaRunGeom g = ola_run_geom(N, N / 2);
+    static const int cus = []() {
+      int dev = 0, n = 256;
+      if (hipGetDevice(&dev) == hipSuccess) (void) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+      return n > 0 ? n : 256;
+    }();
+    // one pass of the chip: a run per (resident workgroup x transform)
+    const int64_t places = (int64_t) cus * (g.threads == 256 ? 3 : 1) * g.T;
+    const int per = (int) std::min<int64_t>(64, std::max<int64_t>(1, cdiv(nseg, places)));
+    const int64_t rows = cdiv(nseg, per);
+    const int rpg = (int) std::max<int64_t>(1, cdiv(rows, 64)), ngr = (int) cdiv(rows, rpg);
+    if (!rc) rc = part.reserve((size_t) (rows + ngr) * N * sizeof(float));
+    float *p1 = part.as<float>(), *p2 = p1 + (size_t) rows * N;
+    if (!rc) rc = welch_run_launch((const cpx *) dxv, (const float *) dwv, c->tw.as<cpx>(), p1, N, nseg, per, st);
     if (!rc) {
       hipLaunchKernelGGL(welch_sum_groups_kernel, dim3(nblk(N), (unsigned) ngr), dim3(256), 0, st, p1, p2, N, (int) rows, rpg);
       hipLaunchKernelGGL(welch_sum_kernel, dim3(nblk(N)), dim3(256), 0, st, p2, (float *) dS, N, ngr);
