@@ -26,6 +26,7 @@
 #include "common.hpp"
 #include <cmath>
 #include <cstdlib>
+#include <vector>
 
 namespace tsdgpu {
 
@@ -44,10 +45,10 @@ struct SosSection {
   float b0, b1, b2, a1, a2;
   float seed;                 // 1: first-sample seed (SOIS), 0: zero start (RIIFoS)
   float df1;                  // 1: FormeDirecte1 (filtre-rt.cc:384-393), 0: FormeDirecte2 (:369-380)
-  float pad1;
-  float A[6][4];              // (M^L)^(2^k), k = 0..5, row-major 2x2, M = [[-a1,-a2],[1,0]]
-  float c1[LANE_FLOATS];      // output response to start state d1 (per in-lane sample index)
-  float c2[LANE_FLOATS];      // output response to start state d2
+  float sg;                   // +1 / -1: the scans carry (d1, delta = d1 - sg d2) instead of (d1, d2), see sos_cascade
+  float A[6][4];              // T (M^L)^(2^k) T^-1, k = 0..5, row-major 2x2, M = [[-a1,-a2],[1,0]], T = [[1,0],[1,-sg]]
+  float c1[LANE_FLOATS];      // output response to start state (d1, delta) = (1, 0) (per in-lane sample index)
+  float c2[LANE_FLOATS];      // output response to start state (d1, delta) = (0, 1)
   // the same tables for the narrow warm-up steps (L = NARROW_FLOATS / channels samples per lane)
   float An[6][4];
   float c1n[NARROW_FLOATS], c2n[NARROW_FLOATS];
@@ -65,11 +66,33 @@ __device__ __forceinline__ void wave_sync()
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// The stream state of the handle is the reference's: per (section, channel) (d1, d2, x1, x2).  The running image a wave keeps
+// in LDS holds (d1, delta = d1 - sg d2, x1, x2) -- the coordinates of the scans, see sos_cascade.
+__device__ __forceinline__ void state_load(float *sst, const float *__restrict__ st, const SosSection *__restrict__ sec, int nsec, int lane)
+{
+  for (int i = lane; i < nsec * 8; i += 64) {
+    float v = st[1 + i];
+    if ((i & 3) == 1) v = st[i] - sec[i >> 3].sg * v;
+    sst[i] = v;
+  }
+}
+__device__ __forceinline__ void state_store(float *__restrict__ st, const float *sst, const SosSection *__restrict__ sec, int nsec, int lane)
+{
+  if (lane == 0) st[0] = 1.f;
+  for (int i = lane; i < nsec * 8; i += 64) st[1 + i] = (i & 3) == 1 ? sec[i >> 3].sg * (sst[i - 1] - sst[i]) : sst[i];
+}
+
 // One cascade pass over the wave's samples held in registers: lane l owns LF consecutive floats
 // (LF / NCH samples per channel), v in, v out.  Per section: zero-state run, Kogge-Stone scan of the
 // end states over the 64 lanes, zero-input correction of every sample; the running state of every
 // (section, channel) lives in sst (LDS) and is advanced to the end of these 64 * LF floats.
 // NARROW selects the tables of the NARROW_FLOATS-per-lane warm-up steps.
+// Coordinates of the carried state: (d1, delta = d1 - sg d2), sg = the sign of the poles' real part.  A narrow-band
+// section has its poles next to +1 (or -1): M^n ~ [[n+1, -n], [n, -(n-1)]], and a DC level of 10^6 in (d1, d2) -- what
+// a cut-off of 1e-4 makes of an offset of 0.5 -- went through the scan as the difference of products of 10^9: the
+// states came out with an absolute error of ~100 where the sequential recurrence has 0.1 (outputs 10-25 x noisier than
+// the reference's own float32 run against float64).  In (level, slope) coordinates the same maps are
+// ~[[1, n], [~0, 1]]: no cancellation.  The zero-state run of a lane produces moderate values, so its delta is exact.
 template <int NCH, int LF, bool NARROW>
 __device__ __forceinline__ void sos_cascade(float (&v)[LF], const SosSection *__restrict__ sec, int nsec, float *sst, int lane,
                                             bool do_seed)
@@ -89,7 +112,8 @@ __device__ __forceinline__ void sos_cascade(float (&v)[LF], const SosSection *__
       if (do_seed && k.seed != 0.f) {
         // premier_appel: every memory of the section = its own first input (filtre-rt.cc:361-365)
         const float x0 = __shfl(v[c], 0);
-        sin1 = sin0 = xin1 = xin2 = x0;
+        sin1 = xin1 = xin2 = x0;
+        sin0 = x0 - k.sg * x0;
       }
       float d1 = 0.f, d2 = 0.f;
       if (k.df1 == 0.f) {
@@ -135,7 +159,7 @@ __device__ __forceinline__ void sos_cascade(float (&v)[LF], const SosSection *__
         }
       }
       // lane 0 absorbs the start state: P = M^L * S_in + Z
-      float p1 = d1, p0 = d2;
+      float p1 = d1, p0 = fmaf(-k.sg, d2, d1);
       if (lane == 0) {
         p1 = fmaf(A[0][0], sin1, fmaf(A[0][1], sin0, p1));
         p0 = fmaf(A[0][2], sin1, fmaf(A[0][3], sin0, p0));
@@ -171,12 +195,22 @@ __device__ __forceinline__ void sos_cascade(float (&v)[LF], const SosSection *__
 // starts from zero state `warm_sub` whole sub-tiles plus `warm_nar` narrow steps (256 floats each, one
 // 16-B load per lane, a 4-float recurrence per lane and section: a fifth of a sub-tile's work) before
 // its first sample -- the host picks them so that the state transition over the warm-up is below 1e-9.
-template <int NCH>
+//
+// MODE 0 is that scheme.  A filter whose memory is long against the call (a DC blocker, a smoother with a cut-off of
+// 1e-4: warm-ups of 10^5 samples and more, or no decay at all) would leave it a handful of chunks -- down to ONE wave
+// walking the whole vector.  Such calls carry the state EXACTLY instead (tsdgpu_sos_step):
+//   MODE 1  every chunk but the last runs from zero state (chunk 0: from the stream state) WITHOUT storing outputs and
+//           publishes its end state E_c = carry[c];
+//   (sos_carry_scan_kernel turns the E_c into the true start states: S_{c+1} = Phi^L S_c + E_c, S_1 = E_0)
+//   MODE 2  every chunk starts from carry[c] = S_c and stores its outputs: no warm-up.
+// 12 B per sample instead of 8, whatever the pole radius.
+template <int NCH, int MODE>
 __global__ __launch_bounds__(64) void sos_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                  const SosSection *__restrict__ sec, int nsec, float gain,
                                                  const float *__restrict__ st_in, float *__restrict__ st_out,
-                                                 int64_t n_sub, int spc, int warm_sub, int warm_nar)
+                                                 int64_t n_sub, int spc, int warm_sub, int warm_nar, float *__restrict__ carry)
 {
+  if (MODE == 1 && blockIdx.x + 1 == gridDim.x) return;       // nobody starts from the last chunk's end state
   __shared__ __attribute__((aligned(16))) float lds[64 * LDS_LANE_PITCH];
   __shared__ float sst[SOS_MAX_SEC * 8];          // running state per (section, channel): 4 floats
   const int lane = threadIdx.x;
@@ -188,11 +222,13 @@ __global__ __launch_bounds__(64) void sos_kernel(const float *__restrict__ x, fl
 
   // running state per section and channel: wave-uniform, kept in LDS (indexed by the
   // runtime section number; a register array would go to scratch)
-  for (int i = lane; i < nsec * 8; i += 64) sst[i] = first_chunk ? st_in[1 + i] : 0.f;
+  if (first_chunk) state_load(sst, st_in, sec, nsec, lane);
+  else
+    for (int i = lane; i < nsec * 8; i += 64) sst[i] = MODE == 2 ? carry[(size_t) chunk * (nsec * 8) + i] : 0.f;
   wave_sync();
 
   int64_t t = t_first;
-  if (!first_chunk) {
+  if (MODE == 0 && !first_chunk) {
     t = t_first - warm_sub;
     // narrow warm-up steps come first in time: they cover the floats just before sub-tile t
     const float *xw = x + t * SUB_FLOATS - (int64_t) warm_nar * (64 * NARROW_FLOATS);
@@ -223,7 +259,7 @@ __global__ __launch_bounds__(64) void sos_kernel(const float *__restrict__ x, fl
 
     sos_cascade<NCH, LANE_FLOATS, false>(v, sec, nsec, sst, lane, first_chunk && !seeded && t == 0);
 
-    if (t >= t_first) {
+    if (MODE != 1 && t >= t_first) {
       // ---- gain, transpose back, store 16 B per lane
 #pragma unroll
       for (int i = 0; i < LANE_QUADS; i++) {
@@ -241,10 +277,106 @@ __global__ __launch_bounds__(64) void sos_kernel(const float *__restrict__ x, fl
     }
   }
 
+  if (MODE == 1) {
+    for (int i = lane; i < nsec * 8; i += 64) carry[(size_t) chunk * (nsec * 8) + i] = sst[i];
+    return;
+  }
   // the wave that owns the last sub-tile publishes the stream state
-  if (t_last == n_sub && t_last > t_first) {
-    if (lane == 0) st_out[0] = 1.f;
-    for (int i = lane; i < nsec * 8; i += 64) st_out[1 + i] = sst[i];
+  if (t_last == n_sub && t_last > t_first) state_store(st_out, sst, sec, nsec, lane);
+}
+
+// The chunks' zero-state end states E_c (carry[c], the layout of the running state image: per (section, channel) four
+// floats, the first two being (d1, delta)) -> the chunks' true start states, in place: carry[c] <- S_c, c >= 1, with
+//   S_1 = E_0 (chunk 0 ran from the stream state),  S_{c+1} = Phi^L S_c + E_c,
+// i.e. S_{c+1} = T_c, the running sums T_c = sum_{i <= c} (Phi^L)^(c-i) E_i.  A sequential recurrence of C matrix-vector
+// products would take a millisecond, a Kogge-Stone scan from one workgroup half of one (measured: each of its levels
+// waits on global memory): the chunks go in blocks of CARRY_BLOCK instead, a wave per block walking it with the vector
+// and the matrix in LDS, everything in double:
+//   phase 1  (a wave per block)   local sums from zero:  loc_c = P loc_{c-1} + E_c  inside the block       -> ws[c]
+//   phase 2  (one wave)           block starts:          G_{g+1} = PB G_g + loc_{last of g},  G_0 = 0       -> gs[g]
+//   phase 3  (a wave per block)   V = G_g;  per chunk:   V = P V,  T_c = V + loc_c,  carry[c + 1] = T_c
+// with P = Phi^L and PB = Phi^(L CARRY_BLOCK) (m x m, row-major, m = 2 nsec; host).  2 x CARRY_BLOCK + C / CARRY_BLOCK
+// dependent steps of ~100 cycles.
+constexpr int CARRY_BLOCK = 64;
+
+template <int MP>
+__global__ __launch_bounds__(64) void sos_carry_kernel(float *__restrict__ carry, const double *__restrict__ Pg, double *__restrict__ ws,
+                                                       double *__restrict__ gs, int C, int nsec, int nch, int phase)
+{
+  extern __shared__ double cl[];                 // P (m x m), V (per), W (per), In (CARRY_BLOCK x per)
+  const int m = 2 * nsec, per = nch * m, lane = threadIdx.x, rec = nsec * 8;
+  double *P = cl, *V = cl + m * m, *W = V + per, *In = W + per;
+  const double *src = phase == 2 ? Pg + (size_t) m * m : Pg;
+  for (int i = lane; i < m * m; i += 64) P[i] = src[i];
+  auto slot = [&](int r) {     // r = ch * m + i  ->  float index inside a chunk's carry record
+    const int ch = r / m, i = r - ch * m;
+    return ((i >> 1) * 2 + ch) * 4 + (i & 1);
+  };
+  // the inputs of the block's steps come into LDS first (a load inside the recurrence costs its full latency per step:
+  // 0.6 us per step measured, against ~50 ns)
+  const int G = (C + CARRY_BLOCK - 1) / CARRY_BLOCK;
+  const int g = blockIdx.x, c0 = g * CARRY_BLOCK, c1 = min(C, c0 + CARRY_BLOCK);
+  const int nb = phase == 2 ? G - 1 : c1 - c0;
+  for (int e = lane; e < nb * per; e += 64) {
+    const int q = e / per, r = e - q * per;
+    if (phase == 1) In[e] = (double) carry[(size_t) (c0 + q) * rec + slot(r)];
+    else if (phase == 2) In[e] = ws[(size_t) (min(C, (q + 1) * CARRY_BLOCK) - 1) * per + r];
+    else In[e] = ws[(size_t) c0 * per + e];
+  }
+  for (int r = lane; r < per; r += 64) V[r] = phase == 3 ? gs[(size_t) g * per + r] : 0.0;
+  if (phase == 2)
+    for (int r = lane; r < per; r += 64) gs[r] = 0.0;
+  wave_sync();
+  if (MP > 0) {
+    // m <= MP <= 16 (up to 8 sections) and a row per lane: the lane's row of P and its component of the vector stay in
+    // registers, the other components come by wave shuffles -- no LDS round trip and no barrier inside the recurrence.
+    // (A lone wave issues an instruction every 4-8 cycles: the step is as long as its instruction count -- hence MP,
+    // the compile-time bound of m; the rolled loop below takes ~1000 cycles per step.)
+    const bool actif = lane < per;
+    const int ch = actif ? lane / m : 0, i = actif ? lane - ch * m : 0, chm = ch * m;
+    constexpr int MQ = MP > 0 ? MP : 1;
+    double prow[MQ];
+#pragma unroll
+    for (int j = 0; j < MQ; j++) prow[j] = (actif && j < m) ? P[i * m + j] : 0.0;
+    double v = actif ? V[lane] : 0.0;
+    for (int q = 0; q < nb; q++) {
+      const double inq = actif ? In[q * per + lane] : 0.0;
+      // (prow is zero beyond m; the lanes beyond `per` hold zeros: a shuffle past the vector brings a finite value)
+      double a0 = phase == 3 ? 0.0 : inq, a1 = 0.0;
+#pragma unroll
+      for (int j = 0; j < MQ; j += 2) {
+        a0 = fma(prow[j], __shfl(v, (chm + j) & 63), a0);
+        if (j + 1 < MQ) a1 = fma(prow[j + 1], __shfl(v, (chm + j + 1) & 63), a1);
+      }
+      v = a0 + a1;
+      if (actif) In[q * per + lane] = phase == 3 ? v + inq : v;
+    }
+    wave_sync();
+  } else {
+    for (int q = 0; q < nb; q++) {
+      // W = P V (+ the step's input); every lane handles rows lane, lane + 64
+      for (int r = lane; r < per; r += 64) {
+        const int ch = r / m, i = r - ch * m;
+        double acc = phase == 3 ? 0.0 : In[q * per + r];
+        for (int j = 0; j < m; j++) acc = fma(P[i * m + j], V[ch * m + j], acc);
+        W[r] = acc;
+      }
+      wave_sync();
+      // (results wait in LDS, over the inputs they replace: a global store inside the loop makes the next barrier wait
+      // for its acknowledgement -- 0.5 us per step)
+      for (int r = lane; r < per; r += 64) {
+        const double w = W[r];
+        V[r] = w;
+        In[q * per + r] = phase == 3 ? w + In[q * per + r] : w;
+      }
+      wave_sync();
+    }
+  }
+  for (int e = lane; e < nb * per; e += 64) {
+    const int q = e / per, r = e - q * per;
+    if (phase == 1) ws[(size_t) c0 * per + e] = In[e];
+    else if (phase == 2) gs[(size_t) per + e] = In[e];
+    else if (c0 + q + 1 < C) carry[(size_t) (c0 + q + 1) * rec + slot(r)] = (float) In[e];
   }
 }
 
@@ -265,7 +397,7 @@ __global__ __launch_bounds__(64) void sos_tail_kernel(const float *__restrict__ 
   __shared__ float buf[64 * NARROW_FLOATS];
   const int lane = threadIdx.x;
   const bool seeded = st[0] != 0.f;
-  for (int i = lane; i < nsec * 8; i += 64) sst[i] = st[1 + i];
+  state_load(sst, st, sec, nsec, lane);
   wave_sync();
   int64_t f = f0;
   // (1) narrow steps
@@ -287,7 +419,7 @@ __global__ __launch_bounds__(64) void sos_tail_kernel(const float *__restrict__ 
     const bool df1 = k.df1 != 0.f, graine = k.seed != 0.f && !seeded && f == 0;    // first sample of the stream: seeded sections
     float *ss = &sst[(sidx * 2 + c) * 4];
     float d1 = 0.f, d2 = 0.f, x1 = 0.f, x2 = 0.f, out = 0.f;
-    if (actif) { d1 = ss[0]; d2 = ss[1]; x1 = ss[2]; x2 = ss[3]; }
+    if (actif) { d1 = ss[0]; d2 = k.sg * (ss[0] - ss[1]); x1 = ss[2]; x2 = ss[3]; }
     for (int t = 0; t < ms + nsec - 1; t++) {
       const float amont = __shfl_up(out, NCH);             // what the previous section produced at the previous step
       const int i = t - sidx;
@@ -313,13 +445,10 @@ __global__ __launch_bounds__(64) void sos_tail_kernel(const float *__restrict__ 
     }
     wave_sync();
     for (int i = lane; i < m; i += 64) y[f + i] = buf[i];
-    if (actif) { ss[0] = d1; ss[1] = d2; ss[2] = x1; ss[3] = x2; }
+    if (actif) { ss[0] = d1; ss[1] = d1 - k.sg * d2; ss[2] = x1; ss[3] = x2; }
     wave_sync();
   }
-  if (f1 > f0) {
-    if (lane == 0) st[0] = 1.f;
-    for (int i = lane; i < nsec * 8; i += 64) st[1 + i] = sst[i];
-  }
+  if (f1 > f0) state_store(st, sst, sec, nsec, lane);
 }
 
 }  // namespace tsdgpu
@@ -340,6 +469,11 @@ struct tsdgpu_sos {
   bool capturable = false;      // tsdgpu_sos_set_capturable: the state is back in d_state[0] after every step
   int64_t halo = 0;             // W: samples after which the state transition is below 1e-9
   DevBuf in_stage, out_stage;
+  // exact carry of the state from chunk to chunk (long-memory filters, see sos_kernel): DF2 chains only
+  bool df2 = true;
+  std::vector<double> phi;      // one-step zero-input transition of the whole cascade, m x m, m = 2 nsec
+  DevBuf carry, scan_ws, scan_P;
+  int64_t scan_L = 0;           // the chunk length (samples) scan_P was made for (< 0: no tables for that length)
 };
 
 namespace {
@@ -393,9 +527,63 @@ int64_t compute_halo(const std::vector<SosSection> &sec)
   return -1;   // does not decay (unstable or marginal filter)
 }
 
+// Phi: the one-step zero-input transition of the cascade's DF2 state (2 per section), m x m row-major, in double
+std::vector<double> cascade_transition(const std::vector<SosSection> &sec)
+{
+  const int m = 2 * (int) sec.size();
+  std::vector<double> P((size_t) m * m, 0.0);
+  for (int j = 0; j < m; j++) {
+    // unit vector j of the (d1, delta) coordinates -> (d1, d2), one step, back
+    std::vector<double> st((size_t) m, 0.0);
+    const double sg = sec[j / 2].sg;
+    if (j & 1) st[j] = -sg;                 // delta = 1: d1 = 0, d2 = -sg
+    else { st[j] = 1.0; st[j + 1] = sg; }   // d1 = 1, delta = 0: d2 = sg
+    cascade_step(sec, st, 0.0);
+    for (int i = 0; i < m; i += 2) {
+      P[(size_t) i * m + j] = st[i];
+      P[(size_t) (i + 1) * m + j] = st[i] - (double) sec[i / 2].sg * st[i + 1];
+    }
+  }
+  return P;
+}
+void matmul(const std::vector<double> &A, const std::vector<double> &B, std::vector<double> &C, int m)
+{
+  C.assign((size_t) m * m, 0.0);
+  for (int i = 0; i < m; i++)
+    for (int k = 0; k < m; k++) {
+      const double a = A[(size_t) i * m + k];
+      if (a == 0) continue;
+      for (int j = 0; j < m; j++) C[(size_t) i * m + j] += a * B[(size_t) k * m + j];
+    }
+}
+// Phi^e by squaring
+void matpow(const std::vector<double> &phi, int m, int64_t e, std::vector<double> &R)
+{
+  std::vector<double> B = phi, T;
+  R.assign((size_t) m * m, 0.0);
+  for (int i = 0; i < m; i++) R[(size_t) i * m + i] = 1.0;
+  for (; e > 0; e >>= 1) {
+    if (e & 1) { matmul(R, B, T, m); R.swap(T); }
+    if (e > 1) { matmul(B, B, T, m); B.swap(T); }
+  }
+}
+// P = Phi^L, PB = Phi^(L CARRY_BLOCK); false when a power leaves the float range (a filter that blows up)
+bool carry_tables(const std::vector<double> &phi, int m, int64_t L, std::vector<double> &out)
+{
+  std::vector<double> P, PB;
+  matpow(phi, m, L, P);
+  matpow(P, m, CARRY_BLOCK, PB);
+  out = P;
+  out.insert(out.end(), PB.begin(), PB.end());
+  for (double v : out)
+    if (!std::isfinite(v) || std::fabs(v) > 1e30) return false;
+  return true;
+}
+
 void fill_tables_for(SosSection &k, int L, int NF, float *c1, float *c2, float (*Aout)[4]);
 void fill_tables(SosSection &k, int L)
 {
+  k.sg = k.a1 <= 0.f ? 1.f : -1.f;          // poles' real part = -a1 / 2
   fill_tables_for(k, L, LANE_FLOATS, k.c1, k.c2, k.A);
   // narrow warm-up steps: NARROW_FLOATS floats per lane = L * NARROW_FLOATS / LANE_FLOATS samples per channel
   fill_tables_for(k, L * NARROW_FLOATS / LANE_FLOATS, NARROW_FLOATS, k.c1n, k.c2n, k.An);
@@ -405,9 +593,10 @@ void fill_tables_for(SosSection &k, int L, int NF, float *c1o, float *c2o, float
   const double a1 = k.a1, a2 = k.a2;
   // DF1 carries (y1, y2): the correction is the all-pole zero-input response itself
   const double b0 = k.df1 != 0.f ? 1.0 : k.b0, b1 = k.df1 != 0.f ? 0.0 : k.b1, b2 = k.df1 != 0.f ? 0.0 : k.b2;
-  // zero-input responses from unit start states (d1,d2) = (1,0) and (0,1)
+  // zero-input responses from unit start states (d1, delta) = (1,0) and (0,1), i.e. (d1, d2) = (1, sg) and (0, -sg)
+  const double sg = k.sg;
   for (int which = 0; which < 2; which++) {
-    double d1 = which == 0 ? 1.0 : 0.0, d2 = which == 0 ? 0.0 : 1.0;
+    double d1 = which == 0 ? 1.0 : 0.0, d2 = which == 0 ? sg : -sg;
     for (int i = 0; i < NF; i++) {
       double o = 0;
       if (i < L) {
@@ -428,7 +617,10 @@ void fill_tables_for(SosSection &k, int L, int NF, float *c1o, float *c2o, float
     for (int j = 0; j < 4; j++) A[j] = t[j];
   }
   for (int kk = 0; kk < 6; kk++) {
-    for (int j = 0; j < 4; j++) Aout[kk][j] = (float) A[j];
+    // T A T^-1 with T = [[1,0],[1,-sg]], T^-1 = [[1,0],[sg,-sg]]
+    const double B[4] = {A[0] + sg * A[1], -sg * A[1], A[2] + sg * A[3], -sg * A[3]};        // A T^-1
+    const double Tm[4] = {B[0], B[1], B[0] - sg * B[2], B[1] - sg * B[3]};                    // T (A T^-1)
+    for (int j = 0; j < 4; j++) Aout[kk][j] = (float) Tm[j];
     const double t[4] = {A[0] * A[0] + A[1] * A[2], A[0] * A[1] + A[1] * A[3], A[2] * A[0] + A[3] * A[2],
                          A[2] * A[1] + A[3] * A[3]};
     for (int j = 0; j < 4; j++) A[j] = t[j];
@@ -495,6 +687,8 @@ int tsdgpu::sos_create_ex(tsdgpu_sos **out, int data_type, const float *coefs_ho
   }
   s->nsec = (int) sec.size();
   s->halo = compute_halo(sec);
+  s->df2 = forme == 2;
+  s->phi = cascade_transition(sec);
 
   int rc = TSDGPU_OK;
   do {
@@ -591,14 +785,75 @@ int tsdgpu_sos_step(tsdgpu_sos *s, const void *x, void *y, int64_t n, void *stre
       const int64_t warm_cost = warm_sub + cdiv(warm_nar, 5);
       spc = std::max<int64_t>({2, 4 * warm_cost, warm_sub + 1, n_sub / TARGET});
     }
-    const int64_t nchunks = cdiv(n_sub, spc);
+    int64_t nchunks = cdiv(n_sub, spc);
     TSD_CHECK(nchunks <= 0x7fffffff, "sos_step: too many chunks");
-    if (nch == 1)
-      hipLaunchKernelGGL(sos_kernel<1>, dim3((unsigned) nchunks), dim3(64), 0, st, (const float *) dx, (float *) dy,
-                         s->d_sec, s->nsec, s->gain, st_in, st_out, n_sub, (int) spc, (int) warm_sub, (int) warm_nar);
-    else
-      hipLaunchKernelGGL(sos_kernel<2>, dim3((unsigned) nchunks), dim3(64), 0, st, (const float *) dx, (float *) dy,
-                         s->d_sec, s->nsec, s->gain, st_in, st_out, n_sub, (int) spc, (int) warm_sub, (int) warm_nar);
+    // a memory that is long against the call leaves few chunks (one, without decay): carry the state exactly from chunk
+    // to chunk instead -- two passes over x and a scan of the chunks' end states (see sos_kernel)
+    static const bool no_exact = getenv("TSDGPU_SOS_NO_EXACT_CARRY") != nullptr;
+    static const int64_t EX_TARGET = 4096;
+    const int64_t spc_ex = std::max<int64_t>(1, n_sub / EX_TARGET), nch_ex = cdiv(n_sub, spc_ex);
+    bool exact = false;
+    if (!no_exact && s->df2 && !s->capturable && nch_ex >= 8) {
+      // which is cheaper (microseconds, rough): a wave alone takes tw per sub-tile (latency-bound: 1.5 + 0.4 per section,
+      // measured on the sequential chunk), the chip as a whole moves a sub-tile's 16 KB at ~4 TB/s; the carry kernels
+      // cost three short launches of 64 dependent steps (12 us each at m <= 4, 40 at m = 16, more on the generic loop)
+      const int m = 2 * s->nsec, per = nch * m;
+      const double tw = 1.5 + 0.4 * s->nsec, bw = (double) n_sub * (SUB_FLOATS * 8.0) / 4e6;
+      const double warm_cost = s->halo < 0 ? 0.0 : (double) warm_sub + (double) warm_nar / 5.0;
+      const double t_norm = std::max((spc + warm_cost) * tw, bw * (1.0 + warm_cost / (double) spc));
+      const double carry_us = (per > 64 || m > 16) ? 100.0 + 3.0 * per : 9.0 + 7.0 * (m <= 2 ? 2 : m <= 4 ? 4 : m <= 8 ? 8 : 16);
+      const double t_ex = 2.0 * std::max(spc_ex * tw, 0.75 * bw) + carry_us;
+      exact = t_ex < 0.8 * t_norm;
+    }
+    if (exact) {
+      const int m = 2 * s->nsec;
+      const int64_t L = spc_ex * sub_samples;
+      if (s->scan_L != L && s->scan_L != -L) {
+        std::vector<double> P;
+        if (carry_tables(s->phi, m, L, P)) {
+          if ((rc = s->scan_P.reserve(P.size() * sizeof(double)))) return rc;
+          TSD_HIP(hipMemcpyAsync(s->scan_P.p, P.data(), P.size() * sizeof(double), hipMemcpyHostToDevice, st));
+          TSD_HIP(hipStreamSynchronize(st));             // (P dies with this scope)
+          s->scan_L = L;
+        } else {
+          s->scan_L = -L;                                // the powers leave the float range: the sequential chunk it is
+        }
+      }
+      if (s->scan_L == -L) exact = false;
+    }
+    if (exact) {
+      const int m = 2 * s->nsec, per = nch * m, G = (int) cdiv(nch_ex, CARRY_BLOCK);
+      const size_t rec = (size_t) s->nsec * 8, img = (size_t) nch_ex * per;
+      if ((rc = s->carry.reserve((size_t) nch_ex * rec * sizeof(float)))) return rc;
+      if ((rc = s->scan_ws.reserve((img + (size_t) G * per) * sizeof(double)))) return rc;
+      float *carry = s->carry.as<float>();
+      double *ws = s->scan_ws.as<double>(), *gs = ws + img;
+      const size_t cl = ((size_t) m * m + 2 * per + (size_t) CARRY_BLOCK * per) * sizeof(double);
+#define SOS_LAUNCH(NCH, MODE)                                                                                              \
+  hipLaunchKernelGGL((sos_kernel<NCH, MODE>), dim3((unsigned) nch_ex), dim3(64), 0, st, (const float *) dx, (float *) dy, s->d_sec, \
+                     s->nsec, s->gain, st_in, st_out, n_sub, (int) spc_ex, 0, 0, carry)
+      if (nch == 1) SOS_LAUNCH(1, 1); else SOS_LAUNCH(2, 1);
+      const int mp = per > 64 || m > 16 ? 0 : m <= 2 ? 2 : m <= 4 ? 4 : m <= 8 ? 8 : 16;
+#define CARRY_LAUNCH(MP)                                                                                                   \
+  do {                                                                                                                     \
+    (void) hipFuncSetAttribute((const void *) sos_carry_kernel<MP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    for (int phase = 1; phase <= 3; phase++)                                                                               \
+      hipLaunchKernelGGL(sos_carry_kernel<MP>, dim3(phase == 2 ? 1u : (unsigned) G), dim3(64), cl, st, carry, s->scan_P.as<double>(), \
+                         ws, gs, (int) nch_ex, s->nsec, nch, phase);                                                       \
+  } while (0)
+      if (mp == 2) CARRY_LAUNCH(2); else if (mp == 4) CARRY_LAUNCH(4); else if (mp == 8) CARRY_LAUNCH(8);
+      else if (mp == 16) CARRY_LAUNCH(16); else CARRY_LAUNCH(0);
+#undef CARRY_LAUNCH
+      if (nch == 1) SOS_LAUNCH(1, 2); else SOS_LAUNCH(2, 2);
+#undef SOS_LAUNCH
+      nchunks = nch_ex;
+    } else if (nch == 1) {
+      hipLaunchKernelGGL((sos_kernel<1, 0>), dim3((unsigned) nchunks), dim3(64), 0, st, (const float *) dx, (float *) dy,
+                         s->d_sec, s->nsec, s->gain, st_in, st_out, n_sub, (int) spc, (int) warm_sub, (int) warm_nar, (float *) nullptr);
+    } else {
+      hipLaunchKernelGGL((sos_kernel<2, 0>), dim3((unsigned) nchunks), dim3(64), 0, st, (const float *) dx, (float *) dy,
+                         s->d_sec, s->nsec, s->gain, st_in, st_out, n_sub, (int) spc, (int) warm_sub, (int) warm_nar, (float *) nullptr);
+    }
     TSD_HIP(hipGetLastError());
     s->cur ^= 1;
   }
@@ -664,6 +919,9 @@ int tsdgpu_sos_destroy(tsdgpu_sos *s)
   if (s->d_state[1]) (void) hipFree(s->d_state[1]);
   s->in_stage.release();
   s->out_stage.release();
+  s->carry.release();
+  s->scan_ws.release();
+  s->scan_P.release();
   delete s;
   return TSDGPU_OK;
 }

@@ -19,6 +19,7 @@ run TSDGPU_RFFT_TWO_PASS=1 tests/test_fft_gpu.py
 run TSDGPU_POLY_COMPOSED=1 tests/test_polyphase_gpu.py
 run TSDGPU_SOS_WIDE_WARMUP=1 tests/test_sos_gpu.py tests/test_sharded_gpu.py
 run TSDGPU_SOS_CHUNKS=16384 tests/test_sos_gpu.py
+run TSDGPU_SOS_NO_EXACT_CARRY=1 tests/test_sos_gpu.py tests/test_sharded_gpu.py -k "not long_memory"
 # (the tests that assert WHICH path serves a filter, or its speed, are about the default choice)
 run TSDGPU_RII_LITERAL=1 tests/test_polyphase_gpu.py -k "not block_parallel and not under_2ms and not cliff and not literal_fallback and not complex_coefficients"
 run TSDGPU_NO_BOUNCE=1 tests/test_fir_gpu.py tests/test_sos_gpu.py tests/test_fft_gpu.py
