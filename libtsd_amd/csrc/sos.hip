@@ -295,22 +295,23 @@ __global__ __launch_bounds__(64) void sos_kernel(const float *__restrict__ x, fl
 //   phase 1  (a wave per block)   local sums from zero:  loc_c = P loc_{c-1} + E_c  inside the block       -> ws[c]
 //   phase 2  (one wave)           block starts:          G_{g+1} = PB G_g + loc_{last of g},  G_0 = 0       -> gs[g]
 //   phase 3  (a wave per block)   V = G_g;  per chunk:   V = P V,  T_c = V + loc_c,  carry[c + 1] = T_c
-// with P = Phi^L and PB = Phi^(L CARRY_BLOCK) (m x m, row-major, m = 2 nsec; host).  2 x CARRY_BLOCK + C / CARRY_BLOCK
+// with P = Phi^L and PB = Phi^(L CARRY_BLOCK) (m x m, row-major; m = comps x nsec, comps = 2 values per section -- (d1, delta) --
+// for a DF2 chain, 4 -- (y1, delta, x1, x2) -- when a section is in FormeDirecte1; host).  2 x CARRY_BLOCK + C / CARRY_BLOCK
 // dependent steps of ~100 cycles.
 constexpr int CARRY_BLOCK = 64;
 
 template <int MP>
 __global__ __launch_bounds__(64) void sos_carry_kernel(float *__restrict__ carry, const double *__restrict__ Pg, double *__restrict__ ws,
-                                                       double *__restrict__ gs, int C, int nsec, int nch, int phase)
+                                                       double *__restrict__ gs, int C, int nsec, int nch, int comps, int phase)
 {
   extern __shared__ double cl[];                 // P (m x m), V (per), W (per), In (CARRY_BLOCK x per)
-  const int m = 2 * nsec, per = nch * m, lane = threadIdx.x, rec = nsec * 8;
+  const int m = comps * nsec, per = nch * m, lane = threadIdx.x, rec = nsec * 8;
   double *P = cl, *V = cl + m * m, *W = V + per, *In = W + per;
   const double *src = phase == 2 ? Pg + (size_t) m * m : Pg;
   for (int i = lane; i < m * m; i += 64) P[i] = src[i];
   auto slot = [&](int r) {     // r = ch * m + i  ->  float index inside a chunk's carry record
-    const int ch = r / m, i = r - ch * m;
-    return ((i >> 1) * 2 + ch) * 4 + (i & 1);
+    const int ch = r / m, i = r - ch * m, sc = i / comps;
+    return (sc * 2 + ch) * 4 + (i - sc * comps);
   };
   // the inputs of the block's steps come into LDS first (a load inside the recurrence costs its full latency per step:
   // 0.6 us per step measured, against ~50 ns)
@@ -469,9 +470,9 @@ struct tsdgpu_sos {
   bool capturable = false;      // tsdgpu_sos_set_capturable: the state is back in d_state[0] after every step
   int64_t halo = 0;             // W: samples after which the state transition is below 1e-9
   DevBuf in_stage, out_stage;
-  // exact carry of the state from chunk to chunk (long-memory filters, see sos_kernel): DF2 chains only
-  bool df2 = true;
-  std::vector<double> phi;      // one-step zero-input transition of the whole cascade, m x m, m = 2 nsec
+  // exact carry of the state from chunk to chunk (long-memory filters, see sos_kernel)
+  int comps = 2;                // state values per section and channel in the carry: 2 (DF2 chain) or 4 (a DF1 section: + its last two inputs)
+  std::vector<double> phi;      // one-step zero-input transition of the whole cascade, m x m, m = comps x nsec
   DevBuf carry, scan_ws, scan_P;
   int64_t scan_L = 0;           // the chunk length (samples) scan_P was made for (< 0: no tables for that length)
 };
@@ -527,21 +528,49 @@ int64_t compute_halo(const std::vector<SosSection> &sec)
   return -1;   // does not decay (unstable or marginal filter)
 }
 
-// Phi: the one-step zero-input transition of the cascade's DF2 state (2 per section), m x m row-major, in double
-std::vector<double> cascade_transition(const std::vector<SosSection> &sec)
+// Phi: the one-step zero-input transition of the cascade in the coordinates of the waves' running state image, m x m
+// row-major, in double; m = comps per section: (d1 | y1, delta = that - sg * (d2 | y2)) and, with comps = 4, (x1, x2), the last
+// two inputs of a FormeDirecte1 section (zero rows and columns for a DF2 section of a mixed chain)
+std::vector<double> cascade_transition(const std::vector<SosSection> &sec, int comps)
 {
-  const int m = 2 * (int) sec.size();
+  const int ns = (int) sec.size(), m = comps * ns;
   std::vector<double> P((size_t) m * m, 0.0);
   for (int j = 0; j < m; j++) {
-    // unit vector j of the (d1, delta) coordinates -> (d1, d2), one step, back
-    std::vector<double> st((size_t) m, 0.0);
-    const double sg = sec[j / 2].sg;
-    if (j & 1) st[j] = -sg;                 // delta = 1: d1 = 0, d2 = -sg
-    else { st[j] = 1.0; st[j + 1] = sg; }   // d1 = 1, delta = 0: d2 = sg
-    cascade_step(sec, st, 0.0);
-    for (int i = 0; i < m; i += 2) {
-      P[(size_t) i * m + j] = st[i];
-      P[(size_t) (i + 1) * m + j] = st[i] - (double) sec[i / 2].sg * st[i + 1];
+    // unit vector j of the image -> natural states (a, b, x1, x2) per section
+    std::vector<double> a((size_t) ns, 0.0), b((size_t) ns, 0.0), x1((size_t) ns, 0.0), x2((size_t) ns, 0.0);
+    const int sj = j / comps, cj = j - sj * comps;
+    const double sgj = sec[sj].sg;
+    if (cj == 0) { a[sj] = 1.0; b[sj] = sgj; }        // level 1, slope 0
+    else if (cj == 1) b[sj] = -sgj;                   // slope 1
+    else if (cj == 2) x1[sj] = 1.0;
+    else x2[sj] = 1.0;
+    // one step of the cascade with a zero input
+    double v = 0.0;
+    for (int q = 0; q < ns; q++) {
+      const SosSection &k = sec[q];
+      if (k.df1 == 0.f) {
+        const double d = v - (double) k.a1 * a[q] - (double) k.a2 * b[q];
+        const double o = (double) k.b0 * d + (double) k.b1 * a[q] + (double) k.b2 * b[q];
+        b[q] = a[q];
+        a[q] = d;
+        v = o;
+      } else {
+        const double fir = (double) k.b0 * v + (double) k.b1 * x1[q] + (double) k.b2 * x2[q];
+        const double o = fir - (double) k.a1 * a[q] - (double) k.a2 * b[q];
+        x2[q] = x1[q];
+        x1[q] = v;
+        b[q] = a[q];
+        a[q] = o;
+        v = o;
+      }
+    }
+    for (int q = 0; q < ns; q++) {
+      P[(size_t) (q * comps) * m + j] = a[q];
+      P[(size_t) (q * comps + 1) * m + j] = a[q] - (double) sec[q].sg * b[q];
+      if (comps == 4) {
+        P[(size_t) (q * comps + 2) * m + j] = sec[q].df1 != 0.f ? x1[q] : 0.0;
+        P[(size_t) (q * comps + 3) * m + j] = sec[q].df1 != 0.f ? x2[q] : 0.0;
+      }
     }
   }
   return P;
@@ -687,8 +716,10 @@ int tsdgpu::sos_create_ex(tsdgpu_sos **out, int data_type, const float *coefs_ho
   }
   s->nsec = (int) sec.size();
   s->halo = compute_halo(sec);
-  s->df2 = forme == 2;
-  s->phi = cascade_transition(sec);
+  s->comps = 2;
+  for (const SosSection &k : sec)
+    if (k.df1 != 0.f) s->comps = 4;
+  s->phi = cascade_transition(sec, s->comps);
 
   int rc = TSDGPU_OK;
   do {
@@ -793,11 +824,11 @@ int tsdgpu_sos_step(tsdgpu_sos *s, const void *x, void *y, int64_t n, void *stre
     static const int64_t EX_TARGET = 4096;
     const int64_t spc_ex = std::max<int64_t>(1, n_sub / EX_TARGET), nch_ex = cdiv(n_sub, spc_ex);
     bool exact = false;
-    if (!no_exact && s->df2 && !s->capturable && nch_ex >= 8) {
+    if (!no_exact && !s->capturable && nch_ex >= 8) {
       // which is cheaper (microseconds, rough): a wave alone takes tw per sub-tile (latency-bound: 1.5 + 0.4 per section,
       // measured on the sequential chunk), the chip as a whole moves a sub-tile's 16 KB at ~4 TB/s; the carry kernels
       // cost three short launches of 64 dependent steps (12 us each at m <= 4, 40 at m = 16, more on the generic loop)
-      const int m = 2 * s->nsec, per = nch * m;
+      const int m = s->comps * s->nsec, per = nch * m;
       const double tw = 1.5 + 0.4 * s->nsec, bw = (double) n_sub * (SUB_FLOATS * 8.0) / 4e6;
       const double warm_cost = s->halo < 0 ? 0.0 : (double) warm_sub + (double) warm_nar / 5.0;
       const double t_norm = std::max((spc + warm_cost) * tw, bw * (1.0 + warm_cost / (double) spc));
@@ -806,7 +837,7 @@ int tsdgpu_sos_step(tsdgpu_sos *s, const void *x, void *y, int64_t n, void *stre
       exact = t_ex < 0.8 * t_norm;
     }
     if (exact) {
-      const int m = 2 * s->nsec;
+      const int m = s->comps * s->nsec;
       const int64_t L = spc_ex * sub_samples;
       if (s->scan_L != L && s->scan_L != -L) {
         std::vector<double> P;
@@ -822,7 +853,7 @@ int tsdgpu_sos_step(tsdgpu_sos *s, const void *x, void *y, int64_t n, void *stre
       if (s->scan_L == -L) exact = false;
     }
     if (exact) {
-      const int m = 2 * s->nsec, per = nch * m, G = (int) cdiv(nch_ex, CARRY_BLOCK);
+      const int m = s->comps * s->nsec, per = nch * m, G = (int) cdiv(nch_ex, CARRY_BLOCK);
       const size_t rec = (size_t) s->nsec * 8, img = (size_t) nch_ex * per;
       if ((rc = s->carry.reserve((size_t) nch_ex * rec * sizeof(float)))) return rc;
       if ((rc = s->scan_ws.reserve((img + (size_t) G * per) * sizeof(double)))) return rc;
@@ -839,7 +870,7 @@ int tsdgpu_sos_step(tsdgpu_sos *s, const void *x, void *y, int64_t n, void *stre
     (void) hipFuncSetAttribute((const void *) sos_carry_kernel<MP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
     for (int phase = 1; phase <= 3; phase++)                                                                               \
       hipLaunchKernelGGL(sos_carry_kernel<MP>, dim3(phase == 2 ? 1u : (unsigned) G), dim3(64), cl, st, carry, s->scan_P.as<double>(), \
-                         ws, gs, (int) nch_ex, s->nsec, nch, phase);                                                       \
+                         ws, gs, (int) nch_ex, s->nsec, nch, s->comps, phase);                                                     \
   } while (0)
       if (mp == 2) CARRY_LAUNCH(2); else if (mp == 4) CARRY_LAUNCH(4); else if (mp == 8) CARRY_LAUNCH(8);
       else if (mp == 16) CARRY_LAUNCH(16); else CARRY_LAUNCH(0);

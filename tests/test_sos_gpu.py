@@ -288,3 +288,81 @@ def test_sos_long_memory_exact_carry(tg, orc, cplx, order, fc):
     ms = (time.perf_counter() - t0) / 5 * 1e3
     print("long memory", order, fc, cplx, "ms per 2^22 samples", round(ms, 3))
     assert ms < 0.5, ms                              # (1.5 - 3.2 ms on the sequential chunk)
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("order,fc", [(2, 1e-4), (3, 1e-4), (12, 0.002)])
+def test_sos_long_memory_forme_directe_1(tg, orc, cplx, order, fc):
+    """The exact carry with FormeDirecte1 sections: the carried state of a section then includes its last two inputs."""
+    import time
+    import torch
+    z, p, mn, md = orc.design_butter_lp(order, fc)
+    ref = orc.SosChain(z, p, mn, md, forme=1)
+    co, gain, r1 = ref.coefs()
+    g = tg.Sos(co, gain, tg.C64 if cplx else tg.F32, r1, forme=1)
+    n = (1 << 20) + 333
+    x = rand(n, cplx, 6) + np.float32(0.5)
+    yref = ref.step(x)
+    y = g.step(x)
+    # the float64 run of the same chain arbitrates (FormeDirecte1 seeds all four memories of a section with its first input,
+    # filtre-rt.cc:361-365; the trailing first-order section starts from zero and carries the gain, :407-437,567-570)
+    from scipy.signal import lfilter, lfiltic
+    v = x.astype(np.complex128 if cplx else np.float64)
+    for b0, b1, b2, a1, a2 in np.asarray(co, np.float32).astype(np.float64).reshape(-1, 5):
+        zi = lfiltic([b0, b1, b2], [1.0, a1, a2], y=[v[0], v[0]], x=[v[0], v[0]])
+        v, _ = lfilter([b0, b1, b2], [1.0, a1, a2], v, zi=zi.astype(v.dtype))
+    if r1 is not None:
+        q = np.asarray(r1, np.float32).astype(np.float64)
+        v = lfilter([q[0], q[1]], [1.0, q[2]], v)
+    else:
+        v = v * np.float64(np.float32(gain))
+    noise = relerr(yref, v)
+    print("long memory DF1", order, fc, cplx, "err", relerr(y, v), "reference's own", noise)
+    assert relerr(y, v) <= max(2e-5, noise), (relerr(y, v), noise)
+    g2 = tg.Sos(co, gain, tg.C64 if cplx else tg.F32, r1, forme=1)
+    cuts = [0, 300001, 300001 + 2048 * 130, 900000, n]
+    y2 = np.concatenate([g2.step(x[a:b]) for a, b in zip(cuts[:-1], cuts[1:])])
+    assert relerr(y2, v) <= max(2e-5, noise)
+    xd = torch.randn((1 << 22) * (2 if cplx else 1), device="cuda")
+    xd = torch.view_as_complex(xd.view(-1, 2)) if cplx else xd
+    yd = torch.empty_like(xd)
+    g.step(xd, yd)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        g.step(xd, yd)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / 5 * 1e3
+    print("long memory DF1", order, fc, cplx, "ms per 2^22 samples", round(ms, 3))
+    assert ms < 0.6, ms
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_exponential_smoother_and_dc_blocker_long_memory(tg, orc, cplx):
+    """filtre_lexp(gamma) and filtre_dc(fc) (filtre-rt.cc:764-781) with time constants of 10^5 samples -- THE long-memory
+    filters of everyday use -- through tsdgpu_rii: y_n = y_{n-1} + g (x_n - y_{n-1}) and y_n = a ((x_n - x_{n-1}) + y_{n-1})."""
+    import time
+    import torch
+    n = (1 << 21) + 5
+    x = rand(n, cplx, 9) + np.float32(3.0)
+    for nu, de in (([1e-5, 0.0], [1.0, -(1.0 - 1e-5)]), ([1.0 - 2e-5, -(1.0 - 2e-5)], [1.0, -(1.0 - 2e-5)])):
+        dt = tg.C64 if cplx else tg.F32
+        g = tg.Rii(np.array(nu, np.float32), np.array(de, np.float32), dt)
+        y = g.step(x)
+        from scipy.signal import lfilter
+        ex = lfilter(np.array(nu, np.float32).astype(np.float64), np.array(de, np.float32).astype(np.float64), x.astype(np.complex128 if cplx else np.float64))
+        # the reference's float32 recursion (real data: FiltreRII<float, float>; the complex one on the real coefficients)
+        yr = (orc.RiiC if cplx else orc.Rii)(np.array(nu, np.float32), np.array(de, np.float32)).step(x)
+        bruit = relerr(yr, ex)
+        assert relerr(y, ex) <= max(2e-5, bruit), (nu, relerr(y, ex), bruit)
+        xd = torch.from_numpy(x[:1 << 21].copy()).cuda()
+        yd = torch.empty_like(xd)
+        g.step(xd, yd)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            g.step(xd, yd)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 5 * 1e3
+        print("lexp / dc", nu, cplx, "path", g.path, "ms per 2^21 samples", round(ms, 3))
+        assert ms < 0.5, ms
