@@ -95,8 +95,9 @@ __device__ __forceinline__ void state_store(float *__restrict__ st, const float 
 // ~[[1, n], [~0, 1]]: no cancellation.  The zero-state run of a lane produces moderate values, so its delta is exact.
 template <int NCH, int LF, bool NARROW>
 __device__ __forceinline__ void sos_cascade(float (&v)[LF], const SosSection *__restrict__ sec, int nsec, float *sst, int lane,
-                                            bool do_seed)
+                                            bool do_seed, int last = 63)
 {
+  // `last`: the lane whose end state is carried on (63; a partial sub-tile of the ragged end stops at an earlier lane)
   constexpr int L = LF / NCH;
 #pragma unroll 1
   for (int s = 0; s < nsec; s++) {
@@ -145,7 +146,7 @@ __device__ __forceinline__ void sos_cascade(float (&v)[LF], const SosSection *__
         const float my1 = v[(L - 1) * NCH + c], my2 = v[(L - 2) * NCH + c];
         float xp1 = __shfl_up(my1, 1), xp2 = __shfl_up(my2, 1);
         if (lane == 0) { xp1 = xin1; xp2 = xin2; }
-        if (lane == 63) { ss[2] = my1; ss[3] = my2; }
+        if (lane == last) { ss[2] = my1; ss[3] = my2; }
 #pragma unroll
         for (int i = 0; i < L; i++) {
           const float xin = v[i * NCH + c];
@@ -181,7 +182,7 @@ __device__ __forceinline__ void sos_cascade(float (&v)[LF], const SosSection *__
 #pragma unroll
       for (int i = 0; i < L; i++) v[i * NCH + c] = fmaf(c1[i], s1, fmaf(c2[i], s0, v[i * NCH + c]));
       // state after the last sample, carried on
-      if (lane == 63) {
+      if (lane == last) {
         ss[0] = p1;
         ss[1] = p0;
       }
@@ -382,9 +383,10 @@ __global__ __launch_bounds__(64) void sos_carry_kernel(float *__restrict__ carry
 }
 
 // Ragged end (the samples after the last whole sub-tile; a whole call of fewer than 2048 floats): ONE wave.
-//  (1) every whole group of 256 floats runs as a narrow step of the block-parallel cascade -- the steps of a chunk's
-//      warm-up, this time with their outputs stored;
-//  (2) the last < 256 floats go through the sections as a systolic pipeline: lane (section, channel) applies the reference
+//  (1) its whole lanes (32 floats each) run as ONE pass of the block-parallel cascade over a partial sub-tile: the lanes past
+//      the data run on zeros and the state carried on is taken at the last lane with data (a first version stepped through
+//      groups of 256 floats with the narrow warm-up tables, up to 7 passes: 46 us for a 1000-sample complex block);
+//  (2) the last < 32 floats go through the sections as a systolic pipeline: lane (section, channel) applies the reference
 //      recurrence literally to sample t - section at step t and hands its output to the next section's lane by a shuffle,
 //      the samples sitting in LDS -- m + nsec steps of a few tens of cycles.
 // (The first version walked the samples section after section from global memory, one dependent load per sample: 0.9 us per
@@ -395,20 +397,47 @@ __global__ __launch_bounds__(64) void sos_tail_kernel(const float *__restrict__ 
                                                       int nsec, float gain, float *__restrict__ st, int64_t f0, int64_t f1)
 {
   __shared__ float sst[SOS_MAX_SEC * 8];
-  __shared__ float buf[64 * NARROW_FLOATS];
+  __shared__ float buf[LANE_FLOATS];
+  __shared__ __attribute__((aligned(16))) float lds[64 * LDS_LANE_PITCH];
   const int lane = threadIdx.x;
   const bool seeded = st[0] != 0.f;
   state_load(sst, st, sec, nsec, lane);
   wave_sync();
   int64_t f = f0;
-  // (1) narrow steps
-  for (; f + 64 * NARROW_FLOATS <= f1; f += 64 * NARROW_FLOATS) {
-    const float4 q = *reinterpret_cast<const float4 *>(x + f + 4 * lane);
-    float v4[NARROW_FLOATS] = {q.x, q.y, q.z, q.w};
-    sos_cascade<NCH, NARROW_FLOATS, true>(v4, sec, nsec, sst, lane, !seeded && f == 0);
-    *reinterpret_cast<float4 *>(y + f + 4 * lane) = make_float4(v4[0] * gain, v4[1] * gain, v4[2] * gain, v4[3] * gain);
+  // (1) the whole lanes of the partial sub-tile (32 floats each) as ONE pass of the block-parallel cascade: the lanes past
+  // the data run on zeros, the state carried on is the one of the last lane with data
+  const int nl = (int) ((f1 - f0) / LANE_FLOATS);
+  if (nl > 0) {
+    const int nf = nl * LANE_FLOATS;
+    float v[LANE_FLOATS];
+#pragma unroll
+    for (int i = 0; i < LANE_QUADS; i++) {
+      const int p = 4 * (i * 64 + lane);
+      const float4 q = p < nf ? *reinterpret_cast<const float4 *>(x + f + p) : make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4 *>(&lds[(p / LANE_FLOATS) * LDS_LANE_PITCH + (p % LANE_FLOATS)]) = q;
+    }
+    wave_sync();
+#pragma unroll
+    for (int i = 0; i < LANE_QUADS; i++) {
+      const float4 q = *reinterpret_cast<const float4 *>(&lds[lane * LDS_LANE_PITCH + 4 * i]);
+      v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w;
+    }
+    wave_sync();
+    sos_cascade<NCH, LANE_FLOATS, false>(v, sec, nsec, sst, lane, !seeded && f == 0, nl - 1);
+#pragma unroll
+    for (int i = 0; i < LANE_QUADS; i++)
+      *reinterpret_cast<float4 *>(&lds[lane * LDS_LANE_PITCH + 4 * i]) =
+          make_float4(v[4 * i] * gain, v[4 * i + 1] * gain, v[4 * i + 2] * gain, v[4 * i + 3] * gain);
+    wave_sync();
+#pragma unroll
+    for (int i = 0; i < LANE_QUADS; i++) {
+      const int p = 4 * (i * 64 + lane);
+      if (p < nf) *reinterpret_cast<float4 *>(y + f + p) = *reinterpret_cast<const float4 *>(&lds[(p / LANE_FLOATS) * LDS_LANE_PITCH + (p % LANE_FLOATS)]);
+    }
+    wave_sync();
+    f += nf;
   }
-  // (2) systolic tail over the m = f1 - f < 256 floats left
+  // (2) systolic tail over the m = f1 - f < 32 floats left
   const int m = (int) (f1 - f), ms = m / NCH;
   if (ms > 0) {
     for (int i = lane; i < m; i += 64) buf[i] = x[f + i];
@@ -815,6 +844,10 @@ int tsdgpu_sos_step(tsdgpu_sos *s, const void *x, void *y, int64_t n, void *stre
       static const int64_t TARGET = getenv("TSDGPU_SOS_CHUNKS") ? atoll(getenv("TSDGPU_SOS_CHUNKS")) : 4096;
       const int64_t warm_cost = warm_sub + cdiv(warm_nar, 5);
       spc = std::max<int64_t>({2, 4 * warm_cost, warm_sub + 1, n_sub / TARGET});
+      // ... unless the call is short of filling the chip anyway: then the shortest chunks finish first (a wave alone takes
+      // ~4 us per sub-tile: 4097 complex samples in one chunk of 4 sub-tiles cost 38 us)
+      const int64_t spc_min = std::max<int64_t>(1, warm_sub + 1);
+      if (cdiv(n_sub, spc_min) <= 2048) spc = spc_min;
     }
     int64_t nchunks = cdiv(n_sub, spc);
     TSD_CHECK(nchunks <= 0x7fffffff, "sos_step: too many chunks");
