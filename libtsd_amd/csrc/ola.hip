@@ -547,6 +547,16 @@ __global__ void welch_sum_kernel(const float *__restrict__ part, float *__restri
 
 inline unsigned nblk(int64_t total) { return (unsigned) cdiv(total, 256); }
 
+// a few hundred samples from one device buffer to another: a kernel (a hipMemcpyAsync of that size spends 15-40 us in the
+// runtime -- the buffering calls of a stream fed in blocks shorter than Ne cost 52 us on average with it)
+int copy_small(cpx *dst, const cpx *src, int64_t count, hipStream_t st)
+{
+  if (count <= 0) return TSDGPU_OK;
+  hipLaunchKernelGGL(ola_gather_kernel, dim3(nblk(count)), dim3(256), 0, st, (const cpx *) nullptr, 0, src, (int64_t) 0, dst, (int) count);
+  TSD_HIP(hipGetLastError());
+  return TSDGPU_OK;
+}
+
 int ola_alloc(cpx **p, size_t count)
 {
   TSD_HIP(hipMalloc((void **) p, std::max<size_t>(count, 1) * sizeof(cpx)));
@@ -625,8 +635,10 @@ int tsdgpu_ola_set_response(tsdgpu_ola *h, const void *H)
     if (!h->d_fast) TSD_HIP(hipMalloc((void **) &h->d_fast, t3.size() * sizeof(cpx)));
     if (!h->d_svg_tmp) TSD_HIP(hipMalloc((void **) &h->d_svg_tmp, 512 * sizeof(cpx)));
     TSD_HIP(hipMemcpy(h->d_fast, t3.data(), t3.size() * sizeof(cpx), hipMemcpyHostToDevice));
-  } else if (!unfused && !h->windowed && ola_run_fits(h->N, h->Ne)) {
-    // the other geometries whose frame and carried block fit the LDS: one kernel too (ola_run_kernel)
+  }
+  if (!unfused && !h->windowed && ola_run_fits(h->N, h->Ne)) {
+    // the other geometries whose frame and carried block fit the LDS: one kernel too (ola_run_kernel) -- which also serves the
+    // ragged calls of the default geometry (waiting samples in front of x), the in-wave kernel taking the whole-block ones
     const int N = h->N;
     std::vector<cpx> tb((size_t) N + N / 16);
     TSD_HIP(hipMemcpy(tb.data(), h->d_H, (size_t) N * sizeof(cpx), hipMemcpyDeviceToHost));
@@ -693,7 +705,7 @@ int tsdgpu_ola_analyse(tsdgpu_ola *h, const void *x, int64_t n, void **spectra, 
       TSD_HIP(hipGetLastError());
     }
   } else if (n > 0) {
-    TSD_HIP(hipMemcpyAsync(h->d_rest + h->nrest, dx, (size_t) n * sizeof(cpx), hipMemcpyDeviceToDevice, st));
+    if ((rc = copy_small(h->d_rest + h->nrest, dx, n, st))) return rc;
   }
   h->nrest = left;
   h->pending_blocks = (int) B;
@@ -804,9 +816,9 @@ int tsdgpu_ola_step(tsdgpu_ola *h, const void *x, int64_t n, void *y, int64_t *n
       dxv = h->in_stage.p;
     }
     const cpx *dx = (const cpx *) dxv;
-    if (left > 0) TSD_HIP(hipMemcpyAsync(h->d_rest, dx + nout, (size_t) left * sizeof(cpx), hipMemcpyDeviceToDevice, st));
+    if ((rc = copy_small(h->d_rest, dx + nout, left, st))) return rc;
     if ((rc = ola1024_launch(dx, (cpx *) dyv, h->d_fast, h->d_svg, h->d_svg_tmp, B, st))) return rc;
-    TSD_HIP(hipMemcpyAsync(h->d_svg, h->d_svg_tmp, (size_t) Ne * sizeof(cpx), hipMemcpyDeviceToDevice, st));
+    std::swap(h->d_svg, h->d_svg_tmp);            // (the last wave wrote the new tail beside the one the first wave read)
     if ((rc = finish_out(y, (size_t) nout * sizeof(cpx), dyv, staged, st))) return rc;
     if (dxv != x && !staged) TSD_HIP(hipStreamSynchronize(st));    // (a staged input must outlive its kernels)
     h->nrest = (int) left;
@@ -835,9 +847,9 @@ int tsdgpu_ola_step(tsdgpu_ola *h, const void *x, int64_t n, void *y, int64_t *n
     }
     const cpx *dx = (const cpx *) dxv;
     // block 0 made contiguous: the waiting samples, then the head of x (rest has room for a whole block)
-    if (h->nrest > 0) TSD_HIP(hipMemcpyAsync(h->d_rest + h->nrest, dx, (size_t) (Ne - h->nrest) * sizeof(cpx), hipMemcpyDeviceToDevice, st));
+    if (h->nrest > 0 && (rc = copy_small(h->d_rest + h->nrest, dx, Ne - h->nrest, st))) return rc;
     if ((rc = ola_run_launch(h->nrest > 0 ? h->d_rest : dx, h->nrest, dx, (cpx *) dyv, h->d_run, h->d_svg, h->d_svg_tmp, Ne, h->N, B, st))) return rc;
-    TSD_HIP(hipMemcpyAsync(h->d_svg, h->d_svg_tmp, (size_t) Ne * sizeof(cpx), hipMemcpyDeviceToDevice, st));
+    std::swap(h->d_svg, h->d_svg_tmp);
     if (left > 0) {
       // the samples after the last whole block lie inside x (B >= 1): rest is only written
       hipLaunchKernelGGL(ola_gather_kernel, dim3(nblk(left)), dim3(256), 0, st, h->d_rest, 0, dx, nout - h->nrest, h->d_rest, (int) left);
