@@ -162,7 +162,7 @@ bool framed_fft_launch(const tsdgpu_fft *plan, const FrameSrc &S, int64_t nfr, c
 // ones here are not scaled; the inverse is the conjugate of the forward transform of the conjugate.
 // Every thread of the workgroup passes every barrier: runs past the end carry zeros.
 template <int R0, int THREADS, bool HALF>
-__global__ __launch_bounds__(THREADS, THREADS == 256 ? 3 : 2) void ola_run_kernel(const cpx *__restrict__ blk0, int nrest, const cpx *__restrict__ x,
+__global__ __launch_bounds__(THREADS, THREADS == 256 ? 3 : THREADS == 512 ? 2 : 4) void ola_run_kernel(const cpx *__restrict__ blk0, int nrest, const cpx *__restrict__ x,
                                                        cpx *__restrict__ y, const cpx *__restrict__ Hs, const cpx *__restrict__ TW,
                                                        const cpx *__restrict__ svg_in, cpx *__restrict__ svg_out, int Ne, int N, int tpt,
                                                        int64_t B, int per)
@@ -275,7 +275,8 @@ OlaRunGeom ola_run_geom(int N, int Ne)
 bool ola_run_fits(int N, int Ne)
 {
   const OlaRunGeom g = ola_run_geom(N, Ne);
-  return N >= 16 && g.threads <= 512 && g.lds <= 160 * 1024;
+  // (N = 16384 -- 1024 threads, 128 registers each -- only with the carried block in registers)
+  return N >= 16 && (g.threads <= 512 || (g.threads == 1024 && g.half)) && g.lds <= 160 * 1024;
 }
 
 // B >= 1 whole blocks of [rest ++ x] -> y; tables = Hs (N), TW (N/16).  y may not alias x (runs re-read their predecessor).
@@ -294,7 +295,7 @@ int ola_run_launch(const cpx *blk0, int nrest, const cpx *x, cpx *y, const cpx *
     if (hipGetDevice(&dev) == hipSuccess) (void) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
     return n > 0 ? n : 256;
   }();
-  const int64_t slots = (int64_t) cus * std::max<int64_t>(1, std::min<int64_t>(g.threads == 256 ? 3 : 1, (160 * 1024) / g.lds));   // (registers: 3 waves per SIMD)
+  const int64_t slots = (int64_t) cus * std::max<int64_t>(1, std::min<int64_t>(g.threads == 256 ? 3 : 1, (int64_t) ((160 * 1024) / g.lds)));   // (registers: 3 waves per SIMD)
   int per = 1;
   int64_t best = -1;
   for (int c = 1; c <= 32; c++) {
@@ -316,6 +317,7 @@ int ola_run_launch(const cpx *blk0, int nrest, const cpx *x, cpx *y, const cpx *
   else if (g.threads == 256) RUN_PICK(256, false);
   else if (g.threads == 512 && g.half) RUN_PICK(512, true);
   else if (g.threads == 512) RUN_PICK(512, false);
+  else if (g.threads == 1024 && g.half) RUN_PICK(1024, true);
   else return set_err(TSDGPU_ERR_UNSUPPORTED, "ola: frame of %d points does not fit the fused kernel", N);   // (set_response does not select it)
 #undef RUN_PICK
 #undef RUN_LAUNCH
@@ -330,7 +332,7 @@ int ola_run_launch(const cpx *blk0, int nrest, const cpx *x, cpx *y, const cpx *
 // traffic per sample and a row per run, against the |X|^2 plane (4 B per segment sample written, then read) of the
 // framed transform + summation passes.
 template <int R0, int THREADS>
-__global__ __launch_bounds__(THREADS, THREADS == 256 ? 3 : 2) void welch_run_kernel(const cpx *__restrict__ x, const float *__restrict__ w,
+__global__ __launch_bounds__(THREADS, THREADS == 256 ? 3 : THREADS == 512 ? 2 : 4) void welch_run_kernel(const cpx *__restrict__ x, const float *__restrict__ w,
                                                                                     const cpx *__restrict__ TW, float *__restrict__ part,
                                                                                     int N, int tpt, int64_t nseg, int per)
 {
@@ -389,6 +391,7 @@ int welch_run_launch(const cpx *x, const float *w, const cpx *TW, float *part, i
   } while (0)
   if (g.threads == 256) WR_PICK(256);
   else if (g.threads == 512) WR_PICK(512);
+  else if (g.threads == 1024) WR_PICK(1024);
   else return set_err(TSDGPU_ERR_UNSUPPORTED, "welch: N = %d does not fit the fused kernel", N);
 #undef WR_PICK
 #undef WR_LAUNCH
@@ -934,7 +937,7 @@ int tsdgpu_welch(const void *x, int64_t n, int N, const float *window, float *S,
     return rc;
   }
   if (!rc && nseg > 0 && !multi && N >= 16 && (N & (N - 1)) == 0 && ola_run_fits(N, N / 2)) {
-    // the other powers of two up to 8192: ONE kernel on the LDS transform keeps the running sums in registers (welch_run_kernel)
+    // the other powers of two up to 16384: ONE kernel on the LDS transform keeps the running sums in registers (welch_run_kernel)
     if (c->tw_N != N) {
       std::vector<cpx> tw((size_t) N / 16);
       const double PI = 3.14159265358979323846;

@@ -150,7 +150,7 @@ def test_welch_matches_oracle(N):
         assert np.max(np.abs(S - ref)) <= TOL * max(np.max(ref), 1e-30), (N, n)
 
 
-@pytest.mark.parametrize("N", [64, 256, 1024, 4096, 8192])
+@pytest.mark.parametrize("N", [64, 256, 1024, 4096, 8192, 16384])
 def test_welch_long_device_input(N):
     """2^22 samples resident on the device: runs of several segments per transform; white noise of variance 2 ->
     every bin sums to segments * (window energy) * 2 / N within the statistical spread; the first 50 segments and a
@@ -212,7 +212,7 @@ def test_fused_default_geometry_long_runs():
     assert relerr(yh[d:], yr[:len(yh) - d]) <= 2e-5
 
 
-@pytest.mark.parametrize("Ne,K", [(2048, 127), (3000, 500), (4096, 1025), (6000, 2000), (64, 33), (100, 20), (16, 15), (900, 100)])
+@pytest.mark.parametrize("Ne,K", [(2048, 127), (3000, 500), (4096, 1025), (6000, 2000), (8192, 127), (64, 33), (100, 20), (16, 15), (900, 100)])
 def test_fused_other_geometries_long_runs(Ne, K):
     """Every other geometry without window whose frame fits the LDS runs as ONE kernel too (ola.hip, ola_run_kernel):
     N/16 threads own a run of consecutive blocks, the carried block in registers (Ne = N/2) or in LDS.  Long calls
