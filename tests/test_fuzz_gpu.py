@@ -70,6 +70,45 @@ def test_fuzz_sos(tg, orc, seed):
     assert relerr(y, yref) <= TOL, (seed, order, fc, forme, cplx)
 
 
+@pytest.mark.parametrize("seed", range(3 * SCALE))
+def test_fuzz_sos_long_memory(tg, orc, seed):
+    """cut-offs of 1e-5 ... 1e-2: the warm-up scheme, the exact carry of the state from chunk to chunk and the
+    sequential chunk, whichever the call's length selects; ragged calls; the float64 run of the chain arbitrates"""
+    from scipy.signal import lfilter, lfiltic
+    rng = np.random.default_rng(2500 + seed)
+    cplx = bool(rng.integers(2))
+    order = int(rng.choice([1, 2, 3, 4, 6]))
+    fc = float(10.0 ** rng.uniform(-5, -2))
+    forme = int(rng.choice([1, 2]))
+    z, p, mn, md = orc.design_butter_lp(order, fc)
+    ref = orc.SosChain(z, p, mn, md, forme=forme)
+    co, gain, r1 = ref.coefs()
+    g = tg.Sos(co, gain, tg.C64 if cplx else tg.F32, r1, forme=forme)
+    x = rand(rng, int(rng.choice([16384, 70000, 300001])), cplx) + np.float32(rng.uniform(-1, 1))
+    yref = ref.step(x)
+    if forme == 2:
+        # the oracle's own float64 run of the DF2 chain (real data; real coefficients: the two channels apart)
+        v = ref.run_f64(x.real) + 1j * ref.run_f64(x.imag) if cplx else ref.run_f64(x)
+    else:
+        # FormeDirecte1: every memory of a section = its first input (filtre-rt.cc:361-365); the trailing first-order
+        # section starts from zero and carries the gain (:407-437,567-570)
+        v = x.astype(np.complex128 if cplx else np.float64)
+        for b0, b1, b2, a1, a2 in np.asarray(co, np.float32).astype(np.float64).reshape(-1, 5):
+            zi = lfiltic([b0, b1, b2], [1.0, a1, a2], y=[v[0], v[0]], x=[v[0], v[0]])
+            v, _ = lfilter([b0, b1, b2], [1.0, a1, a2], v, zi=zi.astype(v.dtype))
+        if r1 is not None:
+            q = np.asarray(r1, np.float32).astype(np.float64)
+            v = lfilter([q[0], q[1]], [1.0, q[2]], v)
+        else:
+            v = v * np.float64(np.float32(gain))
+    y = np.concatenate([g.step(x[a:b].copy()) for a, b in random_chunks(rng, len(x))])
+    bruit = relerr(yref, v)
+    # (as close to the float64 answer as the reference's own float32 run is; where that run is itself a few percent off --
+    # order 6 at fc = 1e-5: states of 1e8 whose ulp exceeds the input -- two float32 evaluations are two noise
+    # realisations: factor 4, as for the ill-conditioned direct forms of test_fuzz_rii)
+    assert relerr(y, v) <= max(2e-5, bruit if bruit < 1e-3 else 4 * bruit), (seed, order, fc, forme, cplx, len(x), relerr(y, v), bruit)
+
+
 @pytest.mark.parametrize("seed", range(8 * SCALE))
 def test_fuzz_resampler(tg, orc, seed):
     rng = np.random.default_rng(3000 + seed)
