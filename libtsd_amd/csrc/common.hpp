@@ -69,6 +69,8 @@ int pipelined_host_step_var(const void *x, int64_t n, size_t esz_in, void *y, si
                             hipStream_t user_stream, const std::function<int64_t(int64_t)> &out_cap,
                             const std::function<int(const void *, void *, int64_t, int64_t, int64_t *, hipStream_t)> &step);
 bool host_ranges_overlap(const void *a, size_t na, const void *b, size_t nb);
+// small device-to-device copy as a kernel launch (see common.hip)
+int device_copy_small(void *dst, const void *src, size_t bytes, hipStream_t st);
 bool host_pipe_enabled();     // false with TSDGPU_NO_PIPE=1 (A/B switch: whole-vector staging instead)
 
 // Scratch of a STATELESS entry point (xcorr, welch, delay estimate ...): buffers and plans are borrowed for the call from a

@@ -305,7 +305,8 @@ int fir_partitioned_step(tsdgpu_fir *f, const void *dx, void *dy, int64_t n, hip
 int fir_settle_history(tsdgpu_fir *f, hipStream_t st)
 {
   if (!f->capturable || f->cur == 0) return TSDGPU_OK;
-  TSD_HIP(hipMemcpyAsync(f->hist[0], f->hist[1], (size_t) f->HL * dtype_size(f->data_type), hipMemcpyDeviceToDevice, st));
+  const int rc = device_copy_small(f->hist[0], f->hist[1], (size_t) f->HL * dtype_size(f->data_type), st);
+  if (rc) return rc;
   f->cur = 0;
   return TSDGPU_OK;
 }
@@ -462,9 +463,9 @@ int tsdgpu_fir_get_history(tsdgpu_fir *f, void *dst, void *stream)
   hipStream_t st = (hipStream_t) stream;
   const size_t sz = dtype_size(f->data_type);
   const char *src = (const char *) f->hist[f->cur] + (size_t) (f->HL - (f->K - 1)) * sz;
-  const bool dev = is_device_ptr(dst);
-  TSD_HIP(hipMemcpyAsync(dst, src, (size_t) (f->K - 1) * sz, dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
-  if (!dev) TSD_HIP(hipStreamSynchronize(st));
+  if (is_device_ptr(dst)) return device_copy_small(dst, src, (size_t) (f->K - 1) * sz, st);
+  TSD_HIP(hipMemcpyAsync(dst, src, (size_t) (f->K - 1) * sz, hipMemcpyDeviceToHost, st));
+  TSD_HIP(hipStreamSynchronize(st));
   return TSDGPU_OK;
 }
 
@@ -475,9 +476,9 @@ int tsdgpu_fir_set_history(tsdgpu_fir *f, const void *src, void *stream)
   hipStream_t st = (hipStream_t) stream;
   const size_t sz = dtype_size(f->data_type);
   char *dst = (char *) f->hist[f->cur] + (size_t) (f->HL - (f->K - 1)) * sz;
-  const bool dev = is_device_ptr(src);
-  TSD_HIP(hipMemcpyAsync(dst, src, (size_t) (f->K - 1) * sz, dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
-  if (!dev) TSD_HIP(hipStreamSynchronize(st));
+  if (is_device_ptr(src)) return device_copy_small(dst, src, (size_t) (f->K - 1) * sz, st);
+  TSD_HIP(hipMemcpyAsync(dst, src, (size_t) (f->K - 1) * sz, hipMemcpyHostToDevice, st));
+  TSD_HIP(hipStreamSynchronize(st));
   return TSDGPU_OK;
 }
 

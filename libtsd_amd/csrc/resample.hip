@@ -120,7 +120,7 @@ __global__ __launch_bounds__(RS_THREADS) void resample_kernel(const T *__restric
     const int H = P.K - 1;
     for (int i = threadIdx.x; i < H; i += RS_THREADS) {
       const int64_t g = P.n - H + i;
-      hist_next[i] = g < 0 ? hist[H + g] : x[g];
+      hist_next[i] = g < 0 ? (hist ? hist[H + g] : zero_of(T{})) : x[g];
     }
     return;
   }
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(RS_THREADS) void resample_kernel(const T *__restric
         T v = zero_of(T{});
         if (lane + j * 64 < RS_TI + K) {
           if (rel < 0) {
-            if (rel >= -(int64_t) (K - 1)) v = hist[(K - 1) + rel];
+            if (hist && rel >= -(int64_t) (K - 1)) v = hist[(K - 1) + rel];
           } else if (rel < P.n) {
             v = x[rel];
           }
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(64 * RS15_WAVES) void resample15_kernel(const T *__
   if (blockIdx.x == gridDim.x - 1) {      // (see resample_kernel: the next window history rides in this launch)
     for (int i = threadIdx.x; i < 14; i += 64 * RS15_WAVES) {
       const int64_t g = P.n - 14 + i;
-      hist_next[i] = g < 0 ? hist[14 + g] : x[g];
+      hist_next[i] = g < 0 ? (hist ? hist[14 + g] : zero_of(T{})) : x[g];
     }
     return;
   }
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(64 * RS15_WAVES) void resample15_kernel(const T *__
         T v = zero_of(T{});
         if (lane + j * 64 < RS_TI + K) {
           if (rel < 0) {
-            if (rel >= -(int64_t) (K - 1)) v = hist[(K - 1) + rel];
+            if (hist && rel >= -(int64_t) (K - 1)) v = hist[(K - 1) + rel];
           } else if (rel < P.n) {
             v = x[rel];
           }
@@ -561,6 +561,7 @@ struct tsdgpu_resampler {
   float inv_den[32] = {0};
   float *d_lut = nullptr;
   void *d_hist[2] = {nullptr, nullptr};
+  bool hist_zero = true;       // the window history is all zeros (start, reset, seek without samples): the kernels get a null pointer instead of a cleared buffer
   int cur = 0;
   // stream position
   int64_t pos = 0, cum_pos = 0;
@@ -877,23 +878,25 @@ int tsdgpu_resampler_step(tsdgpu_resampler *r, const void *x, int64_t n, void *y
   const int64_t pgrid = std::min<int64_t>(cdiv(tiles, RS_WAVES), (int64_t) 256 * per_cu);
   const size_t wb15 = ((size_t) (RS15_LATE_STORE ? RS15_TILE_PAD + P.rec_cap : std::max(RS15_TILE_PAD, P.rec_cap)) * sz + 15) / 16 * 16;
   const size_t lds15 = (size_t) ((r->nph + 1) * 20 + 4) * 4 + RS15_WAVES * wb15 + 64;
+  const void *hcur = r->hist_zero ? nullptr : r->d_hist[r->cur];
   if (r->K == 15 && r->mode == 0 && lds15 <= 158 * 1024) {     // fused kernel; larger ratios fall back to the generic one
     const int64_t g15 = std::min<int64_t>(cdiv(tiles, RS15_WAVES), 256);
     if (r->data_type == TSDGPU_C64)
       hipLaunchKernelGGL(resample15_kernel<float2>, dim3((unsigned) g15 + 1), dim3(64 * RS15_WAVES), lds15, st, (const float2 *) dx,
-                         (const float2 *) r->d_hist[r->cur], (float2 *) dy, r->d_lut, r->d_ck, P, (int) tiles, (float2 *) r->d_hist[r->cur ^ 1]);
+                         (const float2 *) hcur, (float2 *) dy, r->d_lut, r->d_ck, P, (int) tiles, (float2 *) r->d_hist[r->cur ^ 1]);
     else
       hipLaunchKernelGGL(resample15_kernel<float>, dim3((unsigned) g15 + 1), dim3(64 * RS15_WAVES), lds15, st, (const float *) dx,
-                         (const float *) r->d_hist[r->cur], (float *) dy, r->d_lut, r->d_ck, P, (int) tiles, (float *) r->d_hist[r->cur ^ 1]);
+                         (const float *) hcur, (float *) dy, r->d_lut, r->d_ck, P, (int) tiles, (float *) r->d_hist[r->cur ^ 1]);
   } else {
 #define RS_LAUNCH(T, KT)                                                                                            \
   hipLaunchKernelGGL((resample_kernel<T, KT>), dim3((unsigned) pgrid + 1), dim3(RS_THREADS), lds, st, (const T *) dx, \
-                     (const T *) r->d_hist[r->cur], (T *) dy, r->d_lut, r->d_ck, P, (int) tiles, (T *) r->d_hist[r->cur ^ 1])
+                     (const T *) hcur, (T *) dy, r->d_lut, r->d_ck, P, (int) tiles, (T *) r->d_hist[r->cur ^ 1])
   if (r->data_type == TSDGPU_C64) RS_LAUNCH(float2, 0); else RS_LAUNCH(float, 0);
 #undef RS_LAUNCH
   }
   TSD_HIP(hipGetLastError());
   if (r->K > 1) r->cur ^= 1;      // (the launch wrote the next window history into the other buffer)
+  r->hist_zero = false;
   r->pos += n;
   r->cum_pos = cum_end;
   if (n_out) *n_out = nout;
@@ -905,9 +908,7 @@ int tsdgpu_resampler_reset(tsdgpu_resampler *r)
   TSD_CHECK(r != nullptr, "resampler_reset: NULL handle");
   r->pos = 0;
   r->cum_pos = 0;
-  const size_t hb = (size_t) std::max(r->K - 1, 1) * dtype_size(r->data_type);
-  TSD_HIP(hipMemset(r->d_hist[r->cur], 0, hb));
-  TSD_HIP(hipStreamSynchronize(nullptr));      // a device memset may return before it has run
+  r->hist_zero = true;
   return TSDGPU_OK;
 }
 
@@ -926,14 +927,18 @@ int tsdgpu_resampler_seek(tsdgpu_resampler *r, int64_t pos, const void *hist, vo
   }
   r->pos = pos;
   r->cum_pos = c;
-  const size_t hb = (size_t) std::max(r->K - 1, 1) * dtype_size(r->data_type);
   if (hist && r->K > 1) {
-    const bool dev = is_device_ptr(hist);
-    TSD_HIP(hipMemcpyAsync(r->d_hist[r->cur], hist, (size_t) (r->K - 1) * dtype_size(r->data_type),
-                           dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
-    if (!dev) TSD_HIP(hipStreamSynchronize(st));
+    const size_t hb = (size_t) (r->K - 1) * dtype_size(r->data_type);
+    if (is_device_ptr(hist)) {
+      const int rc = device_copy_small(r->d_hist[r->cur], hist, hb, st);
+      if (rc) return rc;
+    } else {
+      TSD_HIP(hipMemcpyAsync(r->d_hist[r->cur], hist, hb, hipMemcpyHostToDevice, st));
+      TSD_HIP(hipStreamSynchronize(st));
+    }
+    r->hist_zero = false;
   } else {
-    TSD_HIP(hipMemsetAsync(r->d_hist[r->cur], 0, hb, st));
+    r->hist_zero = true;          // (no launch: the kernels take a null history as zeros)
   }
   return TSDGPU_OK;
 }

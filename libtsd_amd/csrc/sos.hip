@@ -939,7 +939,7 @@ int tsdgpu_sos_step(tsdgpu_sos *s, const void *x, void *y, int64_t n, void *stre
   }
   if (s->capturable && s->cur == 1) {
     // same launch arguments at every step (see tsdgpu_fir_set_capturable): the state goes back to buffer 0
-    TSD_HIP(hipMemcpyAsync(s->d_state[0], s->d_state[1], STATE_FLOATS * 4, hipMemcpyDeviceToDevice, st));
+    if ((rc = device_copy_small(s->d_state[0], s->d_state[1], STATE_FLOATS * 4, st))) return rc;
     s->cur = 0;
   }
   return finish_out(y, bytes, dy, staged, st);
