@@ -354,8 +354,11 @@ int tsdgpu_detector_step(tsdgpu_detector *d, const void *x, int64_t n, float *sc
   d->cur = nxt;
   // results: the score vector (if asked for) and ONE small copy of the peak records
   if (scores) {
-    const bool dev = is_device_ptr(scores);
-    TSD_HIP(hipMemcpyAsync(scores, d->sbuf[cur] + d->P, (size_t) n * sizeof(float), dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
+    if (is_device_ptr(scores)) {
+      if ((rc = device_copy_small(scores, d->sbuf[cur] + d->P, (size_t) n * sizeof(float), st))) return rc;
+    } else {
+      TSD_HIP(hipMemcpyAsync(scores, d->sbuf[cur] + d->P, (size_t) n * sizeof(float), hipMemcpyDeviceToHost, st));
+    }
   }
   std::vector<char> host(sizeof(DetHeader) + (size_t) d->max_recs * sizeof(tsdgpu_peak));
   {

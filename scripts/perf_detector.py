@@ -37,6 +37,18 @@ def main():
             print(json.dumps({"Ne": Ne, "M": M, "mode": "ola" if mode == 0 else "fir", "us_per_block_host": round(host, 1),
                               "us_per_block_resident": round(dev, 1), "Msamples_s_resident": round(Ne / dev, 1)}))
 
+    # long resident vectors through ONE step (what Detecteur::step(x) of the mirror does): many blocks of the
+    # correlator per call
+    for Ne in (512, 1024, 4096):
+        n = (1 << 22) // Ne * Ne
+        xd = torch.view_as_complex(0.1 * torch.randn(n, 2, device="cuda"))
+        for mode in (0, 1):
+            d = t.Detector(pat, Ne, mode, threshold=0.9)
+            d.step(xd)
+            us = med(lambda: d.step(xd), 30)
+            print(json.dumps({"Ne": Ne, "M": M, "mode": "ola" if mode == 0 else "fir", "n_per_call": n, "us_per_call_resident": round(us, 1),
+                              "Msamples_s_resident": round(n / us, 1)}))
+
 
 if __name__ == "__main__":
     main()
