@@ -98,6 +98,95 @@ __global__ __launch_bounds__(256) void polyfir_fused_kernel(const T *__restrict_
     y[o] = acc;
   }
 }
+// Decimators of small rate (2 <= R <= PF_ROWS_MAXR; the half-band stages of filtre_reechan are R = 2): the same sums by
+// POLYPHASE ROWS.  The fused kernel above lets lane t read the staged sample (t R + c - k) for tap k: a lane stride of R
+// samples on the LDS banks (2-way conflicts at R = 2 -- decimation by 2 ran slower than by 3) and one tap read per product.
+// Here the samples are staged phase-major -- row p = (index mod R), column = index / R -- and the taps regrouped by row
+// (row r: the taps k = r, r + R, ..., oldest first; they meet the samples of phase (c - r) mod R), so that
+//     y[o0 + t] = sum_r sum_m  gr[r][m] * X[phase_r][t + col0_r + m]
+// reads consecutive columns in consecutive lanes (conflict-free), four taps per broadcast 16-byte read, and skips the rows
+// and quadruples of taps that are zero: the half-band filter, half of whose taps vanish, costs a quarter of the LDS cycles.
+// (The products are summed class by class instead of oldest sample first: same values to rounding, and the same bits
+// however the stream is cut in calls.)
+constexpr int PF_ROWS_MAXR = 16;
+template <typename T>
+__global__ __launch_bounds__(256) void decim_rows_kernel(const T *__restrict__ x, const T *__restrict__ hist, T *__restrict__ y,
+                                                         const float *__restrict__ g, int R, int W, int64_t start, int HW, int64_t n,
+                                                         int64_t nout, int TO, int Lr, int pitch)
+{
+  extern __shared__ __attribute__((aligned(16))) char dr_raw[];
+  float *gr = reinterpret_cast<float *>(dr_raw);                          // R rows of Lr taps (Lr a multiple of 4)
+  int *range = reinterpret_cast<int *>(gr + R * Lr);                      // per row: first and one-past-last non-zero quadruple
+  T *X = reinterpret_cast<T *>(range + 2 * PF_ROWS_MAXR);                 // R rows of `pitch` samples
+  const int t = threadIdx.x;
+  const int64_t o0 = (int64_t) blockIdx.x * TO, o1 = min(o0 + TO, nout);
+  const int64_t oldest = o0 * R + start - (W - 1);                        // oldest sample of output o0 (may be negative: history)
+  const int64_t i_lo = (oldest >= 0 ? oldest / R : -((-oldest + R - 1) / R)) * R;      // floored to a multiple of R
+  const int cc = (int) (o0 * R + start - i_lo);                           // staged index of output o0's newest sample
+  // taps by class r = k mod R, oldest first: gr[r][mm] = g[r + (jmax_r - mm) R] -- the same table whatever the call's
+  // alignment, so that the order of the sums, hence every output bit, does not depend on how a stream is cut in calls
+  for (int idx = t; idx < R * Lr; idx += 256) {
+    const int r = idx / Lr, mm = idx - r * Lr;
+    const int jmax = r < W ? (W - 1 - r) / R : -1;
+    gr[idx] = mm <= jmax ? g[r + (jmax - mm) * R] : 0.f;
+  }
+  // samples, phase-major; everything past the data is zero (the padded taps multiply it)
+  for (int i0 = t; i0 < R * pitch; i0 += 256 * 8) {
+    T v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int i = i0 + 256 * u;
+      const int64_t idx = i_lo + i;
+      v[u] = pf_zero(T{});
+      if (i < R * pitch) {
+        if (idx < 0) {
+          if (idx >= -(int64_t) HW) v[u] = hist[HW + idx];
+        } else if (idx < n) {
+          v[u] = x[idx];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int i = i0 + 256 * u;
+      if (i < R * pitch) X[(i % R) * pitch + i / R] = v[u];
+    }
+  }
+  __syncthreads();
+  if (t < R) {
+    int a = Lr / 4, b = 0;
+    for (int q = 0; q < Lr / 4; q++) {
+      const float *w = gr + t * Lr + 4 * q;
+      if (w[0] != 0.f || w[1] != 0.f || w[2] != 0.f || w[3] != 0.f) {
+        a = min(a, q);
+        b = q + 1;
+      }
+    }
+    range[2 * t] = a;
+    range[2 * t + 1] = b;
+  }
+  __syncthreads();
+  for (int tt = t; tt < (int) (o1 - o0); tt += 256) {
+    T acc = pf_zero(T{});
+    for (int r = 0; r < R; r++) {
+      // class r meets the samples of phase (cc - r) mod R, its oldest one in column (cc - r - phase) / R - jmax_r
+      const int jmax = r < W ? (W - 1 - r) / R : 0;
+      const int ph = (cc - r) % R, col0 = (cc - r - ph) / R - jmax;
+      const T *xr = X + ph * pitch + tt + col0;
+      const float *gp = gr + r * Lr;
+      const int qa = range[2 * r], qb = range[2 * r + 1];
+      for (int q = qa; q < qb; q++) {
+        const float4 w = *reinterpret_cast<const float4 *>(gp + 4 * q);
+        acc = pf_mac(acc, w.x, xr[4 * q]);
+        acc = pf_mac(acc, w.y, xr[4 * q + 1]);
+        acc = pf_mac(acc, w.z, xr[4 * q + 2]);
+        acc = pf_mac(acc, w.w, xr[4 * q + 3]);
+      }
+    }
+    y[o0 + tt] = acc;
+  }
+}
+
 // new_hist = last HW samples of (old_hist ++ x[0..n))
 template <typename T>
 __global__ void pf_hist_update_kernel(const T *__restrict__ x, const T *__restrict__ old_hist, T *__restrict__ new_hist, int HW,
@@ -300,6 +389,20 @@ int fused_setup(tsdgpu_polyfir *p, const std::vector<float> &g, int NPH, int W, 
 template <typename T>
 int fused_step(tsdgpu_polyfir *p, const void *dx, void *dy, int stride, int64_t start, int64_t n, int64_t nout, hipStream_t st)
 {
+  static const bool sans_rangs = getenv("TSDGPU_POLY_NO_ROWS") != nullptr;
+  if (nout > 0 && !sans_rangs && p->NPH == 1 && stride >= 2 && stride <= PF_ROWS_MAXR && p->W >= 32) {
+    // decimators of small rate and at least 32 taps: polyphase rows (decim_rows_kernel).  (Shorter filters are bound by the
+    // staging, which the phase-major scatter makes dearer: 15 taps at R = 2, 2^26 samples: 0.22 against 0.18 ms.)
+    const int Lr = ((p->W + stride - 1) / stride + 1 + 3) / 4 * 4, pitch = p->TO + Lr + 4;
+    const size_t lds = (size_t) stride * Lr * sizeof(float) + 2 * PF_ROWS_MAXR * sizeof(int) + (size_t) stride * pitch * sizeof(T);
+    if (lds <= 150 * 1024) {
+      (void) hipFuncSetAttribute((const void *) decim_rows_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      hipLaunchKernelGGL(decim_rows_kernel<T>, dim3((unsigned) cdiv(nout, p->TO)), dim3(256), lds, st, (const T *) dx, (const T *) p->d_hist[p->cur],
+                         (T *) dy, p->d_g, stride, p->W, start, p->HW, n, nout, p->TO, Lr, pitch);
+      TSD_HIP(hipGetLastError());
+      nout = 0;                                  // (served; the history update below still runs)
+    }
+  }
   if (nout > 0) {
     const int64_t span = (int64_t) (p->TO / p->NPH + 1) * stride + p->W;
     const size_t lds = (size_t) ((p->NPH * p->W + 3) & ~3) * sizeof(float) + (size_t) span * sizeof(T);

@@ -53,6 +53,9 @@ def main():
     for R in (2, 3, 8, 33, 62, 63, 100, 500):
         g = t.PolyFir(t.POLY_DECIM, t.C64, h, R)
         row[f"decim {R}"] = ms_per_call(lambda: g.step(xc))
+    for K in (31, 63):
+        g = t.PolyFir(t.POLY_HALFBAND, t.C64, orc.design_rif_fen(K, "lp", 0.25))
+        row[f"half-band {K} taps"] = ms_per_call(lambda: g.step(xc))
     for R in (2, 3, 8, 33, 62, 63, 100):
         g = t.PolyFir(t.POLY_UPS, t.C64, h, R)
         xs = xc[: n // R]
