@@ -61,6 +61,15 @@ def test_sos_and_rii_host_pipeline(tg, orc):
     m = 4000
     ref = orc.Rii(nu, de).step(x[:m])
     assert np.abs(yh[:m] - ref).max() <= 1e-5 * np.abs(ref).max()
+    # a long-memory smoother (exact carry of the state inside every chunk of the pipeline, the stream state between them)
+    g = np.float32(3e-5)
+    lis = (np.array([g, 0.0], np.float32), np.array([1.0, -(1.0 - g)], np.float32))
+    xo = x + np.float32(2.0)
+    yh = tg.Rii(*lis, tg.F32).step(xo)
+    yd = tg.Rii(*lis, tg.F32).step(torch.from_numpy(xo).cuda()).cpu().numpy()
+    from scipy.signal import lfilter
+    ex = lfilter(lis[0].astype(np.float64), lis[1].astype(np.float64), xo.astype(np.float64))
+    assert np.abs(yh - ex).max() <= 2e-5 * np.abs(ex).max() and np.abs(yd - ex).max() <= 2e-5 * np.abs(ex).max()
 
 
 # variable output length: the resampler and the integer-rate stages report each chunk's output count on the host and
