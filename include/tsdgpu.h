@@ -321,6 +321,9 @@ int tsdgpu_delay_estimate(const void *x, const void *y, int n, float *delay, flo
  * multi-device notion: this stands behind the SAME step() of FiltreRIF / ChaineSOIS /
  * AdaptationRythmeSimple (src/filtrage/filtre-rt.cc:53-109,440-572; src/reechan/ra.cc:13-79) for
  * vectors that are worth spreading over a node.  No collective, nothing exchanged but the halos.
+ * (SOS cascades whose warm-up would exceed 2^16 samples, or that do not decay at all, are sharded EXACTLY instead: every
+ * shard but the first runs from zero state, the end states -- a few floats per section -- meet on the host, the true start
+ * states follow from the cascade's transition matrix over a shard, and the shards run again: tsdgpu_sharded_halo is 0.)
  * devices: nshards device ordinals (NULL: shard g on device g % device_count); several shards may name
  * the same device.  Calls are synchronous and keep the streaming contract (the tail of one call is the
  * halo of the next call's first shard).

@@ -44,6 +44,14 @@ struct Rendezvous {
 };
 }  // namespace
 
+namespace tsdgpu {
+// sos.hip: the stream state of a cascade as a host vector, and its zero-input propagation over L samples (+ an end state)
+int sos_state_floats();
+int sos_state_get(tsdgpu_sos *s, float *host, hipStream_t st);
+int sos_state_set(tsdgpu_sos *s, const float *host, hipStream_t st);
+bool sos_state_propagate(const tsdgpu_sos *s, int64_t L, const float *in, const float *add, float *out);
+}
+
 struct tsdgpu_sharded {
   int kind = 0, data_type = 0, nshards = 0;
   int64_t H = 0;                         // halo length in samples
@@ -55,6 +63,13 @@ struct tsdgpu_sharded {
   std::vector<char> carry;               // host: the last H inputs of the stream (zeros before its start)
   int64_t seen = 0;                      // inputs consumed so far (all calls)
   int64_t out_total = 0;                 // resampler: outputs produced so far
+  // SOS cascades whose warm-up would be longer than a shard is worth (or that do not decay): EXACT sharding instead of
+  // halos.  Every shard but the first runs from zero state and hands its end state E_g to the host; the true start states
+  // follow from S_{g+1} = Phi^(L_g) S_g + E_g (a 2-sections-wide product per shard, in double); the shards run again from
+  // them.  The exchange is a few hundred bytes per shard through the host -- no collective; `sos_state` is the stream's
+  // state between calls.
+  bool exact = false;
+  std::vector<float> sos_state;
   size_t esz() const { return dtype_size(data_type); }
 };
 
@@ -208,9 +223,13 @@ int tsdgpu_sos_sharded_create(tsdgpu_sharded **out, int data_type, const float *
     rc = with_device(h->dev[g], [&] { return tsdgpu_sos_create((tsdgpu_sos **) &h->handle[g], data_type, coefs_host, nsec, gain, rii1_host, forme); });
   if (!rc) {
     h->H = tsdgpu_sos_halo((tsdgpu_sos *) h->handle[0]);
-    if (h->H < 0 || h->H > ((int64_t) 1 << 24))
-      rc = set_err(TSDGPU_ERR_UNSUPPORTED, "sos_sharded_create: this cascade decays too slowly for warm-up sharding (halo %lld samples)",
-                   (long long) h->H);
+    static const bool toujours_halo = getenv("TSDGPU_SHARD_SOS_HALO") != nullptr;
+    if (h->H < 0 || (h->H > 65536 && !toujours_halo) || h->H > ((int64_t) 1 << 24)) {
+      // a warm-up of more than 2^16 samples per shard (or no decay at all): the exact scheme
+      h->exact = true;
+      h->H = 0;
+      h->sos_state.assign((size_t) sos_state_floats(), 0.f);
+    }
   }
   if (!rc) rc = sharded_finish_create(h);
   if (rc) {
@@ -314,8 +333,25 @@ int tsdgpu_sharded_step_host(tsdgpu_sharded *h, const void *x, int64_t n, void *
   std::vector<int> rcs((size_t) N, TSDGPU_OK);
   std::vector<std::string> msgs((size_t) N);
   std::vector<int64_t> outs((size_t) N, 0);
-  Rendezvous rdv;
-  rdv.n = N;
+  Rendezvous rdv, rdv2;
+  rdv.n = rdv2.n = N;
+  // exact SOS sharding: the shards' end states, the first and the last shard with samples, the stream state after the call
+  std::vector<float> etats, etat_final;
+  int first = 0, dernier = 0;
+  if (h->exact) {
+    etats.assign((size_t) N * sos_state_floats(), 0.f);
+    etat_final = h->sos_state;
+    first = -1;
+    for (int q = 0; q < N; q++) {
+      int64_t ql, qh;
+      tsdgpu_sharded_bounds(h, n, q, &ql, &qh);
+      if (qh > ql) {
+        if (first < 0) first = q;
+        dernier = q;
+      }
+    }
+    if (first < 0) first = 0;
+  }
   auto work = [&](int g) {
     int rc = TSDGPU_OK;
     int64_t lo, hi;
@@ -341,6 +377,47 @@ int tsdgpu_sharded_step_host(tsdgpu_sharded *h, const void *x, int64_t n, void *
       if (hipStreamSynchronize(st) != hipSuccess && !rc) rc = set_err(TSDGPU_ERR_HIP, "upload sync failed");
     } while (0);
     rdv.wait();                                         // every shard holds its inputs: y may now be written
+    if (h->exact) {
+      // exact SOS sharding: zero-state pass (the first shard with samples: the true pass), end states to the host, the
+      // true start states by propagation, second pass.  Every thread passes both rendezvous whatever failed.
+      tsdgpu_sos *sg = (tsdgpu_sos *) h->handle[g];
+      const int SF = sos_state_floats();
+      hipStream_t st = h->stream[g];
+      if (!rc && cnt > 0) {
+        std::vector<float> zero((size_t) SF, 0.f);
+        zero[0] = 1.f;                                  // (zero memories, no first-sample seed)
+        rc = sos_state_set(sg, g == first ? h->sos_state.data() : zero.data(), st);
+        if (!rc) rc = tsdgpu_sos_step(sg, h->in[g].p, h->out[g].p, cnt, st);
+        if (!rc) rc = sos_state_get(sg, &etats[(size_t) g * SF], st);
+      }
+      rcs[(size_t) g] = rc;
+      if (rc) msgs[(size_t) g] = tsdgpu_last_error();
+      rdv2.wait();
+      bool ok = true;
+      for (int q = 0; q < N; q++) ok = ok && rcs[(size_t) q] == TSDGPU_OK;
+      if (ok && cnt > 0) {
+        if (g != first) {
+          std::vector<float> cur(etats.begin() + (size_t) first * SF, etats.begin() + (size_t) (first + 1) * SF), nxt((size_t) SF);
+          for (int q = first + 1; q < g && !rc; q++) {
+            int64_t ql, qh;
+            tsdgpu_sharded_bounds(h, n, q, &ql, &qh);
+            if (!sos_state_propagate(sg, qh - ql, cur.data(), &etats[(size_t) q * SF], nxt.data()))
+              rc = set_err(TSDGPU_ERR_UNSUPPORTED, "sharded sos: the cascade's state transition over a shard leaves the float range");
+            cur.swap(nxt);
+          }
+          if (!rc) rc = sos_state_set(sg, cur.data(), st);
+          if (!rc) rc = tsdgpu_sos_step(sg, h->in[g].p, h->out[g].p, cnt, st);
+        }
+        if (!rc && g == dernier) rc = sos_state_get(sg, etat_final.data(), st);
+        if (!rc && hipMemcpyAsync(ys + (size_t) lo * esz, h->out[g].p, (size_t) cnt * esz, hipMemcpyDeviceToHost, st) != hipSuccess)
+          rc = set_err(TSDGPU_ERR_HIP, "download failed: %s", hipGetErrorString(hipGetLastError()));
+        if (hipStreamSynchronize(st) != hipSuccess && !rc) rc = set_err(TSDGPU_ERR_HIP, "shard %d: stream sync failed", g);
+      }
+      outs[(size_t) g] = cnt;
+      rcs[(size_t) g] = rc;
+      if (rc) msgs[(size_t) g] = tsdgpu_last_error();
+      return;
+    }
     if (!rc) {
       const int64_t ocap = h->kind == K_RES ? off[(size_t) g + 1] - off[(size_t) g] : cnt;
       int64_t got = 0;
@@ -375,6 +452,7 @@ int tsdgpu_sharded_step_host(tsdgpu_sharded *h, const void *x, int64_t n, void *
   }
   h->seen += n;
   h->out_total += total;
+  if (h->exact) h->sos_state = etat_final;
   if (n_out) *n_out = total;
   return TSDGPU_OK;
 }
@@ -397,6 +475,65 @@ int tsdgpu_sharded_step_parts(tsdgpu_sharded *h, const void *const *x_parts, con
   if (n == 0) return TSDGPU_OK;
   int prev = 0;
   TSD_HIP(hipGetDevice(&prev));
+  if (h->exact) {
+    // exact SOS sharding (see tsdgpu_sharded): pass 1 of the later shards goes to a scratch buffer (a part may be filtered
+    // in place), the end states come to the host, pass 2 starts from the propagated states
+    const int SF = sos_state_floats();
+    std::vector<float> etats((size_t) N * SF, 0.f), zero((size_t) SF, 0.f), fin = h->sos_state;
+    zero[0] = 1.f;
+    int first = -1, dernier = 0, rc = TSDGPU_OK;
+    for (int g = 0; g < N; g++)
+      if (counts[g] > 0) {
+        if (first < 0) first = g;
+        dernier = g;
+      }
+    for (int g = 0; g < N && !rc; g++) {
+      if (counts[g] == 0) continue;
+      TSD_HIP(hipSetDevice(h->dev[g]));
+      tsdgpu_sos *sg = (tsdgpu_sos *) h->handle[g];
+      TSD_CHECK(!y_capacities || y_capacities[g] >= counts[g], "sharded_step_parts: output capacity of part %d", g);
+      rc = sos_state_set(sg, g == first ? h->sos_state.data() : zero.data(), h->stream[g]);
+      void *dst = y_parts[g];
+      if (!rc && g != first) {
+        rc = h->scratch[g].reserve((size_t) counts[g] * esz);
+        dst = h->scratch[g].p;
+      }
+      if (!rc) rc = tsdgpu_sos_step(sg, x_parts[g], dst, counts[g], h->stream[g]);
+    }
+    for (int g = 0; g < N && !rc; g++) {
+      if (counts[g] == 0) continue;
+      TSD_HIP(hipSetDevice(h->dev[g]));
+      rc = sos_state_get((tsdgpu_sos *) h->handle[g], &etats[(size_t) g * SF], h->stream[g]);
+    }
+    if (!rc && first >= 0) {
+      std::vector<float> cur(etats.begin() + (size_t) first * SF, etats.begin() + (size_t) (first + 1) * SF), nxt((size_t) SF);
+      for (int g = first + 1; g < N && !rc; g++) {
+        if (counts[g] == 0) continue;
+        TSD_HIP(hipSetDevice(h->dev[g]));
+        tsdgpu_sos *sg = (tsdgpu_sos *) h->handle[g];
+        rc = sos_state_set(sg, cur.data(), h->stream[g]);
+        if (!rc) rc = tsdgpu_sos_step(sg, x_parts[g], y_parts[g], counts[g], h->stream[g]);
+        if (!rc && !sos_state_propagate(sg, counts[g], cur.data(), &etats[(size_t) g * SF], nxt.data()))
+          rc = set_err(TSDGPU_ERR_UNSUPPORTED, "sharded sos: the cascade's state transition over a shard leaves the float range");
+        cur.swap(nxt);
+      }
+      if (!rc) {
+        TSD_HIP(hipSetDevice(h->dev[dernier]));
+        rc = sos_state_get((tsdgpu_sos *) h->handle[dernier], fin.data(), h->stream[dernier]);
+      }
+    }
+    for (int g = 0; g < N; g++) {
+      (void) hipSetDevice(h->dev[g]);
+      if (hipStreamSynchronize(h->stream[g]) != hipSuccess && !rc) rc = set_err(TSDGPU_ERR_HIP, "shard %d: stream sync failed", g);
+    }
+    (void) hipSetDevice(prev);
+    if (rc) return rc;
+    for (int g = 0; g < N; g++)
+      if (out_counts) out_counts[g] = counts[g];
+    h->sos_state = fin;
+    h->seen += n;
+    return TSDGPU_OK;
+  }
   // (1) halos, device to device: the last H samples before each shard, walking back over the parts and
   //     ending in the carry of the previous calls
   int rc = TSDGPU_OK;
@@ -466,6 +603,7 @@ int tsdgpu_sharded_reset(tsdgpu_sharded *h)
 {
   TSD_CHECK(h != nullptr, "sharded_reset: NULL handle");
   std::fill(h->carry.begin(), h->carry.end(), 0);
+  std::fill(h->sos_state.begin(), h->sos_state.end(), 0.f);
   h->seen = 0;
   h->out_total = 0;
   for (int g = 0; g < h->nshards; g++) {

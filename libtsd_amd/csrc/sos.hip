@@ -975,6 +975,76 @@ int tsdgpu_sos_reset_on(tsdgpu_sos *s, void *stream)
 
 int64_t tsdgpu_sos_halo(const tsdgpu_sos *s) { return s ? s->halo : -1; }
 
+}  // extern "C"
+
+// ---- the stream state as a host vector (internal: the exact sharding of long-memory cascades, sharded.hip) ------------
+// layout: [0] = "first sample seen" flag, then per (section, channel) (d1, d2, x1, x2) -- what the kernels publish
+namespace tsdgpu {
+int sos_state_floats() { return STATE_FLOATS; }
+int sos_state_get(tsdgpu_sos *s, float *host, hipStream_t st)
+{
+  TSD_HIP(hipMemcpyAsync(host, s->d_state[s->cur], STATE_FLOATS * sizeof(float), hipMemcpyDeviceToHost, st));
+  TSD_HIP(hipStreamSynchronize(st));
+  return TSDGPU_OK;
+}
+int sos_state_set(tsdgpu_sos *s, const float *host, hipStream_t st)
+{
+  TSD_HIP(hipMemcpyAsync(s->d_state[s->cur], host, STATE_FLOATS * sizeof(float), hipMemcpyHostToDevice, st));
+  TSD_HIP(hipStreamSynchronize(st));            // (`host` may die with the caller's scope)
+  return TSDGPU_OK;
+}
+// out = Phi^L in + add: the state `in` after L samples of zero input (Phi^L in the scans' coordinates, double) plus the end
+// state `add` of a zero-state run over those L samples (null: none); the flag of `out` is set when either has it.
+// false when the powers leave the float range
+bool sos_state_propagate(const tsdgpu_sos *s, int64_t L, const float *in, const float *add, float *out)
+{
+  const int ns = s->nsec, comps = s->comps, m = comps * ns;
+  for (int i = 0; i < STATE_FLOATS; i++) out[i] = in[i];
+  if (add && add[0] != 0.f) out[0] = 1.f;
+  if (m == 0) return true;
+  std::vector<double> P;
+  matpow(s->phi, m, std::max<int64_t>(L, 0), P);
+  for (double v : P)
+    if (!std::isfinite(v) || std::fabs(v) > 1e30) return false;
+  std::vector<SosSection> sec((size_t) ns);
+  if (hipMemcpy(sec.data(), s->d_sec, (size_t) ns * sizeof(SosSection), hipMemcpyDeviceToHost) != hipSuccess) return false;
+  for (int ch = 0; ch < s->nch; ch++) {
+    std::vector<double> v((size_t) m, 0.0), w((size_t) m, 0.0);
+    for (int q = 0; q < ns; q++) {
+      const float *r = in + state_index(q, ch);
+      const double sg = sec[q].sg;
+      v[(size_t) q * comps] = r[0];
+      v[(size_t) q * comps + 1] = (double) r[0] - sg * (double) r[1];
+      if (comps == 4) { v[(size_t) q * comps + 2] = r[2]; v[(size_t) q * comps + 3] = r[3]; }
+    }
+    for (int i = 0; i < m; i++) {
+      double a = 0;
+      for (int j = 0; j < m; j++) a += P[(size_t) i * m + j] * v[j];
+      w[i] = a;
+    }
+    if (add) {
+      for (int q = 0; q < ns; q++) {
+        const float *r = add + state_index(q, ch);
+        const double sg = sec[q].sg;
+        w[(size_t) q * comps] += r[0];
+        w[(size_t) q * comps + 1] += (double) r[0] - sg * (double) r[1];
+        if (comps == 4) { w[(size_t) q * comps + 2] += r[2]; w[(size_t) q * comps + 3] += r[3]; }
+      }
+    }
+    for (int q = 0; q < ns; q++) {
+      float *r = out + state_index(q, ch);
+      const double sg = sec[q].sg;
+      r[0] = (float) w[(size_t) q * comps];
+      r[1] = (float) (sg * (w[(size_t) q * comps] - w[(size_t) q * comps + 1]));
+      if (comps == 4) { r[2] = (float) w[(size_t) q * comps + 2]; r[3] = (float) w[(size_t) q * comps + 3]; }
+    }
+  }
+  return true;
+}
+}  // namespace tsdgpu
+
+extern "C" {
+
 int tsdgpu_sos_destroy(tsdgpu_sos *s)
 {
   if (!s) return TSDGPU_OK;

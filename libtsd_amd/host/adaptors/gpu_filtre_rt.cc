@@ -124,8 +124,9 @@ template <typename T> struct ChaineSOISGpu : FiltreGen<T> {
   {
     const entier n = x.rows();
     if (x.data() != y.data()) dimensionne(y, n);
-    // warm-up sharding needs a cascade that forgets its past within a bounded halo
-    if (mode < 0 && n > 0) mode = (tsd_amd::choisit_fragments(x, y) && tsdgpu_sos_halo(h) >= 0 && tsdgpu_sos_halo(h) <= (1 << 20)) ? 1 : 0;
+    // (any cascade shards: by warm-up halos when it forgets its past within 2^16 samples, by an exact exchange of the
+    // shards' end states otherwise -- tsdgpu_sos_sharded_create picks)
+    if (mode < 0 && n > 0) mode = tsd_amd::choisit_fragments(x, y) ? 1 : 0;
     if (mode == 1) {
       tsd_amd::exige_hote_fragments(x, "filtre_sois");
       if (!hs && tsdgpu_sos_sharded_create(&hs, dtype_of<T>(), coefs_sections.data(), (int) (coefs_sections.size() / 5), gain_v,

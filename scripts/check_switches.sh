@@ -20,6 +20,7 @@ run TSDGPU_POLY_COMPOSED=1 tests/test_polyphase_gpu.py
 run TSDGPU_POLY_NO_ROWS=1 tests/test_polyphase_gpu.py tests/test_host_pipeline_gpu.py
 run TSDGPU_SOS_WIDE_WARMUP=1 tests/test_sos_gpu.py tests/test_sharded_gpu.py
 run TSDGPU_SOS_CHUNKS=16384 tests/test_sos_gpu.py
+run TSDGPU_SHARD_SOS_HALO=1 tests/test_sharded_gpu.py -k "not long_memory"
 run TSDGPU_SOS_NO_EXACT_CARRY=1 tests/test_sos_gpu.py tests/test_sharded_gpu.py -k "not long_memory"
 # (the tests that assert WHICH path serves a filter, or its speed, are about the default choice)
 run TSDGPU_RII_LITERAL=1 tests/test_polyphase_gpu.py -k "not block_parallel and not under_2ms and not cliff and not literal_fallback and not complex_coefficients"

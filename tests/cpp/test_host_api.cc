@@ -240,10 +240,14 @@ static void test_fragments()
   const Veccf x = randcn(n);
   const Vecf h = design_rif_fen(127, "lp", 0.02f), hc = design_rif_fen(31, "lp", 0.2f);
   const auto butter = design_riia(12, "lp", "butt", 0.25f);
+  // (lent: a first-order low-pass at fc = 1e-5, memory of 5e5 samples: sharded exactly -- end states through the host -- not by warm-up halos)
+  const auto lent = design_riia(1, "lp", "butt", 1e-5f);
   tsd_amd::fixe_fragments(0);
   const Veccf y1 = filtrer<cfloat>(Design(h), x), yd1 = filtrer<cfloat>(Design(hc), x), s1 = filtrer<cfloat>(Design(butter), x), r1 = rééchan(x, 160.0f / 147);
+  const Veccf l1 = filtrer<cfloat>(Design(lent), x);
   tsd_amd::fixe_fragments(3);
   const Veccf y3 = filtrer<cfloat>(Design(h), x), yd3 = filtrer<cfloat>(Design(hc), x), s3 = filtrer<cfloat>(Design(butter), x), r3 = rééchan(x, 160.0f / 147);
+  const Veccf l3 = filtrer<cfloat>(Design(lent), x);
   // streaming across calls on ONE sharded object: large call, small call, large call
   auto f = filtre_rif<float, cfloat>(hc);
   Veccf ys(n);
@@ -256,6 +260,7 @@ static void test_fragments()
   CHECK(ecart_rel(yd3, yd1) == 0.f, "sharded filtrer (direct) must be bit-exact: %g", ecart_rel(yd3, yd1));
   CHECK(ecart_rel(ys, yd1) == 0.f, "sharded filtre_rif across calls: %g", ecart_rel(ys, yd1));
   CHECK(ecart_rel(s3, s1) <= 1e-6f, "sharded filtre_sois: %g", ecart_rel(s3, s1));
+  CHECK(ecart_rel(l3, l1) <= 2e-5f, "sharded filtre_sois (long memory, exact exchange of the end states): %g", ecart_rel(l3, l1));
   CHECK(r3.rows() == r1.rows() && ecart_rel(r3, r1) == 0.f, "sharded rééchan must be bit-exact: %d vs %d outputs, %g", r3.rows(), r1.rows(), ecart_rel(r3, r1));
 }
 

@@ -29,6 +29,62 @@ def calls(n, parts):
     return list(zip(cuts[:-1], cuts[1:]))
 
 
+@pytest.mark.parametrize("N", [2, 5])
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("order,fc,forme", [(2, 1e-4, 2), (1, 1e-5, 2), (4, 1e-4, 1), (3, 1e-4, 2)])
+def test_sos_sharded_long_memory_exact(tg, orc, N, cplx, order, fc, forme):
+    """Cascades whose warm-up would exceed 2^16 samples per shard (or that do not decay) are sharded EXACTLY: every shard but
+    the first runs from zero state, the end states go to the host, the true start states follow from the cascade's
+    transition matrix over a shard (double), the shards run again.  Host form and resident parts (one of them in place),
+    several ragged calls (the stream state is carried between calls), against the single handle -- which itself sits
+    within the reference's float32 noise of the float64 answer (test_sos_long_memory_exact_carry)."""
+    import torch
+    z, p, mn, md = orc.design_butter_lp(order, fc)
+    co, gain, r1 = orc.SosChain(z, p, mn, md, forme=forme).coefs()
+    dt = tg.C64 if cplx else tg.F32
+    x = rand(600000, cplx, 13) + np.float32(0.7)
+    one = tg.Sos(co, gain, dt, r1, forme=forme)
+    sh = tg.Sharded("sos", dt, N, devices=[0] * N, coefs=co, gain=gain, rii1=r1, forme=forme)
+    assert sh.halo == 0                                    # no halo: the exact scheme
+    ref, got = [], []
+    for lo, hi in calls(len(x), (0.00001, 0.3, 0.8)):       # (the first call has fewer samples than shards)
+        ref.append(one.step(x[lo:hi].copy()))
+        got.append(sh.step_host(x[lo:hi].copy()))
+    ref, got = np.concatenate(ref), np.concatenate(got)
+    # The float64 run of the chain arbitrates, with the band the reference's own float32 recursion holds against it: the
+    # states cross the shard (and call) boundaries as the reference's float (d1, d2) pairs, which round the slope of a
+    # narrow-band section -- as the reference does at every sample (2.7e-4 between the two groupings at fc = 1e-4, where
+    # the reference is at 6.5e-3)
+    oref = orc.SosChain(z, p, mn, md, forme=forme)
+    yref = oref.step(x)
+    if forme == 2:
+        v = oref.run_f64(x.real) + 1j * oref.run_f64(x.imag) if cplx else oref.run_f64(x)
+    else:
+        from scipy.signal import lfilter, lfiltic
+        v = x.astype(np.complex128 if cplx else np.float64)
+        for b0, b1, b2, a1, a2 in np.asarray(co, np.float32).astype(np.float64).reshape(-1, 5):
+            zi = lfiltic([b0, b1, b2], [1.0, a1, a2], y=[v[0], v[0]], x=[v[0], v[0]])
+            v, _ = lfilter([b0, b1, b2], [1.0, a1, a2], v, zi=zi.astype(v.dtype))
+        if r1 is not None:
+            q = np.asarray(r1, np.float32).astype(np.float64)
+            v = lfilter([q[0], q[1]], [1.0, q[2]], v)
+        else:
+            v = v * np.float64(np.float32(gain))
+    bande = max(2e-5, float(np.abs(yref - v).max() / np.abs(v).max()))
+    err = lambda a: float(np.abs(a - v[:len(a)]).max() / np.abs(v).max())
+    assert err(ref) <= bande and err(got) <= bande, (err(ref), err(got), bande)
+    # resident parts, the second one filtered in place
+    sh2 = tg.Sharded("sos", dt, 3, devices=[0, 0, 0], coefs=co, gain=gain, rii1=r1, forme=forme)
+    cuts = [0, 150000, 150007, 420000]
+    parts = [torch.from_numpy(x[a:b].copy()).to("cuda:0") for a, b in zip(cuts[:-1], cuts[1:])]
+    outs = [torch.empty_like(parts[0]), parts[1], torch.empty_like(parts[2])]
+    ys = sh2.step_parts(parts, outs)
+    y2 = np.concatenate([t.cpu().numpy() for t in ys])
+    tail = sh2.step_host(x[420000:].copy())                 # the stream goes on in the host form
+    full = np.concatenate([y2, tail])
+    assert err(full) <= bande, (err(full), bande)
+
+
 @pytest.mark.parametrize("N", [2, 3, 8])
 @pytest.mark.parametrize("cplx", [False, True])
 def test_fir_sharded_host_bit_exact(tg, orc, N, cplx):
