@@ -372,12 +372,16 @@ int fused_setup(tsdgpu_polyfir *p, const std::vector<float> &g, int NPH, int W, 
   p->NPH = NPH;
   p->W = W;
   p->HW = std::max(W - 1, 1);
-  const size_t hb = (size_t) p->HW * dtype_size(p->data_type);
-  if (hipMalloc((void **) &p->d_g, g.size() * sizeof(float)) != hipSuccess || hipMalloc(&p->d_hist[0], hb) != hipSuccess ||
-      hipMalloc(&p->d_hist[1], hb) != hipSuccess)
+  // ONE allocation -- the taps, then the two (zero) histories, 16-byte aligned -- and ONE upload of its host image (three
+  // allocations, a copy, two memsets and a synchronisation before: a third of a one-shot rééchan(x, 4))
+  const size_t hb = ((size_t) p->HW * dtype_size(p->data_type) + 15) / 16 * 16, gb = (g.size() * sizeof(float) + 15) / 16 * 16;
+  std::vector<char> image(gb + 2 * hb, 0);
+  std::memcpy(image.data(), g.data(), g.size() * sizeof(float));
+  if (hipMalloc((void **) &p->d_g, image.size()) != hipSuccess)
     return set_err(TSDGPU_ERR_HIP, "polyfir_create: hipMalloc failed: %s", hipGetErrorString(hipGetLastError()));
-  if (hipMemcpy(p->d_g, g.data(), g.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemset(p->d_hist[0], 0, hb) != hipSuccess || hipMemset(p->d_hist[1], 0, hb) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess)
+  p->d_hist[0] = (char *) p->d_g + gb;
+  p->d_hist[1] = (char *) p->d_g + gb + hb;
+  if (hipMemcpy(p->d_g, image.data(), image.size(), hipMemcpyHostToDevice) != hipSuccess)
     return set_err(TSDGPU_ERR_HIP, "polyfir_create: upload failed: %s", hipGetErrorString(hipGetLastError()));
   (void) hipFuncSetAttribute((const void *) polyfir_fused_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void) hipFuncSetAttribute((const void *) polyfir_fused_kernel<float2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -456,10 +460,14 @@ int tsdgpu_polyfir_create(tsdgpu_polyfir **out, int kind, int data_type, const f
       if (kind == TSDGPU_POLY_HALFBAND) c = ((i & 1) == 0 ? c : 0.f) + (i == ntaps / 2 ? 0.5f : 0.f);
       h[k] = c;
     }
-    tsdgpu_fir *f = nullptr;
-    rc = tsdgpu_fir_create(&f, data_type, TSDGPU_F32, h.data(), ntaps, TSDGPU_FIR_AUTO);
-    if (!rc) p->fir.push_back(f);
-    if (!rc) rc = fused_setup(p, h, 1, ntaps, R);
+    // (the composition -- a full-rate FIR, then the pick -- only where the fused kernel does not serve: building its
+    // handle costs a one-shot rééchan() 30 us per stage)
+    rc = fused_setup(p, h, 1, ntaps, R);
+    if (!rc && !p->fused) {
+      tsdgpu_fir *f = nullptr;
+      rc = tsdgpu_fir_create(&f, data_type, TSDGPU_F32, h.data(), ntaps, TSDGPU_FIR_AUTO);
+      if (!rc) p->fir.push_back(f);
+    }
   } else if (kind == TSDGPU_POLY_UPS) {
     // coefs = c * R, zero-padded to a multiple of R (polyphase.cc:259-270); phase i correlates
     // the K/R-sample window with coefs[(R-1-i) + j*R]
@@ -468,15 +476,14 @@ int tsdgpu_polyfir_create(tsdgpu_polyfir **out, int kind, int data_type, const f
     while (c.size() % (size_t) R) c.push_back(0.f);
     const int W = (int) c.size() / R;
     std::vector<float> gall;
-    for (int i = 0; i < R && !rc; i++) {
-      std::vector<float> g((size_t) W);
-      for (int k = 0; k < W; k++) g[k] = c[(size_t) (R - 1 - i) + (size_t) (W - 1 - k) * R];
+    for (int i = 0; i < R; i++)
+      for (int k = 0; k < W; k++) gall.push_back(c[(size_t) (R - 1 - i) + (size_t) (W - 1 - k) * R]);
+    rc = fused_setup(p, gall, R, W, 1);
+    for (int i = 0; i < R && !rc && !p->fused; i++) {      // the composition (R branch FIRs + interleave) only without the fused kernel
       tsdgpu_fir *f = nullptr;
-      rc = tsdgpu_fir_create(&f, data_type, TSDGPU_F32, g.data(), W, TSDGPU_FIR_AUTO);
+      rc = tsdgpu_fir_create(&f, data_type, TSDGPU_F32, gall.data() + (size_t) i * W, W, TSDGPU_FIR_AUTO);
       if (!rc) p->fir.push_back(f);
-      gall.insert(gall.end(), g.begin(), g.end());
     }
-    if (!rc) rc = fused_setup(p, gall, R, W, 1);
   }
   if (rc) {
     tsdgpu_polyfir_destroy(p);
@@ -584,9 +591,7 @@ int tsdgpu_polyfir_destroy(tsdgpu_polyfir *p)
 {
   if (!p) return TSDGPU_OK;
   for (auto *f : p->fir) tsdgpu_fir_destroy(f);
-  if (p->d_g) (void) hipFree(p->d_g);
-  for (void *h : p->d_hist)
-    if (h) (void) hipFree(h);
+  if (p->d_g) (void) hipFree(p->d_g);            // (the histories live in the same allocation)
   p->z.release();
   p->in_stage.release();
   p->out_stage.release();
