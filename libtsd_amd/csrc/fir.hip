@@ -349,16 +349,23 @@ int tsdgpu_fir_create(tsdgpu_fir **out, int data_type, int tap_type, const void 
   int rc = TSDGPU_OK;
   const size_t hbytes = (size_t) f->HL * dtype_size(data_type);
   do {
-    if (hipMalloc(&f->d_hrev, hrev.size()) != hipSuccess ||
-        hipMalloc(&f->hist[0], hbytes) != hipSuccess || hipMalloc(&f->hist[1], hbytes) != hipSuccess) {
-      rc = set_err(TSDGPU_ERR_HIP, "fir_create: hipMalloc failed: %s", hipGetErrorString(hipGetLastError()));
-      break;
+    // ONE allocation (the reversed taps, then the two zeroed histories, each on a 256-byte boundary) and ONE upload of its
+    // host image: what a one-shot filtrer() pays per call (three allocations, a copy, two memsets and a synchronisation before)
+    const size_t tb = (hrev.size() + 255) / 256 * 256, hb = (hbytes + 255) / 256 * 256;
+    {
+      std::vector<char> image(tb + 2 * hb, 0);
+      memcpy(image.data(), hrev.data(), hrev.size());
+      if (hipMalloc(&f->d_hrev, image.size()) != hipSuccess) {
+        rc = set_err(TSDGPU_ERR_HIP, "fir_create: hipMalloc failed: %s", hipGetErrorString(hipGetLastError()));
+        break;
+      }
+      if (hipMemcpy(f->d_hrev, image.data(), image.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        rc = set_err(TSDGPU_ERR_HIP, "fir_create: upload failed: %s", hipGetErrorString(hipGetLastError()));
+        break;
+      }
     }
-    if (hipMemcpy(f->d_hrev, hrev.data(), hrev.size(), hipMemcpyHostToDevice) != hipSuccess ||
-        hipMemset(f->hist[0], 0, hbytes) != hipSuccess || hipMemset(f->hist[1], 0, hbytes) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {   // (a device memset may return before it ran: settled here, steps may come on any stream)
-      rc = set_err(TSDGPU_ERR_HIP, "fir_create: upload failed: %s", hipGetErrorString(hipGetLastError()));
-      break;
-    }
+    f->hist[0] = (char *) f->d_hrev + tb;
+    f->hist[1] = (char *) f->d_hrev + tb + hb;
     if (ntaps > 12289) {
       // beyond the long-filter plan (and beyond what the direct kernel can stage in LDS): partitioned
       f->method = TSDGPU_FIR_OVERLAP_SAVE;
@@ -491,9 +498,7 @@ int tsdgpu_fir_destroy(tsdgpu_fir *f)
   for (tsdgpu_fir *c : f->parts) tsdgpu_fir_destroy(c);
   f->part_x.release();
   f->part_t.release();
-  if (f->d_hrev) (void) hipFree(f->d_hrev);
-  if (f->hist[0]) (void) hipFree(f->hist[0]);
-  if (f->hist[1]) (void) hipFree(f->hist[1]);
+  if (f->d_hrev) (void) hipFree(f->d_hrev);          // (the histories live in the same allocation)
   f->in_stage.release();
   f->out_stage.release();
   delete f;

@@ -729,16 +729,22 @@ int tsdgpu_resampler_create(tsdgpu_resampler **out, int data_type, float ratio, 
   r->ratio = ratio;
   r->inc = 1.f / ratio;                      // ra.cc:29
   const size_t lut_bytes = (size_t) (nphases + 1) * ((K + 3) / 4 * 4) * sizeof(float);
-  const size_t hb = (size_t) std::max(K - 1, 1) * dtype_size(data_type);
+  // ONE allocation (the table with its rows padded to 16 bytes, then the two window histories) and ONE upload of its host
+  // image: a one-shot rééchan() pays for every creation (three allocations, a memset, a strided copy, two memsets and a
+  // synchronisation before)
+  const size_t hb = ((size_t) std::max(K - 1, 1) * dtype_size(data_type) + 15) / 16 * 16, lb = (lut_bytes + 15) / 16 * 16;
   int rc = TSDGPU_OK;
-  if (hipMalloc((void **) &r->d_lut, lut_bytes) != hipSuccess || hipMalloc(&r->d_hist[0], hb) != hipSuccess ||
-      hipMalloc(&r->d_hist[1], hb) != hipSuccess)
+  std::vector<char> image(lb + 2 * hb, 0);
+  for (int c = 0; c <= nphases; c++)
+    std::memcpy(image.data() + (size_t) c * r->gl * sizeof(float), lut_host + (size_t) c * K, (size_t) K * sizeof(float));
+  if (hipMalloc((void **) &r->d_lut, image.size()) != hipSuccess)
     rc = set_err(TSDGPU_ERR_HIP, "resampler_create: hipMalloc failed: %s", hipGetErrorString(hipGetLastError()));
-  else if (hipMemset(r->d_lut, 0, lut_bytes) != hipSuccess ||
-           hipMemcpy2D(r->d_lut, (size_t) r->gl * sizeof(float), lut_host, (size_t) K * sizeof(float), (size_t) K * sizeof(float),
-                       (size_t) nphases + 1, hipMemcpyHostToDevice) != hipSuccess ||
-           hipMemset(r->d_hist[0], 0, hb) != hipSuccess || hipMemset(r->d_hist[1], 0, hb) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess)
+  else if (hipMemcpy(r->d_lut, image.data(), image.size(), hipMemcpyHostToDevice) != hipSuccess)
     rc = set_err(TSDGPU_ERR_HIP, "resampler_create: upload failed: %s", hipGetErrorString(hipGetLastError()));
+  if (!rc) {
+    r->d_hist[0] = (char *) r->d_lut + lb;
+    r->d_hist[1] = (char *) r->d_lut + lb + hb;
+  }
   if (rc) {
     tsdgpu_resampler_destroy(r);
     return rc;
@@ -948,9 +954,7 @@ int64_t tsdgpu_resampler_out_offset(const tsdgpu_resampler *r) { return r ? r->c
 int tsdgpu_resampler_destroy(tsdgpu_resampler *r)
 {
   if (!r) return TSDGPU_OK;
-  if (r->d_lut) (void) hipFree(r->d_lut);
-  if (r->d_hist[0]) (void) hipFree(r->d_hist[0]);
-  if (r->d_hist[1]) (void) hipFree(r->d_hist[1]);
+  if (r->d_lut) (void) hipFree(r->d_lut);            // (the window histories live in the same allocation)
   if (r->d_ck) (void) hipFree(r->d_ck);
   r->in_stage.release();
   r->out_stage.release();

@@ -752,17 +752,20 @@ int tsdgpu::sos_create_ex(tsdgpu_sos **out, int data_type, const float *coefs_ho
 
   int rc = TSDGPU_OK;
   do {
-    const size_t sb = std::max<size_t>(1, sec.size()) * sizeof(SosSection);
-    if (hipMalloc((void **) &s->d_sec, sb) != hipSuccess || hipMalloc((void **) &s->d_state[0], STATE_FLOATS * 4) != hipSuccess ||
-        hipMalloc((void **) &s->d_state[1], STATE_FLOATS * 4) != hipSuccess) {
+    // ONE allocation (the section tables, then the two zeroed state buffers) and ONE upload of its host image
+    const size_t sb = (std::max<size_t>(1, sec.size()) * sizeof(SosSection) + 15) / 16 * 16, stb = ((size_t) STATE_FLOATS * 4 + 15) / 16 * 16;
+    std::vector<char> image(sb + 2 * stb, 0);
+    if (!sec.empty()) std::memcpy(image.data(), sec.data(), sec.size() * sizeof(SosSection));
+    if (hipMalloc((void **) &s->d_sec, image.size()) != hipSuccess) {
       rc = set_err(TSDGPU_ERR_HIP, "sos_create: hipMalloc failed: %s", hipGetErrorString(hipGetLastError()));
       break;
     }
-    if ((!sec.empty() && hipMemcpy(s->d_sec, sec.data(), sec.size() * sizeof(SosSection), hipMemcpyHostToDevice) != hipSuccess) ||
-        hipMemset(s->d_state[0], 0, STATE_FLOATS * 4) != hipSuccess || hipMemset(s->d_state[1], 0, STATE_FLOATS * 4) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
+    if (hipMemcpy(s->d_sec, image.data(), image.size(), hipMemcpyHostToDevice) != hipSuccess) {
       rc = set_err(TSDGPU_ERR_HIP, "sos_create: upload failed: %s", hipGetErrorString(hipGetLastError()));
       break;
     }
+    s->d_state[0] = reinterpret_cast<float *>(reinterpret_cast<char *>(s->d_sec) + sb);
+    s->d_state[1] = reinterpret_cast<float *>(reinterpret_cast<char *>(s->d_sec) + sb + stb);
   } while (0);
   if (rc) {
     tsdgpu_sos_destroy(s);
@@ -1048,9 +1051,7 @@ extern "C" {
 int tsdgpu_sos_destroy(tsdgpu_sos *s)
 {
   if (!s) return TSDGPU_OK;
-  if (s->d_sec) (void) hipFree(s->d_sec);
-  if (s->d_state[0]) (void) hipFree(s->d_state[0]);
-  if (s->d_state[1]) (void) hipFree(s->d_state[1]);
+  if (s->d_sec) (void) hipFree(s->d_sec);           // (the state buffers live in the same allocation)
   s->in_stage.release();
   s->out_stage.release();
   s->carry.release();
