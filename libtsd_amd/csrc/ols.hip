@@ -335,38 +335,63 @@ int ols_plan_create(tsdgpu_fir *f)
     const float *t = (const float *) f->taps_host.data();
     for (int i = 0; i < K; i++) { hr[i] = t[2 * i]; hi[i] = t[2 * i + 1]; }
   }
-  std::vector<double> c(N), s(N);
-  const double PI = 3.14159265358979323846;
-  for (int i = 0; i < N; i++) { c[i] = std::cos(2 * PI * i / N); s[i] = -std::sin(2 * PI * i / N); }
-  std::vector<cpx> H(N), Hreg(N), tw1(N), tw2(N);
-  for (int k = 0; k < N; k++) {
-    double ar = 0, ai = 0;
-    for (int i = 0; i < K; i++) {
-      const int m = (int) (((int64_t) k * i) % N);
-      ar += hr[i] * c[m] - hi[i] * s[m];
-      ai += hr[i] * s[m] + hi[i] * c[m];
+  // a radix-2 transform in double (the plan of a one-shot filtrer() is built per call: the K x N sums of the definition
+  // took 100 us of its 185), the unit roots and the engine's twiddles made once per process, ONE upload
+  struct Tables {
+    std::vector<double> c, s;
+    std::vector<cpx> tw12;
+    Tables() : c(OLS_N / 2), s(OLS_N / 2), tw12(2 * OLS_N)
+    {
+      const double PI = 3.14159265358979323846;
+      for (int i = 0; i < OLS_N / 2; i++) { c[i] = std::cos(2 * PI * i / OLS_N); s[i] = -std::sin(2 * PI * i / OLS_N); }
+      fill_twiddles(tw12.data(), tw12.data() + OLS_N);
     }
-    H[k] = mk((float) (ar / N), (float) (ai / N));
+  };
+  static const Tables *tb = new Tables();
+  std::vector<double> ar(N, 0.0), ai(N, 0.0);
+  int logn = 0;
+  while ((1 << logn) < N) logn++;
+  for (int i = 0; i < K; i++) {                         // bit-reversed placement of the zero-padded taps
+    int rv = 0;
+    for (int b = 0; b < logn; b++) rv |= ((i >> b) & 1) << (logn - 1 - b);
+    ar[rv] = hr[i];
+    ai[rv] = hi[i];
   }
+  for (int len = 2; len <= N; len <<= 1) {
+    const int half = len / 2, step = N / len;
+    for (int base = 0; base < N; base += len)
+      for (int j = 0; j < half; j++) {
+        const double wr = tb->c[(size_t) j * step], wi = tb->s[(size_t) j * step];
+        const int a = base + j, b = a + half;
+        const double tr = ar[b] * wr - ai[b] * wi, ti = ar[b] * wi + ai[b] * wr;
+        ar[b] = ar[a] - tr; ai[b] = ai[a] - ti;
+        ar[a] += tr; ai[a] += ti;
+      }
+  }
+  std::vector<cpx> img(3 * (size_t) N);
   for (int lane = 0; lane < 64; lane++)
-    for (int r = 0; r < 16; r++) Hreg[r * 64 + lane] = H[freq_index(lane, r)];
-  fill_twiddles(tw1.data(), tw2.data());
+    for (int r = 0; r < 16; r++) {
+      const int k = freq_index(lane, r);
+      img[r * 64 + lane] = mk((float) (ar[k] / N), (float) (ai[k] / N));
+    }
+  std::copy(tb->tw12.begin(), tb->tw12.end(), img.begin() + N);
   const size_t bytes = (size_t) N * sizeof(cpx);
   if (hipMalloc(&f->d_H, 3 * bytes) != hipSuccess)
     return set_err(TSDGPU_ERR_HIP, "ols: hipMalloc failed: %s", hipGetErrorString(hipGetLastError()));
-  char *d = (char *) f->d_H;
-  if (hipMemcpy(d, Hreg.data(), bytes, hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(d + bytes, tw1.data(), bytes, hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemcpy(d + 2 * bytes, tw2.data(), bytes, hipMemcpyHostToDevice) != hipSuccess)
+  if (hipMemcpy(f->d_H, img.data(), 3 * bytes, hipMemcpyHostToDevice) != hipSuccess)
     return set_err(TSDGPU_ERR_HIP, "ols: upload failed: %s", hipGetErrorString(hipGetLastError()));
-  // persistent grid: as many waves as the device keeps resident
-  int dev = 0, cus = 256, per_cu = 8;
-  (void) hipGetDevice(&dev);
-  (void) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ols_kernel<false>, 64, 0) != hipSuccess || per_cu < 1) {
-    (void) hipGetLastError();
-    per_cu = 8;
-  }
+  // persistent grid: as many waves as the device keeps resident (asked once per process: the devices of a node are alike)
+  static const std::pair<int, int> occ = []() {
+    int dev = 0, cus = 256, per_cu = 8;
+    (void) hipGetDevice(&dev);
+    (void) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ols_kernel<false>, 64, 0) != hipSuccess || per_cu < 1) {
+      (void) hipGetLastError();
+      per_cu = 8;
+    }
+    return std::make_pair(cus, per_cu);
+  }();
+  const int cus = occ.first, per_cu = occ.second;
   f->ols_grid = cus * per_cu;
   if (const char *g = getenv("TSDGPU_OLS_WAVES_PER_CU")) f->ols_grid = cus * atoi(g);
   if (getenv("TSDGPU_DEBUG")) fprintf(stderr, "[tsdgpu] ols plan: N=%d K=%d L=%d cus=%d occupancy/CU=%d grid=%d\n", N, K, f->ols_L, cus, per_cu, f->ols_grid);
