@@ -26,6 +26,7 @@ struct tsdgpu_ola {
   tsdgpu::DevBuf frames, spectra, in_stage, out_stage;
   tsdgpu::cpx *d_fast = nullptr;           // fast path (Ne = 512, N = 1024, no window): response in register order / N + twiddles (3 x 1024)
   tsdgpu::cpx *d_svg_tmp = nullptr;        // Ne: the new tail, written by the last wave while the first one may still read d_svg
+  tsdgpu::cpx *d_bloc = nullptr;           // ONE allocation behind d_svg, d_svg_tmp, d_last, d_prev_half, d_rest
   tsdgpu::cpx *d_run = nullptr;            // any other geometry without window: response / N (N values), then W_N^i, i < N/16
 };
 
@@ -595,10 +596,18 @@ int tsdgpu_ola_create(tsdgpu_ola **out, int block_len, int min_zeros, const floa
   h->windowed = window != nullptr;
   h->cnt_ech = -(Ne / 2);
   int rc = tsdgpu_fft_create(&h->plan, h->N, 1);
-  if (!rc) rc = ola_alloc(&h->d_svg, Ne);
-  if (!rc) rc = ola_alloc(&h->d_last, Ne);
-  if (!rc) rc = ola_alloc(&h->d_prev_half, Ne / 2);
-  if (!rc) rc = ola_alloc(&h->d_rest, Ne);
+  if (!rc) {
+    // the carried vectors in ONE zeroed allocation (five allocations, five memsets and five synchronisations before)
+    const size_t q = ((size_t) Ne + 1) / 2 * 2;          // 16-byte slots
+    rc = ola_alloc(&h->d_bloc, 5 * q);
+    if (!rc) {
+      h->d_svg = h->d_bloc;
+      h->d_svg_tmp = h->d_bloc + q;
+      h->d_last = h->d_bloc + 2 * q;
+      h->d_rest = h->d_bloc + 3 * q;
+      h->d_prev_half = h->d_bloc + 4 * q;
+    }
+  }
   if (!rc && window) {
     if (hipMalloc((void **) &h->d_fen, Ne * sizeof(float)) != hipSuccess ||
         hipMemcpy(h->d_fen, window, Ne * sizeof(float), hipMemcpyDefault) != hipSuccess)
@@ -636,7 +645,6 @@ int tsdgpu_ola_set_response(tsdgpu_ola *h, const void *H)
     TSD_HIP(hipMemcpy(Hh.data(), h->d_H, 1024 * sizeof(cpx), hipMemcpyDeviceToHost));
     ola1024_tables(Hh.data(), t3.data());
     if (!h->d_fast) TSD_HIP(hipMalloc((void **) &h->d_fast, t3.size() * sizeof(cpx)));
-    if (!h->d_svg_tmp) TSD_HIP(hipMalloc((void **) &h->d_svg_tmp, 512 * sizeof(cpx)));
     TSD_HIP(hipMemcpy(h->d_fast, t3.data(), t3.size() * sizeof(cpx), hipMemcpyHostToDevice));
   }
   if (!unfused && !h->windowed && ola_run_fits(h->N, h->Ne)) {
@@ -652,7 +660,6 @@ int tsdgpu_ola_set_response(tsdgpu_ola *h, const void *H)
       tb[(size_t) N + i] = make_float2((float) std::cos(a), (float) std::sin(a));
     }
     if (!h->d_run) TSD_HIP(hipMalloc((void **) &h->d_run, tb.size() * sizeof(cpx)));
-    if (!h->d_svg_tmp) TSD_HIP(hipMalloc((void **) &h->d_svg_tmp, (size_t) h->Ne * sizeof(cpx)));
     TSD_HIP(hipMemcpy(h->d_run, tb.data(), tb.size() * sizeof(cpx), hipMemcpyHostToDevice));
   }
   return TSDGPU_OK;
@@ -1034,7 +1041,7 @@ int tsdgpu_ola_destroy(tsdgpu_ola *h)
 {
   if (!h) return TSDGPU_OK;
   if (h->plan) tsdgpu_fft_destroy(h->plan);
-  for (void *q : {(void *) h->d_fen, (void *) h->d_H, (void *) h->d_svg, (void *) h->d_last, (void *) h->d_prev_half, (void *) h->d_rest, (void *) h->d_fast, (void *) h->d_svg_tmp, (void *) h->d_run})
+  for (void *q : {(void *) h->d_fen, (void *) h->d_H, (void *) h->d_bloc, (void *) h->d_fast, (void *) h->d_run})
     if (q) (void) hipFree(q);
   h->frames.release();
   h->spectra.release();
