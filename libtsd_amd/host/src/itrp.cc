@@ -3,6 +3,10 @@
 // interpolators are libtsd's own objects and filtre_itrp probes them through coefs() (adaptors/gpu_ra.cc).
 #include "tsd/filtrage.hpp"
 
+#include <cstring>
+#include <mutex>
+#include <string>
+
 namespace tsd {
 namespace filtrage {
 
@@ -16,6 +20,24 @@ template <typename T> InterpolateurSinc<T>::InterpolateurSinc(const Interpolateu
   this->nom = detail::fmt("sinc - ncoefs={}, nphases={}, fcut={}, fen={}", nc, c.nphases, c.fcut, c.fenetre);
   this->nphases = c.nphases;
   auto &lut = this->lut;
+  // (a one-shot rééchan() designs this table at every call -- 33 us for the 256 x 15 table of filtre_reechan: the last few
+  // designs are kept, keyed by their parameters)
+  struct Memo {
+    std::mutex m;
+    std::vector<std::pair<std::string, std::vector<float>>> tables;
+  };
+  static Memo *memo = new Memo();
+  uint32_t fb;
+  std::memcpy(&fb, &c.fcut, sizeof fb);
+  const std::string clef = detail::fmt("{}/{}/{}/{}", nc, c.nphases, fb, c.fenetre);
+  {
+    std::lock_guard<std::mutex> g(memo->m);
+    for (const auto &e : memo->tables)
+      if (e.first == clef) {
+        lut = e.second;
+        return;
+      }
+  }
   lut.resize((size_t) (c.nphases + 1) * nc);
   const Vecf ls = linspace((float) (-nc / 2), (float) ((nc - 1) / 2), nc);
   for (entier j = 0; j <= c.nphases; j++) {
@@ -27,6 +49,9 @@ template <typename T> InterpolateurSinc<T>::InterpolateurSinc(const Interpolateu
       lut[(size_t) j * nc + i] = c.fenetre == "hn" ? hv * (0.5f + 2 * 0.25f * std::cos(t)) : hv;
     }
   }
+  std::lock_guard<std::mutex> g(memo->m);
+  if (memo->tables.size() >= 8) memo->tables.erase(memo->tables.begin());
+  memo->tables.emplace_back(clef, lut);
 }
 template <typename T> Vecf InterpolateurLut<T>::coefs(float τ)
 {
