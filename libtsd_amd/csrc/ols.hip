@@ -311,7 +311,9 @@ bool ols_preferred(const tsdgpu_fir *f)
   // K = 514 .. 12289: the long-filter plan (ols_long.hip, blocks of 4096..16384 on the Stockham engine;
   // measured crossover with the 1024-point wave blocks: K = 513 -> 0.313 ms here, 0.294 ms there)
   if (ols_long_supported(f)) return true;
-  if (f->data_type == TSDGPU_C64) return f->K >= 48 && f->K <= 513;
+  // (complex data, real taps, 2^26 samples, round 2: direct 0.186 / 0.192 / 0.234 ms at 16 / 48 / 64 taps against 0.219 ms
+  // overlap-save whatever the count: the crossover sits at ~57 taps)
+  if (f->data_type == TSDGPU_C64) return f->K >= (f->tap_type == TSDGPU_F32 ? 57 : 48) && f->K <= 513;
   return f->tap_type == TSDGPU_F32 && f->K >= 40 && f->K <= 513;
 }
 
