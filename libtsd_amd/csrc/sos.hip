@@ -502,6 +502,7 @@ struct tsdgpu_sos {
   // exact carry of the state from chunk to chunk (long-memory filters, see sos_kernel)
   int comps = 2;                // state values per section and channel in the carry: 2 (DF2 chain) or 4 (a DF1 section: + its last two inputs)
   std::vector<double> phi;      // one-step zero-input transition of the whole cascade, m x m, m = comps x nsec
+  std::vector<float> sg_host;   // per section: the sign of the scans' coordinates (SosSection::sg)
   DevBuf carry, scan_ws, scan_P;
   int64_t scan_L = 0;           // the chunk length (samples) scan_P was made for (< 0: no tables for that length)
 };
@@ -749,6 +750,7 @@ int tsdgpu::sos_create_ex(tsdgpu_sos **out, int data_type, const float *coefs_ho
   for (const SosSection &k : sec)
     if (k.df1 != 0.f) s->comps = 4;
   s->phi = cascade_transition(sec, s->comps);
+  for (const SosSection &k : sec) s->sg_host.push_back(k.sg);
 
   int rc = TSDGPU_OK;
   do {
@@ -1009,13 +1011,11 @@ bool sos_state_propagate(const tsdgpu_sos *s, int64_t L, const float *in, const 
   matpow(s->phi, m, std::max<int64_t>(L, 0), P);
   for (double v : P)
     if (!std::isfinite(v) || std::fabs(v) > 1e30) return false;
-  std::vector<SosSection> sec((size_t) ns);
-  if (hipMemcpy(sec.data(), s->d_sec, (size_t) ns * sizeof(SosSection), hipMemcpyDeviceToHost) != hipSuccess) return false;
   for (int ch = 0; ch < s->nch; ch++) {
     std::vector<double> v((size_t) m, 0.0), w((size_t) m, 0.0);
     for (int q = 0; q < ns; q++) {
       const float *r = in + state_index(q, ch);
-      const double sg = sec[q].sg;
+      const double sg = s->sg_host[(size_t) q];
       v[(size_t) q * comps] = r[0];
       v[(size_t) q * comps + 1] = (double) r[0] - sg * (double) r[1];
       if (comps == 4) { v[(size_t) q * comps + 2] = r[2]; v[(size_t) q * comps + 3] = r[3]; }
@@ -1028,7 +1028,7 @@ bool sos_state_propagate(const tsdgpu_sos *s, int64_t L, const float *in, const 
     if (add) {
       for (int q = 0; q < ns; q++) {
         const float *r = add + state_index(q, ch);
-        const double sg = sec[q].sg;
+        const double sg = s->sg_host[(size_t) q];
         w[(size_t) q * comps] += r[0];
         w[(size_t) q * comps + 1] += (double) r[0] - sg * (double) r[1];
         if (comps == 4) { w[(size_t) q * comps + 2] += r[2]; w[(size_t) q * comps + 3] += r[3]; }
@@ -1036,7 +1036,7 @@ bool sos_state_propagate(const tsdgpu_sos *s, int64_t L, const float *in, const 
     }
     for (int q = 0; q < ns; q++) {
       float *r = out + state_index(q, ch);
-      const double sg = sec[q].sg;
+      const double sg = s->sg_host[(size_t) q];
       r[0] = (float) w[(size_t) q * comps];
       r[1] = (float) (sg * (w[(size_t) q * comps] - w[(size_t) q * comps + 1]));
       if (comps == 4) { r[2] = (float) w[(size_t) q * comps + 2]; r[3] = (float) w[(size_t) q * comps + 3]; }
