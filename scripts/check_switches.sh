@@ -19,7 +19,7 @@ run TSDGPU_RFFT_TWO_PASS=1 tests/test_fft_gpu.py
 run TSDGPU_POLY_COMPOSED=1 tests/test_polyphase_gpu.py
 run TSDGPU_POLY_NO_ROWS=1 tests/test_polyphase_gpu.py tests/test_host_pipeline_gpu.py
 run TSDGPU_SOS_WIDE_WARMUP=1 tests/test_sos_gpu.py tests/test_sharded_gpu.py
-run TSDGPU_SOS_CHUNKS=16384 tests/test_sos_gpu.py
+run TSDGPU_SOS_CHUNKS=4096 tests/test_sos_gpu.py
 run TSDGPU_SHARD_SOS_HALO=1 tests/test_sharded_gpu.py -k "not long_memory"
 run TSDGPU_SOS_NO_EXACT_CARRY=1 tests/test_sos_gpu.py tests/test_sharded_gpu.py -k "not long_memory"
 # (the tests that assert WHICH path serves a filter, or its speed, are about the default choice)
