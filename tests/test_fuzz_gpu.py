@@ -244,6 +244,28 @@ def test_fuzz_ola(tg, orc, seed):
             assert np.abs(y - yr).max() <= TOL * max(np.abs(yr).max(), 1.0) * 4, (seed, Ne, nz, windowed, n)
 
 
+@pytest.mark.parametrize("seed", range(3 * SCALE))
+def test_fuzz_welch(tg, orc, seed):
+    """psd_welch sums: the fused kernels (powers of two from 16 to 16384: runs of segments per transform, partial groups at
+    the end of a call), the in-wave one (1024) and the framed-transform path (other sizes), on host and resident data"""
+    from oracle import ola_oracle as oo
+    import torch
+    rng = np.random.default_rng(9200 + seed)
+    N = int(rng.choice([2, 16, 32, 64, 100, 128, 256, 512, 1000, 1024, 2048, 4096, 8192, 16384]))
+    nseg = int(rng.choice([0, 1, 2, 3, 17, 64, 65, 200]))
+    n = max(0, nseg * (N // 2) + N + int(rng.integers(0, max(N // 2, 1)))) if nseg else int(rng.integers(0, N + 1))
+    n = min(n, 3_000_000)
+    x = rand(rng, n, True)
+    w = oo.fen_hann_periodique(N) if N > 2 else np.ones(N, np.float32)
+    ref, nref = oo.psd_welch_sum(x, N, w)
+    S, ns = tg.welch(x, N, w)
+    assert ns == nref, (seed, N, n)
+    assert np.abs(S - ref).max() <= TOL * max(float(ref.max()), 1e-30), (seed, N, n)
+    if n:
+        S2, _ = tg.welch(torch.from_numpy(x).cuda(), N, w)
+        assert np.abs(S2 - ref).max() <= TOL * max(float(ref.max()), 1e-30), (seed, N, n, "resident")
+
+
 @pytest.mark.parametrize("seed", range(4 * SCALE))
 def test_fuzz_rfft_and_correlations(tg, orc, seed):
     from oracle import ola_oracle as oo
