@@ -846,7 +846,8 @@ int tsdgpu_sos_step(tsdgpu_sos *s, const void *x, void *y, int64_t n, void *stre
       }
       // chunk length: enough chunks to fill the chip, but the warm-up never more than a quarter of the
       // chunk's work (a narrow step counts as a fifth of a sub-tile)
-      // (chunks of two sub-tiles at 2^26 samples: 0.1267 ms against 0.1317 with 4096 chunks of eight -- measured twice, interleaved)
+      // (with the quarter rule above: 8192 chunks of four sub-tiles at 2^26 samples, 0.1267 ms against 0.1317 with 4096 chunks of
+      // eight -- measured twice, interleaved)
       static const int64_t TARGET = getenv("TSDGPU_SOS_CHUNKS") ? atoll(getenv("TSDGPU_SOS_CHUNKS")) : 16384;
       const int64_t warm_cost = warm_sub + cdiv(warm_nar, 5);
       spc = std::max<int64_t>({2, 4 * warm_cost, warm_sub + 1, n_sub / TARGET});
