@@ -39,6 +39,9 @@ constexpr int SUB_FLOATS = 64 * LANE_FLOATS;      // floats per sub-tile (2048)
 constexpr int LDS_LANE_PITCH = LANE_FLOATS + 4;   // floats: + 4 pad -> conflict-free b128 both ways (36: 9 x 16 B, odd; 20: 5 x 16 B, odd)
 constexpr int LANE_QUADS = LANE_FLOATS / 4;
 
+#ifndef SOS_WARM_FACTOR               // a chunk is at least this many times its warm-up's cost long
+#define SOS_WARM_FACTOR 4
+#endif
 constexpr int NARROW_FLOATS = 4;      // floats per lane of a warm-up step (one 16-B load, no transposition)
 
 struct SosSection {
@@ -850,7 +853,7 @@ int tsdgpu_sos_step(tsdgpu_sos *s, const void *x, void *y, int64_t n, void *stre
       // eight -- measured twice, interleaved)
       static const int64_t TARGET = getenv("TSDGPU_SOS_CHUNKS") ? atoll(getenv("TSDGPU_SOS_CHUNKS")) : 16384;
       const int64_t warm_cost = warm_sub + cdiv(warm_nar, 5);
-      spc = std::max<int64_t>({2, 4 * warm_cost, warm_sub + 1, n_sub / TARGET});
+      spc = std::max<int64_t>({2, SOS_WARM_FACTOR * warm_cost, warm_sub + 1, n_sub / TARGET});
       // ... unless the call is short of filling the chip anyway: then the shortest chunks finish first (a wave alone takes
       // ~4 us per sub-tile: 4097 complex samples in one chunk of 4 sub-tiles cost 38 us)
       const int64_t spc_min = std::max<int64_t>(1, warm_sub + 1);
