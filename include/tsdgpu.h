@@ -208,6 +208,19 @@ int tsdgpu_sos_set_capturable(tsdgpu_sos *s, int on);   /* see tsdgpu_fir_set_ca
 /* number of warm-up samples a chunk needs before its first output for the carried state
  * to be exact to 2^-30 (multi-GPU halo size); -1 if the filter decays too slowly.       */
 int64_t tsdgpu_sos_halo(const tsdgpu_sos *s);
+/* The carried memories of the chain as a host vector of tsdgpu_sos_state_floats() floats: [0] = "the first sample has been
+ * seen" (the seed of filtre-rt.cc:361-365 is spent), then per (section, channel) the reference's (d1, d2) -- FormeDirecte1:
+ * (y1, y2, x1, x2) (:367-394).  What a process-per-GPU sharding of a cascade with a LONG memory exchanges instead of a
+ * warm-up halo (libtsd_amd/sharding.py, sos_step_exact): every rank but the first filters its chunk from zero memories
+ * (state {1, 0, 0 ...}), the end states are all-gathered, rank r starts again from
+ *     S_r = propagate(L_{r-1}, S_{r-1}, E_{r-1}),   S_1 = E_0
+ * tsdgpu_sos_propagate_state: state_out = (the state `state_in` after n_samples of zero input) + end_state (NULL: none),
+ * in double, host only; TSDGPU_ERR_UNSUPPORTED when the transition over n_samples leaves the float range.            */
+int tsdgpu_sos_state_floats(void);
+int tsdgpu_sos_get_state(tsdgpu_sos *s, float *state_host, void *stream);
+int tsdgpu_sos_set_state(tsdgpu_sos *s, const float *state_host, void *stream);
+int tsdgpu_sos_propagate_state(const tsdgpu_sos *s, int64_t n_samples, const float *state_in, const float *end_state,
+                               float *state_out);
 int tsdgpu_sos_destroy(tsdgpu_sos *s);
 
 /* --------------------------------------------------------------------------------------

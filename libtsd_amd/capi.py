@@ -55,6 +55,10 @@ def _declare(L):
     L.tsdgpu_fir_method_used.argtypes = [vp]
     L.tsdgpu_fir_destroy.argtypes = [vp]
     L.tsdgpu_sos_create.argtypes = [C.POINTER(vp), i32, vp, i32, fl, vp, i32]
+    L.tsdgpu_sos_state_floats.restype = i32
+    L.tsdgpu_sos_get_state.argtypes = [vp, vp, vp]
+    L.tsdgpu_sos_set_state.argtypes = [vp, vp, vp]
+    L.tsdgpu_sos_propagate_state.argtypes = [vp, i64, vp, vp, vp]
     L.tsdgpu_sos_step.argtypes = [vp, vp, vp, i64, vp]
     L.tsdgpu_sos_reset.argtypes = [vp]
     L.tsdgpu_sos_halo.argtypes = [vp]
@@ -415,6 +419,24 @@ class Sos:
 
     def reset(self):
         _check(lib().tsdgpu_sos_reset(self._h))
+
+    # the carried memories as a host vector (see tsdgpu_sos_get_state): what the exact sharding of sharding.py exchanges
+    def get_state(self, stream=None):
+        st = np.zeros(lib().tsdgpu_sos_state_floats(), np.float32)
+        _check(lib().tsdgpu_sos_get_state(self._h, st.ctypes.data, stream))
+        return st
+
+    def set_state(self, state, stream=None):
+        st = np.ascontiguousarray(state, dtype=np.float32)
+        assert st.size == lib().tsdgpu_sos_state_floats()
+        _check(lib().tsdgpu_sos_set_state(self._h, st.ctypes.data, stream))
+
+    def propagate_state(self, n_samples, state, end_state=None):
+        a = np.ascontiguousarray(state, dtype=np.float32)
+        e = None if end_state is None else np.ascontiguousarray(end_state, dtype=np.float32)
+        out = np.zeros_like(a)
+        _check(lib().tsdgpu_sos_propagate_state(self._h, int(n_samples), a.ctypes.data, None if e is None else e.ctypes.data, out.ctypes.data))
+        return out
 
     def close(self):
         if self._h:

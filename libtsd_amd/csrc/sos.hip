@@ -1053,6 +1053,26 @@ bool sos_state_propagate(const tsdgpu_sos *s, int64_t L, const float *in, const 
 
 extern "C" {
 
+int tsdgpu_sos_state_floats(void) { return tsdgpu::sos_state_floats(); }
+int tsdgpu_sos_get_state(tsdgpu_sos *s, float *state_host, void *stream)
+{
+  TSD_CHECK(s != nullptr && state_host != nullptr, "sos_get_state: NULL argument");
+  return tsdgpu::sos_state_get(s, state_host, (hipStream_t) stream);
+}
+int tsdgpu_sos_set_state(tsdgpu_sos *s, const float *state_host, void *stream)
+{
+  TSD_CHECK(s != nullptr && state_host != nullptr, "sos_set_state: NULL argument");
+  return tsdgpu::sos_state_set(s, state_host, (hipStream_t) stream);
+}
+int tsdgpu_sos_propagate_state(const tsdgpu_sos *s, int64_t n_samples, const float *state_in, const float *end_state, float *state_out)
+{
+  TSD_CHECK(s != nullptr && state_in != nullptr && state_out != nullptr && n_samples >= 0, "sos_propagate_state: bad argument");
+  if (!tsdgpu::sos_state_propagate(s, n_samples, state_in, end_state, state_out))
+    return set_err(TSDGPU_ERR_UNSUPPORTED, "sos_propagate_state: the transition over %lld samples leaves the float range", (long long) n_samples);
+  return TSDGPU_OK;
+}
+
+
 int tsdgpu_sos_destroy(tsdgpu_sos *s)
 {
   if (!s) return TSDGPU_OK;

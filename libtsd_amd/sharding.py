@@ -41,3 +41,42 @@ def max_over_ranks(value, device, world):
     t = torch.tensor([value], device="cpu" if dist.get_backend() == "gloo" else device, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def sos_step_exact(sos, x_chunk, chunk_len, rank, world, stream_state=None, group=None):
+    """One call of a cascade whose memory is too long for a warm-up halo (tsdgpu_sos_halo < 0, or longer than a
+    chunk is worth), one rank per chunk: the path's one real exchange step, so ONE small collective.
+
+    Every rank but the first filters its chunk from zero memories; the end states E_r (a few floats per section,
+    Sos.get_state) are ALL-GATHERED together with the chunk lengths; rank r > 0 rebuilds its true start state
+    S_r = propagate(L_{r-1}, S_{r-1}, E_{r-1}) with S_1 = E_0 (Sos.propagate_state: the cascade's transition matrix
+    over a chunk, in double, on the host) and filters its chunk again.  `stream_state`: the state of the stream before
+    this call (rank 0 uses it; None = a fresh stream).  Returns (y_chunk, state of the stream after the call) -- the
+    latter on every rank, for the next call's rank 0."""
+    import numpy as np
+    nf = sos.get_state().size
+    zero = np.zeros(nf, np.float32)
+    zero[0] = 1.0                      # zero memories, first-sample seed spent
+    fresh = np.zeros(nf, np.float32)
+    sos.set_state((fresh if stream_state is None else stream_state) if rank == 0 else zero)
+    if chunk_len > 0:
+        y, end = sos.step(x_chunk), sos.get_state()
+    else:                              # an empty chunk leaves the stream where it was (rank 0) / adds nothing (the others)
+        y = x_chunk
+        end = (fresh if stream_state is None else np.asarray(stream_state, np.float32)) if rank == 0 else np.zeros(nf, np.float32)
+    mine = np.concatenate([end, np.array([float(chunk_len)], np.float32)]).astype(np.float32)
+    if world == 1:
+        return y, mine[:nf]
+    on_dev = dist.get_backend(group) != "gloo"
+    dev = x_chunk.device if (on_dev and hasattr(x_chunk, "device")) else "cpu"
+    t_mine = torch.from_numpy(mine).to(dev)
+    parts = [torch.empty_like(t_mine) for _ in range(world)]
+    dist.all_gather(parts, t_mine, group=group)          # RCCL on the GPU node, gloo in the rehearsals
+    parts = [p.cpu().numpy() for p in parts]
+    cur = parts[0][:nf]                                   # E_0: the true state after rank 0's chunk
+    for q in range(1, world):
+        if q == rank and chunk_len > 0:
+            sos.set_state(cur)
+            y = sos.step(x_chunk)
+        cur = sos.propagate_state(int(parts[q][nf]), cur, parts[q][:nf])
+    return y, cur

@@ -69,6 +69,26 @@ def main():
         if np.abs(ref - got).max() > 1e-6 * np.abs(ref).max():
             fails.append(f"SOS: {np.abs(ref - got).max()} (peak {np.abs(ref).max()})")
 
+    # ---- SOS with a long memory (first-order low-pass at fc = 1e-5: 5e5 samples; order 3 at 1e-4): no halo can warm it
+    #      up -- exact exchange of the end states (ONE all_gather), two calls in a row (the stream state carried between)
+    from oracle import pyoracle as orc
+    for order, fc, tol in ((1, 1e-5, 2e-5), (3, 1e-4, 2e-3)):
+        z, p, mn, md = orc.design_butter_lp(order, fc)
+        co, gain, r1 = orc.SosChain(z, p, mn, md).coefs()
+        f = t.Sos(co, gain, t.F32, r1)
+        xo = xr + np.float32(0.5)
+        got, etat = [], None
+        for a, b in ((0, 250001), (250001, n)):
+            lo2, hi2 = sharding.chunk_bounds(b - a, rank, world)
+            xc = torch.from_numpy(xo[a + lo2:a + hi2].copy()).to(dev)
+            yc, etat = sharding.sos_step_exact(f, xc, hi2 - lo2, rank, world, etat)
+            got.append(gather(yc))
+        if rank == 0:
+            got = np.concatenate(got)
+            ref = t.Sos(co, gain, t.F32, r1).step(torch.from_numpy(xo).to(dev)).cpu().numpy()
+            if np.abs(ref - got).max() > tol * np.abs(ref).max():
+                fails.append(f"SOS exact (order {order}, fc {fc}): {np.abs(ref - got).max() / np.abs(ref).max()}")
+
     # ---- resampler 160/147: seek to the chunk's stream position with the 14-sample window (bit-exact)
     ratio = np.float32(160.0) / np.float32(147.0)
     r = t.Resampler(ratio, t.C64)
