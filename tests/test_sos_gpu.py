@@ -366,3 +366,36 @@ def test_exponential_smoother_and_dc_blocker_long_memory(tg, orc, cplx):
         ms = (time.perf_counter() - t0) / 5 * 1e3
         print("lexp / dc", nu, cplx, "path", g.path, "ms per 2^21 samples", round(ms, 3))
         assert ms < 0.5, ms
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("order,fc,forme", [(12, 0.25, 2), (3, 1e-3, 1), (1, 1e-5, 2)])
+def test_sos_state_vector_and_propagation(tg, orc, cplx, order, fc, forme):
+    """tsdgpu_sos_get_state / set_state / propagate_state: the stream cut in two; the second half filtered from zero
+    memories plus the first half's state propagated over its length (in double, on the host) = the second half filtered
+    from that state = the whole stream in one handle.  (What the exact sharding exchanges.)"""
+    z, p, mn, md = orc.design_butter_lp(order, fc)
+    co, gain, r1 = orc.SosChain(z, p, mn, md, forme=forme).coefs()
+    dt = tg.C64 if cplx else tg.F32
+    x = rand(100000, cplx, 21) + np.float32(0.3)
+    whole = tg.Sos(co, gain, dt, r1, forme=forme).step(x)
+    a = tg.Sos(co, gain, dt, r1, forme=forme)
+    ya = a.step(x[:40000].copy())
+    st = a.get_state()
+    assert st[0] == 1.0 and st.size == tg.lib().tsdgpu_sos_state_floats()
+    b = tg.Sos(co, gain, dt, r1, forme=forme)
+    b.set_state(st)
+    yb = b.step(x[40000:].copy())
+    y = np.concatenate([ya, yb])
+    assert relerr(y, whole) <= 1e-5                       # the state vector IS the stream state (tilings shift: rounding)
+    # end state of the second half two ways: from the carried state, and zero-state run + propagation
+    zero = np.zeros_like(st)
+    zero[0] = 1.0
+    c = tg.Sos(co, gain, dt, r1, forme=forme)
+    c.set_state(zero)
+    c.step(x[40000:].copy())
+    via = c.propagate_state(60000, st, c.get_state())
+    direct = b.get_state()
+    scale = max(float(np.abs(direct[1:]).max()), 1e-6)
+    assert np.abs(via[1:] - direct[1:]).max() <= 5e-5 * scale, np.abs(via[1:] - direct[1:]).max() / scale
+    assert np.array_equal(a.propagate_state(0, st), st)   # zero samples: the identity
