@@ -210,7 +210,8 @@ int tsdgpu_sos_set_capturable(tsdgpu_sos *s, int on);   /* see tsdgpu_fir_set_ca
 int64_t tsdgpu_sos_halo(const tsdgpu_sos *s);
 /* The carried memories of the chain as a host vector of tsdgpu_sos_state_floats() floats: [0] = "the first sample has been
  * seen" (the seed of filtre-rt.cc:361-365 is spent), then per (section, channel) the reference's (d1, d2) -- FormeDirecte1:
- * (y1, y2, x1, x2) (:367-394).  What a process-per-GPU sharding of a cascade with a LONG memory exchanges instead of a
+ * (y1, y2, x1, x2) (:367-394); records are four floats wide, index 1 + (section * 2 + channel) * 4, and the slots a chain
+ * does not use (the second channel of real data, the last two of a FormeDirecte2 section) are unspecified.  What a process-per-GPU sharding of a cascade with a LONG memory exchanges instead of a
  * warm-up halo (libtsd_amd/sharding.py, sos_step_exact): every rank but the first filters its chunk from zero memories
  * (state {1, 0, 0 ...}), the end states are all-gathered, rank r starts again from
  *     S_r = propagate(L_{r-1}, S_{r-1}, E_{r-1}),   S_1 = E_0
