@@ -45,38 +45,50 @@ def max_over_ranks(value, device, world):
 
 def sos_step_exact(sos, x_chunk, chunk_len, rank, world, stream_state=None, group=None):
     """One call of a cascade whose memory is too long for a warm-up halo (tsdgpu_sos_halo < 0, or longer than a
-    chunk is worth), one rank per chunk: the path's one real exchange step, so ONE small collective.
+    chunk is worth), one rank per chunk: the path's one real exchange step, so the one place with a collective.
 
-    Every rank but the first filters its chunk from zero memories; the end states E_r (a few floats per section,
-    Sos.get_state) are ALL-GATHERED together with the chunk lengths; rank r > 0 rebuilds its true start state
-    S_r = propagate(L_{r-1}, S_{r-1}, E_{r-1}) with S_1 = E_0 (Sos.propagate_state: the cascade's transition matrix
-    over a chunk, in double, on the host) and filters its chunk again.  `stream_state`: the state of the stream before
-    this call (rank 0 uses it; None = a fresh stream).  Returns (y_chunk, state of the stream after the call) -- the
-    latter on every rank, for the next call's rank 0."""
+    The first rank WITH samples filters its chunk from the stream's state, every later one from zero memories; the
+    end states E_r (a few floats per section, Sos.get_state) are ALL-GATHERED; rank r rebuilds its true start state
+    S_r = propagate(L_{r-1}, S_{r-1}, E_{r-1}), S_{first+1} = E_first (Sos.propagate_state: the cascade's transition
+    matrix over a chunk, in double, on the host) and filters its chunk again.  `stream_state`: the state of the stream
+    before this call (None = a fresh stream: the first sample seeds the sections).  Returns (y_chunk, state of the
+    stream after the call) -- the latter on every rank, for the next call."""
     import numpy as np
     nf = sos.get_state().size
-    zero = np.zeros(nf, np.float32)
-    zero[0] = 1.0                      # zero memories, first-sample seed spent
     fresh = np.zeros(nf, np.float32)
-    sos.set_state((fresh if stream_state is None else stream_state) if rank == 0 else zero)
-    if chunk_len > 0:
-        y, end = sos.step(x_chunk), sos.get_state()
-    else:                              # an empty chunk leaves the stream where it was (rank 0) / adds nothing (the others)
-        y = x_chunk
-        end = (fresh if stream_state is None else np.asarray(stream_state, np.float32)) if rank == 0 else np.zeros(nf, np.float32)
-    mine = np.concatenate([end, np.array([float(chunk_len)], np.float32)]).astype(np.float32)
+    before = fresh if stream_state is None else np.asarray(stream_state, np.float32)
     if world == 1:
-        return y, mine[:nf]
+        if chunk_len <= 0:
+            return x_chunk, before
+        sos.set_state(before)
+        return sos.step(x_chunk), sos.get_state()
     on_dev = dist.get_backend(group) != "gloo"
     dev = x_chunk.device if (on_dev and hasattr(x_chunk, "device")) else "cpu"
-    t_mine = torch.from_numpy(mine).to(dev)
-    parts = [torch.empty_like(t_mine) for _ in range(world)]
-    dist.all_gather(parts, t_mine, group=group)          # RCCL on the GPU node, gloo in the rehearsals
-    parts = [p.cpu().numpy() for p in parts]
-    cur = parts[0][:nf]                                   # E_0: the true state after rank 0's chunk
-    for q in range(1, world):
-        if q == rank and chunk_len > 0:
+
+    def all_gather(vec):
+        t_mine = torch.from_numpy(np.asarray(vec, np.float32)).to(dev)
+        parts = [torch.empty_like(t_mine) for _ in range(world)]
+        dist.all_gather(parts, t_mine, group=group)          # RCCL on the GPU node, gloo in the rehearsals
+        return [p.cpu().numpy() for p in parts]
+
+    lens = [int(v[0]) for v in all_gather([float(chunk_len)])]
+    with_samples = [q for q in range(world) if lens[q] > 0]
+    if not with_samples:
+        return x_chunk, before
+    first = with_samples[0]
+    zero = np.zeros(nf, np.float32)
+    zero[0] = 1.0                      # zero memories, first-sample seed spent
+    y, end = x_chunk, np.zeros(nf, np.float32)
+    if chunk_len > 0:
+        sos.set_state(before if rank == first else zero)
+        y, end = sos.step(x_chunk), sos.get_state()
+    ends = all_gather(end)
+    cur = ends[first]                  # the true state after the first chunk
+    for q in range(first + 1, world):
+        if lens[q] <= 0:
+            continue
+        if q == rank:
             sos.set_state(cur)
             y = sos.step(x_chunk)
-        cur = sos.propagate_state(int(parts[q][nf]), cur, parts[q][:nf])
+        cur = sos.propagate_state(lens[q], cur, ends[q])
     return y, cur

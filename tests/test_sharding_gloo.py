@@ -91,3 +91,76 @@ def test_sharded_fir_resampler_sos_match_single_process(orc, world):
     z, p, mn, md = orc.design_butter_lp(12, 0.25)
     ysref = orc.SosChain(z, p, mn, md).step(x.real.copy())
     assert np.abs(np.concatenate([r[4] for r in res]) - ysref).max() <= 1e-6 * np.abs(ysref).max()
+
+
+# ---- exact sharding of a long-memory cascade: the all_gather orchestration of sharding.sos_step_exact, on CPU --------
+class _ToySos:
+    """The state-vector interface of capi.Sos (get_state / set_state / propagate_state / step) on a first-order smoother
+    y[n] = a y[n-1] + (1 - a) x[n] in float64 -- stands in for the HIP cascade so that the exchange runs without a GPU."""
+
+    def __init__(self, a):
+        self.a, self.st = float(a), np.zeros(2, np.float32)        # [flag, y1]
+
+    def get_state(self):
+        return self.st.copy()
+
+    def set_state(self, s):
+        self.st = np.asarray(s, np.float32).copy()
+
+    def propagate_state(self, n, state, end_state=None):
+        out = np.array([max(state[0], 0.0 if end_state is None else end_state[0]), state[1] * self.a ** int(n)], np.float64)
+        if end_state is not None:
+            out[1] += end_state[1]
+        return out.astype(np.float32)
+
+    def step(self, x):
+        x = np.asarray(x, np.float64)
+        y = np.empty_like(x)
+        prev = float(self.st[1]) if self.st[0] else float(x[0])      # first-sample seed, like SOIS
+        for i, v in enumerate(x):
+            prev = self.a * prev + (1.0 - self.a) * v
+            y[i] = prev
+        self.st = np.array([1.0, prev], np.float32)
+        return y
+
+
+def _worker_exact(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from libtsd_amd import sharding
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal(20011) + 0.5
+    a = 1.0 - 1e-4
+    f, etat, outs = _ToySos(a), None, []
+    for lo, hi in ((0, 3), (3, 9000), (9000, 20011)):          # the first call has fewer samples than ranks
+        l2, h2 = sharding.chunk_bounds(hi - lo, rank, world)
+        y, etat = sharding.sos_step_exact(f, x[lo + l2:lo + h2], h2 - l2, rank, world, etat)
+        parts = [None] * world
+        dist.gather_object(np.asarray(y, np.float64)[:h2 - l2], parts if rank == 0 else None, dst=0)
+        if rank == 0:
+            outs.append(np.concatenate(parts))
+    if rank == 0:
+        ref = _ToySos(a).step(x)
+        got = np.concatenate(outs)
+        q.put(float(np.abs(got - ref).max() / np.abs(ref).max()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sos_exact_exchange_on_gloo(world):
+    """sharding.sos_step_exact -- zero-state pass, ONE all_gather of the end states and chunk lengths, start states by
+    propagation, second pass, stream state handed to the next call -- with a stub cascade, `world` CPU ranks, three
+    calls (one of them shorter than the number of ranks)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29650 + world
+    procs = [ctx.Process(target=_worker_exact, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+    assert all(p.exitcode == 0 for p in procs)
+    err = q.get(timeout=5)
+    assert err <= 1e-6, err              # (the stub keeps its state in float32 between passes)
