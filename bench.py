@@ -6,9 +6,10 @@ stream, with the dominant kernel's HBM GB/s against the 8 TB/s roofline.
 
 A "step" is one pass of the FIR (filtre_rif semantics, C ABI tsdgpu_fir_step) over one
 2^26-sample Veccf batch already resident in HBM.  With N GPUs the stream is sharded by
-contiguous chunk (weak scaling: 2^26 samples per GPU); before every step each rank receives
-its K-1-sample halo from its left neighbour over RCCL (torch.distributed send/recv) and
-installs it as the filter history -- the only exchange the path needs.
+contiguous chunk (weak scaling: 2^26 samples per GPU); every step posts the exchange of the
+K-1-sample halo with the left neighbour over RCCL (torch.distributed send/recv), launches the
+halo-free interior of the chunk at once and the K-1 edge outputs once the halo has arrived --
+the only exchange the path needs, off the step's critical path.
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -89,8 +90,8 @@ def _time_cpu(fn, units_per_call, unit, what, seconds_target=12.0):
 
 
 # ---------------------------------------------------------------------------------------
-# Workloads.  Each provides: exchange() (the per-step neighbour exchange, if any), step(),
-# units per step per GPU, algorithmic bytes per step per GPU, and a CPU leg on the oracle.
+# Workloads.  Each provides: step() (N > 1: the neighbour exchange is posted inside it, before the
+# halo-free interior is launched), units per step per GPU, algorithmic bytes per step per GPU, and a CPU leg on the oracle.
 # ---------------------------------------------------------------------------------------
 class FirWorkload:
     """configs[1]: 127-tap FIR on 2^26 cfloat per GPU; halo = K-1 samples from the left rank."""
@@ -106,7 +107,14 @@ class FirWorkload:
         self.halo_out = torch.view_as_real(self.x[self.n - (K_TAPS - 1):].clone())
         self.halo_in_c = torch.zeros(K_TAPS - 1, dtype=self.x.dtype, device=dev)
         self.halo_in = torch.view_as_real(self.halo_in_c)
-        self.f = t.Fir(self.h, t.C64, t.FIR_AUTO if method is None else method)
+        self.dist = world > 1 or args.force_dist
+        if self.dist:
+            # one rank per chunk: interior launched before the halo arrives, edge after (sharding.OverlappedFir)
+            from libtsd_amd import sharding
+            self.ov = sharding.OverlappedFir(t, self.h, t.C64, method)
+            self.f = self.ov.main
+        else:
+            self.f = t.Fir(self.h, t.C64, t.FIR_AUTO if method is None else method)
         self.method = {t.FIR_DIRECT: "direct", t.FIR_OVERLAP_SAVE: "overlap-save"}[self.f.method]
         self.units = float(self.n)
         self.alg_bytes = 16.0 * self.n            # 8 B read + 8 B written per complex sample
@@ -115,18 +123,18 @@ class FirWorkload:
         self.config = {"workload": "configs[1]: 127-tap FIR (design_rif_fen lp 0.02, real taps via filtrer()) "
                                    "on 2^%d-sample Veccf per GPU, inputs resident in HBM" % args.log2n,
                        "method": self.method, "samples_per_gpu": self.n,
-                       "sharding": "contiguous chunks, K-1 halo via RCCL send/recv" if world > 1 else "single GPU"}
-        self.traffic_ok = self.method == "overlap-save" and args.log2n == LOG2N     # the shape the PMC passes were run on
-
-    def exchange(self):
-        if self.world == 1:
-            return                    # one GPU: no neighbour; the handle streams on from its own history
-        from libtsd_amd import sharding
-        sharding.exchange_left_halo(self.halo_out, self.halo_in, self.rank, self.world)
-        self.f.set_history(self.halo_in_c)
+                       "sharding": "contiguous chunks, K-1 halo via RCCL send/recv posted before the interior launch, "
+                                   "edge (first K-1 outputs) launched behind it" if self.dist else "single GPU"}
+        self.ring = args.force_dist and world == 1
+        self.traffic_ok = self.method == "overlap-save" and args.log2n == LOG2N and not self.dist     # the shape the PMC passes were run on
 
     def step(self):
-        self.f.step(self.x, self.y)   # launched on torch's current stream (passed through the C ABI)
+        if not self.dist:
+            self.f.step(self.x, self.y)   # one GPU: no neighbour; launched on torch's current stream (passed through the C ABI)
+            return
+        from libtsd_amd import sharding
+        ex = sharding.start_halo_exchange(self.halo_out, self.halo_in, self.rank, self.world, ring=self.ring, result=self.halo_in_c)
+        self.ov.step(self.x, self.y, ex, first=(self.rank == 0 and not self.ring))
 
     def cpu_baseline(self):
         from oracle import pyoracle as orc
@@ -174,9 +182,6 @@ class FftWorkload:
                        "sharding": "batch index split, no exchange" if world > 1 else "single GPU"}
         self.traffic_ok = self.batch == 256
 
-    def exchange(self):
-        pass
-
     def step(self):
         self.p.step(self.x, True, self.y)
 
@@ -202,30 +207,33 @@ class SosWorkload:
         g = torch.Generator(device=dev).manual_seed(4 + rank)
         self.x = torch.randn(self.n, device=dev, generator=g)
         self.y = torch.empty_like(self.x)
-        self.f = t.Sos(self.co, 1.0, t.F32)
+        self.dist = world > 1 or args.force_dist
+        self.ring = args.force_dist and world == 1
+        if self.dist:
+            from libtsd_amd import sharding
+            self.ov = sharding.OverlappedSos(t, self.co, 1.0, t.F32)
+            self.f = self.ov.main
+        else:
+            self.f = t.Sos(self.co, 1.0, t.F32)
         self.halo = int(self.f.halo)
         self.halo_out = self.x[self.n - self.halo:].clone()
         self.halo_in = torch.zeros(self.halo, dtype=self.x.dtype, device=dev)
-        self.scratch = torch.empty_like(self.halo_in)
         self.units = float(self.n)
         self.alg_bytes = 8.0 * self.n
         self.metric = "Msamples/s, 6-section SOS IIR on 2^%d float stream" % args.log2n
         self.dtype = "f32"
         self.config = {"workload": "configs[3]: 6 DF2 biquads (Butterworth order 12, fc 0.25) on 2^%d-sample Vecf per GPU" % args.log2n,
                        "halo_samples": self.halo,
-                       "sharding": "contiguous chunks, warm-up halo via RCCL send/recv" if world > 1 else "single GPU"}
-        self.traffic_ok = args.log2n == LOG2N
-
-    def exchange(self):
-        from libtsd_amd import sharding
-        if self.world > 1:
-            sharding.exchange_left_halo(self.halo_out, self.halo_in, self.rank, self.world)
-            self.f.reset()
-            if self.rank > 0:
-                self.f.step(self.halo_in, self.scratch)
+                       "sharding": "contiguous chunks, warm-up halo via RCCL send/recv posted before the interior launch" if self.dist else "single GPU"}
+        self.traffic_ok = args.log2n == LOG2N and not self.dist
 
     def step(self):
-        self.f.step(self.x, self.y)
+        if not self.dist:
+            self.f.step(self.x, self.y)
+            return
+        from libtsd_amd import sharding
+        ex = sharding.start_halo_exchange(self.halo_out, self.halo_in, self.rank, self.world, ring=self.ring)
+        self.ov.step(self.x, self.y, ex, first=(self.rank == 0 and not self.ring))
 
     def cpu_baseline(self):
         from oracle import pyoracle as orc
@@ -245,7 +253,11 @@ class ResampleWorkload:
     def __init__(self, t, torch, dev, rank, world, args):
         self.rank, self.world = rank, world
         self.n = 1 << 27
-        self.r = t.Resampler(np.float32(160.0) / np.float32(147.0), t.C64)
+        from libtsd_amd import sharding
+        self.dist = world > 1 or args.force_dist
+        self.ring = args.force_dist and world == 1
+        self.ov = sharding.OverlappedResampler(t, np.float32(160.0) / np.float32(147.0), t.C64) if self.dist else None
+        self.r = self.ov.main if self.dist else t.Resampler(np.float32(160.0) / np.float32(147.0), t.C64)
         g = torch.Generator(device=dev).manual_seed(5 + rank)
         self.x = torch.view_as_complex(torch.randn(self.n, 2, device=dev, generator=g))
         self.pos = rank * self.n
@@ -261,17 +273,18 @@ class ResampleWorkload:
         self.dtype = "f32 (complex64 data, f32 LUT taps)"
         self.config = {"workload": "configs[4]: filtre_reechan(160/147) interpolator on a 2^27-sample Veccf shard per GPU "
                                    "(2^30 over 8 GPUs)", "outputs_per_gpu": self.nout,
-                       "sharding": "contiguous input chunks, 14-sample halo via RCCL send/recv + seek" if world > 1 else "single GPU"}
-        self.traffic_ok = True
-
-    def exchange(self):
-        from libtsd_amd import sharding
-        sharding.exchange_left_halo(self.halo_out, self.halo_in, self.rank, self.world)
-        # (also at N = 1: every step resamples the same 2^27-sample shard from stream position `pos`)
-        self.r.seek(self.pos, self.halo_in_c if self.rank > 0 else None)
+                       "sharding": "contiguous input chunks, 14-sample halo via RCCL send/recv posted before the interior launch + seek" if self.dist else "single GPU"}
+        self.traffic_ok = not self.dist
 
     def step(self):
-        self.r.step(self.x, self.y)
+        if not self.dist:
+            # every step resamples the same 2^27-sample shard from stream position `pos`
+            self.r.seek(self.pos, None)
+            self.r.step(self.x, self.y)
+            return
+        from libtsd_amd import sharding
+        ex = sharding.start_halo_exchange(self.halo_out, self.halo_in, self.rank, self.world, ring=self.ring, result=self.halo_in_c)
+        self.ov.step(self.x, self.y, self.pos, ex, first=(self.rank == 0 and not self.ring))
 
     def cpu_baseline(self):
         from oracle import pyoracle as orc
@@ -294,6 +307,10 @@ def main():
     ap.add_argument("--log2n", type=int, default=LOG2N, help="fir/sos: samples per GPU = 2^log2n (default: the BASELINE size)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     args = ap.parse_args()
+    # TSDGPU_BENCH_FORCE_DIST=1: `--gpus 1` also goes through init_process_group(backend) and the multi-rank step (the halo
+    # exchange becomes a self send / receive: a circular stream) -- how ONE GPU exercises the RCCL calls of the N > 1 path.
+    # A diagnostic mode: the headline line is the default one.
+    args.force_dist = os.environ.get("TSDGPU_BENCH_FORCE_DIST", "0") not in ("", "0")
 
     import torch
     import torch.distributed as dist
@@ -303,7 +320,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 or args.gpus > 1:
+    backend = None
+    if world > 1 or args.gpus > 1 or args.force_dist:
         assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus}"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -323,8 +341,10 @@ def main():
 
     w = WORKLOADS[args.workload](t, torch, dev, rank, world, args)
 
+    in_dist = dist.is_initialized()
+
     def barrier():
-        if world > 1:
+        if in_dist:
             dist.barrier()
 
     def run(wl, steps, warmup):
@@ -333,22 +353,19 @@ def main():
         barrier packet between two launches (measured: ~6 us per step on the 0.22 ms FIR step), which belongs
         to the measurement, not to the path."""
         for _ in range(warmup):
-            wl.exchange()
             wl.step()
         barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
-            wl.exchange()
-            wl.step()
+            wl.step()         # (N > 1: posts the halo exchange, launches the interior, waits for the halo, launches the edge)
         torch.cuda.synchronize()
         barrier()
         dt = time.perf_counter() - t0
-        dt = sharding.max_over_ranks(dt, dev, world)
+        dt = sharding.max_over_ranks(dt, dev, world, force=in_dist)
         # kernel duration: the same steps again, every launch bracketed by events on its stream
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
         for i in range(steps):
-            wl.exchange()
             evs[i][0].record()
             wl.step()
             evs[i][1].record()
@@ -363,8 +380,7 @@ def main():
     # timed steps below are unchanged.
     PRE_WARM = 150 if args.workload in ("fir", "sos") else 20
     for _ in range(PRE_WARM):
-        w.exchange()       # (every rank runs the same count: the halo exchanges pair up)
-        w.step()
+        w.step()           # (every rank runs the same count: the halo exchanges pair up)
     torch.cuda.synchronize()
     dt, kern_ms = run(w, args.steps, args.warmup)
     value = w.units * world * args.steps / dt / 1e6
@@ -379,6 +395,9 @@ def main():
     if rank == 0:
         cfg = dict(w.config)
         cfg["pre_warm_steps"] = PRE_WARM
+        # "did the collective library see N ranks" is answerable from the record
+        cfg["backend"] = (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if in_dist else "none (one process, one GPU)"
+        cfg["world_size"] = dist.get_world_size() if in_dist else 1
         out = {
             "metric": w.metric, "value": round(value, 1), "unit": w.unit,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -396,9 +415,14 @@ def main():
     if world == 1:
         if args.workload == "fir":
             # secondary line: the direct kernel on the same data (rank-local, N=1 only)
-            wd = FirWorkload(t, torch, dev, rank, world, args, method=t.FIR_DIRECT)
-            sd = max(3, args.steps // 4)
-            dt_d, kern_d = run(wd, sd, 1)
+            # (same pre-warm and at least 20 timed steps: measured cold on 5 steps the line moved 25 % with --steps)
+            args_d = argparse.Namespace(**dict(vars(args), force_dist=False))
+            wd = FirWorkload(t, torch, dev, rank, world, args_d, method=t.FIR_DIRECT)
+            sd = max(20, args.steps // 4)
+            for _ in range(PRE_WARM // 2):
+                wd.step()
+            torch.cuda.synchronize()
+            dt_d, kern_d = run(wd, sd, 5)
             out["direct"] = {"value": round(wd.units * sd / dt_d / 1e6, 1), "unit": "Msamples/s",
                              "kernel_ms": round(kern_d, 4),
                              "hbm_frac": round(wd.alg_bytes / (kern_d * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -407,7 +431,7 @@ def main():
             out["cpu_baseline"] = w.cpu_baseline()
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if in_dist:
         dist.destroy_process_group()
 
 

@@ -107,6 +107,7 @@ int tsdgpu_fir_create(tsdgpu_fir **out, int data_type, int tap_type,
                       const void *taps_host, int ntaps, int method);
 int tsdgpu_fir_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, void *stream);
 int tsdgpu_fir_reset(tsdgpu_fir *f);                     /* history <- zeros */
+int tsdgpu_fir_reset_on(tsdgpu_fir *f, void *stream);    /* the same, ordered on `stream` (no host wait) */
 /* History = the last ntaps-1 input samples (oldest first); this is the halo a multi-GPU
  * caller exchanges between neighbouring chunks.  dst/src: host or device pointers.      */
 int tsdgpu_fir_get_history(tsdgpu_fir *f, void *dst, void *stream);
@@ -344,8 +345,14 @@ int tsdgpu_delay_estimate(const void *x, const void *y, int n, float *delay, flo
  *   tsdgpu_sharded_step_host   x, y HOST vectors: each shard stages its chunk on its own thread and
  *                              stream; the halos are read from the host vector itself.
  *   tsdgpu_sharded_step_parts  x_parts[g] / y_parts[g] RESIDENT on device g (counts[g] samples): halos
- *                              move device to device (hipMemcpyPeerAsync over xGMI).  For the resampler
- *                              y_capacities[g] bounds the outputs of shard g, out_counts[g] returns them.
+ *                              move device to device (hipMemcpyPeerAsync over xGMI) on side streams while each
+ *                              shard already filters the interior of its part; only the launch of a part's first
+ *                              halo-length outputs waits for its halo.  For the resampler y_capacities[g] bounds
+ *                              the outputs of shard g, out_counts[g] returns them.  The shards run on the handle's own
+ *                              streams: this form first waits for ALL prior work on the shards' devices
+ *                              (hipDeviceSynchronize) so that the parts have been produced;
+ *   tsdgpu_sharded_step_parts_on  the same, ordered by events instead: producer_streams[g] is the stream whose work
+ *                              produced x_parts[g] (NULL = the null stream); nothing else is waited for.
  * ------------------------------------------------------------------------------------ */
 typedef struct tsdgpu_sharded tsdgpu_sharded;
 int tsdgpu_fir_sharded_create(tsdgpu_sharded **out, int data_type, int tap_type, const void *taps_host, int ntaps, int method,
@@ -362,6 +369,8 @@ int64_t tsdgpu_sharded_out_count(tsdgpu_sharded *h, int64_t n);           /* out
 int tsdgpu_sharded_step_host(tsdgpu_sharded *h, const void *x, int64_t n, void *y, int64_t y_capacity, int64_t *n_out);
 int tsdgpu_sharded_step_parts(tsdgpu_sharded *h, const void *const *x_parts, const int64_t *counts, void *const *y_parts,
                               const int64_t *y_capacities, int64_t *out_counts);
+int tsdgpu_sharded_step_parts_on(tsdgpu_sharded *h, const void *const *x_parts, const int64_t *counts, void *const *y_parts,
+                                 const int64_t *y_capacities, int64_t *out_counts, void *const *producer_streams);
 int tsdgpu_sharded_reset(tsdgpu_sharded *h);
 int tsdgpu_sharded_destroy(tsdgpu_sharded *h);
 

@@ -50,6 +50,8 @@ def _declare(L):
     L.tsdgpu_fir_create.argtypes = [C.POINTER(vp), i32, i32, vp, i32, i32]
     L.tsdgpu_fir_step.argtypes = [vp, vp, vp, i64, vp]
     L.tsdgpu_fir_reset.argtypes = [vp]
+    L.tsdgpu_fir_reset_on.argtypes = [vp, vp]
+    L.tsdgpu_sos_reset_on.argtypes = [vp, vp]
     L.tsdgpu_fir_get_history.argtypes = [vp, vp, vp]
     L.tsdgpu_fir_set_history.argtypes = [vp, vp, vp]
     L.tsdgpu_fir_method_used.argtypes = [vp]
@@ -96,6 +98,7 @@ def _declare(L):
     L.tsdgpu_sharded_out_count.restype = i64
     L.tsdgpu_sharded_step_host.argtypes = [vp, vp, i64, vp, i64, C.POINTER(i64)]
     L.tsdgpu_sharded_step_parts.argtypes = [vp, C.POINTER(vp), C.POINTER(i64), C.POINTER(vp), C.POINTER(i64), C.POINTER(i64)]
+    L.tsdgpu_sharded_step_parts_on.argtypes = [vp, C.POINTER(vp), C.POINTER(i64), C.POINTER(vp), C.POINTER(i64), C.POINTER(i64), C.POINTER(vp)]
     L.tsdgpu_sharded_reset.argtypes = [vp]
     L.tsdgpu_sharded_destroy.argtypes = [vp]
     L.tsdgpu_xcorr.argtypes = [vp, vp, i32, i32, i32, vp, vp]
@@ -215,6 +218,10 @@ class Fir:
 
     def reset(self):
         _check(lib().tsdgpu_fir_reset(self._h))
+
+    def reset_on(self, like=None, stream=None):
+        """reset ordered on a stream (default: the current torch stream of `like`'s device): no host wait"""
+        _check(lib().tsdgpu_fir_reset_on(self._h, _stream_of(like, stream) if like is not None else stream))
 
     def get_history(self, dst, stream=None):
         _check(lib().tsdgpu_fir_get_history(self._h, _ptr(dst), _stream_of(dst, stream)))
@@ -419,6 +426,9 @@ class Sos:
 
     def reset(self):
         _check(lib().tsdgpu_sos_reset(self._h))
+
+    def reset_on(self, like=None, stream=None):
+        _check(lib().tsdgpu_sos_reset_on(self._h, _stream_of(like, stream) if like is not None else stream))
 
     # the carried memories as a host vector (see tsdgpu_sos_get_state): what the exact sharding of sharding.py exchanges
     def get_state(self, stream=None):
@@ -651,8 +661,9 @@ class Sharded:
         _check(lib().tsdgpu_sharded_step_host(self._h, _ptr(x) if n else None, n, _ptr(y) if cap else None, y.shape[0], C.byref(got)))
         return y[: got.value]
 
-    def step_parts(self, xs, ys=None, capacities=None):
-        """xs: list of torch tensors, xs[g] resident on the device of shard g -> list of output tensors."""
+    def step_parts(self, xs, ys=None, capacities=None, device_sync=False):
+        """xs: list of torch tensors, xs[g] resident on the device of shard g -> list of output tensors.  The shards wait
+        for what torch's current streams hold (events); device_sync=True: the plain entry point, which waits for the devices."""
         N = self.nshards
         assert len(xs) == N
         cnt = (C.c_int64 * N)(*[int(t.shape[0]) for t in xs])
@@ -665,7 +676,13 @@ class Sharded:
         got = (C.c_int64 * N)()
         xp = (C.c_void_p * N)(*[_ptr(t) if t.shape[0] else None for t in xs])
         yp = (C.c_void_p * N)(*[_ptr(t) if t.shape[0] else None for t in ys])
-        _check(lib().tsdgpu_sharded_step_parts(self._h, xp, cnt, yp, caps, got))
+        if device_sync:
+            _check(lib().tsdgpu_sharded_step_parts(self._h, xp, cnt, yp, caps, got))
+        else:
+            # ordered by events on the streams that produced the parts: torch's current stream of each part's device
+            import torch
+            sp = (C.c_void_p * N)(*[torch.cuda.current_stream(t.device).cuda_stream for t in xs])
+            _check(lib().tsdgpu_sharded_step_parts_on(self._h, xp, cnt, yp, caps, got, sp))
         return [t[: got[g]] for g, t in enumerate(ys)]
 
     def reset(self):

@@ -1,5 +1,6 @@
 // common.hip -- error reporting and host/device staging for the C-ABI shim.
 #include "common.hpp"
+#include "per_device.hpp"
 #include <map>
 #include <vector>
 #include <string>
@@ -102,69 +103,46 @@ struct Bounce {
   hipStream_t st[BOUNCE_SLOTS] = {nullptr, nullptr, nullptr, nullptr};
   bool pending[BOUNCE_SLOTS] = {false, false, false, false};
   int next = 0;
+  int dev = 0;        // the device its events belong to (per_device.hpp: never used under another current device)
 };
-// Blocks are never given back to the runtime: a thread borrows one for its lifetime and returns it to this list when it
-// ends (no HIP call at thread or process exit; the next borrower waits on whatever the previous one left pending), so the
-// page-locked memory held is 100 KiB x the largest number of threads that ever staged small buffers at the same time.
-struct BouncePool {
-  std::mutex m;
-  std::vector<Bounce *> libres;
-  Bounce *prend()
-  {
-    {
-      std::lock_guard<std::mutex> l(m);
-      if (!libres.empty()) {
-        Bounce *b = libres.back();
-        libres.pop_back();
-        return b;
-      }
-    }
-    static const bool off = getenv("TSDGPU_NO_BOUNCE") != nullptr;
-    if (off) return nullptr;
-    char *blk = nullptr;
-    if (hipHostMalloc((void **) &blk, BOUNCE_MAX * (BOUNCE_SLOTS + 1), hipHostMallocDefault) != hipSuccess) {
-      (void) hipGetLastError();
-      return nullptr;
-    }
-    Bounce *b = new Bounce();
-    for (int i = 0; i < BOUNCE_SLOTS; i++) {
-      b->in[i] = blk + (size_t) i * BOUNCE_MAX;
-      if (hipEventCreateWithFlags(&b->ev[i], hipEventDisableTiming) != hipSuccess) {
-        (void) hipGetLastError();
-        return nullptr;       // (a box that cannot create an event has bigger problems: the block is abandoned)
-      }
-    }
-    b->out = blk + (size_t) BOUNCE_SLOTS * BOUNCE_MAX;
-    return b;
-  }
-  void rend(Bounce *b)
-  {
-    std::lock_guard<std::mutex> l(m);
-    libres.push_back(b);
-  }
-};
-BouncePool &bounce_pool()
+// Blocks are never given back to the runtime: a thread borrows one PER DEVICE it works on for its lifetime and returns
+// them to the per-device lists when it ends (no HIP call at thread or process exit; the next borrower waits on whatever
+// the previous one left pending), so the page-locked memory held is 100 KiB x the largest number of (thread, device)
+// pairs that ever staged small buffers at the same time.
+Bounce *bounce_make(int)
 {
-  static BouncePool *p = new BouncePool();      // never destroyed: threads may end after main() has returned
+  static const bool off = getenv("TSDGPU_NO_BOUNCE") != nullptr;
+  if (off) return nullptr;
+  char *blk = nullptr;
+  if (hipHostMalloc((void **) &blk, BOUNCE_MAX * (BOUNCE_SLOTS + 1), hipHostMallocDefault) != hipSuccess) {
+    (void) hipGetLastError();
+    return nullptr;
+  }
+  Bounce *b = new Bounce();
+  for (int i = 0; i < BOUNCE_SLOTS; i++) {
+    b->in[i] = blk + (size_t) i * BOUNCE_MAX;
+    if (hipEventCreateWithFlags(&b->ev[i], hipEventDisableTiming) != hipSuccess) {      // (created on the CURRENT device = the key)
+      (void) hipGetLastError();
+      return nullptr;       // (a box that cannot create an event has bigger problems: the block is abandoned)
+    }
+  }
+  b->out = blk + (size_t) BOUNCE_SLOTS * BOUNCE_MAX;
+  return b;
+}
+PerDevicePool<Bounce> &bounce_pool()
+{
+  static PerDevicePool<Bounce> *p = new PerDevicePool<Bounce>();      // never destroyed: threads may end after main() has returned
   return *p;
 }
-struct BounceRef {
-  Bounce *b = nullptr;
-  bool tried = false;
-  ~BounceRef() { if (b) bounce_pool().rend(b); }
-  Bounce *get()
-  {
-    if (!tried) {
-      tried = true;
-      b = bounce_pool().prend();
-    }
-    return b;
-  }
-};
 Bounce *bounce()
 {
-  static thread_local BounceRef r;
-  return r.get();
+  static thread_local PerDeviceHeld<Bounce> held;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    (void) hipGetLastError();
+    return nullptr;
+  }
+  return held.get(bounce_pool(), dev, bounce_make);
 }
 }  // namespace
 

@@ -463,6 +463,13 @@ int tsdgpu_fir_reset(tsdgpu_fir *f)
   return TSDGPU_OK;
 }
 
+int tsdgpu_fir_reset_on(tsdgpu_fir *f, void *stream)
+{
+  TSD_CHECK(f != nullptr, "fir_reset: NULL handle");
+  TSD_HIP(hipMemsetAsync(f->hist[f->cur], 0, (size_t) f->HL * dtype_size(f->data_type), (hipStream_t) stream));
+  return TSDGPU_OK;
+}
+
 int tsdgpu_fir_get_history(tsdgpu_fir *f, void *dst, void *stream)
 {
   TSD_CHECK(f != nullptr && dst != nullptr, "fir_get_history: NULL argument");

@@ -52,13 +52,90 @@ int sos_state_set(tsdgpu_sos *s, const float *host, hipStream_t st);
 bool sos_state_propagate(const tsdgpu_sos *s, int64_t L, const float *in, const float *add, float *out);
 }
 
+namespace {
+// Restores the caller's current device on EVERY exit path of an entry point that switches devices.
+struct DeviceGuard {
+  int prev = 0;
+  bool ok = false;
+  DeviceGuard() { ok = hipGetDevice(&prev) == hipSuccess; if (!ok) (void) hipGetLastError(); }
+  ~DeviceGuard() { if (ok) (void) hipSetDevice(prev); }
+};
+
+// One persistent host thread per shard beyond the first (tsdgpu_sharded_step_host): created at the handle's first host call,
+// parked on a condition variable between calls, joined when the handle is destroyed.  (A std::thread per shard per call
+// cost a thread creation + its first hipSetDevice on every step.)
+struct ShardWorkers {
+  std::vector<std::thread> th;
+  std::mutex m;
+  std::condition_variable cv, cv_done;
+  const std::function<void(int)> *job = nullptr;
+  uint64_t gen = 0;
+  int pending = 0;
+  bool stop = false;
+  void start(int nshards)
+  {
+    if (!th.empty() || nshards < 2) return;
+    for (int g = 1; g < nshards; g++)
+      th.emplace_back([this, g] {
+        uint64_t seen = 0;
+        for (;;) {
+          const std::function<void(int)> *f = nullptr;
+          {
+            std::unique_lock<std::mutex> l(m);
+            cv.wait(l, [&] { return stop || gen != seen; });
+            if (stop) return;
+            seen = gen;
+            f = job;
+          }
+          (*f)(g);
+          {
+            std::lock_guard<std::mutex> l(m);
+            if (--pending == 0) cv_done.notify_all();
+          }
+        }
+      });
+  }
+  // f(g) for g = 1 .. nshards-1 on the workers, f(0) on the caller; returns when all have finished
+  void run(int nshards, const std::function<void(int)> &f)
+  {
+    start(nshards);
+    {
+      std::lock_guard<std::mutex> l(m);
+      job = &f;
+      pending = (int) th.size();
+      gen++;
+    }
+    cv.notify_all();
+    f(0);
+    std::unique_lock<std::mutex> l(m);
+    cv_done.wait(l, [&] { return pending == 0; });
+    job = nullptr;
+  }
+  ~ShardWorkers()
+  {
+    {
+      std::lock_guard<std::mutex> l(m);
+      stop = true;
+    }
+    cv.notify_all();
+    for (auto &t : th) t.join();
+  }
+};
+}  // namespace
+
 struct tsdgpu_sharded {
   int kind = 0, data_type = 0, nshards = 0;
   int64_t H = 0;                         // halo length in samples
   int K = 0;                             // resampler / FIR taps
   std::vector<int> dev;
   std::vector<void *> handle;            // tsdgpu_fir* / tsdgpu_sos* / tsdgpu_resampler*
+  std::vector<void *> edge;              // FIR / resampler: a second handle of the same operator for the first H outputs of a
+                                         // resident part (the interior is launched on `handle` before the halo has arrived)
   std::vector<hipStream_t> stream;
+  std::vector<hipStream_t> hstream;      // resident form: the halo copies of shard g run here, beside the interior on stream[g]
+  std::vector<hipEvent_t> ev_ready, ev_halo, ev_tail;   // part g produced / halo g landed / the call's tail read out of part g
+  char *pin_carry = nullptr;             // page-locked staging of the new carry (resident form: an asynchronous D2H)
+  ShardWorkers workers;
   std::vector<DevBuf> halo, in, out, scratch;
   std::vector<char> carry;               // host: the last H inputs of the stream (zeros before its start)
   int64_t seen = 0;                      // inputs consumed so far (all calls)
@@ -105,7 +182,12 @@ int sharded_alloc(tsdgpu_sharded **out, int kind, int data_type, int nshards, co
     h->dev.push_back(d);
   }
   h->handle.assign((size_t) nshards, nullptr);
+  h->edge.assign((size_t) nshards, nullptr);
   h->stream.assign((size_t) nshards, nullptr);
+  h->hstream.assign((size_t) nshards, nullptr);
+  h->ev_ready.assign((size_t) nshards, nullptr);
+  h->ev_halo.assign((size_t) nshards, nullptr);
+  h->ev_tail.assign((size_t) nshards, nullptr);
   h->halo.resize((size_t) nshards);
   h->in.resize((size_t) nshards);
   h->out.resize((size_t) nshards);
@@ -120,9 +202,17 @@ int sharded_finish_create(tsdgpu_sharded *h)
   for (int g = 0; g < h->nshards; g++) {
     const int rc = with_device(h->dev[g], [&]() -> int {
       TSD_HIP(hipStreamCreateWithFlags(&h->stream[g], hipStreamNonBlocking));
+      TSD_HIP(hipStreamCreateWithFlags(&h->hstream[g], hipStreamNonBlocking));
+      TSD_HIP(hipEventCreateWithFlags(&h->ev_ready[g], hipEventDisableTiming));
+      TSD_HIP(hipEventCreateWithFlags(&h->ev_halo[g], hipEventDisableTiming));
+      TSD_HIP(hipEventCreateWithFlags(&h->ev_tail[g], hipEventDisableTiming));
       return h->halo[g].reserve((size_t) std::max<int64_t>(h->H, 1) * h->esz());
     });
     if (rc) return rc;
+  }
+  if (h->H > 0 && hipHostMalloc((void **) &h->pin_carry, (size_t) h->H * h->esz(), hipHostMallocDefault) != hipSuccess) {
+    (void) hipGetLastError();
+    h->pin_carry = nullptr;              // (the resident form then reads the tail with a blocking copy)
   }
   // neighbours exchange halos device to device in the resident form
   for (int g = 1; g < h->nshards; g++)
@@ -204,7 +294,12 @@ int tsdgpu_fir_sharded_create(tsdgpu_sharded **out, int data_type, int tap_type,
   h->K = ntaps;
   h->H = std::max(ntaps - 1, 0);
   for (int g = 0; g < nshards && !rc; g++)
-    rc = with_device(h->dev[g], [&] { return tsdgpu_fir_create((tsdgpu_fir **) &h->handle[g], data_type, tap_type, taps_host, ntaps, method); });
+    rc = with_device(h->dev[g], [&] {
+      const int rc2 = tsdgpu_fir_create((tsdgpu_fir **) &h->handle[g], data_type, tap_type, taps_host, ntaps, method);
+      if (rc2 || ntaps < 2) return rc2;
+      // the first K-1 outputs of a resident part: one small launch of the direct kernel
+      return tsdgpu_fir_create((tsdgpu_fir **) &h->edge[g], data_type, tap_type, taps_host, ntaps, TSDGPU_FIR_DIRECT);
+    });
   if (!rc) rc = sharded_finish_create(h);
   if (rc) {
     tsdgpu_sharded_destroy(h);
@@ -248,7 +343,11 @@ int tsdgpu_resampler_sharded_create(tsdgpu_sharded **out, int data_type, float r
   h->K = K;
   h->H = std::max(K - 1, 0);
   for (int g = 0; g < nshards && !rc; g++)
-    rc = with_device(h->dev[g], [&] { return tsdgpu_resampler_create((tsdgpu_resampler **) &h->handle[g], data_type, ratio, lut_host, K, nphases); });
+    rc = with_device(h->dev[g], [&] {
+      const int rc2 = tsdgpu_resampler_create((tsdgpu_resampler **) &h->handle[g], data_type, ratio, lut_host, K, nphases);
+      if (rc2 || K < 2) return rc2;
+      return tsdgpu_resampler_create((tsdgpu_resampler **) &h->edge[g], data_type, ratio, lut_host, K, nphases);
+    });
   if (!rc) rc = sharded_finish_create(h);
   if (rc) {
     tsdgpu_sharded_destroy(h);
@@ -435,13 +534,10 @@ int tsdgpu_sharded_step_host(tsdgpu_sharded *h, const void *x, int64_t n, void *
     rcs[(size_t) g] = rc;
     if (rc) msgs[(size_t) g] = tsdgpu_last_error();
   };
-  std::vector<std::thread> th;
-  for (int g = 1; g < N; g++) th.emplace_back(work, g);
-  int prev = 0;
-  (void) hipGetDevice(&prev);
-  work(0);
-  for (auto &t : th) t.join();
-  (void) hipSetDevice(prev);
+  {
+    DeviceGuard guard;                 // (work(0) runs on the calling thread and switches its device)
+    h->workers.run(N, work);
+  }
   int64_t total = 0;
   for (int g = 0; g < N; g++) {
     if (rcs[(size_t) g]) {
@@ -457,8 +553,16 @@ int tsdgpu_sharded_step_host(tsdgpu_sharded *h, const void *x, int64_t n, void *
   return TSDGPU_OK;
 }
 
-int tsdgpu_sharded_step_parts(tsdgpu_sharded *h, const void *const *x_parts, const int64_t *counts, void *const *y_parts,
-                              const int64_t *y_capacities, int64_t *out_counts)
+// The resident form.  `producers` (may be NULL): producers[g] = the stream whose work produced x_parts[g] (and last touched
+// y_parts[g]); the shard streams wait for an event recorded there.  Without it the call first waits for ALL prior work on the
+// shards' devices (hipDeviceSynchronize), which is what a caller gets from tsdgpu_sharded_step_parts.
+//
+// Schedule (FIR, resampler): the halo copies run on a side stream per shard while the shard's stream already filters the
+// INTERIOR of its part -- everything behind the first H samples, primed with the part's own first H samples, on the main
+// handle -- and only the EDGE launch (the first H outputs, on the shard's second handle) waits for the halo.  A part filtered
+// in place first lets the copies that read its tail (the next shards' halos, the call's carry) finish.
+static int sharded_step_parts_impl(tsdgpu_sharded *h, const void *const *x_parts, const int64_t *counts, void *const *y_parts,
+                                   const int64_t *y_capacities, int64_t *out_counts, void *const *producers)
 {
   TSD_CHECK(h != nullptr && x_parts != nullptr && counts != nullptr && y_parts != nullptr, "sharded_step_parts: NULL argument");
   const size_t esz = h->esz();
@@ -473,8 +577,28 @@ int tsdgpu_sharded_step_parts(tsdgpu_sharded *h, const void *const *x_parts, con
   }
   n = lo[(size_t) N];
   if (n == 0) return TSDGPU_OK;
-  int prev = 0;
-  TSD_HIP(hipGetDevice(&prev));
+  DeviceGuard guard;                                   // the caller's device comes back on every exit path
+  TSD_CHECK(guard.ok, "sharded_step_parts: hipGetDevice failed");
+  // (0) the parts must have been produced: an event per part on its producer's stream, or a device-wide wait
+  if (producers) {
+    for (int g = 0; g < N; g++)
+      if (counts[g] > 0) {
+        TSD_HIP(hipSetDevice(h->dev[g]));
+        TSD_HIP(hipEventRecord(h->ev_ready[g], (hipStream_t) producers[g]));
+      }
+  } else {
+    std::vector<int> vus;
+    for (int g = 0; g < N; g++)
+      if (counts[g] > 0 && std::find(vus.begin(), vus.end(), h->dev[g]) == vus.end()) {
+        vus.push_back(h->dev[g]);
+        TSD_HIP(hipSetDevice(h->dev[g]));
+        TSD_HIP(hipDeviceSynchronize());
+      }
+  }
+  auto wait_ready = [&](hipStream_t st, int part) -> int {
+    if (producers && counts[part] > 0) TSD_HIP(hipStreamWaitEvent(st, h->ev_ready[part], 0));
+    return TSDGPU_OK;
+  };
   if (h->exact) {
     // exact SOS sharding (see tsdgpu_sharded): pass 1 of the later shards goes to a scratch buffer (a part may be filtered
     // in place), the end states come to the host, pass 2 starts from the propagated states
@@ -492,7 +616,8 @@ int tsdgpu_sharded_step_parts(tsdgpu_sharded *h, const void *const *x_parts, con
       TSD_HIP(hipSetDevice(h->dev[g]));
       tsdgpu_sos *sg = (tsdgpu_sos *) h->handle[g];
       TSD_CHECK(!y_capacities || y_capacities[g] >= counts[g], "sharded_step_parts: output capacity of part %d", g);
-      rc = sos_state_set(sg, g == first ? h->sos_state.data() : zero.data(), h->stream[g]);
+      rc = wait_ready(h->stream[g], g);
+      if (!rc) rc = sos_state_set(sg, g == first ? h->sos_state.data() : zero.data(), h->stream[g]);
       void *dst = y_parts[g];
       if (!rc && g != first) {
         rc = h->scratch[g].reserve((size_t) counts[g] * esz);
@@ -526,7 +651,6 @@ int tsdgpu_sharded_step_parts(tsdgpu_sharded *h, const void *const *x_parts, con
       (void) hipSetDevice(h->dev[g]);
       if (hipStreamSynchronize(h->stream[g]) != hipSuccess && !rc) rc = set_err(TSDGPU_ERR_HIP, "shard %d: stream sync failed", g);
     }
-    (void) hipSetDevice(prev);
     if (rc) return rc;
     for (int g = 0; g < N; g++)
       if (out_counts) out_counts[g] = counts[g];
@@ -534,26 +658,42 @@ int tsdgpu_sharded_step_parts(tsdgpu_sharded *h, const void *const *x_parts, con
     h->seen += n;
     return TSDGPU_OK;
   }
-  // (1) halos, device to device: the last H samples before each shard, walking back over the parts and
-  //     ending in the carry of the previous calls
+  auto in_place = [&](int g) {
+    if (counts[g] == 0 || h->kind == K_RES) return false;
+    const char *xa = (const char *) x_parts[g], *ya = (const char *) y_parts[g];
+    const size_t len = (size_t) counts[g] * esz;
+    return xa < ya + len && ya < xa + len;
+  };
+  // readers[p]: events a part filtered in place must wait for before anything is written into it
+  std::vector<std::vector<hipEvent_t>> readers((size_t) N);
   int rc = TSDGPU_OK;
-  for (int g = 0; g < N && !rc; g++) {
+  // (1) halos, device to device, on the shards' side streams: the last H samples before each shard, walking back over the
+  //     parts and ending in the carry of the previous calls
+  for (int g = 0; g < N && H > 0; g++) {
     TSD_HIP(hipSetDevice(h->dev[g]));
+    hipStream_t hs = h->hstream[g];
     int64_t need = H;
     char *dst = (char *) h->halo[g].p;
     for (int p = g - 1; p >= 0 && need > 0; p--) {
       const int64_t take = std::min(need, counts[p]);
       if (take > 0) {
+        rc = wait_ready(hs, p);
+        if (rc) return rc;
         const char *src = (const char *) x_parts[p] + (size_t) (counts[p] - take) * esz;
-        if (h->dev[p] == h->dev[g]) TSD_HIP(hipMemcpyAsync(dst + (size_t) (need - take) * esz, src, (size_t) take * esz, hipMemcpyDeviceToDevice, h->stream[g]));
-        else TSD_HIP(hipMemcpyPeerAsync(dst + (size_t) (need - take) * esz, h->dev[g], src, h->dev[p], (size_t) take * esz, h->stream[g]));
+        if (h->dev[p] == h->dev[g]) TSD_HIP(hipMemcpyAsync(dst + (size_t) (need - take) * esz, src, (size_t) take * esz, hipMemcpyDeviceToDevice, hs));
+        else TSD_HIP(hipMemcpyPeerAsync(dst + (size_t) (need - take) * esz, h->dev[g], src, h->dev[p], (size_t) take * esz, hs));
+        readers[(size_t) p].push_back(h->ev_halo[g]);
         need -= take;
       }
     }
-    if (need > 0) TSD_HIP(hipMemcpyAsync(dst, h->carry.data() + (size_t) (H - need) * esz, (size_t) need * esz, hipMemcpyHostToDevice, h->stream[g]));
+    if (need > 0) TSD_HIP(hipMemcpyAsync(dst, h->carry.data() + (size_t) (H - need) * esz, (size_t) need * esz, hipMemcpyHostToDevice, hs));
+    TSD_HIP(hipEventRecord(h->ev_halo[g], hs));
   }
-  // the new carry: the tail of this call, gathered to the host (small) before any shard writes in place
+  // the new carry: the tail of this call, read out of the last parts before any of them is overwritten in place --
+  // asynchronously into page-locked memory (gathered into the handle only when the call has succeeded)
   std::vector<char> nc = h->carry;
+  struct Piece { int64_t at, len; };
+  std::vector<Piece> pieces;
   {
     int64_t need = std::min(H, n), kept = H - need;
     if (kept > 0 && need > 0) std::memmove(nc.data(), nc.data() + (size_t) need * esz, (size_t) kept * esz);
@@ -562,32 +702,82 @@ int tsdgpu_sharded_step_parts(tsdgpu_sharded *h, const void *const *x_parts, con
       const int64_t take = std::min(need, counts[p]);
       if (take > 0) {
         TSD_HIP(hipSetDevice(h->dev[p]));
-        TSD_HIP(hipMemcpy(nc.data() + (size_t) (fill - take) * esz, (const char *) x_parts[p] + (size_t) (counts[p] - take) * esz,
-                          (size_t) take * esz, hipMemcpyDeviceToHost));
+        const char *src = (const char *) x_parts[p] + (size_t) (counts[p] - take) * esz;
+        rc = wait_ready(h->hstream[p], p);
+        if (rc) return rc;
+        if (h->pin_carry) {
+          TSD_HIP(hipMemcpyAsync(h->pin_carry + (size_t) (fill - take) * esz, src, (size_t) take * esz, hipMemcpyDeviceToHost, h->hstream[p]));
+          TSD_HIP(hipEventRecord(h->ev_tail[p], h->hstream[p]));
+          readers[(size_t) p].push_back(h->ev_tail[p]);
+          pieces.push_back(Piece{fill - take, take});
+        } else {
+          TSD_HIP(hipMemcpyAsync(nc.data() + (size_t) (fill - take) * esz, src, (size_t) take * esz, hipMemcpyDeviceToHost, h->hstream[p]));
+          TSD_HIP(hipStreamSynchronize(h->hstream[p]));
+        }
         fill -= take;
         need -= take;
       }
     }
-    for (int g = 0; g < N; g++) {
-      TSD_HIP(hipSetDevice(h->dev[g]));
-      TSD_HIP(hipStreamSynchronize(h->stream[g]));     // halos landed: in-place shards may start
-    }
   }
   // (2) the shards, concurrently (one stream each; the enqueue itself is cheap)
   std::vector<int64_t> got((size_t) N, 0);
+  static const bool no_split = getenv("TSDGPU_SHARD_NO_OVERLAP") != nullptr;     // A/B switch: wait for the halo, one launch
   for (int g = 0; g < N && !rc; g++) {
     TSD_HIP(hipSetDevice(h->dev[g]));
+    hipStream_t st = h->stream[g];
     const int64_t pos = h->seen + lo[(size_t) g];
-    const int64_t ycap = y_capacities ? y_capacities[g] : counts[g];
-    rc = run_shard(h, g, h->halo[g].p, std::min(H, pos), pos, x_parts[g], y_parts[g], counts[g], ycap, &got[(size_t) g]);
-    if (h->kind != K_RES) got[(size_t) g] = counts[g];
+    const int64_t cnt = counts[g];
+    const int64_t ycap = y_capacities ? y_capacities[g] : cnt;
+    rc = wait_ready(st, g);
+    if (rc) break;
+    if (in_place(g))
+      for (hipEvent_t e : readers[(size_t) g]) TSD_HIP(hipStreamWaitEvent(st, e, 0));
+    const bool split = !no_split && H > 0 && cnt > H && h->edge[g] != nullptr && (h->kind == K_FIR || h->kind == K_RES);
+    if (!split) {
+      if (H > 0) TSD_HIP(hipStreamWaitEvent(st, h->ev_halo[g], 0));
+      rc = run_shard(h, g, h->halo[g].p, std::min(H, pos), pos, x_parts[g], y_parts[g], cnt, ycap, &got[(size_t) g]);
+      if (h->kind != K_RES) got[(size_t) g] = cnt;
+      continue;
+    }
+    const char *xg = (const char *) x_parts[g];
+    char *yg = (char *) y_parts[g];
+    if (h->kind == K_FIR) {
+      tsdgpu_fir *fm = (tsdgpu_fir *) h->handle[g], *fe = (tsdgpu_fir *) h->edge[g];
+      rc = tsdgpu_fir_set_history(fm, xg, st);                                   // interior: primed with the part's own head
+      if (!rc) rc = tsdgpu_fir_step(fm, xg + (size_t) H * esz, yg + (size_t) H * esz, cnt - H, st);
+      if (rc) break;
+      TSD_HIP(hipStreamWaitEvent(st, h->ev_halo[g], 0));                         // edge: the first H outputs need the halo
+      rc = tsdgpu_fir_set_history(fe, h->halo[g].p, st);
+      if (!rc) rc = tsdgpu_fir_step(fe, xg, yg, H, st);
+      got[(size_t) g] = cnt;
+    } else {
+      tsdgpu_resampler *rm = (tsdgpu_resampler *) h->handle[g], *re = (tsdgpu_resampler *) h->edge[g];
+      // outputs of the first H inputs / of the whole part, from the schedule
+      rc = tsdgpu_resampler_seek(re, pos, nullptr, st);
+      if (rc) break;
+      const int64_t o0 = tsdgpu_resampler_out_offset(re);
+      rc = tsdgpu_resampler_seek(re, pos + H, nullptr, st);
+      if (rc) break;
+      const int64_t c_edge = tsdgpu_resampler_out_offset(re) - o0;
+      int64_t g1 = 0, g0 = 0;
+      if (c_edge > ycap) { rc = set_err(TSDGPU_ERR_INVALID, "sharded_step_parts: output capacity of part %d", g); break; }
+      rc = tsdgpu_resampler_seek(rm, pos + H, xg, st);                           // interior: window = the part's own head
+      if (!rc) rc = tsdgpu_resampler_step(rm, xg + (size_t) H * esz, cnt - H, yg + (size_t) c_edge * esz, ycap - c_edge, &g1, st);
+      if (rc) break;
+      TSD_HIP(hipStreamWaitEvent(st, h->ev_halo[g], 0));
+      rc = tsdgpu_resampler_seek(re, pos, h->halo[g].p, st);
+      if (!rc && c_edge > 0) rc = tsdgpu_resampler_step(re, xg, H, yg, c_edge, &g0, st);
+      if (!rc && g0 != c_edge) rc = set_err(TSDGPU_ERR_INVALID, "shard %d: edge produced %lld outputs, the schedule says %lld", g, (long long) g0, (long long) c_edge);
+      got[(size_t) g] = g0 + g1;
+    }
   }
   for (int g = 0; g < N; g++) {
     (void) hipSetDevice(h->dev[g]);
     if (hipStreamSynchronize(h->stream[g]) != hipSuccess && !rc) rc = set_err(TSDGPU_ERR_HIP, "shard %d: stream sync failed", g);
+    if (hipStreamSynchronize(h->hstream[g]) != hipSuccess && !rc) rc = set_err(TSDGPU_ERR_HIP, "shard %d: halo stream sync failed", g);
   }
-  (void) hipSetDevice(prev);
   if (rc) return rc;
+  for (const Piece &pc : pieces) std::memcpy(nc.data() + (size_t) pc.at * esz, h->pin_carry + (size_t) pc.at * esz, (size_t) pc.len * esz);
   int64_t total = 0;
   for (int g = 0; g < N; g++) {
     if (out_counts) out_counts[g] = got[(size_t) g];
@@ -597,6 +787,19 @@ int tsdgpu_sharded_step_parts(tsdgpu_sharded *h, const void *const *x_parts, con
   h->seen += n;
   h->out_total += total;
   return TSDGPU_OK;
+}
+
+int tsdgpu_sharded_step_parts(tsdgpu_sharded *h, const void *const *x_parts, const int64_t *counts, void *const *y_parts,
+                              const int64_t *y_capacities, int64_t *out_counts)
+{
+  return sharded_step_parts_impl(h, x_parts, counts, y_parts, y_capacities, out_counts, nullptr);
+}
+
+int tsdgpu_sharded_step_parts_on(tsdgpu_sharded *h, const void *const *x_parts, const int64_t *counts, void *const *y_parts,
+                                 const int64_t *y_capacities, int64_t *out_counts, void *const *producer_streams)
+{
+  TSD_CHECK(producer_streams != nullptr, "sharded_step_parts_on: NULL stream list (tsdgpu_sharded_step_parts waits for the devices instead)");
+  return sharded_step_parts_impl(h, x_parts, counts, y_parts, y_capacities, out_counts, producer_streams);
 }
 
 int tsdgpu_sharded_reset(tsdgpu_sharded *h)
@@ -629,14 +832,23 @@ int tsdgpu_sharded_destroy(tsdgpu_sharded *h)
       else if (h->kind == K_SOS) tsdgpu_sos_destroy((tsdgpu_sos *) h->handle[g]);
       else tsdgpu_resampler_destroy((tsdgpu_resampler *) h->handle[g]);
     }
+    if (h->edge[g]) {
+      if (h->kind == K_FIR) tsdgpu_fir_destroy((tsdgpu_fir *) h->edge[g]);
+      else if (h->kind == K_RES) tsdgpu_resampler_destroy((tsdgpu_resampler *) h->edge[g]);
+    }
     if (h->stream[g]) (void) hipStreamDestroy(h->stream[g]);
+    if (h->hstream[g]) (void) hipStreamDestroy(h->hstream[g]);
+    if (h->ev_ready[g]) (void) hipEventDestroy(h->ev_ready[g]);
+    if (h->ev_halo[g]) (void) hipEventDestroy(h->ev_halo[g]);
+    if (h->ev_tail[g]) (void) hipEventDestroy(h->ev_tail[g]);
     h->halo[g].release();
     h->in[g].release();
     h->out[g].release();
     h->scratch[g].release();
   }
+  if (h->pin_carry) (void) hipHostFree(h->pin_carry);
   (void) hipSetDevice(prev);
-  delete h;
+  delete h;                              // (joins the shard workers)
   return TSDGPU_OK;
 }
 

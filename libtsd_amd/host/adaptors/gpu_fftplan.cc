@@ -9,6 +9,7 @@
 #include <mutex>
 #include <map>
 #include "tsd_amd/extensions.hpp"
+#include "reserve_plans.hpp"
 
 namespace tsd_amd {
 
@@ -21,61 +22,37 @@ using tsd::fourier::FFTPlan;
 // libtsd's fft() / ifft() make a plan per CALL (fourier.hpp:163-205).  A device plan costs 30 us (n = 4096) to 1.1 ms (2^20) to
 // build -- its twiddle tables -- so finished plans go to a small per-size reserve instead of being destroyed, and the next
 // plan of that size takes one from there (a handle serves one caller at a time: it leaves the reserve while in use).
-struct ReservePlans {
-  std::mutex m;
-  std::map<entier, std::vector<tsdgpu_fft *>> libres;
-  size_t total = 0;
-  tsdgpu_fft *prend(entier n)
-  {
-    std::lock_guard<std::mutex> l(m);
-    auto it = libres.find(n);
-    if (it == libres.end() || it->second.empty()) return nullptr;
-    tsdgpu_fft *h = it->second.back();
-    it->second.pop_back();
-    total--;
-    return h;
-  }
-  void rend(entier n, tsdgpu_fft *h)
-  {
-    if (!h) return;
-    {
-      std::lock_guard<std::mutex> l(m);
-      auto &v = libres[n];
-      if (v.size() < 4 && total < 64) {        // a few plans per size, a few dozen sizes
-        v.push_back(h);
-        total++;
-        return;
-      }
-    }
-    tsdgpu_fft_destroy(h);
-  }
-};
-static ReservePlans &reserve_plans()
+// The reserve is keyed by (device, n): a plan's tables live on the device it was created on (reserve_plans.hpp).
+static void detruit_fft(tsdgpu_fft *h) { tsdgpu_fft_destroy(h); }
+static ReserveParCle<tsdgpu_fft> &reserve_plans()
 {
-  static ReservePlans *r = new ReservePlans();      // never destroyed: plans may be returned during static destruction
+  static ReserveParCle<tsdgpu_fft> *r = new ReserveParCle<tsdgpu_fft>(detruit_fft);      // never destroyed: plans may be returned during static destruction
   return *r;
 }
 
 struct FFTPlanGpu : FFTPlan {
   tsdgpu_fft *h = nullptr;
   entier n = -1;
+  int dev = -1;                      // the device h lives on
   bouléen avant_defaut = true;
-  virtual ~FFTPlanGpu() { reserve_plans().rend(n, h); }     // FFTPlan has no virtual destructor: make_shared's deleter knows the type
+  virtual ~FFTPlanGpu() { reserve_plans().rend(dev, n, h); }     // FFTPlan has no virtual destructor: make_shared's deleter knows the type
   void configure(entier n_, bouléen avant, bouléen)
   {
     avant_defaut = avant;
-    if (n_ == n) return;
-    reserve_plans().rend(n, h);
+    const int ici = tsdgpu_current_device();
+    if (n_ == n && (h == nullptr || ici == dev)) return;
+    reserve_plans().rend(dev, n, h);
     h = nullptr;
     n = n_;
+    dev = ici;
     if (n < 1) return;
-    h = reserve_plans().prend(n);
+    h = reserve_plans().prend(dev, n);
     if (!h && tsdgpu_fft_create(&h, n, 1)) gpu_fail("FFTPlan::configure");
   }
   void step(const Veccf &x, Veccf &y, bouléen avant)
   {
     if (x.rows() <= 0) échec("FFTPlan::step: empty input");          // assertion(x.rows() > 0), fourier.cc:414
-    if (x.rows() != n) configure(x.rows(), avant_defaut, true);
+    if (x.rows() != n || tsdgpu_current_device() != dev) configure(x.rows(), avant_defaut, true);
     if (x.data() != y.data()) dimensionne(y, n);
     if (tsdgpu_fft_step(h, x.data(), y.data(), 1, avant ? 1 : 0, nullptr)) gpu_fail("FFTPlan::step");
   }
@@ -87,59 +64,34 @@ void installe_fftplan_gpu() { tsd::fourier::fftplan_defaut = fftplan_gpu; }
 // RTFRPlan (fourier.cc:280-355) on tsdgpu_rfft: packed n/2-point complex FFT, untangling with the
 // 0.5/sqrt(2) factors and the forced conjugate symmetry all run on the device.
 // (the same reserve for the real-input plans: rfft() / fft(Vecf) make one per call too)
-struct ReservePlansReels {
-  std::mutex m;
-  std::map<entier, std::vector<tsdgpu_rfft *>> libres;
-  size_t total = 0;
-  tsdgpu_rfft *prend(entier n)
-  {
-    std::lock_guard<std::mutex> l(m);
-    auto it = libres.find(n);
-    if (it == libres.end() || it->second.empty()) return nullptr;
-    tsdgpu_rfft *h = it->second.back();
-    it->second.pop_back();
-    total--;
-    return h;
-  }
-  void rend(entier n, tsdgpu_rfft *h)
-  {
-    if (!h) return;
-    {
-      std::lock_guard<std::mutex> l(m);
-      auto &v = libres[n];
-      if (v.size() < 4 && total < 64) {
-        v.push_back(h);
-        total++;
-        return;
-      }
-    }
-    tsdgpu_rfft_destroy(h);
-  }
-};
-static ReservePlansReels &reserve_plans_reels()
+static void detruit_rfft(tsdgpu_rfft *h) { tsdgpu_rfft_destroy(h); }
+static ReserveParCle<tsdgpu_rfft> &reserve_plans_reels()
 {
-  static ReservePlansReels *r = new ReservePlansReels();
+  static ReserveParCle<tsdgpu_rfft> *r = new ReserveParCle<tsdgpu_rfft>(detruit_rfft);
   return *r;
 }
 
 struct RTFRPlanGpu : FiltreGen<float, cfloat> {
   entier n = -1;
+  int dev = -1;
   tsdgpu_rfft *h = nullptr;
   explicit RTFRPlanGpu(entier n_) { configure(n_); }
-  ~RTFRPlanGpu() { reserve_plans_reels().rend(n, h); }
+  ~RTFRPlanGpu() { reserve_plans_reels().rend(dev, n, h); }
   void configure(entier n_)
   {
-    if (n_ == n) return;
-    reserve_plans_reels().rend(n, h);
+    const int ici = tsdgpu_current_device();
+    if (n_ == n && (h == nullptr || ici == dev)) return;
+    reserve_plans_reels().rend(dev, n, h);
     h = nullptr;
     n = n_;
+    dev = ici;
     if (n <= 0) return;
-    h = reserve_plans_reels().prend(n);
+    h = reserve_plans_reels().prend(dev, n);
     if (!h && tsdgpu_rfft_create(&h, n)) gpu_fail("rtfrplan_création");
   }
   void step(const Vecf &x, Veccf &y)
   {
-    if (x.rows() != n) configure(x.rows());
+    if (x.rows() != n || tsdgpu_current_device() != dev) configure(x.rows());
     if (n <= 0) {
       dimensionne(y, 0);
       return;

@@ -12,38 +12,183 @@ def chunk_bounds(n_total, rank, world):
     return (n_total * rank) // world, (n_total * (rank + 1)) // world
 
 
-def exchange_left_halo(tail_out, halo_in, rank, world, group=None):
-    """Every rank sends `tail_out` (the last samples of its chunk) to rank+1 and receives the
-    tail of rank-1 into `halo_in`; rank 0's halo_in is left untouched (zeros = the reference's
-    empty delay line, filtre-rt.cc:64).  One batched isend/irecv pair per rank."""
-    if world == 1:
-        return halo_in
-    # gloo (CPU tests, single-GPU rehearsals of the multi-rank path) has no point-to-point on device
-    # tensors: stage through the host there; RCCL sends device memory directly
+class HaloExchange:
+    """One posted left-neighbour exchange: `finish()` makes the halo usable on the current stream.
+
+    RCCL ("nccl"): the transfer runs on the process group's own stream, ordered after what the current stream held when
+    it was posted; `finish()` is a stream dependency, not a host wait -- whatever is launched between `start` and
+    `finish` (the halo-free interior of the step) overlaps with the exchange.  gloo (CPU tests, one-GPU rehearsals):
+    no point-to-point on device tensors, so the tail is staged through the host and `finish()` blocks."""
+
+    def __init__(self, works, halo_in, staged, result=None):
+        self.works, self.halo_in, self.staged, self.result = works, halo_in, staged, result
+
+    def finish(self):
+        for w in self.works:
+            w.wait()
+        self.works = []
+        if self.staged is not None:
+            self.halo_in.copy_(self.staged)
+            self.staged = None
+        return self.halo_in if self.result is None else self.result
+
+
+def start_halo_exchange(tail_out, halo_in, rank, world, group=None, ring=False, result=None):
+    """Posts the exchange of `exchange_left_halo` and returns at once (-> HaloExchange).  `ring=True` closes the chain
+    (the last rank sends to rank 0, rank 0 receives): the layout of a circular stream, and with world == 1 a self
+    send / receive -- how a single GPU exercises the RCCL point-to-point path.  `result`: what finish() returns instead
+    of halo_in (complex samples travel as their float32 view: pass the complex view of the same storage here)."""
+    if world == 1 and not (ring and dist.is_initialized()):
+        return HaloExchange([], halo_in, None, result)
+    # gloo has no point-to-point on device tensors: stage through the host there; RCCL sends device memory directly
     via_host = dist.get_backend(group) == "gloo" and tail_out.is_cuda
     src = tail_out.cpu() if via_host else tail_out
     dst = torch.empty_like(halo_in, device="cpu") if via_host else halo_in
     ops = []
-    if rank + 1 < world:
-        ops.append(dist.P2POp(dist.isend, src, rank + 1, group))
-    if rank > 0:
-        ops.append(dist.P2POp(dist.irecv, dst, rank - 1, group))
-    for w in dist.batch_isend_irecv(ops):
-        w.wait()
-    if via_host and rank > 0:
-        halo_in.copy_(dst)
-    return halo_in
+    if rank + 1 < world or ring:
+        ops.append(dist.P2POp(dist.isend, src, (rank + 1) % world, group))
+    receives = rank > 0 or ring
+    if receives:
+        ops.append(dist.P2POp(dist.irecv, dst, (rank - 1) % world, group))
+    works = dist.batch_isend_irecv(ops) if ops else []
+    return HaloExchange(works, halo_in, dst if (via_host and receives) else None, result)
 
 
-def max_over_ranks(value, device, world):
-    if world == 1:
+def exchange_left_halo(tail_out, halo_in, rank, world, group=None, ring=False):
+    """Every rank sends `tail_out` (the last samples of its chunk) to rank+1 and receives the
+    tail of rank-1 into `halo_in`; rank 0's halo_in is left untouched (zeros = the reference's
+    empty delay line, filtre-rt.cc:64).  One batched isend/irecv pair per rank."""
+    return start_halo_exchange(tail_out, halo_in, rank, world, group, ring).finish()
+
+
+# ---- a sharded step with the exchange OFF its critical path (SURVEY.md 8e: "exchange once per call and overlap with the
+# interior tile computation").  Only the first H outputs of a chunk depend on the neighbour's samples; everything behind
+# them needs the chunk alone.  So a rank posts the exchange, launches the INTERIOR on its main handle -- primed with the
+# chunk's own first H samples -- and only then waits for the halo and filters the EDGE (the first H samples) on a second,
+# small handle of the same operator.  Two launches on the operator's stream, the halo wait between them.
+class OverlappedFir:
+    """FIR (tsdgpu_fir): H = K - 1.  Same outputs as set_history(halo) + step(x) on one handle: bit for bit with the
+    direct kernel (an output's sum does not depend on where the call starts); the overlap-save blocks shift by H samples."""
+
+    def __init__(self, t, taps, data_type, method=None):
+        self.main = t.Fir(taps, data_type, t.FIR_AUTO if method is None else method)
+        self.edge = t.Fir(taps, data_type, t.FIR_DIRECT)        # H outputs: the direct kernel is one small launch
+        self.H = self.main.K - 1
+
+    def interior(self, x, y):
+        H = self.H
+        if x.shape[0] <= H:
+            return False
+        self.main.set_history(x[:H])
+        self.main.step(x[H:], y[H:])
+        return True
+
+    def edge_step(self, x, y, halo, first):
+        """halo: the H samples before the chunk (ignored when `first`: the stream starts here, zero delay line)."""
+        H = min(self.H, x.shape[0])
+        if first:
+            self.edge.reset_on(x)
+        else:
+            self.edge.set_history(halo)          # (all K-1 samples of the delay line)
+        if H > 0:
+            self.edge.step(x[:H], y[:H])
+
+    def step(self, x, y, exchange, first):
+        """exchange: a posted HaloExchange (or None).  Returns y."""
+        split = self.interior(x, y)
+        halo = exchange.finish() if exchange is not None else None
+        if split:
+            self.edge_step(x, y, halo, first)
+        else:                                # a chunk no longer than the halo: nothing to overlap
+            if first:
+                self.main.reset_on(x)
+            else:
+                self.main.set_history(halo)
+            self.main.step(x, y)
+        return y
+
+
+class OverlappedResampler:
+    """Resampler (tsdgpu_resampler) at stream position `pos`: H = K - 1 window samples.  The edge produces the outputs of
+    the chunk's first H inputs, the interior those of the rest -- disjoint output ranges whose border comes from the
+    schedule (out_offset), so the result is bit for bit the single call's."""
+
+    def __init__(self, t, ratio, data_type):
+        self.main = t.Resampler(ratio, data_type)
+        self.edge = t.Resampler(ratio, data_type)
+        self.H = self.main.K - 1
+
+    def counts(self, pos, n):
+        """-> (outputs of the first min(H, n) inputs, outputs of all n) from stream position pos"""
+        self.edge.seek(pos)
+        o0 = self.edge.out_offset
+        self.edge.seek(pos + min(self.H, n))
+        o1 = self.edge.out_offset
+        self.edge.seek(pos + n)
+        return o1 - o0, self.edge.out_offset - o0
+
+    def step(self, x, y, pos, exchange, first):
+        n, H = x.shape[0], self.H
+        c_edge, c_all = self.counts(pos, n)
+        assert y.shape[0] >= c_all
+        split = n > H
+        if split:
+            self.main.seek(pos + H, x[:H])
+            self.main.step(x[H:], y[c_edge:])
+        halo = exchange.finish() if exchange is not None else None
+        self.edge.seek(pos, None if first else halo)
+        if split:
+            if c_edge > 0:
+                self.edge.step(x[:H], y[:c_edge])
+        else:
+            self.edge.step(x, y)
+        return y[:c_all]
+
+
+class OverlappedSos:
+    """SOS cascade (tsdgpu_sos) sharded with a warm-up halo of W = Sos.halo samples (state transition below 1e-9 after W
+    samples).  The interior is warmed up on the chunk's OWN first W samples, the edge -- the first W outputs -- on the
+    neighbour's.  The first rank of a stream runs one plain step (first-sample seed, filtre-rt.cc:361-365)."""
+
+    def __init__(self, t, coefs, gain, data_type, rii1=None):
+        self.main = t.Sos(coefs, gain, data_type, rii1)
+        self.edge = t.Sos(coefs, gain, data_type, rii1)
+        self.W = int(self.main.halo)
+        assert self.W >= 0, "this cascade does not decay: use sos_step_exact"
+        self.scratch = None
+
+    def step(self, x, y, exchange, first):
+        W, n = self.W, x.shape[0]
+        if first:
+            if exchange is not None:
+                exchange.finish()
+            self.main.reset_on(x)
+            self.main.step(x, y)
+            return y
+        if self.scratch is None or self.scratch.shape[0] < W:
+            self.scratch = x.new_empty(max(W, 1))
+        split = n > W
+        if split:
+            self.main.reset_on(x)
+            self.main.step(x[:W], self.scratch[:W])
+            self.main.step(x[W:], y[W:])
+        halo = exchange.finish()
+        self.edge.reset_on(x)
+        self.edge.step(halo, self.scratch[:W])
+        self.edge.step(x[:W] if split else x, y[:W] if split else y)
+        return y
+
+
+def max_over_ranks(value, device, world, force=False):
+    """all_reduce(MAX) of a host scalar (`force`: also with one rank, so that the collective runs)"""
+    if world == 1 and not force:
         return value
     t = torch.tensor([value], device="cpu" if dist.get_backend() == "gloo" else device, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
 
-def sos_step_exact(sos, x_chunk, chunk_len, rank, world, stream_state=None, group=None):
+def sos_step_exact(sos, x_chunk, chunk_len, rank, world, stream_state=None, group=None, force_collective=False):
     """One call of a cascade whose memory is too long for a warm-up halo (tsdgpu_sos_halo < 0, or longer than a
     chunk is worth), one rank per chunk: the path's one real exchange step, so the one place with a collective.
 
@@ -54,24 +199,41 @@ def sos_step_exact(sos, x_chunk, chunk_len, rank, world, stream_state=None, grou
     before this call (None = a fresh stream: the first sample seeds the sections).  Returns (y_chunk, state of the
     stream after the call) -- the latter on every rank, for the next call."""
     import numpy as np
-    nf = sos.get_state().size
+    # every state transfer of this call runs on the stream the cascade's step runs on (the chunk's current torch stream):
+    # a null-stream copy would not wait for a step launched on a non-blocking stream and return the stale pre-step state
+    st = None
+    if hasattr(x_chunk, "is_cuda") and x_chunk.is_cuda:
+        st = torch.cuda.current_stream(x_chunk.device).cuda_stream
+
+    def get_state():
+        return sos.get_state(st) if st is not None else sos.get_state()
+
+    def set_state(v):
+        return sos.set_state(v, st) if st is not None else sos.set_state(v)
+
+    def step(xc):
+        return sos.step(xc, None, st) if st is not None else sos.step(xc)
+
+    nf = get_state().size
     fresh = np.zeros(nf, np.float32)
     before = fresh if stream_state is None else np.asarray(stream_state, np.float32)
-    if world == 1:
+    if world == 1 and not force_collective:
         if chunk_len <= 0:
             return x_chunk, before
-        sos.set_state(before)
-        return sos.step(x_chunk), sos.get_state()
+        set_state(before)
+        return step(x_chunk), get_state()
     on_dev = dist.get_backend(group) != "gloo"
     dev = x_chunk.device if (on_dev and hasattr(x_chunk, "device")) else "cpu"
 
-    def all_gather(vec):
-        t_mine = torch.from_numpy(np.asarray(vec, np.float32)).to(dev)
+    def all_gather(vec, dtype=np.float32):
+        t_mine = torch.from_numpy(np.asarray(vec, dtype)).to(dev)
         parts = [torch.empty_like(t_mine) for _ in range(world)]
         dist.all_gather(parts, t_mine, group=group)          # RCCL on the GPU node, gloo in the rehearsals
         return [p.cpu().numpy() for p in parts]
 
-    lens = [int(v[0]) for v in all_gather([float(chunk_len)])]
+    # the chunk lengths travel as int64: a float32 rounds any length beyond 2^24 samples (the bench shape is 2^26 per
+    # rank), and propagate_state would then apply Phi^(L +- k) instead of Phi^L
+    lens = [int(v[0]) for v in all_gather([int(chunk_len)], np.int64)]
     with_samples = [q for q in range(world) if lens[q] > 0]
     if not with_samples:
         return x_chunk, before
@@ -80,15 +242,15 @@ def sos_step_exact(sos, x_chunk, chunk_len, rank, world, stream_state=None, grou
     zero[0] = 1.0                      # zero memories, first-sample seed spent
     y, end = x_chunk, np.zeros(nf, np.float32)
     if chunk_len > 0:
-        sos.set_state(before if rank == first else zero)
-        y, end = sos.step(x_chunk), sos.get_state()
+        set_state(before if rank == first else zero)
+        y, end = step(x_chunk), get_state()
     ends = all_gather(end)
     cur = ends[first]                  # the true state after the first chunk
     for q in range(first + 1, world):
         if lens[q] <= 0:
             continue
         if q == rank:
-            sos.set_state(cur)
-            y = sos.step(x_chunk)
+            set_state(cur)
+            y = step(x_chunk)
         cur = sos.propagate_state(lens[q], cur, ends[q])
     return y, cur

@@ -51,6 +51,23 @@ def main():
             if np.abs(ref - got).max() > 2e-6 * np.abs(ref).max():
                 fails.append(f"FIR method {method}: {np.abs(ref - got).max()}")
 
+    # ---- the same with the exchange off the critical path: interior launched before the halo wait, edge behind it
+    #      (sharding.OverlappedFir: what bench.py --gpus N runs) -- same outputs, bit for bit for the direct kernel
+    for method in (t.FIR_DIRECT, t.FIR_OVERLAP_SAVE):
+        ov = sharding.OverlappedFir(t, h, t.C64, method)
+        xc = torch.from_numpy(x[lo:hi].copy()).to(dev)
+        yc = torch.empty_like(xc)
+        halo = torch.zeros(126, dtype=torch.complex64, device=dev)
+        ex = sharding.start_halo_exchange(torch.view_as_real(xc[-126:].clone()), torch.view_as_real(halo), rank, world, result=halo)
+        ov.step(xc, yc, ex, first=(rank == 0))
+        got = gather(yc)
+        if rank == 0:
+            ref = t.Fir(h, t.C64, method).step(torch.from_numpy(x).to(dev)).cpu().numpy()
+            if method == t.FIR_DIRECT and not np.array_equal(ref, got):
+                fails.append("overlapped FIR direct: sharded output differs from the single handle")
+            if np.abs(ref - got).max() > 2e-6 * np.abs(ref).max():
+                fails.append(f"overlapped FIR method {method}: {np.abs(ref - got).max()}")
+
     # ---- SOS: warm-up halo
     from scipy.signal import butter
     sos = butter(12, 0.5, output="sos")
@@ -68,6 +85,15 @@ def main():
         ref = t.Sos(co, 1.0, t.F32).step(torch.from_numpy(xr).to(dev)).cpu().numpy()
         if np.abs(ref - got).max() > 1e-6 * np.abs(ref).max():
             fails.append(f"SOS: {np.abs(ref - got).max()} (peak {np.abs(ref).max()})")
+
+    ovs = sharding.OverlappedSos(t, co, 1.0, t.F32)
+    yc = torch.empty_like(xc)
+    halo = torch.zeros(W, dtype=torch.float32, device=dev)
+    ex = sharding.start_halo_exchange(xc[-W:].clone(), halo, rank, world)
+    ovs.step(xc, yc, ex, first=(rank == 0))
+    got = gather(yc)
+    if rank == 0 and np.abs(ref - got).max() > 1e-6 * np.abs(ref).max():
+        fails.append(f"overlapped SOS: {np.abs(ref - got).max()} (peak {np.abs(ref).max()})")
 
     # ---- SOS with a long memory (first-order low-pass at fc = 1e-5: 5e5 samples; order 3 at 1e-4): no halo can warm it
     #      up -- exact exchange of the end states (ONE all_gather), two calls in a row (the stream state carried between)
@@ -101,6 +127,14 @@ def main():
         ref = t.Resampler(ratio, t.C64).step(torch.from_numpy(x).to(dev)).cpu().numpy()
         if len(ref) != len(got) or not np.array_equal(ref, got):
             fails.append(f"resampler: {len(got)} outputs vs {len(ref)}, equal = {len(ref) == len(got) and np.array_equal(ref, got)}")
+
+    ovr = sharding.OverlappedResampler(t, ratio, t.C64)
+    halo = torch.zeros(14, dtype=torch.complex64, device=dev)
+    ex = sharding.start_halo_exchange(torch.view_as_real(xc[-14:].clone()), torch.view_as_real(halo), rank, world, result=halo)
+    yc = torch.empty(int(ovr.main.out_count(hi - lo)) + 8, dtype=torch.complex64, device=dev)
+    got = gather(ovr.step(xc, yc, lo, ex, first=(rank == 0)))
+    if rank == 0 and (len(ref) != len(got) or not np.array_equal(ref, got)):
+        fails.append(f"overlapped resampler: {len(got)} outputs vs {len(ref)}")
 
     ok = torch.tensor([0 if fails else 1])
     dist.broadcast(ok, 0)

@@ -3,6 +3,8 @@ direct-form-I IIR against the CPU oracle (polyphase.cc:54-341, filtre-rt.cc:127-
 import numpy as np
 import pytest
 
+from conftest import perf_guard
+
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
 
@@ -207,7 +209,7 @@ def test_filtre_rii_order6_2p26_under_2ms(tg):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 5
     print(f"filtre_rii order 6, 2^26 floats: {ms:.3f} ms")
-    assert ms < 2.0
+    perf_guard(ms < 2.0, f"filtre_rii order 6, 2^26 floats: {ms:.3f} ms")
 
 
 def test_filtre_rii_high_order_is_not_a_cliff(tg):
@@ -224,4 +226,4 @@ def test_filtre_rii_high_order_is_not_a_cliff(tg):
     t0 = time.perf_counter()
     f.step(x)
     torch.cuda.synchronize()
-    assert time.perf_counter() - t0 < 1.5
+    perf_guard(time.perf_counter() - t0 < 1.5, "6th-order direct form on 2^22 samples took more than 1.5 s")

@@ -5,6 +5,8 @@ sample values within 1e-5 relative."""
 import numpy as np
 import pytest
 
+from conftest import perf_guard
+
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
 R160 = np.float32(160.0) / np.float32(147.0)
@@ -235,4 +237,4 @@ def test_short_period_ratios_far_into_a_stream(tg, orc, ratio):
         g.step(xd[:n1])
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / 5 * 1e3
-    assert ms < 5.0, f"ratio {ratio}: {ms:.1f} ms per 4 M inputs far into the stream"
+    perf_guard(ms < 5.0, f"ratio {ratio}: {ms:.1f} ms per 4 M inputs far into the stream")

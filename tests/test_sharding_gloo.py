@@ -70,7 +70,7 @@ def _worker(rank, world, port, n, K, q):
 @pytest.mark.parametrize("world", [2, 3])
 def test_sharded_fir_resampler_sos_match_single_process(orc, world):
     n, K = 30000, 127
-    port = 29600 + world
+    port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, n, K, q)) for r in range(world)]
@@ -148,6 +148,67 @@ def _worker_exact(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+class _ToySosFast(_ToySos):
+    """The same stub with a vectorised step (scipy lfilter), for chunks of 2^24 samples and more."""
+
+    def step(self, x):
+        from scipy.signal import lfilter
+        x = np.asarray(x, np.float64)
+        prev = float(self.st[1]) if self.st[0] else float(x[0])
+        y, zf = lfilter([1.0 - self.a], [1.0, -self.a], x, zi=[self.a * prev])
+        self.st = np.array([1.0, y[-1]], np.float32)
+        return y
+
+
+def _worker_exact_long(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from libtsd_amd import sharding
+    # a pole at -(1 - 1e-9): the state after L samples is a^L ~ (-1)^L, so a chunk length rounded from 2^24 + 1 to 2^24
+    # (what a float32 all_gather of the lengths did) flips the sign of the propagated start state
+    a = -(1.0 - 1e-9)
+    L = (1 << 24) + 1
+    n = world * L
+    lo, hi = sharding.chunk_bounds(n, rank, world)
+    assert hi - lo == L
+    x = np.random.default_rng(11).standard_normal(n)[lo:hi]         # same stream on every rank, own chunk kept
+    f = _ToySosFast(a)
+    y, etat = sharding.sos_step_exact(f, x, L, rank, world, None)
+    if rank == world - 1:
+        q.put((np.asarray(y[-1000:], np.float64), np.asarray(etat, np.float64)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sos_exact_exchange_chunks_longer_than_2p24():
+    """the chunk lengths must travel as integers -- 2^24 + 1 samples per rank (the bench shape is 2^26).
+    Three ranks: the start state of rank 2 is the first one that goes through propagate_state(len(chunk 1), ...)."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_exact_long, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    tail, etat = q.get(timeout=240)
+    for p in procs:
+        p.join(120)
+    assert all(p.exitcode == 0 for p in procs)
+    a = -(1.0 - 1e-9)
+    x = np.random.default_rng(11).standard_normal(world * ((1 << 24) + 1))
+    ref = _ToySosFast(a).step(x)
+    assert np.abs(tail - ref[-1000:]).max() <= 1e-5 * np.abs(ref).max(), np.abs(tail - ref[-1000:]).max() / np.abs(ref).max()
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_sos_exact_exchange_on_gloo(world):
     """sharding.sos_step_exact -- zero-state pass, ONE all_gather of the end states and chunk lengths, start states by
@@ -155,7 +216,7 @@ def test_sos_exact_exchange_on_gloo(world):
     calls (one of them shorter than the number of ranks)."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29650 + world
+    port = _free_port()
     procs = [ctx.Process(target=_worker_exact, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()

@@ -4,6 +4,8 @@ Tolerance: max|y - y_ref| <= 1e-5 * max|y_ref| (the block-parallel recursion re-
 import numpy as np
 import pytest
 
+from conftest import perf_guard
+
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
 
@@ -185,7 +187,7 @@ def test_sos_unaligned_device_views(tg, orc, cplx, ox, oy):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     assert relerr(yd[oy:oy + n].cpu().numpy(), ref.step(x[ox:ox + n])) <= TOL
-    assert dt < 0.5, f"unaligned views took {dt:.2f} s"      # the sequential kernel would need seconds
+    perf_guard(dt < 0.5, f"unaligned views took {dt:.2f} s")      # the sequential kernel would need seconds
     # in place on an unaligned view
     ref2, g2 = chains(orc, tg, 12, 0.25, cplx)
     z = xd.clone()
@@ -244,7 +246,7 @@ def test_sos_small_and_ragged_blocks_are_not_a_cliff(tg, orc):
             g.step(xd, yd)
         torch.cuda.synchronize()
         us = (time.perf_counter() - t0) / 20 * 1e6
-        assert us < 400, f"a {n}-float step takes {us:.0f} us"
+        perf_guard(us < 400, f"a {n}-float step takes {us:.0f} us")
 
 
 @pytest.mark.parametrize("cplx", [False, True])
@@ -287,7 +289,7 @@ def test_sos_long_memory_exact_carry(tg, orc, cplx, order, fc):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / 5 * 1e3
     print("long memory", order, fc, cplx, "ms per 2^22 samples", round(ms, 3))
-    assert ms < 0.5, ms                              # (1.5 - 3.2 ms on the sequential chunk)
+    perf_guard(ms < 0.5, ms)                         # (1.5 - 3.2 ms on the sequential chunk)
 
 
 @pytest.mark.parametrize("cplx", [False, True])
@@ -334,7 +336,7 @@ def test_sos_long_memory_forme_directe_1(tg, orc, cplx, order, fc):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / 5 * 1e3
     print("long memory DF1", order, fc, cplx, "ms per 2^22 samples", round(ms, 3))
-    assert ms < 0.6, ms
+    perf_guard(ms < 0.6, ms)
 
 
 @pytest.mark.parametrize("cplx", [False, True])
@@ -365,7 +367,7 @@ def test_exponential_smoother_and_dc_blocker_long_memory(tg, orc, cplx):
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / 5 * 1e3
         print("lexp / dc", nu, cplx, "path", g.path, "ms per 2^21 samples", round(ms, 3))
-        assert ms < 0.5, ms
+        perf_guard(ms < 0.5, ms)
 
 
 @pytest.mark.parametrize("cplx", [False, True])

@@ -15,3 +15,12 @@ def test_wave_fft_header_on_cpu(tmp_path):
                    check=True, capture_output=True)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
+
+
+def test_per_device_keying_on_cpu(tmp_path):
+    """bounce blocks and plan reserves are keyed by device (tests/cpu/test_per_device.cc)."""
+    exe = str(tmp_path / "t_per_device")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-pthread", "-fsanitize=address,undefined", "-o", exe,
+                    os.path.join(ROOT, "tests", "cpu", "test_per_device.cc")], check=True, capture_output=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout + r.stderr
