@@ -37,7 +37,7 @@ K_TAPS = 127
 # gfx950 correction of MI355X_MICROARCH.md (HBM section): FETCH_SIZE counts 64 B per 128-B request on wide
 # coalesced reads -> x2; WRITE_SIZE is exact.  The dominant kernels of each workload:
 TRAFFIC_KERNELS = {
-    "fir": ["ols_kernel<false>"],
+    "fir": ["ols_kernel<false"],
     "fft": ["fft1m_cols_kernel<1>", "fft1m_cols_kernel<2>"],
     "sos": ["sos_kernel"],
     "resample": ["resample15_kernel"],

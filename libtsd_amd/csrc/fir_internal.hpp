@@ -21,6 +21,9 @@ struct tsdgpu_fir {
   int ols_N = 0;            // FFT block size
   int ols_L = 0;            // valid outputs per block = N - (K-1)
   int ols_grid = 0;         // persistent grid size (waves)
+  unsigned *d_ctr = nullptr;   // work counters of the dynamic block hand-out (ols.hip: OlsDyn), behind d_H
+  int ctr_nc = 0;              // how many of them the launches so far have used
+  unsigned ctr_base = 0;       // their common value before the next launch (every launch advances all of them alike)
   bool ols_long = false;    // long-filter plan (ols_long.hip): N = 4096..16384, H in natural order + W_N table
   // partitioned plan for more than 12289 taps: the taps cut in segments of part_S, one child filter per
   // segment (each on the long-filter overlap-save plan), y = sum_p child_p(x delayed by p * part_S)

@@ -28,6 +28,13 @@ constexpr int OLS_N = 1024;
 #ifndef OLS_SCALAR
 #define OLS_SCALAR 1
 #endif
+#ifndef OLS_RUN_DEFAULT   // blocks per run of a wave (ols_body): 1 = every block loads its whole overlap again
+#define OLS_RUN_DEFAULT 2
+#endif
+#ifndef OLS_DYN_DEFAULT   // counters of the dynamic hand-out (OlsDyn); 0 = static partition
+#define OLS_DYN_DEFAULT 16
+#endif
+constexpr int OLS_MAX_CTR = 32;
 #ifndef OLS_WIDE   // experiment: 16-B global accesses (layout NOT the FFT's: ablation only)
 #define OLS_WIDE 0
 #endif
@@ -107,12 +114,33 @@ __device__ __forceinline__ void ols_fetch(cv (&v)[16], const cv *__restrict__ x,
 //
 // Blocks [b_lo, b_hi) are processed with block b = b_lo + slot + i*G.  The EDGE variant is
 // launched with G = 1 per edge block.
-template <bool EDGE, bool REAL>
+// R0 > 0 (interior launches, overlap of exactly R0 rows of 64 samples): a wave walks RUNS of R consecutive blocks and the
+// R0 overlap rows of a block inside a run are the last R0 input rows of the block before it -- copied from registers
+// before the transform overwrites them instead of being loaded again.  Every sample then crosses the L2 1 + R0/(16 - R0)/R
+// times instead of 1 + R0/(16 - R0) (K = 127: 1.036 with R = 4 against 1.143), while the grid still sweeps one contiguous
+// span of G*R blocks per round (fully chunked streams -- one per wave for the whole call -- measured slower).
+// R0 = 0: every block loads its 16 rows (any overlap; R is 1).
+//
+// DYN: the runs are handed out DYNAMICALLY instead of run = slot + round * G.  A persistent grid with a static partition
+// streams 6-9 % below a non-persistent launch of the same copy (scripts/ubench/copy_shapes.hip: 5.5 against 6.05 TB/s --
+// nothing balances the waves, they drift apart and the slowest one ends the launch); pulling the next unit from a few
+// counters brings the copy to 5.9.  NC counters on their own 128-B lines; wave w pulls from counter (w / 8) % NC, so the
+// pullers of one counter sit on all 8 XCDs; a pulled value v stands for unit v * NC + c.  The counters are never reset:
+// every launch starts from `base` (host-tracked) and advances each counter by exactly Q + G / NC -- Q = ceil(units / NC)
+// values inside the quota plus one failing pull per wave -- so the host knows the next launch's base without a memset.
+// The pull for the NEXT run is issued at the start of the current one: its latency hides under R blocks.
+struct OlsDyn {
+  unsigned *ctr;
+  unsigned base, Q;
+  int NC;
+  int64_t nunits;
+};
+template <bool EDGE, bool REAL, int R0, bool DYN>
 __device__ __forceinline__ void ols_body(cv *lds, const void *__restrict__ xv, const void *__restrict__ histv,
                                          void *__restrict__ yv, const cv *__restrict__ Hreg,
                                          const cv *__restrict__ TW1, const cv *__restrict__ TW2, int Km1,
                                          int histlen, int L, int64_t n, int64_t b_lo, int64_t b_hi, int64_t G,
-                                         int64_t w)
+                                         int64_t w, int R, OlsDyn dyn)
 {
   const int lane = threadIdx.x;
   const cv *x = (const cv *) xv, *hist = (const cv *) histv;
@@ -141,7 +169,23 @@ __device__ __forceinline__ void ols_body(cv *lds, const void *__restrict__ xv, c
   // over the 8 XCDs, so w % 8 labels its XCD -- takes block (w % 8) * G/8 + w / 8: blocks that
   // share their K-1 overlap samples run on the same XCD at the same time and the second
   // reader hits that XCD's L2.  Placement only affects speed, never results.
-  int64_t b = EDGE ? b_lo : b_lo + ((G % 8 == 0) ? (w % 8) * (G / 8) + w / 8 : w);
+  const int64_t slot = (G % 8 == 0) ? (w % 8) * (G / 8) + w / 8 : w;
+  const int ctr_c = DYN ? (int) ((w / 8) % dyn.NC) : 0;
+  // -> the next unit of this wave's counter, or -1 once its quota is spent (exactly one failing pull per wave)
+  auto pull = [&]() -> int64_t {
+    for (;;) {
+      unsigned v = 0;
+      if (lane == 0) v = __hip_atomic_fetch_add(dyn.ctr + ctr_c * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v = (unsigned) __builtin_amdgcn_readfirstlane((int) v) - dyn.base;
+      if (v >= dyn.Q) return -1;
+      const int64_t u = (int64_t) v * dyn.NC + ctr_c;
+      if (u < dyn.nunits) return u;                  // (the last row of units may be partial: pull again)
+    }
+  };
+  int64_t unit = EDGE ? 0 : (DYN ? pull() : slot);
+  if (unit < 0) return;
+  int64_t run0 = EDGE ? b_lo : b_lo + unit * R;      // first block of the wave's current run
+  int64_t b = run0;
   if (b >= b_hi) return;
 
   // One block: prefetch the next block into `nxt`, transform `cur` in place, then store it.
@@ -149,11 +193,30 @@ __device__ __forceinline__ void ols_body(cv *lds, const void *__restrict__ xv, c
   // predicated stores): the wait for the prefetch is forced BEFORE this block's stores are
   // issued -- the loads are a whole block old by then, so it costs nothing -- and afterwards
   // nothing waits on the stores: they drain while the next block is being transformed.
-  auto process = [&](cv (&cur)[16], cv (&nxt)[16], int64_t blk) {
-    const bool more = !EDGE && blk + G < b_hi;
+  // nb: the block prefetched while `blk` is transformed; inrun: nb = blk + 1 inside the same run
+  auto process = [&](cv (&cur)[16], cv (&nxt)[16], int64_t blk, int64_t nb, bool inrun) {
+    const bool more = !EDGE && nb < b_hi;
     if (more) {
-      if (REAL) ols_fetch_real<EDGE>(nxt, xr, histr, histlen, Km1, L, n, blk + G, lane);
-      else ols_fetch<EDGE>(nxt, x, hist, histlen, Km1, L, n, blk + G, lane);
+      if (R0 > 0 && inrun) {
+        if (!REAL) {
+          const cv *xb = x + (nb * (int64_t) L - Km1);
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            if (r < R0) nxt[r] = cur[(16 - R0 + r) & 15];                // (cur still holds the raw samples)
+            else nxt[r] = NT ? ntload(xb + 64 * r + lane) : xb[64 * r + lane];
+          }
+        } else {
+          // pair (2 nb, 2 nb + 1): the first block's overlap is the tail of this pair's second block; the second block's
+          // overlap is the tail of the first block being loaded now -- filled in once the loads have landed (below)
+          const float *xa = xr + (2 * nb * (int64_t) L - Km1), *xb = xa + L;
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            if (r < R0) nxt[r] = mkv(cur[(16 - R0 + r) & 15].y, 0.f);
+            else nxt[r] = mkv(xa[64 * r + lane], xb[64 * r + lane]);
+          }
+        }
+      } else if (REAL) ols_fetch_real<EDGE>(nxt, xr, histr, histlen, Km1, L, n, nb, lane);
+      else ols_fetch<EDGE>(nxt, x, hist, histlen, Km1, L, n, nb, lane);
     }
 #ifndef OLS_ABLATE   // measurement only: bit 0 drops the forward FFT, bit 1 the product, bit 2 the inverse
 #define OLS_ABLATE 0
@@ -168,6 +231,10 @@ __device__ __forceinline__ void ols_body(cv *lds, const void *__restrict__ xv, c
     if (more) {
 #pragma unroll
       for (int r = 0; r < 16; r++) asm volatile("" ::"v"(nxt[r]));
+      if (REAL && R0 > 0 && inrun) {
+#pragma unroll
+        for (int r = 0; r < R0; r++) nxt[r].y = nxt[(16 - R0 + r) & 15].x;
+      }
     }
     // sample t = 64*r + lane of the circular convolution is output o0 + t - (K-1)
     const int r0 = Km1 >> 6;   // Km1 is a multiple of 64: rows below r0 are overlap, the rest whole
@@ -210,90 +277,65 @@ __device__ __forceinline__ void ols_body(cv *lds, const void *__restrict__ xv, c
   if (REAL) ols_fetch_real<EDGE>(A, xr, histr, histlen, Km1, L, n, b, lane);
   else ols_fetch<EDGE>(A, x, hist, histlen, Km1, L, n, b, lane);
   if (EDGE) {
-    process(A, B, b);   // edge launches: one block per wave, no prefetch
+    process(A, B, b, b_hi, false);   // edge launches: one block per wave, no prefetch
     return;
   }
-#ifndef OLS_DEPTH   // blocks of prefetch in flight per wave (1: two register sets; 2: three)
-#define OLS_DEPTH 1
-#endif
-#if OLS_DEPTH == 2
-  // Three register sets: while block b is transformed, block b+G is landing (issued a whole block
-  // earlier) and block b+2G has just been requested -- 16 KiB per wave in flight instead of 8.  The wait
-  // forced before the stores names the NEAR set only (vmcnt(30): the far loads stay in flight).
-  cv C[16];
-  auto fetch_into = [&](cv (&dst)[16], int64_t blk) {
-    if (REAL) ols_fetch_real<false>(dst, xr, histr, histlen, Km1, L, n, blk, lane);
-    else ols_fetch<false>(dst, x, hist, histlen, Km1, L, n, blk, lane);
+  int i = 0;                        // position of b inside its run
+  constexpr int64_t END = INT64_MAX;
+  // the run after the current one (requested one run ahead)
+  auto unit_after = [&](int64_t u) -> int64_t {
+    if (DYN) return pull();
+    return b_lo + (u + G) * R < b_hi ? u + G : -1;
   };
-  auto process3 = [&](cv (&cur)[16], cv (&far)[16], cv (&near)[16], int64_t blk) {
-    if (blk + 2 * G < b_hi) fetch_into(far, blk + 2 * G);
-    forward(cur, lds, lane, tw1, tw2, sync);
-#pragma unroll
-    for (int r = 0; r < 16; r++) cur[r] = cmul(cur[r], H[r]);
-    inverse(cur, lds, lane, tw1, tw2, sync);
-    sync();
-    if (blk + G < b_hi) {
-#pragma unroll
-      for (int r = 0; r < 16; r++) asm volatile("" ::"v"(near[r]));
-    }
-    const int r0 = Km1 >> 6;
-    if (!REAL) {
-      cv *yb = y + (blk * (int64_t) L - Km1);
-#pragma unroll
-      for (int r = 0; r < 16; r++)
-        if (r >= r0) yb[64 * r + lane] = cur[r];
-    } else {
-      const int64_t oa = 2 * blk * (int64_t) L, ob = oa + L;
-      float *ya = yr + (oa - Km1), *yb = yr + (ob - Km1);
-#pragma unroll
-      for (int r = 0; r < 16; r++)
-        if (r >= r0) { ya[64 * r + lane] = cur[r].x; yb[64 * r + lane] = cur[r].y; }
-    }
+  int64_t unit_next = unit_after(unit);
+  auto next_of = [&](int64_t &nb, bool &inrun) {
+    inrun = i + 1 < R && b + 1 < b_hi;
+    nb = inrun ? b + 1 : (unit_next >= 0 ? b_lo + unit_next * R : END);
   };
-  if (b + G < b_hi) fetch_into(B, b + G);
+  auto advance = [&](int64_t nb, bool inrun) {
+    if (inrun) i++;
+    else {
+      i = 0;
+      run0 = nb;
+      unit = unit_next;
+      unit_next = unit_after(unit);
+    }
+    b = nb;
+  };
   for (;;) {
-    process3(A, C, B, b);
-    b += G;
-    if (b >= b_hi) break;
-    process3(B, A, C, b);
-    b += G;
-    if (b >= b_hi) break;
-    process3(C, B, A, b);
-    b += G;
-    if (b >= b_hi) break;
+    int64_t nb;
+    bool inrun;
+    next_of(nb, inrun);
+    process(A, B, b, nb, inrun);
+    if (nb >= b_hi) break;
+    advance(nb, inrun);
+    next_of(nb, inrun);
+    process(B, A, b, nb, inrun);
+    if (nb >= b_hi) break;
+    advance(nb, inrun);
   }
-#else
-  for (;;) {
-    process(A, B, b);
-    b += G;
-    if (b >= b_hi) break;
-    process(B, A, b);
-    b += G;
-    if (b >= b_hi) break;
-  }
-#endif
 }
 
 // One launch per step: workgroups [0, G) walk the interior blocks, the next `ne` workgroups
 // take one edge block each (block 0 with the history halo, the ragged last block), and the
 // last workgroup writes the new history (the last `histlen` samples of history ++ x) into
 // the handle's other history buffer.
-template <bool REAL>
+template <bool REAL, int R0, bool DYN>
 __global__ __launch_bounds__(64, 2) void ols_kernel(const void *__restrict__ x, const void *__restrict__ hist,
                                                     void *__restrict__ hist_next, void *__restrict__ y,
                                                     const cpx *__restrict__ Hreg, const cpx *__restrict__ TW1,
                                                     const cpx *__restrict__ TW2, int Km1, int histlen, int L,
                                                     int64_t n, int64_t b_lo, int64_t b_hi, int64_t nblocks, int G,
-                                                    int ne, int64_t n_lo, int64_t b_tail)
+                                                    int ne, int64_t n_lo, int64_t b_tail, int R, OlsDyn dyn)
 {
   __shared__ cv lds[LDS_ELEMS];
   const int w = blockIdx.x;
   if (w < G) {
-    ols_body<false, REAL>(lds, x, hist, y, (const cv *) Hreg, (const cv *) TW1, (const cv *) TW2, Km1, histlen, L, n, b_lo, b_hi, G, w);
+    ols_body<false, REAL, R0, DYN>(lds, x, hist, y, (const cv *) Hreg, (const cv *) TW1, (const cv *) TW2, Km1, histlen, L, n, b_lo, b_hi, G, w, R, dyn);
   } else if (w < G + ne) {
     // edge items: [0, n_lo) need the history halo, [b_tail, nblocks) are ragged at the end
     const int64_t b = (w - G) < n_lo ? (int64_t) (w - G) : b_tail + (w - G - n_lo);
-    ols_body<true, REAL>(lds, x, hist, y, (const cv *) Hreg, (const cv *) TW1, (const cv *) TW2, Km1, histlen, L, n, b, nblocks, 1, 0);
+    ols_body<true, REAL, 0, false>(lds, x, hist, y, (const cv *) Hreg, (const cv *) TW1, (const cv *) TW2, Km1, histlen, L, n, b, nblocks, 1, 0, 1, dyn);
   } else {
     for (int i = threadIdx.x; i < histlen; i += 64) {
       const int64_t g = n - histlen + i;
@@ -378,16 +420,21 @@ int ols_plan_create(tsdgpu_fir *f)
     }
   std::copy(tb->tw12.begin(), tb->tw12.end(), img.begin() + N);
   const size_t bytes = (size_t) N * sizeof(cpx);
-  if (hipMalloc(&f->d_H, 3 * bytes) != hipSuccess)
+  // (the work counters of the dynamic hand-out live behind the tables: zero once, never reset -- see OlsDyn)
+  const size_t ctr_bytes = (size_t) OLS_MAX_CTR * 128;
+  img.resize(3 * (size_t) N + ctr_bytes / sizeof(cpx), mk(0.f, 0.f));
+  if (hipMalloc(&f->d_H, 3 * bytes + ctr_bytes) != hipSuccess)
     return set_err(TSDGPU_ERR_HIP, "ols: hipMalloc failed: %s", hipGetErrorString(hipGetLastError()));
-  if (hipMemcpy(f->d_H, img.data(), 3 * bytes, hipMemcpyHostToDevice) != hipSuccess)
+  if (hipMemcpy(f->d_H, img.data(), 3 * bytes + ctr_bytes, hipMemcpyHostToDevice) != hipSuccess)
     return set_err(TSDGPU_ERR_HIP, "ols: upload failed: %s", hipGetErrorString(hipGetLastError()));
+  f->d_ctr = (unsigned *) ((char *) f->d_H + 3 * bytes);
+  f->ctr_base = 0;
   // persistent grid: as many waves as the device keeps resident (asked once per process: the devices of a node are alike)
   static const std::pair<int, int> occ = []() {
     int dev = 0, cus = 256, per_cu = 8;
     (void) hipGetDevice(&dev);
     (void) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ols_kernel<false>, 64, 0) != hipSuccess || per_cu < 1) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ols_kernel<false, 2, true>, 64, 0) != hipSuccess || per_cu < 1) {
       (void) hipGetLastError();
       per_cu = 8;
     }
@@ -404,6 +451,7 @@ void ols_plan_destroy(tsdgpu_fir *f)
 {
   if (f->d_H) (void) hipFree(f->d_H);
   f->d_H = nullptr;
+  f->d_ctr = nullptr;
 }
 
 int ols_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, hipStream_t st)
@@ -418,27 +466,71 @@ int ols_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, hipStream_t st)
   const int64_t b_lo = std::min<int64_t>(nblocks, f->K > 1 ? cdiv(ovl, LB) : 0);
   const int64_t b_hi = std::max<int64_t>(b_lo, n / LB);
   int64_t grid = 0;
+  // runs of R consecutive blocks per wave (ols_body): only with whole-row overlaps the kernel is specialised for, and only
+  // when there are blocks enough for every wave to get several runs
+  const int r0 = (int) (ovl / 64);
+  const char *run_s = getenv("TSDGPU_OLS_RUN");      // (read per step: scripts/perf_ols_run.py interleaves values in one process)
+  const int run_env = run_s ? atoi(run_s) : OLS_RUN_DEFAULT;
+  // dynamic hand-out of the runs (OlsDyn) unless the step must be capturable in a graph (frozen kernel arguments)
+  const char *nc_s = getenv("TSDGPU_OLS_DYN");       // number of counters; 0 = the static partition
+  int NC = nc_s ? atoi(nc_s) : OLS_DYN_DEFAULT;
+  if (NC < 0 || NC > OLS_MAX_CTR || f->capturable || !f->d_ctr) NC = 0;
+  int R = 1;
+  OlsDyn dyn = {f->d_ctr, f->ctr_base, 0u, NC > 0 ? NC : 1, 0};
   if (b_hi > b_lo) {
     const int64_t nint = b_hi - b_lo;
-    // balance the rounds: every wave gets ceil(nint/grid) or one fewer items, no tail round
-    grid = nint < f->ols_grid ? nint : f->ols_grid;
-    if (nint > grid) {
-      const int64_t rounds = cdiv(nint, grid);
-      grid = cdiv(cdiv(nint, rounds), 8) * 8;
+    if (r0 >= 1 && r0 <= 4 && run_env > 1 && nint >= (int64_t) f->ols_grid * run_env * 2) R = run_env;
+    const int64_t nruns = cdiv(nint, R);
+    const char *min_s = getenv("TSDGPU_OLS_DYN_MIN");        // runs per wave from which the hand-out is dynamic (tests: 0)
+    const int64_t dyn_min = min_s ? atoi(min_s) : 4;
+    if (NC > 0 && nruns >= dyn_min * (int64_t) f->ols_grid) {
+      // whole groups of 8 * NC waves, so that every counter has the same number of pullers
+      grid = std::max<int64_t>(8 * NC, (f->ols_grid / (8 * NC)) * (8 * NC));
+      if (NC != f->ctr_nc) {
+        // another counter count than the launches before (a tuning switch flipped mid-stream): the counters beyond the
+        // old count lag behind the base -- start over from zero
+        TSD_HIP(hipMemsetAsync(f->d_ctr, 0, (size_t) OLS_MAX_CTR * 128, st));
+        f->ctr_base = 0;
+        f->ctr_nc = NC;
+        dyn.base = 0;
+      }
+      dyn.nunits = nruns;
+      dyn.Q = (unsigned) cdiv(nruns, NC);
+      f->ctr_base += dyn.Q + (unsigned) (grid / NC);          // what this launch adds to every counter
+    } else {
+      NC = 0;
+      // balance the rounds: every wave gets ceil(nruns/grid) or one fewer runs, no tail round
+      grid = nruns < f->ols_grid ? nruns : f->ols_grid;
+      if (nruns > grid) {
+        const int64_t rounds = cdiv(nruns, grid);
+        grid = cdiv(cdiv(nruns, rounds), 8) * 8;
+      }
     }
-  }
+  } else NC = 0;
   const int64_t b_lo_w = b_lo;
   // edge items, one wave each: [0, b_lo) read the history halo, [b_hi, nblocks) are ragged
   const int64_t n_lo = b_lo, b_tail = b_hi;
   const int ne = (int) (n_lo + (nblocks - b_tail));
   int64_t e[2] = {n_lo, b_tail};
   const int nxt = f->cur ^ 1;
-#define OLS_LAUNCH(REAL)                                                                                                       \
-  hipLaunchKernelGGL((ols_kernel<REAL>), dim3((unsigned) (grid + ne + 1)), dim3(64), 0, st, x, (const void *) f->hist[f->cur], \
+#define OLS_LAUNCH(REAL, R0, DYN)                                                                                                       \
+  hipLaunchKernelGGL((ols_kernel<REAL, R0, DYN>), dim3((unsigned) (grid + ne + 1)), dim3(64), 0, st, x, (const void *) f->hist[f->cur], \
                      f->hist[nxt], y, d, d + OLS_N, d + 2 * OLS_N, OLS_N - L, f->HL, L, n, b_lo_w, b_hi, nblocks, (int) grid, ne,   \
-                     e[0], e[1])
-  if (real) OLS_LAUNCH(true);
-  else OLS_LAUNCH(false);
+                     e[0], e[1], R, dyn)
+#define OLS_LAUNCH_R0(REAL, DYN)                                        \
+  switch (R > 1 ? r0 : 0) {                                             \
+    case 1: OLS_LAUNCH(REAL, 1, DYN); break;                            \
+    case 2: OLS_LAUNCH(REAL, 2, DYN); break;                            \
+    case 3: OLS_LAUNCH(REAL, 3, DYN); break;                            \
+    case 4: OLS_LAUNCH(REAL, 4, DYN); break;                            \
+    default: OLS_LAUNCH(REAL, 0, DYN); break;                           \
+  }
+  if (real) {
+    if (NC > 0) { OLS_LAUNCH_R0(true, true) } else { OLS_LAUNCH_R0(true, false) }
+  } else {
+    if (NC > 0) { OLS_LAUNCH_R0(false, true) } else { OLS_LAUNCH_R0(false, false) }
+  }
+#undef OLS_LAUNCH_R0
 #undef OLS_LAUNCH
   TSD_HIP(hipGetLastError());
   f->cur = nxt;      // the history update is part of the launch
