@@ -35,6 +35,13 @@ constexpr int OLS_N = 1024;
 #define OLS_DYN_DEFAULT 16
 #endif
 constexpr int OLS_MAX_CTR = 32;
+// waves per workgroup: 1 (tables in registers, 8 waves per CU) or 4 (tables in an LDS image, 139 VGPRs, 12 waves per CU).
+// Measured with the dynamic hand-out (profiles/r3_ols_schedule_ab.txt): 0.2017-0.2032 ms against 0.2081-0.2087 -- at equal
+// wave counts the 46 table reads per block cost 10 %, which the four extra waves do not win back.  The 4-wave flavour is
+// compiled only with -DOLS_WITH_WPW4=1 (scripts/build_variant.sh) and selected with TSDGPU_OLS_WPW=4.
+#ifndef OLS_WITH_WPW4
+#define OLS_WITH_WPW4 0
+#endif
 #ifndef OLS_WIDE   // experiment: 16-B global accesses (layout NOT the FFT's: ablation only)
 #define OLS_WIDE 0
 #endif
@@ -135,24 +142,43 @@ struct OlsDyn {
   int NC;
   int64_t nunits;
 };
-template <bool EDGE, bool REAL, int R0, bool DYN>
-__device__ __forceinline__ void ols_body(cv *lds, const void *__restrict__ xv, const void *__restrict__ histv,
+// The per-lane constants of a block -- twiddles of the two radix-16 stages and the response H, 46 complex values -- either
+// live in registers for the wave's lifetime (LT = false: 96 VGPRs, 200 in all, 2 waves per SIMD) or are read from an LDS
+// image shared by the workgroup's waves at every use (LT = true: 3 waves per SIMD; the kernel wants occupancy:
+// profiles/r3_ols_schedule_ab.txt, 5 / 6 / 7 / 8 waves per CU = 0.245 / 0.225 / 0.216 / 0.205 ms).  The LDS accessors take
+// the lane through an opaque copy made per block: with a loop-invariant address hipcc hoists all 46 reads out of the
+// block loop, back into registers.
+struct RegTab {
+  cv v[16];
+  __device__ __forceinline__ const cv &operator[](int r) const { return v[r]; }
+};
+struct LdsTab {
+  const cv *p;      // p[r * pitch] is this lane's entry r
+  int pitch;
+  __device__ __forceinline__ cv operator[](int r) const { return p[r * pitch]; }
+};
+constexpr int OLS_TAB_ELEMS = 64 * 16 * 2 + 4 * 16;      // tw1 [16][64] | H [16][64] | tw2 [16][4] (tw2 depends on lane & 3 only)
+
+template <bool EDGE, bool REAL, int R0, bool DYN, bool LT>
+__device__ __forceinline__ void ols_body(cv *lds, const cv *ltab, const void *__restrict__ xv, const void *__restrict__ histv,
                                          void *__restrict__ yv, const cv *__restrict__ Hreg,
                                          const cv *__restrict__ TW1, const cv *__restrict__ TW2, int Km1,
                                          int histlen, int L, int64_t n, int64_t b_lo, int64_t b_hi, int64_t G,
-                                         int64_t w, int R, OlsDyn dyn)
+                                         int64_t w, int64_t cgrp, int R, OlsDyn dyn)
 {
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
   const cv *x = (const cv *) xv, *hist = (const cv *) histv;
   cv *y = (cv *) yv;
   const float *xr = (const float *) xv, *histr = (const float *) histv;
   float *yr = (float *) yv;
-  cv tw1[16], tw2[16], H[16];
+  RegTab tw1r, tw2r, Hr;
+  if (!LT) {
 #pragma unroll
-  for (int r = 0; r < 16; r++) {
-    tw1[r] = TW1[r * 64 + lane];
-    tw2[r] = TW2[r * 64 + lane];
-    H[r] = Hreg[r * 64 + lane];
+    for (int r = 0; r < 16; r++) {
+      tw1r.v[r] = TW1[r * 64 + lane];
+      tw2r.v[r] = TW2[r * 64 + lane];
+      Hr.v[r] = Hreg[r * 64 + lane];
+    }
   }
   // One wave per workgroup: its LDS operations execute in order, so exchanging data between
   // lanes needs no s_barrier and -- crucially -- no vmcnt(0) drain (a __syncthreads() would
@@ -169,8 +195,8 @@ __device__ __forceinline__ void ols_body(cv *lds, const void *__restrict__ xv, c
   // over the 8 XCDs, so w % 8 labels its XCD -- takes block (w % 8) * G/8 + w / 8: blocks that
   // share their K-1 overlap samples run on the same XCD at the same time and the second
   // reader hits that XCD's L2.  Placement only affects speed, never results.
-  const int64_t slot = (G % 8 == 0) ? (w % 8) * (G / 8) + w / 8 : w;
-  const int ctr_c = DYN ? (int) ((w / 8) % dyn.NC) : 0;
+  const int64_t slot = (!LT && G % 8 == 0) ? (w % 8) * (G / 8) + w / 8 : w;
+  const int ctr_c = DYN ? (int) (cgrp % dyn.NC) : 0;     // cgrp: rounds of 8 workgroups (one per XCD)
   // -> the next unit of this wave's counter, or -1 once its quota is spent (exactly one failing pull per wave)
   auto pull = [&]() -> int64_t {
     for (;;) {
@@ -221,12 +247,24 @@ __device__ __forceinline__ void ols_body(cv *lds, const void *__restrict__ xv, c
 #ifndef OLS_ABLATE   // measurement only: bit 0 drops the forward FFT, bit 1 the product, bit 2 the inverse
 #define OLS_ABLATE 0
 #endif
-    if (!(OLS_ABLATE & 1)) forward(cur, lds, lane, tw1, tw2, sync);
-    if (!(OLS_ABLATE & 2)) {
+    if (LT) {
+      int ol = lane;
+      asm volatile("" : "+v"(ol));               // opaque per block: the table reads stay inside the loop
+      const LdsTab tw1 = {ltab + ol, 64}, H = {ltab + 1024 + ol, 64}, tw2 = {ltab + 2048 + (ol & 3), 4};
+      if (!(OLS_ABLATE & 1)) forward(cur, lds, lane, tw1, tw2, sync);
+      if (!(OLS_ABLATE & 2)) {
 #pragma unroll
-      for (int r = 0; r < 16; r++) cur[r] = cmul(cur[r], H[r]);
+        for (int r = 0; r < 16; r++) cur[r] = cmul(cur[r], H[r]);
+      }
+      if (!(OLS_ABLATE & 4)) inverse(cur, lds, lane, tw1, tw2, sync);
+    } else {
+      if (!(OLS_ABLATE & 1)) forward(cur, lds, lane, tw1r, tw2r, sync);
+      if (!(OLS_ABLATE & 2)) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) cur[r] = cmul(cur[r], Hr[r]);
+      }
+      if (!(OLS_ABLATE & 4)) inverse(cur, lds, lane, tw1r, tw2r, sync);
     }
-    if (!(OLS_ABLATE & 4)) inverse(cur, lds, lane, tw1, tw2, sync);
     sync();   // LDS is reused by the next block
     if (more) {
 #pragma unroll
@@ -316,28 +354,46 @@ __device__ __forceinline__ void ols_body(cv *lds, const void *__restrict__ xv, c
   }
 }
 
-// One launch per step: workgroups [0, G) walk the interior blocks, the next `ne` workgroups
-// take one edge block each (block 0 with the history halo, the ragged last block), and the
-// last workgroup writes the new history (the last `histlen` samples of history ++ x) into
-// the handle's other history buffer.
-template <bool REAL, int R0, bool DYN>
-__global__ __launch_bounds__(64, 2) void ols_kernel(const void *__restrict__ x, const void *__restrict__ hist,
+// One launch per step: waves [0, G) walk the interior blocks, the next `ne` waves take one edge block each (block 0 with the
+// history halo, the ragged last block), and the wave after them writes the new history (the last `histlen` samples of
+// history ++ x) into the handle's other history buffer.  WPW waves per workgroup: 1 = tables in registers, 2 waves per
+// SIMD; 4 = tables in an LDS image per workgroup, 3 workgroups per CU = 3 waves per SIMD.
+template <bool REAL, int R0, bool DYN, int WPW>
+__global__ __launch_bounds__(64 * WPW, WPW == 1 ? 2 : 3) void ols_kernel(const void *__restrict__ x, const void *__restrict__ hist,
                                                     void *__restrict__ hist_next, void *__restrict__ y,
                                                     const cpx *__restrict__ Hreg, const cpx *__restrict__ TW1,
                                                     const cpx *__restrict__ TW2, int Km1, int histlen, int L,
                                                     int64_t n, int64_t b_lo, int64_t b_hi, int64_t nblocks, int G,
                                                     int ne, int64_t n_lo, int64_t b_tail, int R, OlsDyn dyn)
 {
-  __shared__ cv lds[LDS_ELEMS];
-  const int w = blockIdx.x;
+  constexpr bool LT = WPW > 1;
+  __shared__ cv smem[WPW * LDS_ELEMS + (LT ? OLS_TAB_ELEMS : 0)];
+  const int wv = WPW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+  cv *lds = smem + wv * LDS_ELEMS;
+  const cv *ltab = smem + WPW * LDS_ELEMS;
+  if (LT) {
+    cv *t = smem + WPW * LDS_ELEMS;
+    for (int i = threadIdx.x; i < 1024; i += 64 * WPW) {
+      t[i] = ((const cv *) TW1)[i];
+      t[1024 + i] = ((const cv *) Hreg)[i];
+    }
+    if (threadIdx.x < 64) t[2048 + threadIdx.x] = ((const cv *) TW2)[(threadIdx.x >> 2) * 64 + (threadIdx.x & 3)];      // [r][lane & 3]
+    __syncthreads();          // the only workgroup barrier: from here on the waves are independent
+  }
+  // wave index: workgroups are dealt round-robin over the XCDs, so the waves of workgroups g, g + 8, ... share an XCD; w / (8 WPW)
+  // numbers the rounds of 8 workgroups (the counter choice of the dynamic hand-out), w % 8 ... the static slot map is kept
+  // for WPW = 1 only
+  const int64_t w = (int64_t) blockIdx.x * WPW + wv;
+  const int lane = threadIdx.x & 63;
   if (w < G) {
-    ols_body<false, REAL, R0, DYN>(lds, x, hist, y, (const cv *) Hreg, (const cv *) TW1, (const cv *) TW2, Km1, histlen, L, n, b_lo, b_hi, G, w, R, dyn);
+    ols_body<false, REAL, R0, DYN, LT>(lds, ltab, x, hist, y, (const cv *) Hreg, (const cv *) TW1, (const cv *) TW2, Km1, histlen, L, n, b_lo, b_hi, G,
+                                       w, (int64_t) blockIdx.x / 8, R, dyn);
   } else if (w < G + ne) {
     // edge items: [0, n_lo) need the history halo, [b_tail, nblocks) are ragged at the end
     const int64_t b = (w - G) < n_lo ? (int64_t) (w - G) : b_tail + (w - G - n_lo);
-    ols_body<true, REAL, 0, false>(lds, x, hist, y, (const cv *) Hreg, (const cv *) TW1, (const cv *) TW2, Km1, histlen, L, n, b, nblocks, 1, 0, 1, dyn);
-  } else {
-    for (int i = threadIdx.x; i < histlen; i += 64) {
+    ols_body<true, REAL, 0, false, LT>(lds, ltab, x, hist, y, (const cv *) Hreg, (const cv *) TW1, (const cv *) TW2, Km1, histlen, L, n, b, nblocks, 1, 0, 0, 1, dyn);
+  } else if (w == G + ne) {
+    for (int i = lane; i < histlen; i += 64) {
       const int64_t g = n - histlen + i;
       if (REAL) ((float *) hist_next)[i] = g < 0 ? ((const float *) hist)[histlen + g] : ((const float *) x)[g];
       else ((cpx *) hist_next)[i] = g < 0 ? ((const cpx *) hist)[histlen + g] : ((const cpx *) x)[g];
@@ -430,20 +486,29 @@ int ols_plan_create(tsdgpu_fir *f)
   f->d_ctr = (unsigned *) ((char *) f->d_H + 3 * bytes);
   f->ctr_base = 0;
   // persistent grid: as many waves as the device keeps resident (asked once per process: the devices of a node are alike)
-  static const std::pair<int, int> occ = []() {
-    int dev = 0, cus = 256, per_cu = 8;
+  // waves per workgroup: 4 = tables in LDS, 3 workgroups of 4 waves per CU; 1 = tables in registers, 8 one-wave workgroups
+  const char *wpw_s = getenv("TSDGPU_OLS_WPW");
+  f->ols_wpw = (OLS_WITH_WPW4 && wpw_s && atoi(wpw_s) == 4) ? 4 : 1;
+  static const std::pair<int, std::pair<int, int>> occ = []() {
+    int dev = 0, cus = 256, per_cu1 = 8, per_cu4 = 3;
     (void) hipGetDevice(&dev);
     (void) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ols_kernel<false, 2, true>, 64, 0) != hipSuccess || per_cu < 1) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu1, ols_kernel<false, 2, true, 1>, 64, 0) != hipSuccess || per_cu1 < 1) {
       (void) hipGetLastError();
-      per_cu = 8;
+      per_cu1 = 8;
     }
-    return std::make_pair(cus, per_cu);
+#if OLS_WITH_WPW4
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu4, ols_kernel<false, 2, true, 4>, 256, 0) != hipSuccess || per_cu4 < 1) {
+      (void) hipGetLastError();
+      per_cu4 = 3;
+    }
+#endif
+    return std::make_pair(cus, std::make_pair(per_cu1, 4 * per_cu4));
   }();
-  const int cus = occ.first, per_cu = occ.second;
+  const int cus = occ.first, per_cu = f->ols_wpw == 1 ? occ.second.first : occ.second.second;    // waves per CU
   f->ols_grid = cus * per_cu;
   if (const char *g = getenv("TSDGPU_OLS_WAVES_PER_CU")) f->ols_grid = cus * atoi(g);
-  if (getenv("TSDGPU_DEBUG")) fprintf(stderr, "[tsdgpu] ols plan: N=%d K=%d L=%d cus=%d occupancy/CU=%d grid=%d\n", N, K, f->ols_L, cus, per_cu, f->ols_grid);
+  if (getenv("TSDGPU_DEBUG")) fprintf(stderr, "[tsdgpu] ols plan: N=%d K=%d L=%d cus=%d waves/workgroup=%d waves/CU=%d grid=%d waves\n", N, K, f->ols_L, cus, f->ols_wpw, per_cu, f->ols_grid);
   return TSDGPU_OK;
 }
 
@@ -484,8 +549,9 @@ int ols_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, hipStream_t st)
     const char *min_s = getenv("TSDGPU_OLS_DYN_MIN");        // runs per wave from which the hand-out is dynamic (tests: 0)
     const int64_t dyn_min = min_s ? atoi(min_s) : 4;
     if (NC > 0 && nruns >= dyn_min * (int64_t) f->ols_grid) {
-      // whole groups of 8 * NC waves, so that every counter has the same number of pullers
-      grid = std::max<int64_t>(8 * NC, (f->ols_grid / (8 * NC)) * (8 * NC));
+      // whole groups of 8 * NC workgroups, so that every counter has the same number of pullers
+      const int64_t grp = (int64_t) 8 * NC * f->ols_wpw;
+      grid = std::max<int64_t>(grp, (f->ols_grid / grp) * grp);
       if (NC != f->ctr_nc) {
         // another counter count than the launches before (a tuning switch flipped mid-stream): the counters beyond the
         // old count lag behind the base -- start over from zero
@@ -513,23 +579,32 @@ int ols_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, hipStream_t st)
   const int ne = (int) (n_lo + (nblocks - b_tail));
   int64_t e[2] = {n_lo, b_tail};
   const int nxt = f->cur ^ 1;
-#define OLS_LAUNCH(REAL, R0, DYN)                                                                                                       \
-  hipLaunchKernelGGL((ols_kernel<REAL, R0, DYN>), dim3((unsigned) (grid + ne + 1)), dim3(64), 0, st, x, (const void *) f->hist[f->cur], \
+  const int WPW = f->ols_wpw;
+  const unsigned nwg = (unsigned) cdiv(grid + ne + 1, WPW);
+#define OLS_LAUNCH(REAL, R0, DYN, W)                                                                                                  \
+  hipLaunchKernelGGL((ols_kernel<REAL, R0, DYN, W>), dim3(nwg), dim3(64 * W), 0, st, x, (const void *) f->hist[f->cur],                 \
                      f->hist[nxt], y, d, d + OLS_N, d + 2 * OLS_N, OLS_N - L, f->HL, L, n, b_lo_w, b_hi, nblocks, (int) grid, ne,   \
                      e[0], e[1], R, dyn)
-#define OLS_LAUNCH_R0(REAL, DYN)                                        \
-  switch (R > 1 ? r0 : 0) {                                             \
-    case 1: OLS_LAUNCH(REAL, 1, DYN); break;                            \
-    case 2: OLS_LAUNCH(REAL, 2, DYN); break;                            \
-    case 3: OLS_LAUNCH(REAL, 3, DYN); break;                            \
-    case 4: OLS_LAUNCH(REAL, 4, DYN); break;                            \
-    default: OLS_LAUNCH(REAL, 0, DYN); break;                           \
+#define OLS_LAUNCH_R0(REAL, DYN, W)                                        \
+  switch (R > 1 ? r0 : 0) {                                                \
+    case 1: OLS_LAUNCH(REAL, 1, DYN, W); break;                            \
+    case 2: OLS_LAUNCH(REAL, 2, DYN, W); break;                            \
+    case 3: OLS_LAUNCH(REAL, 3, DYN, W); break;                            \
+    case 4: OLS_LAUNCH(REAL, 4, DYN, W); break;                            \
+    default: OLS_LAUNCH(REAL, 0, DYN, W); break;                           \
   }
+#if OLS_WITH_WPW4
+#define OLS_LAUNCH_W(REAL, DYN) \
+  if (WPW == 1) { OLS_LAUNCH_R0(REAL, DYN, 1) } else { OLS_LAUNCH_R0(REAL, DYN, 4) }
+#else
+#define OLS_LAUNCH_W(REAL, DYN) { OLS_LAUNCH_R0(REAL, DYN, 1) }
+#endif
   if (real) {
-    if (NC > 0) { OLS_LAUNCH_R0(true, true) } else { OLS_LAUNCH_R0(true, false) }
+    if (NC > 0) { OLS_LAUNCH_W(true, true) } else { OLS_LAUNCH_W(true, false) }
   } else {
-    if (NC > 0) { OLS_LAUNCH_R0(false, true) } else { OLS_LAUNCH_R0(false, false) }
+    if (NC > 0) { OLS_LAUNCH_W(false, true) } else { OLS_LAUNCH_W(false, false) }
   }
+#undef OLS_LAUNCH_W
 #undef OLS_LAUNCH_R0
 #undef OLS_LAUNCH
   TSD_HIP(hipGetLastError());

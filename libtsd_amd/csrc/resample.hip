@@ -322,12 +322,22 @@ __global__ __launch_bounds__(RS_THREADS) void resample_kernel(const T *__restric
 #define RS15_LATE_STORE 1
 #endif
 constexpr int RS15_WAVES = RS15_NW;
+// Dynamic hand-out of the tiles (the scheme of the overlap-save FIR, ols.hip: OlsDyn): a persistent grid with a static
+// partition streams 6-9 % below the same bytes handed out in order (scripts/ubench/copy_shapes.hip).  NC counters on their
+// own 128-B lines, workgroup g pulls from counter (g / 8) % NC (its pullers sit on all 8 XCDs), a pulled value v stands for
+// tile v * NC + c; never reset: each launch starts from `base` and advances every counter by Q + pullers-per-counter.
+constexpr int RS_MAX_CTR = 32;
+struct RsDyn {
+  unsigned *ctr;
+  unsigned base, Q;
+  int NC;            // 0: static partition (tile = wave + k * waves)
+};
 constexpr int RS15_TILE_PAD = (RS_TI + 16) + (RS_TI + 16) / 8 + 2;      // padded sample slots per wave
 template <typename T>
 __global__ __launch_bounds__(64 * RS15_WAVES) void resample15_kernel(const T *__restrict__ x, const T *__restrict__ hist,
                                                                      T *__restrict__ y, const float *__restrict__ lut,
                                                                      const RsCk *__restrict__ ck, RsParams P, int ntiles,
-                                                                     T *__restrict__ hist_next)
+                                                                     T *__restrict__ hist_next, RsDyn dyn)
 {
   if (blockIdx.x == gridDim.x - 1) {      // (see resample_kernel: the next window history rides in this launch)
     for (int i = threadIdx.x; i < 14; i += 64 * RS15_WAVES) {
@@ -374,13 +384,44 @@ __global__ __launch_bounds__(64 * RS15_WAVES) void resample15_kernel(const T *__
   };
   const int wtile0 = blockIdx.x * RS15_WAVES + wv;
   const int wstep = (gridDim.x - 1) * RS15_WAVES;
-  int64_t icT = P.tile0 + (int64_t) wtile0 * RS_TI, qT = 0;
-  if (P.lambda > 0 && icT >= P.mu + P.lambda) {
-    const int64_t d = icT - P.mu;
-    qT = d / P.lambda;
-    icT = P.mu + (d - qT * P.lambda);
-  }
-  const int64_t icStep = (int64_t) wstep * RS_TI;
+  // canonical schedule index of tile 0 of this call (inside the tabulated prefix + one period) and its period count
+  int64_t ic0 = P.tile0, q0 = 0;
+  rs_wrap(ic0, q0, P.mu, P.lambda);
+  // -> (canonical index, periods) of tile tix: the tile's absolute index folded back into the table
+  auto tile_ic = [&](int tix_, int64_t &ic_, int64_t &q_) {
+    ic_ = ic0 + (int64_t) tix_ * RS_TI;
+    q_ = q0;
+    if (P.lambda > 0) {
+      const int64_t lim = P.mu + P.lambda;
+      if (ic_ >= lim) {
+        if (ic_ - lim < 64 * P.lambda) {
+          do { ic_ -= P.lambda; q_++; } while (ic_ >= lim);       // (wave-uniform: scalar instructions)
+        } else {
+          const int64_t d = ic_ - P.mu, k = d / P.lambda;
+          q_ += k;
+          ic_ = P.mu + (d - k * P.lambda);
+        }
+      }
+    }
+  };
+  const int ctr_c = dyn.NC > 0 ? (int) ((blockIdx.x / 8) % dyn.NC) : 0;
+  // -> the next tile of this wave (dynamic: from its counter, -1 once the quota is spent -- exactly one failing pull per
+  // wave; static: prev + waves)
+  auto next_tile = [&](int prev) -> int {
+    if (dyn.NC == 0) {
+      const int t = prev < 0 ? wtile0 : prev + wstep;
+      return t < ntiles ? t : -1;
+    }
+    for (;;) {
+      unsigned v = 0;
+      if (lane == 0) v = __hip_atomic_fetch_add(dyn.ctr + ctr_c * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      v = (unsigned) __builtin_amdgcn_readfirstlane((int) v) - dyn.base;
+      if (v >= dyn.Q) return -1;
+      const int64_t t = (int64_t) v * dyn.NC + ctr_c;
+      if (t < ntiles) return (int) t;
+    }
+  };
+  int64_t icT = 0, qT = 0;
 
   constexpr int NPF = (RS_TI + K + 63) / 64;       // 9 samples per lane per tile
   T pf[NPF];
@@ -420,7 +461,13 @@ __global__ __launch_bounds__(64 * RS15_WAVES) void resample15_kernel(const T *__
     if (T0_ + (int64_t) lane * RS_SEG < P.pos + P.n) cpf = ck[ic_ / RS_CK];
   };
 
-  if (wtile0 < ntiles) fetch(wtile0, icT);
+  // the tile being evaluated, the one being prefetched, and (requested a tile ahead) the one after it
+  int tix = next_tile(-1);
+  int ntix = tix >= 0 ? next_tile(tix) : -1;
+  if (tix >= 0) {
+    tile_ic(tix, icT, qT);
+    fetch(tix, icT);
+  }
 #if RS15_LATE_STORE
   int pend_begin = 0, pend_last = 0;       // outputs [pend_begin, pend_last) of the previous tile wait in obuf
   T *pend_y = y;
@@ -429,7 +476,7 @@ __global__ __launch_bounds__(64 * RS15_WAVES) void resample15_kernel(const T *__
     pend_last = 0;
   };
 #endif
-  for (int tix = wtile0; tix < ntiles; tix += wstep) {
+  while (tix >= 0) {
     const int64_t T0 = P.tile0 + (int64_t) tix * RS_TI;
 #pragma unroll
     for (int j = 0; j < NPF; j++) {
@@ -446,9 +493,11 @@ __global__ __launch_bounds__(64 * RS15_WAVES) void resample15_kernel(const T *__
     const float inc = P.inc;
     float phase = bits2f(cpf.phase_bits);
     int64_t cum = (int64_t) cpf.cum + q * P.opp;
-    icT += icStep;
-    rs_wrap(icT, qT, P.mu, P.lambda);
-    if (tix + wstep < ntiles) fetch(tix + wstep, icT);
+    const int nntix = ntix >= 0 ? next_tile(ntix) : -1;      // (its latency hides under this tile's evaluation)
+    if (ntix >= 0) {
+      tile_ic(ntix, icT, qT);
+      fetch(ntix, icT);
+    }
 
     if (in_call) {
       for (int s = (int) (ic % RS_CK); s > 0; s--) {
@@ -509,6 +558,8 @@ __global__ __launch_bounds__(64 * RS15_WAVES) void resample15_kernel(const T *__
     for (int oo = o_begin + lane; oo < last; oo += 64) yt[oo] = obuf[oo];
     wave_sync();
 #endif
+    tix = ntix;
+    ntix = nntix;
   }
 #if RS15_LATE_STORE
   flush();
@@ -582,6 +633,10 @@ struct tsdgpu_resampler {
   RsCk *d_ck = nullptr;
   size_t d_ck_cap = 0, d_ck_n = 0;
   DevBuf in_stage, out_stage;
+  // work counters of the fused kernel's dynamic tile hand-out (RsDyn), behind the histories in d_lut's allocation
+  unsigned *d_ctr = nullptr;
+  unsigned ctr_base = 0;
+  int ctr_nc = 0;
 };
 
 namespace {
@@ -734,7 +789,8 @@ int tsdgpu_resampler_create(tsdgpu_resampler **out, int data_type, float ratio, 
   // synchronisation before)
   const size_t hb = ((size_t) std::max(K - 1, 1) * dtype_size(data_type) + 15) / 16 * 16, lb = (lut_bytes + 15) / 16 * 16;
   int rc = TSDGPU_OK;
-  std::vector<char> image(lb + 2 * hb, 0);
+  const size_t ctr_bytes = (size_t) RS_MAX_CTR * 128;
+  std::vector<char> image(lb + 2 * hb + ctr_bytes, 0);
   for (int c = 0; c <= nphases; c++)
     std::memcpy(image.data() + (size_t) c * r->gl * sizeof(float), lut_host + (size_t) c * K, (size_t) K * sizeof(float));
   if (hipMalloc((void **) &r->d_lut, image.size()) != hipSuccess)
@@ -744,6 +800,7 @@ int tsdgpu_resampler_create(tsdgpu_resampler **out, int data_type, float ratio, 
   if (!rc) {
     r->d_hist[0] = (char *) r->d_lut + lb;
     r->d_hist[1] = (char *) r->d_lut + lb + hb;
+    r->d_ctr = (unsigned *) ((char *) r->d_lut + lb + 2 * hb);      // (lb and hb are multiples of 16 bytes)
   }
   if (rc) {
     tsdgpu_resampler_destroy(r);
@@ -886,13 +943,31 @@ int tsdgpu_resampler_step(tsdgpu_resampler *r, const void *x, int64_t n, void *y
   const size_t lds15 = (size_t) ((r->nph + 1) * 20 + 4) * 4 + RS15_WAVES * wb15 + 64;
   const void *hcur = r->hist_zero ? nullptr : r->d_hist[r->cur];
   if (r->K == 15 && r->mode == 0 && lds15 <= 158 * 1024) {     // fused kernel; larger ratios fall back to the generic one
-    const int64_t g15 = std::min<int64_t>(cdiv(tiles, RS15_WAVES), 256);
+    int64_t g15 = std::min<int64_t>(cdiv(tiles, RS15_WAVES), 256);
+    // dynamic hand-out of the tiles when every wave gets several of them (RsDyn); TSDGPU_RS_DYN = counters, 0 = static
+    const char *nc_s = getenv("TSDGPU_RS_DYN");
+    int NC = nc_s ? atoi(nc_s) : 16;
+    if (NC < 0 || NC > RS_MAX_CTR || !r->d_ctr || 256 % (8 * std::max(NC, 1)) != 0) NC = 0;
+    const char *min_s = getenv("TSDGPU_RS_DYN_MIN");         // tiles per wave from which the hand-out is dynamic (tests: 0)
+    if (tiles < (int64_t) (min_s ? atoi(min_s) : 4) * 256 * RS15_WAVES) NC = 0;
+    RsDyn dyn = {r->d_ctr, r->ctr_base, 0u, NC};
+    if (NC > 0) {
+      g15 = 256;                                             // whole groups of 8 * NC workgroups: equal pullers per counter
+      if (NC != r->ctr_nc) {
+        TSD_HIP(hipMemsetAsync(r->d_ctr, 0, (size_t) RS_MAX_CTR * 128, st));      // (a tuning switch flipped mid-stream)
+        r->ctr_base = 0;
+        r->ctr_nc = NC;
+        dyn.base = 0;
+      }
+      dyn.Q = (unsigned) cdiv(tiles, NC);
+      r->ctr_base += dyn.Q + (unsigned) (g15 / NC * RS15_WAVES);      // what this launch adds to every counter
+    }
     if (r->data_type == TSDGPU_C64)
       hipLaunchKernelGGL(resample15_kernel<float2>, dim3((unsigned) g15 + 1), dim3(64 * RS15_WAVES), lds15, st, (const float2 *) dx,
-                         (const float2 *) hcur, (float2 *) dy, r->d_lut, r->d_ck, P, (int) tiles, (float2 *) r->d_hist[r->cur ^ 1]);
+                         (const float2 *) hcur, (float2 *) dy, r->d_lut, r->d_ck, P, (int) tiles, (float2 *) r->d_hist[r->cur ^ 1], dyn);
     else
       hipLaunchKernelGGL(resample15_kernel<float>, dim3((unsigned) g15 + 1), dim3(64 * RS15_WAVES), lds15, st, (const float *) dx,
-                         (const float *) hcur, (float *) dy, r->d_lut, r->d_ck, P, (int) tiles, (float *) r->d_hist[r->cur ^ 1]);
+                         (const float *) hcur, (float *) dy, r->d_lut, r->d_ck, P, (int) tiles, (float *) r->d_hist[r->cur ^ 1], dyn);
   } else {
 #define RS_LAUNCH(T, KT)                                                                                            \
   hipLaunchKernelGGL((resample_kernel<T, KT>), dim3((unsigned) pgrid + 1), dim3(RS_THREADS), lds, st, (const T *) dx, \
