@@ -38,7 +38,7 @@ K_TAPS = 127
 # coalesced reads -> x2; WRITE_SIZE is exact.  The dominant kernels of each workload:
 TRAFFIC_KERNELS = {
     "fir": ["ols_kernel<false"],
-    "fft": ["fft1m_cols_kernel<1>", "fft1m_cols_kernel<2>"],
+    "fft": ["fft1m_cols_kernel<1", "fft1m_cols_kernel<2"],
     "sos": ["sos_kernel"],
     "resample": ["resample15_kernel"],
 }

@@ -329,6 +329,27 @@ int tsdgpu_xcorr(const void *x, const void *y, int n, int m, int unbiased, void 
 int tsdgpu_delay_estimate(const void *x, const void *y, int n, float *delay, float *score, void *stream);
 
 /* --------------------------------------------------------------------------------------
+ * Real-time spectrum analyser: rt_spectrum / Spectrum::step (src/fourier/fourier.cc:1162-1342).
+ * A block of BS = nsubs x Nf complex samples is cut in nsubs sub-blocks; each is multiplied by the window (Nf values,
+ * already normalised to energy Nf by the caller, fourier.cc:1209-1212), transformed (unitary), |X|^2 taken in fftshift
+ * order; the sub-blocks of nmeans consecutive blocks are summed -- all into one Nf-bin spectrum, or, in sweep mode, sub-block
+ * i into bins [i step, i step + Nf) of a Ns = Nf + (nsubs - 1) step bin spectrum through a mask (Nf values; NULL: ones) and
+ * divided by the number of contributions per bin -- scaled by 1 / (nmeans nsubs Nf) and returned as 10 log10(. + FLT_MIN).
+ * tsdgpu_spectrum_step takes any number of whole blocks (x host or device); every nmeans-th block completes a spectrum, appended
+ * to y (Ns floats each, host or device; n_spectra returns how many).  Sums of an incomplete group stay on the device between
+ * calls.  Everything per-sample runs on the GPU: only x goes up, Ns floats come back per nmeans blocks.
+ * ------------------------------------------------------------------------------------ */
+typedef struct tsdgpu_spectrum tsdgpu_spectrum;
+int tsdgpu_spectrum_create(tsdgpu_spectrum **out, int BS, int nsubs, int nmeans, const float *window_host, int sweep_active,
+                           int sweep_step, const float *mask_host);
+int tsdgpu_spectrum_bins(const tsdgpu_spectrum *h);                /* Ns */
+int tsdgpu_spectrum_pending(const tsdgpu_spectrum *h);             /* blocks accumulated since the last spectrum */
+int tsdgpu_spectrum_step(tsdgpu_spectrum *h, const void *x, int64_t nblocks, float *y, int64_t y_capacity, int64_t *n_spectra,
+                         void *stream);
+int tsdgpu_spectrum_reset(tsdgpu_spectrum *h, void *stream);
+int tsdgpu_spectrum_destroy(tsdgpu_spectrum *h);
+
+/* --------------------------------------------------------------------------------------
  * Several GPUs, ONE process: a long vector cut into contiguous chunks (shard g = samples
  * [n g / N, n (g+1) / N)), one operator handle per shard, and the one small left-neighbour halo each
  * operator needs -- FIR: K-1 input samples; SOS: the warm-up samples of tsdgpu_sos_halo; resampler:

@@ -143,6 +143,12 @@ def _declare(L):
     L.tsdgpu_ola_write_spectra.argtypes = [vp, vp, vp]
     L.tsdgpu_ola_destroy.argtypes = [vp]
     L.tsdgpu_welch.argtypes = [vp, C.c_int64, i32, vp, vp, C.POINTER(C.c_int64), vp]
+    L.tsdgpu_spectrum_create.argtypes = [C.POINTER(vp), i32, i32, i32, vp, i32, i32, vp]
+    L.tsdgpu_spectrum_bins.argtypes = [vp]
+    L.tsdgpu_spectrum_pending.argtypes = [vp]
+    L.tsdgpu_spectrum_step.argtypes = [vp, vp, C.c_int64, vp, C.c_int64, C.POINTER(C.c_int64), vp]
+    L.tsdgpu_spectrum_reset.argtypes = [vp, vp]
+    L.tsdgpu_spectrum_destroy.argtypes = [vp]
 
 
 def device_count():
@@ -384,6 +390,58 @@ def welch(x, N, window):
     nseg = C.c_int64(0)
     _check(lib().tsdgpu_welch(_ptr(x), int(x.shape[0]), int(N), w.ctypes.data, S.ctypes.data, C.byref(nseg), _stream_of(x, None)))
     return S, nseg.value
+
+
+class Spectrum:
+    """rt_spectrum (fourier.cc:1162-1342): blocks of BS = nsubs x Nf samples -> one spectrum in dB per nmeans blocks.
+    window: Nf values already normalised to energy Nf; sweep = (step, mask[Nf] or None) or None."""
+
+    def __init__(self, BS, nsubs, nmeans, window, sweep=None):
+        w = np.ascontiguousarray(window, np.float32)
+        self.BS, self.nsubs, self.nmeans = BS, nsubs, nmeans
+        self._h = C.c_void_p()
+        if sweep is None:
+            _check(lib().tsdgpu_spectrum_create(C.byref(self._h), BS, nsubs, nmeans, w.ctypes.data, 0, 0, None))
+        else:
+            step, mask = sweep
+            m = None if mask is None else np.ascontiguousarray(mask, np.float32)
+            _check(lib().tsdgpu_spectrum_create(C.byref(self._h), BS, nsubs, nmeans, w.ctypes.data, 1, int(step), None if m is None else m.ctypes.data))
+        self.Ns = lib().tsdgpu_spectrum_bins(self._h)
+
+    @property
+    def pending(self):
+        return lib().tsdgpu_spectrum_pending(self._h)
+
+    def step(self, x, y=None, stream=None):
+        """x: whole blocks (numpy / torch complex64) -> [spectra completed by this call, Ns] float32"""
+        assert _dtype_code(x) == C64 and x.shape[0] % self.BS == 0
+        B = x.shape[0] // self.BS
+        nout = (self.pending + B) // self.nmeans
+        if y is None:
+            y = np.empty((nout, self.Ns), np.float32) if isinstance(x, np.ndarray) else x.new_empty((nout, self.Ns), dtype=_torch_f32())
+        got = C.c_int64(0)
+        _check(lib().tsdgpu_spectrum_step(self._h, _ptr(x) if B else None, B, _ptr(y) if nout else None, nout, C.byref(got), _stream_of(x, stream)))
+        assert got.value == nout
+        return y
+
+    def reset(self):
+        _check(lib().tsdgpu_spectrum_reset(self._h, None))
+
+    def close(self):
+        if self._h:
+            lib().tsdgpu_spectrum_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _torch_f32():
+    import torch
+    return torch.float32
 
 
 def rfft(x):

@@ -663,7 +663,7 @@ __global__ __launch_bounds__(256) void fft_odd_dft_kernel(const cpx *__restrict_
 // back to back (measured: pass 1 = 0.65 ms without stores + 0.49 ms without loads = 0.99 ms).
 constexpr int F1M_ROWS = 1088, F1M_PITCH = 17;
 constexpr int F1M_TILE_ELEMS = F1M_ROWS * F1M_PITCH;
-constexpr size_t F1M_LDS = (size_t) (F1M_TILE_ELEMS + 15 * 64 + 16 * 4 + 256) * sizeof(cpx);   // 158,208 B
+constexpr size_t F1M_LDS = (size_t) (F1M_TILE_ELEMS + 15 * 64 + 16 * 4 + 256 + 2) * sizeof(cpx);   // 158,224 B (the last 16: the pulled tile ids)
 
 __device__ __forceinline__ void lds_barrier()
 {
@@ -795,8 +795,10 @@ __device__ __forceinline__ void f1m_issue(const F1mCtx &k, int id, float4 (&q)[8
 }
 
 // one tile: registers -> LDS, (prefetch of the next tile), transform, store
+// nid: the tile whose loads are issued while this one is transformed (PREFETCH); publish: a tile id thread 0 pulled at the
+// start of this tile, left in LDS for everybody before the tile's last barrier (see fft1m_cols_kernel)
 template <int PASS, bool PREFETCH>
-__device__ __forceinline__ void f1m_tile(const F1mCtx &k, int id, float4 (&q)[8], cpx &ta, cpx &td)
+__device__ __forceinline__ void f1m_tile(const F1mCtx &k, int id, int nid, float4 (&q)[8], cpx &ta, cpx &td, int publish = -1, int *lnext = nullptr)
 {
   constexpr int P = F1M_PITCH;
   cpx *tile = k.tile, *col = k.col;
@@ -810,7 +812,7 @@ __device__ __forceinline__ void f1m_tile(const F1mCtx &k, int id, float4 (&q)[8]
   }
   const cpx ta_cur = ta;
   if (PASS == 1 && k.t < 256) k.ltd[k.t] = td;
-  if (PREFETCH) f1m_issue<PASS>(k, id + k.grid, q, ta, td);   // in flight until the next tile's LDS write
+  if (PREFETCH) f1m_issue<PASS>(k, nid, q, ta, td);   // in flight until the next tile's LDS write
   lds_barrier();
   f1c v[16];
   f1c *colc = reinterpret_cast<f1c *>(col);
@@ -851,18 +853,24 @@ __device__ __forceinline__ void f1m_tile(const F1mCtx &k, int id, float4 (&q)[8]
       *reinterpret_cast<float4 *>(yb + (o + step * i)) = make_float4(a.x, a.y, b.x, b.y);
     }
   }
+  if (lnext && k.t == 0) lnext[0] = publish;
   lds_barrier();                                            // the next tile overwrites the LDS image
 }
 
-template <int PASS>
+// ctr != NULL: the tiles are handed out DYNAMICALLY (one counter, never reset: the launch starts from `base` and leaves it
+// at base + ntiles + workgroups -- one failing pull per workgroup) instead of tile = workgroup + k * grid: a static
+// partition of a persistent grid streams 6-9 % below the same traffic handed out in order (scripts/ubench/copy_shapes.hip).
+// Thread 0 pulls the id of the tile after next at the start of a tile and leaves it in LDS before the tile's last barrier.
+template <int PASS, bool DYN>
 __global__ __launch_bounds__(1024) void fft1m_cols_kernel(const cpx *__restrict__ in, cpx *__restrict__ out,
                                                           const cpx *__restrict__ TW1, const cpx *__restrict__ TW2,
                                                           const cpx *__restrict__ TA, const cpx *__restrict__ TD,
-                                                          int inverse, float scale, int zp, int ntiles)
+                                                          int inverse, float scale, int zp, int ntiles, unsigned *ctr, unsigned base)
 {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   cpx *tile = reinterpret_cast<cpx *>(smem_raw);
   cpx *ltw1 = tile + F1M_TILE_ELEMS, *ltw2 = ltw1 + 15 * 64, *ltd = ltw2 + 16 * 4;
+  int *lnext = reinterpret_cast<int *>(ltd + 256);
   const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
   if (t < 15 * 64) ltw1[t] = TW1[64 + t];
   if (t < 64) ltw2[t] = TW2[(t >> 2) * 64 + (t & 3)];
@@ -880,20 +888,52 @@ __global__ __launch_bounds__(1024) void fft1m_cols_kernel(const cpx *__restrict_
   // peeled so that the loop is entered in the same memory-counter state as its back edge
   // (prefetch loads followed by 8 stores): the compiler's wait before the LDS write is then
   // vmcnt(8) -- the stores of the previous tile keep draining -- rather than vmcnt(0).
-  int id = blockIdx.x;
-  if (id >= ntiles) return;
   float4 q[8];
   cpx ta = cmk(1.f, 0.f), td = cmk(1.f, 0.f);
+  if (DYN) {
+    auto pull = [&]() -> int {
+      const unsigned v = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base;
+      return v < (unsigned) ntiles ? (int) v : -1;
+    };
+    if (t == 0) {
+      const int a = pull();
+      lnext[0] = a;
+      lnext[1] = a >= 0 ? pull() : -1;
+    }
+    __syncthreads();
+    int id = lnext[0], nid = lnext[1];
+    __syncthreads();                                         // (lnext[0] is rewritten at the end of the first tile)
+    if (id < 0) return;
+    f1m_issue<PASS>(k, id, q, ta, td);
+    if (nid >= 0) {                                          // (first tile peeled, as below: the loop's memory-counter state)
+      int pulled = -1;
+      if (t == 0) pulled = pull();                           // its latency hides under the tile
+      f1m_tile<PASS, true>(k, id, nid, q, ta, td, pulled, lnext);
+      id = nid;
+      nid = lnext[0];
+      while (nid >= 0) {
+        pulled = -1;
+        if (t == 0) pulled = pull();
+        f1m_tile<PASS, true>(k, id, nid, q, ta, td, pulled, lnext);
+        id = nid;
+        nid = lnext[0];
+      }
+    }
+    f1m_tile<PASS, false>(k, id, -1, q, ta, td);
+    return;
+  }
+  int id = blockIdx.x;
+  if (id >= ntiles) return;
   f1m_issue<PASS>(k, id, q, ta, td);
   if (id + k.grid < ntiles) {
-    f1m_tile<PASS, true>(k, id, q, ta, td);
+    f1m_tile<PASS, true>(k, id, id + k.grid, q, ta, td);
     id += k.grid;
     while (id + k.grid < ntiles) {
-      f1m_tile<PASS, true>(k, id, q, ta, td);
+      f1m_tile<PASS, true>(k, id, id + k.grid, q, ta, td);
       id += k.grid;
     }
   }
-  f1m_tile<PASS, false>(k, id, q, ta, td);
+  f1m_tile<PASS, false>(k, id, -1, q, ta, td);
 }
 
 // ---- helpers for the non power-of-two paths ------------------------------------------------
@@ -1090,6 +1130,8 @@ struct tsdgpu_fft {
   cpx *d_tw1 = nullptr, *d_tw2 = nullptr, *d_thi = nullptr, *d_tlo = nullptr;
   // in-wave 1024-point FFT paths: lane twiddles (2 x 1024) and, for n = 2^20, TA [1024][64] / TD [1024][16]
   cpx *d_w1 = nullptr, *d_w2 = nullptr, *d_ta = nullptr, *d_td = nullptr;
+  unsigned *d_ctr = nullptr;  // n = 2^20: work counter of the dynamic tile hand-out (fft1m_cols_kernel), never reset
+  unsigned ctr_base = 0;      // its value before the next launch
   // even / odd
   tsdgpu_fft *sub = nullptr;
   cpx *d_rot = nullptr;       // W_n^k, k < n (even split)
@@ -1228,8 +1270,14 @@ int plan_init(tsdgpu_fft *p, int n)
         }
         if ((rc = upload(&p->d_ta, ta))) return rc;
         if ((rc = upload(&p->d_td, td))) return rc;
-        (void) hipFuncSetAttribute((const void *) fft1m_cols_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void) hipFuncSetAttribute((const void *) fft1m_cols_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (hipMalloc((void **) &p->d_ctr, 256) != hipSuccess || hipMemset(p->d_ctr, 0, 256) != hipSuccess) {
+          (void) hipGetLastError();
+          p->d_ctr = nullptr;                                // (the static partition then)
+        }
+        (void) hipFuncSetAttribute((const void *) fft1m_cols_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void) hipFuncSetAttribute((const void *) fft1m_cols_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void) hipFuncSetAttribute((const void *) fft1m_cols_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void) hipFuncSetAttribute((const void *) fft1m_cols_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void) hipGetLastError();
       }
     } else if (fast && n >= 16 && n <= S16_MAX_N) {
@@ -1373,6 +1421,7 @@ void plan_destroy(tsdgpu_fft *p)
     if (p->ge[i]) (void) hipEventDestroy(p->ge[i]);
   }
   if (p->ge_in) (void) hipEventDestroy(p->ge_in);
+  if (p->d_ctr) (void) hipFree(p->d_ctr);
   for (cpx *q : {p->d_tw, p->d_tw1, p->d_tw2, p->d_thi, p->d_tlo, p->d_rot, p->d_chirp, p->d_xc, p->d_w1, p->d_w2, p->d_ta, p->d_td, p->d_wm})
     if (q) (void) hipFree(q);
   p->work.release();
@@ -1507,10 +1556,10 @@ int step_device(tsdgpu_fft *p, const cpx *x, cpx *y, int batch, int forward, hip
           const int nb = std::min(GROUP, batch - b0), nt = 64 * nb, grd = std::min(nt, GRID);
           hipStream_t s2 = p->gs[gi & 1];
           cpx *zz = z + (size_t) (gi & 1) * slot;
-          hipLaunchKernelGGL((fft1m_cols_kernel<1>), dim3(grd), dim3(1024), F1M_LDS, s2, x + (size_t) b0 * n, zz, p->d_w1, p->d_w2, p->d_ta,
-                             p->d_td, inverse, 1.0f, ZP, nt);
-          hipLaunchKernelGGL((fft1m_cols_kernel<2>), dim3(grd), dim3(1024), F1M_LDS, s2, zz, y + (size_t) b0 * n, p->d_w1, p->d_w2, p->d_ta,
-                             p->d_td, inverse, 1.0f / 1024.0f, ZP, nt);
+          hipLaunchKernelGGL((fft1m_cols_kernel<1, false>), dim3(grd), dim3(1024), F1M_LDS, s2, x + (size_t) b0 * n, zz, p->d_w1, p->d_w2, p->d_ta,
+                             p->d_td, inverse, 1.0f, ZP, nt, (unsigned *) nullptr, 0u);
+          hipLaunchKernelGGL((fft1m_cols_kernel<2, false>), dim3(grd), dim3(1024), F1M_LDS, s2, zz, y + (size_t) b0 * n, p->d_w1, p->d_w2, p->d_ta,
+                             p->d_td, inverse, 1.0f / 1024.0f, ZP, nt, (unsigned *) nullptr, 0u);
         }
         TSD_HIP(hipGetLastError());
         for (int i = 0; i < 2; i++) {
@@ -1520,10 +1569,22 @@ int step_device(tsdgpu_fft *p, const cpx *x, cpx *y, int batch, int forward, hip
         return TSDGPU_OK;
       }
       const int grid = std::min(ntiles, GRID);
-      hipLaunchKernelGGL((fft1m_cols_kernel<1>), dim3(grid), dim3(1024), F1M_LDS, st, x, z, p->d_w1, p->d_w2, p->d_ta,
-                         p->d_td, inverse, 1.0f, ZP, ntiles);
-      hipLaunchKernelGGL((fft1m_cols_kernel<2>), dim3(grid), dim3(1024), F1M_LDS, st, z, y, p->d_w1, p->d_w2, p->d_ta,
-                         p->d_td, inverse, 1.0f / 1024.0f, ZP, ntiles);
+      // dynamic tile hand-out when every workgroup gets several tiles (TSDGPU_FFT_DYN=0: the static partition)
+      const char *dyn_s = getenv("TSDGPU_FFT_DYN");
+      unsigned *ctr = (p->d_ctr && ntiles >= 4 * grid && !(dyn_s && atoi(dyn_s) == 0)) ? p->d_ctr : nullptr;
+      const unsigned b1 = p->ctr_base, b2 = b1 + (unsigned) ntiles + (unsigned) grid;
+      if (ctr) p->ctr_base = b2 + (unsigned) ntiles + (unsigned) grid;
+      if (ctr) {
+        hipLaunchKernelGGL((fft1m_cols_kernel<1, true>), dim3(grid), dim3(1024), F1M_LDS, st, x, z, p->d_w1, p->d_w2, p->d_ta,
+                           p->d_td, inverse, 1.0f, ZP, ntiles, ctr, b1);
+        hipLaunchKernelGGL((fft1m_cols_kernel<2, true>), dim3(grid), dim3(1024), F1M_LDS, st, z, y, p->d_w1, p->d_w2, p->d_ta,
+                           p->d_td, inverse, 1.0f / 1024.0f, ZP, ntiles, ctr, b2);
+      } else {
+        hipLaunchKernelGGL((fft1m_cols_kernel<1, false>), dim3(grid), dim3(1024), F1M_LDS, st, x, z, p->d_w1, p->d_w2, p->d_ta,
+                           p->d_td, inverse, 1.0f, ZP, ntiles, ctr, b1);
+        hipLaunchKernelGGL((fft1m_cols_kernel<2, false>), dim3(grid), dim3(1024), F1M_LDS, st, z, y, p->d_w1, p->d_w2, p->d_ta,
+                           p->d_td, inverse, 1.0f / 1024.0f, ZP, ntiles, ctr, b2);
+      }
       TSD_HIP(hipGetLastError());
       return TSDGPU_OK;
     }

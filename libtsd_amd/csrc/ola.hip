@@ -332,16 +332,56 @@ int ola_run_launch(const cpx *blk0, int nrest, const cpx *x, cpx *y, const cpx *
 // row part[run][.] gets them in fftshift order, scaled to the engine's unitary transform (|X|^2 / N).  8 B of HBM
 // traffic per sample and a row per run, against the |X|^2 plane (4 B per segment sample written, then read) of the
 // framed transform + summation passes.
+// Which segments a run sums (the run's row of `part` gets the sum):
+//   mode 0  psd_welch: run r = segments [r per, (r + 1) per) of nseg, a segment every N/2 samples
+//   mode 1  rt_spectrum (fourier.cc:1228-1335), every sub-block of a group of blocks into one spectrum: segment s = sample
+//           s N; the call's B blocks of nsubs segments fall into groups -- group 0 completes the cnt0 blocks the handle
+//           has accumulated already (up to nmeans), the others hold nmeans blocks, the last one what is left -- and a group's
+//           segments are cut in rpg runs of per
+//   mode 2  rt_spectrum in sweep mode: sub-block i of every block of a group is a class of its own (segments b nsubs + i,
+//           stride nsubs); class (g, i) is cut in rpg runs of per blocks
+struct SegRuns {
+  int mode, per, hop, nsubs, nmeans, cnt0, rpg;
+  int64_t nseg, B;
+};
+__device__ __forceinline__ void seg_run(const SegRuns &M, int64_t run, int64_t &seg0, int &count, int &stride)
+{
+  if (M.mode == 0) {
+    seg0 = run * M.per;
+    count = (int) max((int64_t) 0, min((int64_t) M.per, M.nseg - seg0));
+    stride = 1;
+    return;
+  }
+  const int64_t cls = run / M.rpg;
+  const int r = (int) (run - cls * M.rpg);
+  const int64_t g = M.mode == 1 ? cls : cls / M.nsubs;
+  const int i = M.mode == 1 ? 0 : (int) (cls - g * M.nsubs);
+  const int64_t be0 = min(M.B, (int64_t) (M.nmeans - M.cnt0));
+  const int64_t bs = g == 0 ? 0 : be0 + (g - 1) * M.nmeans, be = g == 0 ? be0 : min(M.B, bs + M.nmeans);
+  if (M.mode == 1) {
+    seg0 = bs * M.nsubs + (int64_t) r * M.per;
+    count = (int) max((int64_t) 0, min((int64_t) M.per, be * M.nsubs - seg0));
+    stride = 1;
+  } else {
+    const int64_t b0 = bs + (int64_t) r * M.per;
+    count = (int) max((int64_t) 0, min((int64_t) M.per, be - b0));
+    seg0 = b0 * M.nsubs + i;
+    stride = M.nsubs;
+  }
+}
 template <int R0, int THREADS>
 __global__ __launch_bounds__(THREADS, THREADS == 256 ? 3 : THREADS == 512 ? 2 : 4) void welch_run_kernel(const cpx *__restrict__ x, const float *__restrict__ w,
                                                                                     const cpx *__restrict__ TW, float *__restrict__ part,
-                                                                                    int N, int tpt, int64_t nseg, int per)
+                                                                                    int N, int tpt, SegRuns M, int64_t nruns)
 {
   extern __shared__ __attribute__((aligned(16))) char wr_raw[];
-  const int t = threadIdx.x, T = THREADS / tpt, pas = N / 2;
+  const int t = threadIdx.x, T = THREADS / tpt, pas = M.hop, per = M.per;
   const int tl = t / tpt, j0 = t - tl * tpt;
   cpx *s = reinterpret_cast<cpx *>(wr_raw) + (size_t) tl * (N + (N >> 4));
-  const int64_t run = (int64_t) blockIdx.x * T + tl, k_lo = run * per, k_hi = min(nseg, k_lo + (int64_t) per);
+  const int64_t run = (int64_t) blockIdx.x * T + tl;
+  int64_t k_lo = 0;
+  int count = 0, stride = 1;
+  if (run < nruns) seg_run(M, run, k_lo, count, stride);
   auto sync = []() { __syncthreads(); };
   float win[16], acc[16];
 #pragma unroll
@@ -351,10 +391,10 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? 3 : THREADS == 512 ? 2 : 
   }
   cpx v[16];
   for (int it = 0; it < per; it++) {
-    const int64_t k = k_lo + it;
+    const int64_t k = k_lo + (int64_t) it * stride;
     int j = j0;
     asm volatile("" : "+v"(j));        // (see ola_run_kernel: no addresses carried across the loop)
-    const bool live = k < k_hi;
+    const bool live = it < count;
     const cpx *src = x + k * pas;
 #pragma unroll
     for (int m = 0; m < 16; m++) {
@@ -366,25 +406,25 @@ __global__ __launch_bounds__(THREADS, THREADS == 256 ? 3 : THREADS == 512 ? 2 : 
 #pragma unroll
     for (int q = 0; q < 16; q++) acc[q] += v[q].x * v[q].x + v[q].y * v[q].y;    // abs2 (:16)
   }
-  if (k_lo < nseg) {
+  if (run < nruns && (M.mode != 0 || count > 0)) {
     const float g = 1.0f / (float) N;
 #pragma unroll
-    for (int q = 0; q < 16; q++) part[(size_t) run * N + ((j0 + q * tpt + pas) & (N - 1))] = acc[q] * g;
+    for (int q = 0; q < 16; q++) part[(size_t) run * N + ((j0 + q * tpt + N / 2) & (N - 1))] = acc[q] * g;
   }
 }
 
-// rows of partial sums written: part must hold *rows x N floats
-int welch_run_launch(const cpx *x, const float *w, const cpx *TW, float *part, int N, int64_t nseg, int per, hipStream_t st)
+// rows of partial sums written: part must hold nruns x N floats
+int seg_runs_launch(const cpx *x, const float *w, const cpx *TW, float *part, int N, const SegRuns &M, int64_t nruns, hipStream_t st)
 {
   const OlaRunGeom g = ola_run_geom(N, N / 2);
   int logn = 0;
   while ((1 << logn) < N) logn++;
   const int r0 = 1 << ((logn & 3) == 0 ? 4 : (logn & 3));
-  const int64_t grid = cdiv(cdiv(nseg, per), g.T);
+  const int64_t grid = cdiv(nruns, g.T);
 #define WR_LAUNCH(R, TH)                                                                                                 \
   do {                                                                                                                   \
     (void) hipFuncSetAttribute((const void *) welch_run_kernel<R, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-    hipLaunchKernelGGL((welch_run_kernel<R, TH>), dim3((unsigned) grid), dim3(TH), g.lds, st, x, w, TW, part, N, g.tpt, nseg, per); \
+    hipLaunchKernelGGL((welch_run_kernel<R, TH>), dim3((unsigned) grid), dim3(TH), g.lds, st, x, w, TW, part, N, g.tpt, M, nruns); \
   } while (0)
 #define WR_PICK(TH)                                                                                                      \
   do {                                                                                                                   \
@@ -398,6 +438,11 @@ int welch_run_launch(const cpx *x, const float *w, const cpx *TW, float *part, i
 #undef WR_LAUNCH
   TSD_HIP(hipGetLastError());
   return TSDGPU_OK;
+}
+int welch_run_launch(const cpx *x, const float *w, const cpx *TW, float *part, int N, int64_t nseg, int per, hipStream_t st)
+{
+  const SegRuns M = {0, per, N / 2, 1, 1, 0, 1, nseg, 0};
+  return seg_runs_launch(x, w, TW, part, N, M, cdiv(nseg, per), st);
 }
 
 // dst[i] = sample (p0 + i) of [rest ++ x]   (new prev_half / new rest)
@@ -550,6 +595,83 @@ __global__ void welch_sum_kernel(const float *__restrict__ part, float *__restri
 }
 
 inline unsigned nblk(int64_t total) { return (unsigned) cdiv(total, 256); }
+
+// ---- rt_spectrum (fourier.cc:1162-1342) -----------------------------------------------------------------------------
+// sizes the run kernel does not serve (not a power of two, or no room in LDS): the windowed sub-blocks go through the
+// batched plan, then one thread per bin sums |X|^2 over the segments of its run (the plan is unitary: no 1/N here)
+__global__ void spec_frame_kernel(const cpx *__restrict__ x, const float *__restrict__ w, cpx *__restrict__ seg, int N, int64_t total)
+{
+  const int64_t idx = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int j = (int) (idx % N);
+  const cpx v = x[idx];
+  const float f = w[j];
+  seg[idx] = make_float2(v.x * f, v.y * f);                       // x.segment(i * Nf, Nf) * f  (:1248)
+}
+__global__ void spec_power_rows_kernel(const cpx *__restrict__ X, float *__restrict__ part, int N, SegRuns M, int64_t nruns)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t run = blockIdx.y;
+  if (i >= N || run >= nruns) return;
+  int64_t seg0;
+  int count, stride;
+  seg_run(M, run, seg0, count, stride);
+  const int h = N / 2;
+  const int src = i < h ? N - h + i : i - h;                      // fftshift (fourier.hpp:232-248)
+  float acc = 0.f;
+  for (int it = 0; it < count; it++) {
+    const cpx v = X[(seg0 + (int64_t) it * stride) * N + src];
+    acc += v.x * v.x + v.y * v.y;                                 // abs2 (:1249)
+  }
+  part[(size_t) run * N + i] = acc;
+}
+// The groups of a call -> spectra.  blockIdx.y = group.  A group that reaches nmeans blocks gives a row of y:
+//   plain   mag(k) = sum over the group's rows, / (nmeans nsubs Nf), 10 log10(. + FLT_MIN)                 (:1271-1283)
+//   sweep   mag(i step + k) += sum_i(k) masque(k); / (nmeans nsubs Nf); / mag_cnt; the same dB             (:1262-1266)
+// the last group, if incomplete, leaves its sums (per class, unmasked) in acc_out for the next call; group 0 starts from
+// acc_in (two buffers: group 0 and the last group run concurrently).
+struct SpecFin {
+  int Nf, Ns, nsubs, nmeans, cnt0, rpg, sweep, step, G;
+  int64_t B;
+};
+__global__ void spec_finish_kernel(const float *__restrict__ part, const float *__restrict__ acc_in, float *__restrict__ acc_out,
+                                   const float *__restrict__ masque, const float *__restrict__ mag_cnt, float *__restrict__ y, SpecFin F)
+{
+  const int g = blockIdx.y;
+  const int64_t be0 = min(F.B, (int64_t) (F.nmeans - F.cnt0));
+  const int64_t bs = g == 0 ? 0 : be0 + (int64_t) (g - 1) * F.nmeans, be = g == 0 ? be0 : min(F.B, bs + F.nmeans);
+  const bool complete = (g == 0 ? F.cnt0 : 0) + (be - bs) == F.nmeans;
+  const bool last = g == F.G - 1;
+  const int ncls = F.sweep ? F.nsubs : 1;
+  // sum of class c (of this group) at bin k
+  auto total = [&](int c, int k) {
+    float t = g == 0 ? acc_in[(size_t) c * F.Nf + k] : 0.f;
+    const float *rows = part + ((size_t) g * ncls + c) * F.rpg * F.Nf;
+    for (int r = 0; r < F.rpg; r++) t += rows[(size_t) r * F.Nf + k];
+    return t;
+  };
+  const float scale = (float) ((int64_t) F.nmeans * F.nsubs * F.Nf);
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < max(F.Ns, F.Nf); idx += gridDim.x * blockDim.x) {
+    if (complete) {
+      if (idx < F.Ns) {
+        float m = 0.f;
+        if (!F.sweep) m = total(0, idx);
+        else
+          for (int i = 0; i < F.nsubs; i++) {
+            const int k = idx - i * F.step;
+            if (k >= 0 && k < F.Nf) m += total(i, k) * masque[k];
+          }
+        m = m / scale;
+        if (F.sweep) m = m / mag_cnt[idx];
+        y[(size_t) g * F.Ns + idx] = 10.f * log10f(m + 1.17549435e-38f);        // pow2db(mag_moy + numeric_limits<float>::min())
+      }
+      if (last && idx < F.Nf)
+        for (int c = 0; c < ncls; c++) acc_out[(size_t) c * F.Nf + idx] = 0.f;    // mag_moy.setZero()
+    } else if (idx < F.Nf) {                                                    // (only the last group can be incomplete)
+      for (int c = 0; c < ncls; c++) acc_out[(size_t) c * F.Nf + idx] = total(c, idx);
+    }
+  }
+}
 
 // a few hundred samples from one device buffer to another: a kernel (a hipMemcpyAsync of that size spends 15-40 us in the
 // runtime -- the buffering calls of a stream fed in blocks shorter than Ne cost 52 us on average with it)
@@ -1035,6 +1157,177 @@ int tsdgpu_welch(const void *x, int64_t n, int N, const float *window, float *S,
   (void) hipStreamSynchronize(st);
   reserve->rend(c);
   return rc;
+}
+
+// ---- rt_spectrum on the device (fourier.cc:1162-1342) ------------------------------------------------
+// Blocks of BS = nsubs x Nf samples: window x sub-block -> transform -> |X|^2 (fftshift order) summed over the sub-blocks and
+// over nmeans blocks -> dB.  Only x goes up; Ns floats come back per nmeans blocks.  The sums of a group of blocks that is
+// not complete at the end of a call stay on the device (d_acc) until the next call.
+struct tsdgpu_spectrum {
+  int BS = 0, nsubs = 1, nmeans = 1, Nf = 0, Ns = 0, sweep = 0, step = 0;
+  int cnt = 0;                          // blocks accumulated since the last spectrum
+  bool run_kernel = false;              // power-of-two Nf that fits the LDS transform: ONE kernel (welch_run_kernel)
+  float *d_tab = nullptr;               // window (Nf) | masque (Nf) | mag_cnt (Ns) | acc A | acc B (ncls x Nf each) | TW (Nf / 16 complex)
+  float *d_win = nullptr, *d_mask = nullptr, *d_cnt = nullptr, *d_acc[2] = {nullptr, nullptr};
+  cpx *d_tw = nullptr;
+  int cur = 0;
+  tsdgpu_fft *plan = nullptr;           // the other sizes: batched plan
+  DevBuf in_stage, out_stage, part, seg;
+};
+
+int tsdgpu_spectrum_create(tsdgpu_spectrum **out, int BS, int nsubs, int nmeans, const float *window_host, int sweep_active,
+                           int sweep_step, const float *mask_host)
+{
+  TSD_CHECK(out != nullptr, "spectrum_create: out is NULL");
+  *out = nullptr;
+  TSD_CHECK(BS >= 1 && nsubs >= 1 && nmeans >= 1 && BS % nsubs == 0, "spectrum_create: BS = %d, nsubs = %d, nmeans = %d", BS, nsubs, nmeans);
+  TSD_CHECK(window_host != nullptr, "spectrum_create: NULL window");
+  TSD_CHECK(!sweep_active || sweep_step >= 0, "spectrum_create: sweep step %d", sweep_step);
+  tsdgpu_spectrum *h = new tsdgpu_spectrum();
+  h->BS = BS; h->nsubs = nsubs; h->nmeans = nmeans;
+  const int Nf = h->Nf = BS / nsubs;
+  h->sweep = sweep_active ? 1 : 0;
+  h->step = sweep_step;
+  const int Ns = h->Ns = h->sweep ? Nf + (nsubs - 1) * sweep_step : Nf;        // SpectrumConfig::Ns (:1157-1161)
+  const int ncls = h->sweep ? nsubs : 1;
+  h->run_kernel = Nf >= 16 && (Nf & (Nf - 1)) == 0 && ola_run_fits(Nf, Nf / 2) && getenv("TSDGPU_OLA_UNFUSED") == nullptr;
+  // ONE allocation, ONE upload of its host image
+  const size_t ntw = h->run_kernel ? (size_t) Nf / 16 : 0;
+  std::vector<float> img((size_t) 2 * Nf + Ns + 2 * (size_t) ncls * Nf + 2 * ntw, 0.f);
+  float *win = img.data(), *mask = win + Nf, *cnt = mask + Nf;
+  for (int k = 0; k < Nf; k++) {
+    win[k] = window_host[k];
+    mask[k] = mask_host ? mask_host[k] : 1.f;
+  }
+  if (h->sweep) {
+    // mag_cnt (:1196-1202): how many unmasked sub-block bins fall on each bin of the swept spectrum, at least 1
+    for (int i = 0; i < nsubs; i++)
+      for (int k = 0; k < Nf; k++) cnt[(size_t) i * sweep_step + k] += mask[k];
+    for (int j = 0; j < Ns; j++) cnt[j] = std::max(cnt[j], 1.0f);
+  } else {
+    for (int j = 0; j < Ns; j++) cnt[j] = 1.f;
+  }
+  float *tw = cnt + Ns + 2 * (size_t) ncls * Nf;
+  const double PI = 3.14159265358979323846;
+  for (size_t i = 0; i < ntw; i++) {
+    const double a = -2.0 * PI * (double) i / (double) Nf;
+    tw[2 * i] = (float) std::cos(a);
+    tw[2 * i + 1] = (float) std::sin(a);
+  }
+  int rc = TSDGPU_OK;
+  if (hipMalloc((void **) &h->d_tab, img.size() * sizeof(float)) != hipSuccess)
+    rc = set_err(TSDGPU_ERR_HIP, "spectrum_create: hipMalloc failed: %s", hipGetErrorString(hipGetLastError()));
+  else if (hipMemcpy(h->d_tab, img.data(), img.size() * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+    rc = set_err(TSDGPU_ERR_HIP, "spectrum_create: upload failed: %s", hipGetErrorString(hipGetLastError()));
+  if (!rc) {
+    h->d_win = h->d_tab;
+    h->d_mask = h->d_win + Nf;
+    h->d_cnt = h->d_mask + Nf;
+    h->d_acc[0] = h->d_cnt + Ns;
+    h->d_acc[1] = h->d_acc[0] + (size_t) ncls * Nf;
+    h->d_tw = (cpx *) (h->d_acc[1] + (size_t) ncls * Nf);
+    if (!h->run_kernel) rc = tsdgpu_fft_create(&h->plan, Nf, nsubs * std::min(nmeans, 64));
+  }
+  if (rc) {
+    tsdgpu_spectrum_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return TSDGPU_OK;
+}
+
+int tsdgpu_spectrum_bins(const tsdgpu_spectrum *h) { return h ? h->Ns : -1; }
+int tsdgpu_spectrum_pending(const tsdgpu_spectrum *h) { return h ? h->cnt : -1; }
+
+int tsdgpu_spectrum_step(tsdgpu_spectrum *h, const void *x, int64_t nblocks, float *y, int64_t y_capacity, int64_t *n_spectra, void *stream)
+{
+  TSD_CHECK(h != nullptr, "spectrum_step: NULL handle");
+  TSD_CHECK(nblocks >= 0, "spectrum_step: negative block count");
+  if (n_spectra) *n_spectra = 0;
+  if (nblocks == 0) return TSDGPU_OK;
+  TSD_CHECK(x != nullptr, "spectrum_step: NULL input");
+  hipStream_t st = (hipStream_t) stream;
+  const int Nf = h->Nf, Ns = h->Ns, nsubs = h->nsubs, nmeans = h->nmeans;
+  const int64_t B = nblocks, S = B * nsubs;
+  const int64_t nout = (h->cnt + B) / nmeans;                  // spectra completed by this call
+  TSD_CHECK(nout <= y_capacity, "spectrum_step: %lld spectra completed, room for %lld", (long long) nout, (long long) y_capacity);
+  TSD_CHECK(nout == 0 || y != nullptr, "spectrum_step: NULL output");
+  const int64_t be0 = std::min<int64_t>(B, nmeans - h->cnt);
+  const int64_t G = 1 + (B > be0 ? cdiv(B - be0, nmeans) : 0);
+  TSD_CHECK(G <= 65535 && S <= 0x7fffffff, "spectrum_step: %lld blocks in one call", (long long) B);
+  const void *dxv = nullptr;
+  void *dyv = nullptr;
+  bool staged = false;
+  int rc = stage_in(x, (size_t) B * h->BS * sizeof(cpx), h->in_stage, st, &dxv);
+  if (rc) return rc;
+  rc = stage_out(y, (size_t) nout * Ns * sizeof(float), h->out_stage, &dyv, &staged);
+  if (rc) return rc;
+  // runs: a class = the segments that are summed into one spectrum (sweep: one per sub-block index)
+  const int ncls = h->sweep ? nsubs : 1;
+  const int64_t per_class = h->sweep ? nmeans : (int64_t) nmeans * nsubs;         // segments of a full class
+  static const int cus = []() {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  int64_t places = 4096;
+  if (h->run_kernel) {
+    const OlaRunGeom g = ola_run_geom(Nf, Nf / 2);
+    places = (int64_t) cus * (g.threads == 256 ? 3 : 1) * g.T;
+  }
+  const int per = (int) std::min<int64_t>(std::min<int64_t>(64, per_class), std::max<int64_t>(1, cdiv(S, places)));
+  const int rpg = (int) cdiv(per_class, per);
+  const int64_t nruns = G * ncls * rpg;
+  rc = h->part.reserve((size_t) nruns * Nf * sizeof(float));
+  if (rc) return rc;
+  const SegRuns M = {h->sweep ? 2 : 1, per, Nf, nsubs, nmeans, h->cnt, rpg, S, B};
+  if (h->run_kernel) {
+    rc = seg_runs_launch((const cpx *) dxv, h->d_win, h->d_tw, h->part.as<float>(), Nf, M, nruns, st);
+    if (rc) return rc;
+  } else {
+    rc = h->seg.reserve((size_t) S * Nf * sizeof(cpx));
+    if (rc) return rc;
+    const int64_t total = S * Nf;
+    hipLaunchKernelGGL(spec_frame_kernel, dim3(nblk(total)), dim3(256), 0, st, (const cpx *) dxv, h->d_win, h->seg.as<cpx>(), Nf, total);
+    TSD_HIP(hipGetLastError());
+    rc = tsdgpu_fft_step(h->plan, h->seg.p, h->seg.p, (int) S, 1, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(spec_power_rows_kernel, dim3(nblk(Nf), (unsigned) nruns), dim3(256), 0, st, h->seg.as<cpx>(), h->part.as<float>(), Nf, M, nruns);
+    TSD_HIP(hipGetLastError());
+  }
+  const SpecFin F = {Nf, Ns, nsubs, nmeans, h->cnt, rpg, h->sweep, h->step, (int) G, B};
+  hipLaunchKernelGGL(spec_finish_kernel, dim3(nblk(std::max(Ns, Nf)), (unsigned) G), dim3(256), 0, st, h->part.as<float>(), h->d_acc[h->cur],
+                     h->d_acc[h->cur ^ 1], h->d_mask, h->d_cnt, (float *) dyv, F);
+  TSD_HIP(hipGetLastError());
+  h->cur ^= 1;
+  h->cnt = (int) ((h->cnt + B) % nmeans);
+  if (n_spectra) *n_spectra = nout;
+  rc = finish_out(y, (size_t) nout * Ns * sizeof(float), dyv, staged, st);
+  if (rc) return rc;
+  if (dxv != x && !staged) TSD_HIP(hipStreamSynchronize(st));       // (a staged input must outlive its kernels)
+  return TSDGPU_OK;
+}
+
+int tsdgpu_spectrum_reset(tsdgpu_spectrum *h, void *stream)
+{
+  TSD_CHECK(h != nullptr, "spectrum_reset: NULL handle");
+  const int ncls = h->sweep ? h->nsubs : 1;
+  TSD_HIP(hipMemsetAsync(h->d_acc[0], 0, 2 * (size_t) ncls * h->Nf * sizeof(float), (hipStream_t) stream));
+  h->cnt = 0;
+  return TSDGPU_OK;
+}
+
+int tsdgpu_spectrum_destroy(tsdgpu_spectrum *h)
+{
+  if (!h) return TSDGPU_OK;
+  if (h->plan) tsdgpu_fft_destroy(h->plan);
+  if (h->d_tab) (void) hipFree(h->d_tab);
+  h->in_stage.release();
+  h->out_stage.release();
+  h->part.release();
+  h->seg.release();
+  delete h;
+  return TSDGPU_OK;
 }
 
 int tsdgpu_ola_destroy(tsdgpu_ola *h)

@@ -238,69 +238,44 @@ std::tuple<Vecf, Vecf> psd_welch(const Veccf &x, entier N, cstring fen)
 }
 
 // ---- rt_spectrum (fourier.cc:1148-1342) ---------------------------------------------------------------
+// Spectrum::step on the device (tsdgpu_spectrum_*): window x sub-block, transform, |X|^2 in fftshift order, the sums over
+// nsubs x nmeans sub-blocks (sweep: side by side through the masks, divided by the contributions per bin) and the dB all
+// run on the GPU -- x goes up (or is resident already), Ns floats come back with every nmeans-th block.
 namespace {
 struct SpectreGpu : Filtre<cfloat, float, SpectrumConfig> {
-  Vecf f, mag_moy, mag_cnt, masque;
-  entier cntmag = 0, Nf = 0, Ns = 0;
-  tsdgpu_fft *plan = nullptr;
-  ~SpectreGpu() override { tsdgpu_fft_destroy(plan); }
+  entier Nf = 0, Ns = 0;
+  tsdgpu_spectrum *h = nullptr;
+  ~SpectreGpu() override { tsdgpu_spectrum_destroy(h); }
   void configure_impl(const SpectrumConfig &c) override
   {
     if (c.nsubs < 1 || c.BS < c.nsubs || c.nmeans < 1) échec("rt_spectrum: BS = {}, nsubs = {}, nmeans = {}", c.BS, c.nsubs, c.nmeans);
-    cntmag = 0;
     Nf = c.BS / c.nsubs;
-    Ns = Nf;
-    masque = Vecf::ones(Nf);
+    Ns = c.Ns();
+    // masks of the sweep (fourier.cc:1187-1194)
+    Vecf masque = Vecf::ones(Nf);
     if (c.sweep.masque_hf > 0) {
       masque.head(c.sweep.masque_hf).setZero();
       masque.tail(c.sweep.masque_hf).setZero();
     }
     if (c.sweep.masque_bf > 0) masque.segment(Nf / 2 - c.sweep.masque_bf, 2 * c.sweep.masque_bf).setZero();
-    if (c.sweep.active) {
-      Ns = Nf + (c.nsubs - 1) * c.sweep.step;
-      mag_cnt = Vecf::zeros(Ns);
-      for (entier i = 0; i < c.nsubs; i++)
-        for (entier k = 0; k < Nf; k++) mag_cnt(i * c.sweep.step + k) += masque(k);
-      for (entier k = 0; k < Ns; k++) mag_cnt(k) = std::max(mag_cnt(k), 1.0f);   // a sweep step wider than the unmasked band
-    }
-    mag_moy = Vecf::zeros(Ns);
-    f = tsd::filtrage::fenêtre(c.fenetre, Nf, false);
-    // window energy normalised to Nf: the total energy of an uncorrelated signal is preserved
+    Vecf f = tsd::filtrage::fenêtre(c.fenetre, Nf, false);
+    // window energy normalised to Nf: the total energy of an uncorrelated signal is preserved (:1209-1212)
     double e = 0;
     for (entier k = 0; k < Nf; k++) e += (double) f(k) * f(k);
     f *= (float) std::sqrt(Nf / e);
-    tsdgpu_fft_destroy(plan);
-    plan = nullptr;
-    if (tsdgpu_fft_create(&plan, Nf, c.nsubs)) échec("rt_spectrum: {}", tsdgpu_last_error());
+    tsdgpu_spectrum_destroy(h);
+    h = nullptr;
+    if (tsdgpu_spectrum_create(&h, c.BS, c.nsubs, c.nmeans, f.data(), c.sweep.active ? 1 : 0, c.sweep.step, masque.data()))
+      échec("rt_spectrum: {}", tsdgpu_last_error());
   }
   void step(const Veccf &x, Vecf &y) override
   {
     const SpectrumConfig &c = Configurable<SpectrumConfig>::config;
     if (x.rows() != c.BS) échec("Spectrum : dimension invalide ({} au lieu de {}).", x.rows(), c.BS);
-    Veccf w(c.nsubs * Nf);
-    for (entier i = 0; i < c.nsubs; i++)
-      for (entier k = 0; k < Nf; k++) w(i * Nf + k) = x(i * Nf + k) * f(k);
-    if (tsdgpu_fft_step(plan, w.data(), w.data(), c.nsubs, 1, nullptr)) échec("rt_spectrum: {}", tsdgpu_last_error());
-    for (entier i = 0; i < c.nsubs; i++) {
-      const Vecf p = fftshift(abs2(w.segment(i * Nf, Nf)));
-      if (c.sweep.active) {
-        for (entier k = 0; k < Nf; k++) mag_moy(i * c.sweep.step + k) += p(k) * masque(k);
-      } else {
-        mag_moy += p;
-      }
-    }
-    cntmag++;
-    if (cntmag == c.nmeans) {
-      mag_moy /= (float) (c.nmeans * c.nsubs * Nf);
-      if (c.sweep.active)
-        for (entier k = 0; k < Ns; k++) mag_moy(k) /= mag_cnt(k);
-      y.resize(Ns);
-      for (entier k = 0; k < Ns; k++) y(k) = 10 * std::log10(mag_moy(k) + std::numeric_limits<float>::min());
-      mag_moy.setZero();
-      cntmag = 0;
-    } else {
-      y.resize(0);
-    }
+    const bool complet = tsdgpu_spectrum_pending(h) + 1 == c.nmeans;
+    y.resize(complet ? Ns : 0);                                        // (an empty vector until the nmeans-th block, :1334)
+    int64_t n = 0;
+    if (tsdgpu_spectrum_step(h, x.data(), 1, complet ? y.data() : nullptr, complet ? 1 : 0, &n, nullptr)) échec("rt_spectrum: {}", tsdgpu_last_error());
   }
 };
 }  // namespace

@@ -102,6 +102,61 @@ def psd_welch_sum(x, N, window):
     return S, nseg
 
 
+class Spectrum:
+    """rt_spectrum / Spectrum (fourier.cc:1162-1342), statement by statement in float32.
+    sweep = None or (step, masque_bf, masque_hf).  `window`: fenêtre(config.fenetre, Nf, non) BEFORE normalisation."""
+
+    def __init__(self, BS, nmeans, nsubs, window, sweep=None):
+        self.BS, self.nmeans, self.nsubs = BS, nmeans, nsubs
+        Nf = self.Nf = BS // nsubs                                        # :1184
+        self.Ns = Nf
+        self.masque = np.ones(Nf, f32)                                    # :1187-1194
+        self.sweep = sweep
+        if sweep is not None:
+            step, bf, hf = sweep
+            if hf > 0:
+                self.masque[:hf] = 0
+                self.masque[Nf - hf:] = 0
+            if bf > 0:
+                self.masque[Nf // 2 - bf:Nf // 2 + bf] = 0
+            self.Ns = Nf + (nsubs - 1) * step                             # :1198
+            self.mag_cnt = np.zeros(self.Ns, f32)
+            for i in range(nsubs):
+                self.mag_cnt[i * step:i * step + Nf] += self.masque       # :1200-1201
+            self.mag_cnt = np.maximum(self.mag_cnt, f32(1.0))             # :1203
+        self.mag_moy = np.zeros(self.Ns, f32)
+        f = np.asarray(window, f32)
+        # f = sqrt(Nf / abs2(f).somme()) * f  (:1211; somme() accumulates in double, tableau.hpp:656-717)
+        e = f32(np.sum((f * f).astype(f32).astype(np.float64)))
+        self.f = (f32(np.sqrt(f32(Nf) / e)) * f).astype(f32)
+        self.cntmag = 0
+
+    def step(self, x):
+        """one block of BS samples -> Ns floats (dB) every nmeans-th call, else an empty vector (:1236-1336)"""
+        x = np.asarray(x, c64)
+        assert len(x) == self.BS
+        Nf, h = self.Nf, self.Nf // 2
+        for i in range(self.nsubs):
+            X = orc.fft((x[i * Nf:(i + 1) * Nf] * self.f).astype(c64), True)          # plan->step(x.segment(i * Nf, Nf) * f)
+            p = (X.real * X.real + X.imag * X.imag).astype(f32)                       # abs2
+            p = np.concatenate([p[Nf - h:], p[:Nf - h]])                              # fftshift (fourier.hpp:232-248)
+            if self.sweep is not None:
+                step = self.sweep[0]
+                self.mag_moy[i * step:i * step + Nf] += (p * self.masque).astype(f32)  # :1265
+            else:
+                self.mag_moy += p                                                      # :1270 / :1277
+        self.cntmag += 1
+        if self.cntmag < self.nmeans:
+            return np.zeros(0, f32)
+        m = (self.mag_moy / f32(self.nmeans * self.nsubs * Nf)).astype(f32)            # :1284
+        if self.sweep is not None:
+            m = (m / self.mag_cnt).astype(f32)                                        # :1286
+        y = (f32(10) * np.log10(m + np.finfo(f32).tiny, dtype=f32)).astype(f32)        # pow2db(mag_moy + min) (:1287)
+        self.mag_moy[:] = 0
+        self.cntmag = 0
+        return y
+
+
 # ---- correlations and delay estimate: core/src/fourier/fourier.cc:489-597, estimation-delais.cc:9-14,100-118
 def correlation_freq(X0, X1):
     """fourier.cc:489-503: Y(0) = X0(0) conj(X1(0)); Y.tail(n-1) = reversed tails multiplied; times sqrt(n)."""
