@@ -284,8 +284,11 @@ int tsdgpu_rii_create(tsdgpu_rii **out, int data_type, const float *numer_host, 
 /* coefficients of type coef_type (TSDGPU_F32, or TSDGPU_C64 = filtre_rii<cfloat,cfloat>, complex data only).
  * Real coefficients: the denominator is factored on the host and the recursion runs block-parallel as
  * zero-seeded sections on the SOS kernel whenever that cascade reproduces the direct form to 4e-6 on a
- * create-time check; otherwise, and for complex coefficients, the literal sequential recursion runs.
- * tsdgpu_rii_path: 0 = sections only, 1 = FIR kernel + sections, 2 = FIR kernel + literal recursion. */
+ * create-time check; complex coefficients: first-order complex sections (complex poles need no conjugate partner), same
+ * check; otherwise -- poles outside the circle, memories beyond 2^20 samples, cascades that round too differently from the
+ * direct form -- the literal sequential recursion runs.
+ * tsdgpu_rii_path: 0 = sections only, 1 = FIR kernel + sections, 2 = FIR kernel + literal recursion,
+ * 3 = FIR kernel + first-order complex sections. */
 int tsdgpu_rii_create2(tsdgpu_rii **out, int data_type, int coef_type, const void *numer_host, int Kx,
                        const void *denom_host, int Kd);
 int tsdgpu_rii_path(const tsdgpu_rii *r);

@@ -336,13 +336,131 @@ int sos_create_ex(tsdgpu_sos **out, int data_type, const float *coefs_host, int 
                   const float *rii1_host, int forme, int seeded);
 }
 
+
+// ---- filtre_rii<cfloat, cfloat> (filtre-rt.cc:177-289, :795), block-parallel --------------------------------------------
+// 1 / D(z^-1) with a COMPLEX denominator D = d0 prod_s (1 - r_s z^-1) runs as a cascade of first-order complex sections
+// y[n] = v[n] + r_s y[n-1] (complex poles need no conjugate partner), each by the scheme of the SOS kernel: a lane owns 16
+// consecutive samples of a 1024-sample sub-tile and runs the section from zero state; the lanes' end values go through a
+// Kogge-Stone scan of the affine maps y -> a y + e, a = r^16 the same for every lane, so only e travels (6 shuffle steps
+// against the host-made powers a^(2^k)); every sample then gets its carry: c <- r c, y += c.  A wave walks the sub-tiles of
+// its chunk carrying the sections' states exactly; chunk 0 starts from the stream's state, the others `warm` sub-tiles
+// early from zero state, the host having found the warm-up after which the cascade's memory is below 1e-9.
+// tab[s][8] = r, a, a^2, a^4, a^8, a^16, a^32, (pad).
+constexpr int C1_LANE = 16, C1_SUB = 64 * C1_LANE, C1_PITCH = C1_LANE + 2;     // pitch 18 complex = 144 B: conflict-free b128
+constexpr int C1_MAX_SEC = 16;
+__device__ __forceinline__ float2 c1_mul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 c1_fma(float2 a, float2 b, float2 c) { return make_float2(fmaf(a.x, b.x, fmaf(-a.y, b.y, c.x)), fmaf(a.x, b.y, fmaf(a.y, b.x, c.y))); }
+__global__ __launch_bounds__(64) void rii_c1_kernel(const float2 *__restrict__ u, float2 *__restrict__ y, const float2 *__restrict__ tab, int p,
+                                                    float2 gain, const float2 *__restrict__ st_in, float2 *__restrict__ st_out, int64_t n,
+                                                    int64_t n_sub, int spc, int warm)
+{
+  __shared__ __attribute__((aligned(16))) float2 lds[64 * C1_PITCH];
+  __shared__ float2 sst[C1_MAX_SEC];                         // the sections' states: y_s at the last sample done
+  const int lane = threadIdx.x;
+  const int64_t chunk = blockIdx.x, t_first = chunk * spc, t_last = min(t_first + spc, n_sub);
+  int64_t t = max((int64_t) 0, t_first - warm);
+  if (lane < p) sst[lane] = t == 0 ? st_in[lane] : make_float2(0.f, 0.f);
+  auto wsync = []() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  wsync();
+  for (; t < t_last; t++) {
+    const int64_t base = t * C1_SUB;
+    const int m = (int) min((int64_t) C1_SUB, n - base);      // samples of this sub-tile inside the call (the rest reads as zero)
+    // ---- load 16 B per lane (two samples), transpose through LDS: lane gets samples [16 lane, 16 lane + 16)
+    float2 v[C1_LANE];
+#pragma unroll
+    for (int i = 0; i < C1_LANE / 2; i++) {
+      const int e = 2 * (i * 64 + lane);
+      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e + 1 < m) q = *reinterpret_cast<const float4 *>(u + base + e);
+      else if (e < m) { const float2 a = u[base + e]; q.x = a.x; q.y = a.y; }
+      *reinterpret_cast<float4 *>(&lds[(e / C1_LANE) * C1_PITCH + (e % C1_LANE)]) = q;
+    }
+    wsync();
+#pragma unroll
+    for (int i = 0; i < C1_LANE / 2; i++) {
+      const float4 q = *reinterpret_cast<const float4 *>(&lds[lane * C1_PITCH + 2 * i]);
+      v[2 * i] = make_float2(q.x, q.y);
+      v[2 * i + 1] = make_float2(q.z, q.w);
+    }
+    wsync();
+    // (lane, index) of the sub-tile's last real sample: where the sections' states are read
+    const int lstar = (m - 1) / C1_LANE, istar = (m - 1) % C1_LANE;
+    for (int s = 0; s < p; s++) {
+      const float2 r = tab[s * 8], yprev = sst[s];
+      // zero-state run of the lane
+      float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+      for (int i = 0; i < C1_LANE; i++) {
+        acc = c1_fma(r, acc, v[i]);
+        v[i] = acc;
+      }
+      // true end values of the lanes: lane 0 takes the section's state in, then the scan
+      float2 e = acc;
+      if (lane == 0) e = c1_fma(tab[s * 8 + 1], yprev, e);
+#pragma unroll
+      for (int k = 0; k < 6; k++) {
+        const float2 ak = tab[s * 8 + 1 + k];
+        float2 o;
+        o.x = __shfl_up(e.x, 1 << k);
+        o.y = __shfl_up(e.y, 1 << k);
+        if (lane >= (1 << k)) e = c1_fma(ak, o, e);
+      }
+      // the value entering the lane, carried through its samples
+      float2 c;
+      c.x = __shfl_up(e.x, 1);
+      c.y = __shfl_up(e.y, 1);
+      if (lane == 0) c = yprev;
+      float2 fin = make_float2(0.f, 0.f);
+#pragma unroll
+      for (int i = 0; i < C1_LANE; i++) {
+        c = c1_mul(r, c);
+        v[i].x += c.x;
+        v[i].y += c.y;
+        if (i == istar) fin = v[i];
+      }
+      fin.x = __shfl(fin.x, lstar);
+      fin.y = __shfl(fin.y, lstar);
+      if (lane == 0) sst[s] = fin;
+      wsync();
+    }
+    if (t >= t_first) {
+      // ---- x 1 / d0, transpose back, store 16 B per lane
+#pragma unroll
+      for (int i = 0; i < C1_LANE / 2; i++) {
+        const float2 a = c1_mul(v[2 * i], gain), b = c1_mul(v[2 * i + 1], gain);
+        *reinterpret_cast<float4 *>(&lds[lane * C1_PITCH + 2 * i]) = make_float4(a.x, a.y, b.x, b.y);
+      }
+      wsync();
+#pragma unroll
+      for (int i = 0; i < C1_LANE / 2; i++) {
+        const int e2 = 2 * (i * 64 + lane);
+        const float4 q = *reinterpret_cast<const float4 *>(&lds[(e2 / C1_LANE) * C1_PITCH + (e2 % C1_LANE)]);
+        if (e2 + 1 < m) *reinterpret_cast<float4 *>(y + base + e2) = q;
+        else if (e2 < m) y[base + e2] = make_float2(q.x, q.y);
+      }
+      wsync();
+    }
+  }
+  if (t_last == n_sub && t_last > t_first && lane < p) st_out[lane] = sst[lane];     // the wave of the last sub-tile publishes the stream state
+}
+
 struct tsdgpu_rii {
   int data_type = 0, coef_type = 0, Ky = 0, Kx = 0;
   // path 0: the whole H(z) as zero-seeded FormeDirecte1 sections on the block-parallel SOS kernel
   //         (numerator of <= 3 taps folded into the first section)
   // path 1: numerator on the FIR kernel, then the all-pole part 1/D as sections on the SOS kernel
   // path 2: numerator on the FIR kernel, then the literal sequential recursion (reference operation order)
+  // path 3: complex coefficients: numerator on the FIR kernel, then 1 / D as first-order complex sections (rii_c1_kernel)
   int path = 2;
+  int c1_p = 0, c1_cur = 0;                        // path 3: sections, current state buffer
+  int64_t c1_W = 0;                                // ... warm-up in samples
+  float2 c1_gain = {1.f, 0.f};                     // ... 1 / d0
+  float2 *d_c1 = nullptr;                          // ... tab [p][8] | state A [16] | state B [16]
+  DevBuf z;                                        // ... the non-recursive part's output
   tsdgpu_sos *sos = nullptr;
   tsdgpu_fir *fir = nullptr;
   float *d_denom = nullptr, *d_hist = nullptr;     // literal path: denominator (float or float2) and output memory
@@ -615,14 +733,14 @@ namespace {
 
 typedef std::complex<double> cd;
 
-// roots of c[0] z^p + c[1] z^(p-1) + ... + c[p] (c[0] != 0): Aberth-Ehrlich, then a coefficient check
-bool poly_roots(const std::vector<double> &c, std::vector<cd> &r)
+// roots of c[0] z^p + c[1] z^(p-1) + ... + c[p] (c[0] != 0; real or complex coefficients): Aberth-Ehrlich, then a coefficient check
+template <typename TC> bool poly_roots(const std::vector<TC> &c, std::vector<cd> &r)
 {
   const int p = (int) c.size() - 1;
   r.assign((size_t) p, cd(0, 0));
   if (p <= 0) return true;
   double rad = 0;
-  for (int k = 1; k <= p; k++) rad = std::max(rad, std::pow(std::fabs(c[k] / c[0]), 1.0 / k));
+  for (int k = 1; k <= p; k++) rad = std::max(rad, std::pow(std::abs(c[k] / c[0]), 1.0 / k));
   rad = std::max(2 * rad, 1e-3);
   for (int k = 0; k < p; k++) r[k] = std::polar(rad * (0.5 + 0.5 * (k + 1) / p), 2 * M_PI * k / p + 0.4);
   auto eval = [&](cd z, cd &dv) {
@@ -658,8 +776,8 @@ bool poly_roots(const std::vector<double> &c, std::vector<cd> &r)
   }
   double err = 0, nrm = 0;
   for (int k = 0; k <= p; k++) {
-    err = std::max(err, std::abs(e[k] - c[k] / c[0]));
-    nrm = std::max(nrm, std::fabs(c[k] / c[0]));
+    err = std::max(err, std::abs(e[k] - cd(c[k] / c[0])));
+    nrm = std::max(nrm, std::abs(c[k] / c[0]));
   }
   return std::isfinite(err) && err <= 1e-9 * nrm;
 }
@@ -752,6 +870,95 @@ bool cascade_matches_direct_form(const float *num, int Kx, const float *den, int
   return peak > 0 && err <= 4e-6f * peak;   // bar: 1e-5 of the peak on any stream; 2.5x margin for the extremes of long streams
 }
 
+
+// ---- complex denominators: first-order sections (rii_c1_kernel) -------------------------------------------------------
+// poles r_s of D(z^-1) = d0 prod (1 - r_s z^-1); false when the factoring is unreliable or a pole is not inside the circle
+bool factor_denominator_c(const float *den2, int Kd, std::vector<cd> &poles)
+{
+  int p = Kd - 1;
+  while (p > 0 && den2[2 * p] == 0.f && den2[2 * p + 1] == 0.f) p--;
+  poles.clear();
+  if (p == 0) return true;
+  std::vector<cd> c((size_t) p + 1);
+  for (int k = 0; k <= p; k++) c[k] = cd(den2[2 * k], den2[2 * k + 1]);
+  if (!poly_roots(c, poles)) return false;
+  for (const cd &z : poles)
+    if (!(std::abs(z) < 1.0)) return false;
+  // the largest poles first: the sections' order does not change the transfer function, only the rounding
+  std::sort(poles.begin(), poles.end(), [](const cd &a, const cd &b) { return std::abs(a) > std::abs(b); });
+  return true;
+}
+// samples after which the cascade's memory is below 1e-9: the zero-input response from every unit state, in double
+int64_t cascade_c_warmup(const std::vector<cd> &poles, int64_t limit)
+{
+  const int p = (int) poles.size();
+  int64_t W = 0;
+  for (int j = 0; j < p; j++) {
+    std::vector<cd> st((size_t) p, cd(0, 0));
+    st[(size_t) j] = 1.0;
+    int64_t n = 0, calme = 0;
+    while (n < limit && calme < 64) {
+      cd v = 0;                                            // zero input
+      double mx = 0;
+      for (int s = 0; s < p; s++) {
+        v = v + poles[(size_t) s] * st[(size_t) s];
+        st[(size_t) s] = v;
+        mx = std::max(mx, std::abs(v));
+      }
+      n++;
+      calme = mx < 1e-9 ? calme + 1 : 0;
+    }
+    if (n >= limit) return -1;
+    W = std::max(W, n);
+  }
+  return W;
+}
+// create-time check of the float cascade against the reference's direct form (filtre-rt.cc:251-279, complex arithmetic
+// as -fcx-limited-range compiles it), zero memory, 8192 noise samples
+bool cascade_c_matches_direct_form(const float *num2, int Kx, const float *den2, int Kd, const std::vector<cd> &poles)
+{
+  typedef std::complex<float> cf;
+  const int N = 8192, Ky = Kd - 1, p = (int) poles.size();
+  std::vector<cf> x((size_t) N), u((size_t) N), yd((size_t) N), yc((size_t) N);
+  uint32_t lcg = 12345u;
+  auto rnd = [&]() { lcg = lcg * 1664525u + 1013904223u; return (float) ((int32_t) lcg) * (1.0f / 2147483648.0f); };
+  for (int i = 0; i < N; i++) x[i] = cf(rnd(), rnd());
+  auto mul = [](cf a, cf b) { return cf(a.real() * b.real() - a.imag() * b.imag(), a.real() * b.imag() + a.imag() * b.real()); };
+  const cf d0(den2[0], den2[1]);
+  const float nd0 = d0.real() * d0.real() + d0.imag() * d0.imag();
+  for (int j = 0; j < N; j++) {
+    cf sacc(0, 0);
+    for (int i = Kx - 1; i >= 0; i--)
+      if (j - i >= 0) sacc += mul(x[j - i], cf(num2[2 * i], num2[2 * i + 1]));
+    u[j] = sacc;
+  }
+  for (int j = 0; j < N; j++) {
+    cf sacc = u[j];
+    for (int k = 1; k <= Ky; k++)
+      if (j - k >= 0) sacc -= mul(yd[j - k], cf(den2[2 * k], den2[2 * k + 1]));
+    yd[j] = cf((sacc.real() * d0.real() + sacc.imag() * d0.imag()) / nd0, (sacc.imag() * d0.real() - sacc.real() * d0.imag()) / nd0);
+  }
+  const cd g = 1.0 / cd(den2[0], den2[1]);
+  const cf gf((float) g.real(), (float) g.imag());
+  std::vector<cf> st((size_t) p, cf(0, 0)), rf((size_t) p);
+  for (int s = 0; s < p; s++) rf[(size_t) s] = cf((float) poles[(size_t) s].real(), (float) poles[(size_t) s].imag());
+  for (int j = 0; j < N; j++) {
+    cf v = u[j];
+    for (int s = 0; s < p; s++) {
+      v = v + mul(rf[(size_t) s], st[(size_t) s]);
+      st[(size_t) s] = v;
+    }
+    yc[j] = mul(v, gf);
+  }
+  float peak = 0, err = 0;
+  for (int j = 0; j < N; j++) {
+    if (!std::isfinite(yd[j].real()) || !std::isfinite(yc[j].real()) || !std::isfinite(yd[j].imag()) || !std::isfinite(yc[j].imag())) return false;
+    peak = std::max(peak, std::abs(yd[j]));
+    err = std::max(err, std::abs(yd[j] - yc[j]));
+  }
+  return peak > 0 && err <= 4e-6f * peak;
+}
+
 }  // namespace
 
 extern "C" {
@@ -809,6 +1016,41 @@ int tsdgpu_rii_create2(tsdgpu_rii **out, int data_type, int coef_type, const voi
       }
     }
   }
+  if (!reel && !litteral && data_type == TSDGPU_C64) {
+    // complex coefficients: first-order complex sections when every pole lies inside the circle, the memory dies within
+    // 2^20 samples and the float cascade reproduces the direct form on the create-time check
+    std::vector<cd> poles;
+    const float *den2 = (const float *) denom_host, *num2 = (const float *) numer_host;
+    if (factor_denominator_c(den2, Kd, poles) && !poles.empty() && (int) poles.size() <= C1_MAX_SEC) {
+      const int64_t W = cascade_c_warmup(poles, (int64_t) 1 << 20);
+      if (W >= 0 && cascade_c_matches_direct_form(num2, Kx, den2, Kd, poles)) {
+        const int p = (int) poles.size();
+        std::vector<float2> img((size_t) p * 8 + 2 * C1_MAX_SEC, make_float2(0.f, 0.f));
+        for (int sct = 0; sct < p; sct++) {
+          const cd rq = poles[(size_t) sct];
+          cd a = 1.0;
+          for (int i = 0; i < C1_LANE; i++) a *= rq;                  // a = r^16
+          img[(size_t) sct * 8] = make_float2((float) rq.real(), (float) rq.imag());
+          for (int k = 0; k < 6; k++) {
+            img[(size_t) sct * 8 + 1 + k] = make_float2((float) a.real(), (float) a.imag());
+            a *= a;
+          }
+        }
+        const cd g = 1.0 / cd(den2[0], den2[1]);
+        r->c1_gain = make_float2((float) g.real(), (float) g.imag());
+        r->c1_p = p;
+        r->c1_W = W;
+        rc = tsdgpu_fir_create(&r->fir, data_type, TSDGPU_C64, numer_host, Kx, TSDGPU_FIR_AUTO);
+        if (!rc && (hipMalloc((void **) &r->d_c1, img.size() * sizeof(float2)) != hipSuccess ||
+                    hipMemcpy(r->d_c1, img.data(), img.size() * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess))
+          rc = set_err(TSDGPU_ERR_HIP, "rii_create: upload failed: %s", hipGetErrorString(hipGetLastError()));
+        if (rc) { tsdgpu_rii_destroy(r); return rc; }
+        r->path = 3;
+        *out = r;
+        return TSDGPU_OK;
+      }
+    }
+  }
   // literal path
   r->path = 2;
   const size_t cw = reel ? sizeof(float) : sizeof(float2);
@@ -853,6 +1095,27 @@ int tsdgpu_rii_step(tsdgpu_rii *r, const void *x, void *y, int64_t n, void *stre
   if (rc) return rc;
   rc = stage_out(y, bytes, r->out_stage, &dy, &staged);
   if (rc) return rc;
+  if (r->path == 3) {
+    // (1) the non-recursive part into an aligned scratch vector (the chunks' warm-ups re-read their predecessors' inputs: never
+    // in place), (2) the first-order sections from there
+    rc = r->z.reserve(bytes + ((uintptr_t) dy & 15 ? bytes : 0));
+    if (rc) return rc;
+    float2 *zu = r->z.as<float2>(), *zy = ((uintptr_t) dy & 15) ? zu + n : (float2 *) dy;
+    rc = tsdgpu_fir_step(r->fir, dx, zu, n, stream);
+    if (rc) return rc;
+    const int64_t n_sub = cdiv(n, C1_SUB);
+    const int warm = (int) cdiv(r->c1_W, C1_SUB);
+    // chunks: enough of them to fill the chip, the warm-up never more than a quarter of a chunk's work
+    int64_t spc = std::max<int64_t>(std::max<int64_t>(1, 4 * (int64_t) warm), cdiv(n_sub, 8192));
+    const int64_t nchunks = cdiv(n_sub, spc);
+    float2 *st0 = r->d_c1 + (size_t) r->c1_p * 8 + (size_t) r->c1_cur * C1_MAX_SEC, *st1 = r->d_c1 + (size_t) r->c1_p * 8 + (size_t) (r->c1_cur ^ 1) * C1_MAX_SEC;
+    hipLaunchKernelGGL(rii_c1_kernel, dim3((unsigned) nchunks), dim3(64), 0, st, (const float2 *) zu, zy, (const float2 *) r->d_c1, r->c1_p, r->c1_gain,
+                       (const float2 *) st0, st1, n, n_sub, (int) spc, warm);
+    TSD_HIP(hipGetLastError());
+    r->c1_cur ^= 1;
+    if (zy != (float2 *) dy) TSD_HIP(hipMemcpyAsync(dy, zy, bytes, hipMemcpyDeviceToDevice, st));
+    return finish_out(y, bytes, dy, staged, st);
+  }
   rc = tsdgpu_fir_step(r->fir, dx, dy, n, stream);                      // (1) non-recursive part
   if (rc) return rc;
   if (r->path == 1) {
@@ -885,6 +1148,8 @@ int tsdgpu_rii_destroy(tsdgpu_rii *r)
   tsdgpu_fir_destroy(r->fir);
   if (r->d_denom) (void) hipFree(r->d_denom);
   if (r->d_hist) (void) hipFree(r->d_hist);
+  if (r->d_c1) (void) hipFree(r->d_c1);
+  r->z.release();
   r->in_stage.release();
   r->out_stage.release();
   delete r;

@@ -14,6 +14,7 @@ GUARDED = ["tests/test_sos_gpu.py::test_sos_unaligned_device_views",
            "tests/test_sos_gpu.py::test_sos_long_memory_forme_directe_1",
            "tests/test_sos_gpu.py::test_exponential_smoother_and_dc_blocker_long_memory",
            "tests/test_polyphase_gpu.py::test_filtre_rii_order6_2p26_under_2ms",
+           "tests/test_polyphase_gpu.py::test_filtre_rii_complex_order6_2p24_under_1ms",
            "tests/test_polyphase_gpu.py::test_filtre_rii_high_order_is_not_a_cliff",
            "tests/test_resample_gpu.py::test_short_period_ratios_far_into_a_stream"]
 
