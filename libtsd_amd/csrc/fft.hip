@@ -1767,6 +1767,20 @@ int tsdgpu_fft_step(tsdgpu_fft *p, const void *x, void *y, int batch, int forwar
   std::lock_guard<std::mutex> lock(p->order.mu);
   int rc = p->order.enter(st);
   if (rc) return rc;
+  // a large batch on HOST vectors goes through in chunks of whole transforms: H2D of chunk i + 1, the transforms of chunk i
+  // and D2H of chunk i - 1 overlap (common.hpp: pipelined_host_step_var); y may be x
+  if (batch >= 2 && bytes >= PIPE_MIN_BYTES && host_pipe_enabled() && !is_device_ptr(x) && !is_device_ptr(y) &&
+      (x == y || !host_ranges_overlap(x, bytes, y, bytes))) {
+    const int n = p->n;
+    rc = pipelined_host_step_var(
+        x, (int64_t) n * batch, sizeof(cpx), y, sizeof(cpx), nullptr, n, st, [](int64_t c) { return c; },
+        [p, n, forward](const void *cx, void *cy, int64_t cnt, int64_t, int64_t *got, hipStream_t q) {
+          *got = cnt;
+          return step_device(p, (const cpx *) cx, (cpx *) cy, (int) (cnt / n), forward, q);
+        });
+    if (rc) return rc;
+    return p->order.leave(st);
+  }
   rc = stage_in(x, bytes, p->in_stage, st, &dx);
   if (rc) return rc;
   rc = stage_out(y, bytes, p->out_stage, &dy, &staged);
@@ -1858,25 +1872,12 @@ int tsdgpu_rfft_create(tsdgpu_rfft **out, int n)
   return TSDGPU_OK;
 }
 
-int tsdgpu_rfft_step(tsdgpu_rfft *p, const void *x, void *y, int batch, void *stream)
+}  // extern "C"
+// the transform of `batch` real vectors on device pointers (dx: n floats each, dy: n complex each)
+static int rfft_device(tsdgpu_rfft *p, const void *dx, void *dy, int batch, hipStream_t st)
 {
-  TSD_CHECK(p != nullptr, "rfft_step: NULL plan");
-  TSD_CHECK(batch >= 0, "rfft_step: negative batch");
-  if (batch == 0) return TSDGPU_OK;
-  TSD_CHECK(x != nullptr && y != nullptr && x != y, "rfft_step: needs distinct non-NULL buffers");
-  hipStream_t st = (hipStream_t) stream;
   const int n = p->n;
-  const size_t in_bytes = (size_t) n * batch * sizeof(float), out_bytes = (size_t) n * batch * sizeof(cpx);
-  const void *dx = nullptr;
-  void *dy = nullptr;
-  bool staged = false;
-  std::lock_guard<std::mutex> lock(p->order.mu);
-  int rc = p->order.enter(st);
-  if (rc) return rc;
-  rc = stage_in(x, in_bytes, p->in_stage, st, &dx);
-  if (rc) return rc;
-  rc = stage_out(y, out_bytes, p->out_stage, &dy, &staged);
-  if (rc) return rc;
+  int rc = TSDGPU_OK;
   if ((n & 1) == 0 && p->sub->kind == tsdgpu_fft::POW2_S16 && getenv("TSDGPU_RFFT_TWO_PASS") == nullptr) {
     // half-size Stockham transform with the untangling fused into its store: one pass over HBM
     const int h = n / 2, tpt = h / 16, threads = std::max(256, tpt), T = threads / tpt;
@@ -1908,6 +1909,43 @@ int tsdgpu_rfft_step(tsdgpu_rfft *p, const void *x, void *y, int batch, void *st
     rc = step_device(p->sub, (const cpx *) dy, (cpx *) dy, batch, 1, st);
     if (rc) return rc;
   }
+  return TSDGPU_OK;
+}
+extern "C" {
+
+int tsdgpu_rfft_step(tsdgpu_rfft *p, const void *x, void *y, int batch, void *stream)
+{
+  TSD_CHECK(p != nullptr, "rfft_step: NULL plan");
+  TSD_CHECK(batch >= 0, "rfft_step: negative batch");
+  if (batch == 0) return TSDGPU_OK;
+  TSD_CHECK(x != nullptr && y != nullptr && x != y, "rfft_step: needs distinct non-NULL buffers");
+  hipStream_t st = (hipStream_t) stream;
+  const int n = p->n;
+  const size_t in_bytes = (size_t) n * batch * sizeof(float), out_bytes = (size_t) n * batch * sizeof(cpx);
+  const void *dx = nullptr;
+  void *dy = nullptr;
+  bool staged = false;
+  std::lock_guard<std::mutex> lock(p->order.mu);
+  int rc = p->order.enter(st);
+  if (rc) return rc;
+  // a large batch on HOST vectors: chunks of whole transforms through the staging pipeline (see tsdgpu_fft_step)
+  if (batch >= 2 && out_bytes >= PIPE_MIN_BYTES && host_pipe_enabled() && !is_device_ptr(x) && !is_device_ptr(y) &&
+      !host_ranges_overlap(x, in_bytes, y, out_bytes)) {
+    rc = pipelined_host_step_var(
+        x, (int64_t) n * batch, sizeof(float), y, sizeof(cpx), nullptr, n, st, [](int64_t c) { return c; },
+        [p, n](const void *cx, void *cy, int64_t cnt, int64_t, int64_t *got, hipStream_t q) {
+          *got = cnt;
+          return rfft_device(p, cx, cy, (int) (cnt / n), q);
+        });
+    if (rc) return rc;
+    return p->order.leave(st);
+  }
+  rc = stage_in(x, in_bytes, p->in_stage, st, &dx);
+  if (rc) return rc;
+  rc = stage_out(y, out_bytes, p->out_stage, &dy, &staged);
+  if (rc) return rc;
+  rc = rfft_device(p, dx, dy, batch, st);
+  if (rc) return rc;
   rc = finish_out(y, out_bytes, dy, staged, st);
   if (rc) return rc;
   return p->order.leave(st);

@@ -929,6 +929,15 @@ int tsdgpu_ola_write_spectra(tsdgpu_ola *h, const void *host_src, void *stream)
 int tsdgpu_ola_step(tsdgpu_ola *h, const void *x, int64_t n, void *y, int64_t *n_out, void *stream)
 {
   TSD_CHECK(h != nullptr, "ola_step: NULL handle");
+  // a large HOST vector goes through in chunks of whole blocks: H2D of chunk i + 1, the engine on chunk i and D2H of chunk
+  // i - 1 overlap; the engine's state (waiting samples, carried block, sample counter) goes from chunk to chunk as between calls
+  if (x != nullptr && y != nullptr && h->pending_blocks < 0 && (size_t) n * sizeof(cpx) >= PIPE_MIN_BYTES && host_pipe_enabled() &&
+      !is_device_ptr(x) && !is_device_ptr(y) && !host_ranges_overlap(x, (size_t) n * sizeof(cpx), y, (size_t) tsdgpu_ola_max_out(h, n) * sizeof(cpx))) {
+    const int Ne = h->Ne;
+    return pipelined_host_step_var(
+        x, n, sizeof(cpx), y, sizeof(cpx), n_out, Ne, (hipStream_t) stream, [Ne](int64_t c) { return c + Ne; },
+        [h](const void *cx, void *cy, int64_t cnt, int64_t, int64_t *got, hipStream_t q) { return tsdgpu_ola_step(h, cx, cnt, cy, got, q); });
+  }
   if (h->d_fast && h->nrest == 0 && n >= h->Ne && h->pending_blocks < 0 && x != nullptr && y != nullptr) {
     // fast path: B whole blocks through ONE kernel, 16 B of HBM traffic per sample (see ols.hip)
     hipStream_t st = (hipStream_t) stream;

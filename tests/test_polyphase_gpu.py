@@ -161,7 +161,7 @@ def test_filtre_rii_block_parallel(tg, orc, order, cplx):
     assert relerr(chunks(f, x, 300007), ref) <= TOL
 
 
-@pytest.mark.parametrize("order", [1, 3, 6, 11, 16])
+@pytest.mark.parametrize("order", [1, 3, 6, 11, 13])
 def test_filtre_rii_block_parallel_complex_coefficients(tg, orc, order):
     """filtre_rii<cfloat, cfloat> (filtre-rt.cc:177-289, :795) block-parallel: one-sided complex poles --
     no conjugate partners -- as first-order complex sections (tsdgpu_rii_path 3); 2^20 samples against the oracle's literal
@@ -175,9 +175,9 @@ def test_filtre_rii_block_parallel_complex_coefficients(tg, orc, order):
     x = rand(n, True, order)
     ref = orc.RiiC(nu, de).step(x)
     f = tg.Rii(nu, de, tg.C64)
-    # (a direct form of order 16 is ill-conditioned in float32: its create-time check may refuse the cascade -- either path
-    # must reproduce the oracle)
-    assert f.path == 3 or (order >= 16 and f.path == 2), f"order {order}: path {f.path}"
+    # (beyond order ~14 with poles up to 0.75 the complex direct form is so ill-conditioned in float32 that two orderings of
+    # its own sums differ by 2e-5: the create-time check then keeps the literal recursion, which is not what this test is about)
+    assert f.path == 3, f"order {order}: path {f.path}"
     assert relerr(chunks(f, x, 300007), ref) <= TOL
     f2 = tg.Rii(nu, de, tg.C64)
     y = x.copy()
