@@ -175,17 +175,60 @@ TSD_HD int freq_index(int lane, int reg)
 // time sample held by (lane, reg) before forward() / after inverse()
 TSD_HD int time_index(int lane, int reg) { return 64 * reg + lane; }
 
+// Twiddles GENERATED instead of held: PowGen{w1, w2, w4, w8} stands for the table tw[r] = w^r, r = 1..15, of which only the
+// entries 1, 2, 4, 8 are kept (the table's own correctly rounded values); the others are products of the kept ones along
+// the binary expansion of r (w3 = w2 w1, w5 = w4 w1, w6 = w4 w2, w7 = w6 w1 ... w15 = w8 w7: 11 complex products per stage).
+// A generated entry carries the roundings of at most four table values and three products -- raising ONE base value to the
+// r-th power would multiply its rounding by r (measured on the CPU emulation: 5 x the table's error; this form: see
+// tests/cpu/test_fft1024_wave.cc) -- and the 2 x 15 complex table entries of a lane (60 VGPRs) become 2 x 4 (16).
+template <typename C> struct PowGen {
+  C w1, w2, w4, w8;
+};
+template <typename T> struct IsPowGen {
+  static constexpr bool v = false;
+};
+template <typename C> struct IsPowGen<PowGen<C>> {
+  static constexpr bool v = true;
+};
+// v[r] <- v[r] w^r (forward) or v[r] conj(w^r) (inverse), r = 1..15
+template <bool INV, typename C> TSD_HD void mul_powers(C (&v)[16], const PowGen<C> &g)
+{
+  const C p3 = cmul(g.w2, g.w1), p5 = cmul(g.w4, g.w1), p6 = cmul(g.w4, g.w2), p7 = cmul(p6, g.w1);
+  v[1] = ctw<INV>(v[1], g.w1);
+  v[2] = ctw<INV>(v[2], g.w2);
+  v[3] = ctw<INV>(v[3], p3);
+  v[4] = ctw<INV>(v[4], g.w4);
+  v[5] = ctw<INV>(v[5], p5);
+  v[6] = ctw<INV>(v[6], p6);
+  v[7] = ctw<INV>(v[7], p7);
+  v[8] = ctw<INV>(v[8], g.w8);
+  v[9] = ctw<INV>(v[9], cmul(g.w8, g.w1));
+  v[10] = ctw<INV>(v[10], cmul(g.w8, g.w2));
+  v[11] = ctw<INV>(v[11], cmul(g.w8, p3));
+  v[12] = ctw<INV>(v[12], cmul(g.w8, g.w4));
+  v[13] = ctw<INV>(v[13], cmul(g.w8, p5));
+  v[14] = ctw<INV>(v[14], cmul(g.w8, p6));
+  v[15] = ctw<INV>(v[15], cmul(g.w8, p7));
+}
+
 // ---- the phases.  SYNC() must order LDS writes before the following LDS reads of the
 // same wave (a __syncthreads() in a 64-lane workgroup; a no-op per-phase loop on the CPU).
+template <bool INV, typename C, typename TW> TSD_HD void stage_twiddles(C (&v)[16], const TW &tw)
+{
+  if constexpr (IsPowGen<TW>::v) {
+    mul_powers<INV>(v, tw);
+  } else {
+#pragma unroll
+    for (int r = 1; r < 16; r++) v[r] = ctw<INV>(v[r], tw[r]);
+  }
+}
 template <bool INV, typename C, typename TW> TSD_HD void stageA(C (&v)[16], const TW &tw1)
 {
   if (!INV) {
     dft16<false>(v);
-#pragma unroll
-    for (int r = 1; r < 16; r++) v[r] = cmul(v[r], tw1[r]);
+    stage_twiddles<false>(v, tw1);
   } else {
-#pragma unroll
-    for (int r = 1; r < 16; r++) v[r] = cmulc(v[r], tw1[r]);
+    stage_twiddles<true>(v, tw1);
     dft16<true>(v);
   }
 }
@@ -193,11 +236,9 @@ template <bool INV, typename C, typename TW> TSD_HD void stageB(C (&v)[16], cons
 {
   if (!INV) {
     dft16<false>(v);
-#pragma unroll
-    for (int r = 1; r < 16; r++) v[r] = cmul(v[r], tw2[r]);
+    stage_twiddles<false>(v, tw2);
   } else {
-#pragma unroll
-    for (int r = 1; r < 16; r++) v[r] = cmulc(v[r], tw2[r]);
+    stage_twiddles<true>(v, tw2);
     dft16<true>(v);
   }
 }

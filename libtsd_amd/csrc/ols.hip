@@ -42,6 +42,14 @@ constexpr int OLS_MAX_CTR = 32;
 #ifndef OLS_WITH_WPW4
 #define OLS_WITH_WPW4 0
 #endif
+// Twiddles generated from 2 x 4 table entries per lane (fft1024_wave.hpp: PowGen; 168 VGPRs, 3 waves per SIMD) instead of 2 x 15
+// held in registers (200 VGPRs, 2 waves per SIMD).  Measured (profiles/r3_ols_schedule_ab.txt): with H in registers too the
+// kernel spills 31-45 dwords and takes 0.267 ms against 0.2036; with H in a 4-wave workgroup's LDS image (no spill worth the
+// name) 0.2154 ms -- the four extra waves per CU do not pay for the 11 generated products per stage and the H reads.
+// Compiled only with -DOLS_WITH_GEN=1 (scripts/build_variant.sh), selected with TSDGPU_OLS_GEN=1.
+#ifndef OLS_WITH_GEN
+#define OLS_WITH_GEN 0
+#endif
 #ifndef OLS_WIDE   // experiment: 16-B global accesses (layout NOT the FFT's: ablation only)
 #define OLS_WIDE 0
 #endif
@@ -159,7 +167,9 @@ struct LdsTab {
 };
 constexpr int OLS_TAB_ELEMS = 64 * 16 * 2 + 4 * 16;      // tw1 [16][64] | H [16][64] | tw2 [16][4] (tw2 depends on lane & 3 only)
 
-template <bool EDGE, bool REAL, int R0, bool DYN, bool LT>
+// TM: where the twiddles come from -- 0: 2 x 15 table entries per lane in registers; 1: an LDS image shared by the workgroup;
+// 2: GENERATED from the table's entries 1, 2, 4, 8 (fft1024_wave.hpp: PowGen), 16 VGPRs instead of 60: 3 waves per SIMD
+template <bool EDGE, bool REAL, int R0, bool DYN, int TM>
 __device__ __forceinline__ void ols_body(cv *lds, const cv *ltab, const void *__restrict__ xv, const void *__restrict__ histv,
                                          void *__restrict__ yv, const cv *__restrict__ Hreg,
                                          const cv *__restrict__ TW1, const cv *__restrict__ TW2, int Km1,
@@ -171,14 +181,23 @@ __device__ __forceinline__ void ols_body(cv *lds, const cv *ltab, const void *__
   cv *y = (cv *) yv;
   const float *xr = (const float *) xv, *histr = (const float *) histv;
   float *yr = (float *) yv;
+  constexpr bool LT = TM == 1 || TM == 3;          // (3: twiddles generated, H from the workgroup's LDS image)
   RegTab tw1r, tw2r, Hr;
-  if (!LT) {
+  PowGen<cv> g1, g2;
+  if (TM == 0) {
 #pragma unroll
     for (int r = 0; r < 16; r++) {
       tw1r.v[r] = TW1[r * 64 + lane];
       tw2r.v[r] = TW2[r * 64 + lane];
-      Hr.v[r] = Hreg[r * 64 + lane];
     }
+  }
+  if (TM == 0 || TM == 2) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) Hr.v[r] = Hreg[r * 64 + lane];
+  }
+  if (TM >= 2) {
+    g1 = PowGen<cv>{TW1[64 + lane], TW1[128 + lane], TW1[256 + lane], TW1[512 + lane]};
+    g2 = PowGen<cv>{TW2[64 + lane], TW2[128 + lane], TW2[256 + lane], TW2[512 + lane]};
   }
   // One wave per workgroup: its LDS operations execute in order, so exchanging data between
   // lanes needs no s_barrier and -- crucially -- no vmcnt(0) drain (a __syncthreads() would
@@ -247,7 +266,17 @@ __device__ __forceinline__ void ols_body(cv *lds, const cv *ltab, const void *__
 #ifndef OLS_ABLATE   // measurement only: bit 0 drops the forward FFT, bit 1 the product, bit 2 the inverse
 #define OLS_ABLATE 0
 #endif
-    if (LT) {
+    if (TM == 3) {
+      int ol = lane;
+      asm volatile("" : "+v"(ol));               // opaque per block: the table reads stay inside the loop
+      const LdsTab H = {ltab + 1024 + ol, 64};
+      if (!(OLS_ABLATE & 1)) forward(cur, lds, lane, g1, g2, sync);
+      if (!(OLS_ABLATE & 2)) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) cur[r] = cmul(cur[r], H[r]);
+      }
+      if (!(OLS_ABLATE & 4)) inverse(cur, lds, lane, g1, g2, sync);
+    } else if (LT) {
       int ol = lane;
       asm volatile("" : "+v"(ol));               // opaque per block: the table reads stay inside the loop
       const LdsTab tw1 = {ltab + ol, 64}, H = {ltab + 1024 + ol, 64}, tw2 = {ltab + 2048 + (ol & 3), 4};
@@ -257,6 +286,13 @@ __device__ __forceinline__ void ols_body(cv *lds, const cv *ltab, const void *__
         for (int r = 0; r < 16; r++) cur[r] = cmul(cur[r], H[r]);
       }
       if (!(OLS_ABLATE & 4)) inverse(cur, lds, lane, tw1, tw2, sync);
+    } else if (TM == 2) {
+      if (!(OLS_ABLATE & 1)) forward(cur, lds, lane, g1, g2, sync);
+      if (!(OLS_ABLATE & 2)) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) cur[r] = cmul(cur[r], Hr[r]);
+      }
+      if (!(OLS_ABLATE & 4)) inverse(cur, lds, lane, g1, g2, sync);
     } else {
       if (!(OLS_ABLATE & 1)) forward(cur, lds, lane, tw1r, tw2r, sync);
       if (!(OLS_ABLATE & 2)) {
@@ -358,8 +394,8 @@ __device__ __forceinline__ void ols_body(cv *lds, const cv *ltab, const void *__
 // history halo, the ragged last block), and the wave after them writes the new history (the last `histlen` samples of
 // history ++ x) into the handle's other history buffer.  WPW waves per workgroup: 1 = tables in registers, 2 waves per
 // SIMD; 4 = tables in an LDS image per workgroup, 3 workgroups per CU = 3 waves per SIMD.
-template <bool REAL, int R0, bool DYN, int WPW>
-__global__ __launch_bounds__(64 * WPW, WPW == 1 ? 2 : 3) void ols_kernel(const void *__restrict__ x, const void *__restrict__ hist,
+template <bool REAL, int R0, bool DYN, int WPW, bool GEN = false>
+__global__ __launch_bounds__(64 * WPW, (WPW == 1 && !GEN) ? 2 : 3) void ols_kernel(const void *__restrict__ x, const void *__restrict__ hist,
                                                     void *__restrict__ hist_next, void *__restrict__ y,
                                                     const cpx *__restrict__ Hreg, const cpx *__restrict__ TW1,
                                                     const cpx *__restrict__ TW2, int Km1, int histlen, int L,
@@ -386,12 +422,12 @@ __global__ __launch_bounds__(64 * WPW, WPW == 1 ? 2 : 3) void ols_kernel(const v
   const int64_t w = (int64_t) blockIdx.x * WPW + wv;
   const int lane = threadIdx.x & 63;
   if (w < G) {
-    ols_body<false, REAL, R0, DYN, LT>(lds, ltab, x, hist, y, (const cv *) Hreg, (const cv *) TW1, (const cv *) TW2, Km1, histlen, L, n, b_lo, b_hi, G,
+    ols_body<false, REAL, R0, DYN, LT ? (GEN ? 3 : 1) : (GEN ? 2 : 0)>(lds, ltab, x, hist, y, (const cv *) Hreg, (const cv *) TW1, (const cv *) TW2, Km1, histlen, L, n, b_lo, b_hi, G,
                                        w, (int64_t) blockIdx.x / 8, R, dyn);
   } else if (w < G + ne) {
     // edge items: [0, n_lo) need the history halo, [b_tail, nblocks) are ragged at the end
     const int64_t b = (w - G) < n_lo ? (int64_t) (w - G) : b_tail + (w - G - n_lo);
-    ols_body<true, REAL, 0, false, LT>(lds, ltab, x, hist, y, (const cv *) Hreg, (const cv *) TW1, (const cv *) TW2, Km1, histlen, L, n, b, nblocks, 1, 0, 0, 1, dyn);
+    ols_body<true, REAL, 0, false, LT ? (GEN ? 3 : 1) : (GEN ? 2 : 0)>(lds, ltab, x, hist, y, (const cv *) Hreg, (const cv *) TW1, (const cv *) TW2, Km1, histlen, L, n, b, nblocks, 1, 0, 0, 1, dyn);
   } else if (w == G + ne) {
     for (int i = lane; i < histlen; i += 64) {
       const int64_t g = n - histlen + i;
@@ -489,6 +525,9 @@ int ols_plan_create(tsdgpu_fir *f)
   // waves per workgroup: 4 = tables in LDS, 3 workgroups of 4 waves per CU; 1 = tables in registers, 8 one-wave workgroups
   const char *wpw_s = getenv("TSDGPU_OLS_WPW");
   f->ols_wpw = (OLS_WITH_WPW4 && wpw_s && atoi(wpw_s) == 4) ? 4 : 1;
+  // twiddles generated from 2 x 4 table entries per lane (3 waves per SIMD) instead of 2 x 15 held (2 waves per SIMD)
+  const char *gen_s = getenv("TSDGPU_OLS_GEN");
+  f->ols_gen = OLS_WITH_GEN && gen_s && atoi(gen_s) != 0;
   static const std::pair<int, std::pair<int, int>> occ = []() {
     int dev = 0, cus = 256, per_cu1 = 8, per_cu4 = 3;
     (void) hipGetDevice(&dev);
@@ -505,7 +544,17 @@ int ols_plan_create(tsdgpu_fir *f)
 #endif
     return std::make_pair(cus, std::make_pair(per_cu1, 4 * per_cu4));
   }();
-  const int cus = occ.first, per_cu = f->ols_wpw == 1 ? occ.second.first : occ.second.second;    // waves per CU
+  static const int per_cu_gen = []() {
+    int v = 12;
+#if OLS_WITH_GEN
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, ols_kernel<false, 2, true, 1, true>, 64, 0) != hipSuccess || v < 1) {
+      (void) hipGetLastError();
+      v = 12;
+    }
+#endif
+    return v;
+  }();
+  const int cus = occ.first, per_cu = f->ols_wpw == 4 ? occ.second.second : (f->ols_gen ? per_cu_gen : occ.second.first);    // waves per CU
   f->ols_grid = cus * per_cu;
   if (const char *g = getenv("TSDGPU_OLS_WAVES_PER_CU")) f->ols_grid = cus * atoi(g);
   if (getenv("TSDGPU_DEBUG")) fprintf(stderr, "[tsdgpu] ols plan: N=%d K=%d L=%d cus=%d waves/workgroup=%d waves/CU=%d grid=%d waves\n", N, K, f->ols_L, cus, f->ols_wpw, per_cu, f->ols_grid);
@@ -593,9 +642,32 @@ int ols_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, hipStream_t st)
     case 4: OLS_LAUNCH(REAL, 4, DYN, W); break;                            \
     default: OLS_LAUNCH(REAL, 0, DYN, W); break;                           \
   }
-#if OLS_WITH_WPW4
+#define OLS_LAUNCH_G(REAL, R0, DYN)                                                                                                   \
+  hipLaunchKernelGGL((ols_kernel<REAL, R0, DYN, 1, true>), dim3(nwg), dim3(64), 0, st, x, (const void *) f->hist[f->cur],               \
+                     f->hist[nxt], y, d, d + OLS_N, d + 2 * OLS_N, OLS_N - L, f->HL, L, n, b_lo_w, b_hi, nblocks, (int) grid, ne,   \
+                     e[0], e[1], R, dyn)
+#define OLS_LAUNCH_G_R0(REAL, DYN)                                        \
+  switch (R > 1 ? r0 : 0) {                                               \
+    case 1: OLS_LAUNCH_G(REAL, 1, DYN); break;                            \
+    case 2: OLS_LAUNCH_G(REAL, 2, DYN); break;                            \
+    case 3: OLS_LAUNCH_G(REAL, 3, DYN); break;                            \
+    case 4: OLS_LAUNCH_G(REAL, 4, DYN); break;                            \
+    default: OLS_LAUNCH_G(REAL, 0, DYN); break;                           \
+  }
+#if OLS_WITH_WPW4 && OLS_WITH_GEN
+#define OLS_LAUNCH_G4(REAL, R0, DYN)                                                                                                  \
+  hipLaunchKernelGGL((ols_kernel<REAL, R0, DYN, 4, true>), dim3(nwg), dim3(256), 0, st, x, (const void *) f->hist[f->cur],              \
+                     f->hist[nxt], y, d, d + OLS_N, d + 2 * OLS_N, OLS_N - L, f->HL, L, n, b_lo_w, b_hi, nblocks, (int) grid, ne,   \
+                     e[0], e[1], R, dyn)
+#define OLS_LAUNCH_W(REAL, DYN) \
+  if (WPW == 4 && f->ols_gen) { if (R > 1 && r0 == 2) { OLS_LAUNCH_G4(REAL, 2, DYN); } else { OLS_LAUNCH_G4(REAL, 0, DYN); } } \
+  else if (f->ols_gen) { OLS_LAUNCH_G_R0(REAL, DYN) } else if (WPW == 1) { OLS_LAUNCH_R0(REAL, DYN, 1) } else { OLS_LAUNCH_R0(REAL, DYN, 4) }
+#elif OLS_WITH_WPW4
 #define OLS_LAUNCH_W(REAL, DYN) \
   if (WPW == 1) { OLS_LAUNCH_R0(REAL, DYN, 1) } else { OLS_LAUNCH_R0(REAL, DYN, 4) }
+#elif OLS_WITH_GEN
+#define OLS_LAUNCH_W(REAL, DYN) \
+  if (f->ols_gen) { OLS_LAUNCH_G_R0(REAL, DYN) } else { OLS_LAUNCH_R0(REAL, DYN, 1) }
 #else
 #define OLS_LAUNCH_W(REAL, DYN) { OLS_LAUNCH_R0(REAL, DYN, 1) }
 #endif
@@ -605,6 +677,8 @@ int ols_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, hipStream_t st)
     if (NC > 0) { OLS_LAUNCH_W(false, true) } else { OLS_LAUNCH_W(false, false) }
   }
 #undef OLS_LAUNCH_W
+#undef OLS_LAUNCH_G_R0
+#undef OLS_LAUNCH_G
 #undef OLS_LAUNCH_R0
 #undef OLS_LAUNCH
   TSD_HIP(hipGetLastError());
