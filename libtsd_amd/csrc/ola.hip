@@ -26,6 +26,7 @@ struct tsdgpu_ola {
   tsdgpu::DevBuf frames, spectra, in_stage, out_stage;
   tsdgpu::cpx *d_fast = nullptr;           // fast path (Ne = 512, N = 1024, no window): response in register order / N + twiddles (3 x 1024)
   tsdgpu::cpx *d_svg_tmp = nullptr;        // Ne: the new tail, written by the last wave while the first one may still read d_svg
+  tsdgpu::cpx *d_last_tmp = nullptr;       // Ne: the same for `last` (windowed run kernel)
   tsdgpu::cpx *d_bloc = nullptr;           // ONE allocation behind d_svg, d_svg_tmp, d_last, d_prev_half, d_rest
   tsdgpu::cpx *d_run = nullptr;            // any other geometry without window: response / N (N values), then W_N^i, i < N/16
 };
@@ -322,6 +323,203 @@ int ola_run_launch(const cpx *blk0, int nrest, const cpx *x, cpx *y, const cpx *
   else return set_err(TSDGPU_ERR_UNSUPPORTED, "ola: frame of %d points does not fit the fused kernel", N);   // (set_response does not select it)
 #undef RUN_PICK
 #undef RUN_LAUNCH
+  TSD_HIP(hipGetLastError());
+  return TSDGPU_OK;
+}
+
+// ---- the WINDOWED mode (fourier.cc:883-927) as ONE kernel: a run of consecutive blocks emulated statement by statement ----
+// Per block two Hann-windowed frames half a block apart -- A: [second half of the block before | first half of this one],
+// B: the block -- each [Nz zeros | Ne samples] -> FFT -> x H -> IFFT = x2, folded into the two carried vectors exactly as the
+// reference does it:
+//   A:  svg.segment(Ne - Nz, Nz) += x2.head(Nz);  last.tail(h) += svg.head(h) / 2;  y = last;
+//       last.head(h) = svg.tail(h) / 2;  last.tail(h) = 0;  svg = x2.tail(Ne)
+//   B:  svg.tail(Nz) += x2.head(Nz);  last += svg / 2;  svg = x2.segment(Nz, Ne)
+// N/16 threads own a run; frame image, svg and last live in LDS (the reference's own order of additions, no closed form).
+// The state entering block b depends on frames 2b - 3 .. 2b - 1 only (svg is overwritten by every frame, last by step A), so a
+// run that starts at block b_lo >= 2 recomputes frame B of block b_lo - 2 and block b_lo - 1 from zero state and discards their
+// output; the runs that start at block 0 or 1 begin from the handle's state.  16 B of HBM traffic per sample against the ~100 B of the framing /
+// spectrum / inverse-frame / overlap-add passes.  Every thread of the workgroup passes every barrier: dead frames run on zeros.
+// THREADS = 64 (frames of up to 1024 points: a run's N/16 threads lie inside ONE wave): no workgroup barrier at all -- a wave's
+// LDS operations execute in order, wavefront-scope fences keep the compiler from moving them -- so the waves of a CU drift
+// freely and hide each other's LDS latencies (with 256-thread workgroups the ~15 barriers per frame put 4 waves in lockstep:
+// 0.404 ms per 2^24 samples at Ne = 512, slower than the multi-kernel engine).
+template <int R0, int THREADS>
+__global__ __launch_bounds__(THREADS, THREADS <= 256 ? 2 : 1) void olaw_run_kernel(const cpx *__restrict__ blk0, int nrest, const cpx *__restrict__ x,
+                                                        cpx *__restrict__ y, const cpx *__restrict__ Hs, const cpx *__restrict__ TW,
+                                                        const float *__restrict__ fen, const cpx *__restrict__ svg_in,
+                                                        const cpx *__restrict__ last_in, const cpx *__restrict__ prev_half_in,
+                                                        cpx *__restrict__ svg_out, cpx *__restrict__ last_out, int Ne, int N, int tpt,
+                                                        int64_t B, int per, int skip_first)
+{
+  extern __shared__ __attribute__((aligned(16))) char runw_raw[];
+  const int Nz = N - Ne, h = Ne / 2, t = threadIdx.x, T = THREADS / tpt;
+  const int tl = t / tpt, j0 = t - tl * tpt;
+  cpx *s = reinterpret_cast<cpx *>(runw_raw) + (size_t) tl * (N + (N >> 4) + 2 * Ne);
+  cpx *svg = s + N + (N >> 4), *last = svg + Ne;
+  const int64_t b_lo = ((int64_t) blockIdx.x * T + tl) * per, b_hi = min(B, b_lo + (int64_t) per);
+  auto sync = []() {
+    if (THREADS == 64) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+      __syncthreads();
+    }
+  };
+  // the runs that start at block 0 or 1 begin from the handle's state (block 0 is then the second run's whole warm-up); the others
+  // from zeros, two blocks early
+  const bool first_run = b_lo == 0, from_handle = b_lo <= 1 && b_lo < B;
+  for (int i = j0; i < Ne; i += tpt) {
+    svg[i] = from_handle ? svg_in[i] : make_float2(0.f, 0.f);
+    last[i] = from_handle ? last_in[i] : make_float2(0.f, 0.f);
+  }
+  // sample i of block b of [rest ++ x] (block 0 was made contiguous by the host)
+  auto blk = [&](int64_t b, int i) { return b == 0 ? blk0[i] : x[b * Ne - nrest + i]; };
+  cpx v[16];
+  bool first = true;
+  for (int it = -2; it < per; it++) {
+    const int64_t b = b_lo + it;
+#pragma unroll 1
+    for (int f = 0; f < 2; f++) {
+      // frames that exist for this run: the warm-up (frame B of b_lo - 2, both of b_lo - 1) unless the run starts the call,
+      // then the run's own blocks
+      const bool live = b_lo < B && (it >= 0 ? b < b_hi : (!first_run && b >= 0 && (it == -1 || f == 1)));
+      int j = j0;
+      asm volatile("" : "+v"(j));      // (see ola_run_kernel: no addresses carried across the loop)
+#pragma unroll
+      for (int m = 0; m < 16; m++) {
+        const int p = j + m * tpt, i = p - Nz;
+        cpx a = make_float2(0.f, 0.f);
+        if (live && i >= 0) {
+          if (f == 0) a = i < h ? (b == 0 ? prev_half_in[i] : blk(b - 1, h + i)) : blk(b, i - h);      // :885
+          else a = blk(b, i);                                                                          // :910
+          const float w = fen[i];
+          a.x *= w;
+          a.y *= w;
+        }
+        v[m] = a;
+      }
+      if (!first) sync();               // the image is still being read by the last pass of the frame before
+      first = false;
+      s16::transform<R0>(v, s, TW, N, j, tpt, sync);
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        const cpx hh = Hs[j + q * tpt];
+        v[q] = make_float2(v[q].x * hh.x - v[q].y * hh.y, -(v[q].x * hh.y + v[q].y * hh.x));
+      }
+      sync();
+      asm volatile("" : "+v"(j));
+      s16::transform<R0>(v, s, TW, N, j, tpt, sync);
+      asm volatile("" : "+v"(j));
+      // v[q] = conj(x2[j + q tpt])
+      if (live) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+          const int p = j + q * tpt;
+          if (p < Nz) {                                          // svg.segment(Ne - Nz, Nz) += x2.head(Nz)   (:894 / :917)
+            const cpx a = svg[Ne - Nz + p];
+            svg[Ne - Nz + p] = make_float2(a.x + v[q].x, a.y - v[q].y);
+          }
+        }
+      }
+      sync();
+      if (live) {
+        if (f == 0) {
+          for (int i = j; i < h; i += tpt) {                     // last.tail(h) += svg.head(h) / 2   (:897)
+            const cpx a = last[h + i], c = svg[i];
+            last[h + i] = make_float2(a.x + c.x / 2.0f, a.y + c.y / 2.0f);
+          }
+        } else {
+          for (int i = j; i < Ne; i += tpt) {                    // last += svg / 2   (:918)
+            const cpx a = last[i], c = svg[i];
+            last[i] = make_float2(a.x + c.x / 2.0f, a.y + c.y / 2.0f);
+          }
+        }
+      }
+      sync();
+      if (live && f == 0) {
+        if (it >= 0 && !(skip_first && b == 0))                  // y = last   (:898-901; nothing for the very first block)
+          for (int i = j; i < Ne; i += tpt) y[(b - skip_first) * Ne + i] = last[i];
+        for (int i = j; i < h; i += tpt) {                       // last.head(h) = svg.tail(h) / 2; last.tail(h) = 0   (:903-904)
+          const cpx c = svg[h + i];
+          last[i] = make_float2(c.x / 2.0f, c.y / 2.0f);
+          last[h + i] = make_float2(0.f, 0.f);
+        }
+      }
+      sync();
+      if (live) {
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+          const int p = j + q * tpt;
+          if (p >= Nz) svg[p - Nz] = make_float2(v[q].x, -v[q].y);      // svg = x2.tail(Ne)   (:907 / :919)
+        }
+      }
+    }
+  }
+  sync();
+  if (b_lo < B && b_hi == B)
+    for (int i = j0; i < Ne; i += tpt) {
+      svg_out[i] = svg[i];
+      last_out[i] = last[i];
+    }
+}
+
+struct OlawGeom {
+  int tpt, threads, T;
+  size_t lds;
+};
+OlawGeom olaw_geom(int N, int Ne)
+{
+  OlawGeom g;
+  g.tpt = std::max(N / 16, 1);
+  g.threads = g.tpt <= 64 ? 64 : std::max(256, g.tpt);       // (a run inside one wave: one-wave workgroups, no barriers)
+  g.T = g.threads / g.tpt;
+  g.lds = (size_t) g.T * (N + N / 16 + 2 * Ne) * sizeof(cpx);
+  return g;
+}
+bool olaw_run_fits(int N, int Ne)
+{
+  const OlawGeom g = olaw_geom(N, Ne);
+  // (only frames of up to 1024 points, whose runs lie inside one wave: with workgroup barriers the kernel is slower than the
+  // multi-kernel engine -- 0.416 against 0.373 ms per 2^24 samples at Ne = N = 4096; 0.317 against 0.375 at Ne = N = 512)
+  return N >= 16 && g.threads == 64 && g.lds <= 160 * 1024 && (Ne & 1) == 0;
+}
+// B >= 1 whole blocks of [rest ++ x] -> y (B - skip_first blocks of output); tables = Hs (N), TW (N/16)
+int olaw_run_launch(const cpx *blk0, int nrest, const cpx *x, cpx *y, const cpx *tables, const float *fen, const cpx *svg_in, const cpx *last_in,
+                    const cpx *prev_half_in, cpx *svg_out, cpx *last_out, int Ne, int N, int64_t B, int skip_first, hipStream_t st)
+{
+  const OlawGeom g = olaw_geom(N, Ne);
+  int logn = 0;
+  while ((1 << logn) < N) logn++;
+  const int r0 = 1 << ((logn & 3) == 0 ? 4 : (logn & 3));
+  static const int cus = []() {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n > 0 ? n : 256;
+  }();
+  // blocks per run: a run costs per + 1.5 blocks (its warm-up), the workgroups pass over the chip in rounds
+  const int64_t slots = (int64_t) cus * std::max<int64_t>(1, std::min<int64_t>(g.threads == 64 ? 16 : g.threads == 256 ? 2 : 1, (int64_t) ((160 * 1024) / g.lds)));
+  int per = 1;
+  int64_t best = -1;
+  for (int c = 1; c <= 64; c++) {
+    const int64_t wgs = cdiv(cdiv(B, c), g.T), cost = cdiv(wgs, slots) * (2 * c + 3);
+    if (best < 0 || cost < best) best = cost, per = c;
+  }
+  const int64_t grid = cdiv(cdiv(B, per), g.T);
+  if (grid > 0x7fffffff) return set_err(TSDGPU_ERR_UNSUPPORTED, "ola: too many blocks in one call");
+#define RUNW_LAUNCH(R, TH)                                                                                                \
+  do {                                                                                                                   \
+    (void) hipFuncSetAttribute((const void *) olaw_run_kernel<R, TH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+    hipLaunchKernelGGL((olaw_run_kernel<R, TH>), dim3((unsigned) grid), dim3(TH), g.lds, st, blk0, nrest, x, y, tables, tables + N, fen, svg_in, last_in, prev_half_in, svg_out, last_out, Ne, N, g.tpt, B, per, skip_first); \
+  } while (0)
+#define RUNW_PICK(TH)                                                                                                    \
+  do {                                                                                                                   \
+    if (r0 == 16) RUNW_LAUNCH(16, TH); else if (r0 == 8) RUNW_LAUNCH(8, TH); else if (r0 == 4) RUNW_LAUNCH(4, TH); else RUNW_LAUNCH(2, TH); \
+  } while (0)
+  if (g.threads == 64) RUNW_PICK(64);
+  else return set_err(TSDGPU_ERR_UNSUPPORTED, "ola: frame of %d points does not fit the fused windowed kernel", N);
+#undef RUNW_PICK
+#undef RUNW_LAUNCH
   TSD_HIP(hipGetLastError());
   return TSDGPU_OK;
 }
@@ -721,13 +919,14 @@ int tsdgpu_ola_create(tsdgpu_ola **out, int block_len, int min_zeros, const floa
   if (!rc) {
     // the carried vectors in ONE zeroed allocation (five allocations, five memsets and five synchronisations before)
     const size_t q = ((size_t) Ne + 1) / 2 * 2;          // 16-byte slots
-    rc = ola_alloc(&h->d_bloc, 5 * q);
+    rc = ola_alloc(&h->d_bloc, 6 * q);
     if (!rc) {
       h->d_svg = h->d_bloc;
       h->d_svg_tmp = h->d_bloc + q;
       h->d_last = h->d_bloc + 2 * q;
       h->d_rest = h->d_bloc + 3 * q;
       h->d_prev_half = h->d_bloc + 4 * q;
+      h->d_last_tmp = h->d_bloc + 5 * q;
     }
   }
   if (!rc && window) {
@@ -769,7 +968,7 @@ int tsdgpu_ola_set_response(tsdgpu_ola *h, const void *H)
     if (!h->d_fast) TSD_HIP(hipMalloc((void **) &h->d_fast, t3.size() * sizeof(cpx)));
     TSD_HIP(hipMemcpy(h->d_fast, t3.data(), t3.size() * sizeof(cpx), hipMemcpyHostToDevice));
   }
-  if (!unfused && !h->windowed && ola_run_fits(h->N, h->Ne)) {
+  if (!unfused && (h->windowed ? olaw_run_fits(h->N, h->Ne) : ola_run_fits(h->N, h->Ne))) {
     // the other geometries whose frame and carried block fit the LDS: one kernel too (ola_run_kernel) -- which also serves the
     // ragged calls of the default geometry (waiting samples in front of x), the in-wave kernel taking the whole-block ones
     const int N = h->N;
@@ -967,7 +1166,7 @@ int tsdgpu_ola_step(tsdgpu_ola *h, const void *x, int64_t n, void *y, int64_t *n
     if (n_out) *n_out = nout;
     return TSDGPU_OK;
   }
-  if (h->d_run && h->pending_blocks < 0 && n >= 0 && (n == 0 || x != nullptr) && ((int64_t) h->nrest + n) / h->Ne >= 1 && y != nullptr) {
+  if (h->d_run && !h->windowed && h->pending_blocks < 0 && n >= 0 && (n == 0 || x != nullptr) && ((int64_t) h->nrest + n) / h->Ne >= 1 && y != nullptr) {
     // any other geometry without window: B whole blocks of [rest ++ x] through ONE kernel (ola_run_kernel)
     hipStream_t st = (hipStream_t) stream;
     const int Ne = h->Ne;
@@ -1000,6 +1199,49 @@ int tsdgpu_ola_step(tsdgpu_ola *h, const void *x, int64_t n, void *y, int64_t *n
     if (dxv != x && !staged) TSD_HIP(hipStreamSynchronize(st));    // (a staged input must outlive its kernels)
     h->nrest = (int) left;
     h->cnt_ech += nout;
+    if (n_out) *n_out = nout;
+    return TSDGPU_OK;
+  }
+  if (h->d_run && h->windowed && h->pending_blocks < 0 && n >= 0 && (n == 0 || x != nullptr) && ((int64_t) h->nrest + n) / h->Ne >= 1 && y != nullptr) {
+    // the windowed mode: B whole blocks of [rest ++ x] through ONE kernel (olaw_run_kernel)
+    hipStream_t st = (hipStream_t) stream;
+    const int Ne = h->Ne;
+    const int64_t tot = (int64_t) h->nrest + n, B = tot / Ne, left = tot - B * Ne;
+    const int skip = h->cnt_ech < 0 ? 1 : 0;                       // (:899-901: the very first block gives no output)
+    const int64_t nout = (B - skip) * Ne;
+    if (n_out) *n_out = 0;
+    TSD_CHECK(B <= (1 << 24), "ola_step: %lld blocks in one call", (long long) B);
+    const void *dxv = nullptr;
+    void *dyv = nullptr;
+    bool staged = false;
+    int rc = stage_in(x, (size_t) n * sizeof(cpx), h->in_stage, st, &dxv);
+    if (rc) return rc;
+    if ((rc = stage_out(y, (size_t) nout * sizeof(cpx), h->out_stage, &dyv, &staged))) return rc;
+    if (nout > 0 && host_ranges_overlap(dxv, (size_t) n * sizeof(cpx), dyv, (size_t) nout * sizeof(cpx))) {
+      // in place on the device: a run re-reads the blocks before it, which the run before may already have overwritten
+      if ((rc = h->in_stage.reserve((size_t) n * sizeof(cpx)))) return rc;
+      TSD_HIP(hipMemcpyAsync(h->in_stage.p, dxv, (size_t) n * sizeof(cpx), hipMemcpyDeviceToDevice, st));
+      dxv = h->in_stage.p;
+    }
+    const cpx *dx = (const cpx *) dxv;
+    // block 0 made contiguous: the waiting samples, then the head of x (rest has room for a whole block)
+    if (h->nrest > 0 && (rc = copy_small(h->d_rest + h->nrest, dx, Ne - h->nrest, st))) return rc;
+    if ((rc = olaw_run_launch(h->nrest > 0 ? h->d_rest : dx, h->nrest, dx, (cpx *) dyv, h->d_run, h->d_fen, h->d_svg, h->d_last, h->d_prev_half,
+                              h->d_svg_tmp, h->d_last_tmp, Ne, h->N, B, skip, st)))
+      return rc;
+    std::swap(h->d_svg, h->d_svg_tmp);
+    std::swap(h->d_last, h->d_last_tmp);
+    // the second half of the last block waits for the next call's first frame (:926); then the samples after the last whole block
+    hipLaunchKernelGGL(ola_gather_kernel, dim3(nblk(Ne / 2)), dim3(256), 0, st, h->d_rest, h->nrest, dx, (B - 1) * Ne + Ne / 2, h->d_prev_half, Ne / 2);
+    TSD_HIP(hipGetLastError());
+    if (left > 0) {
+      hipLaunchKernelGGL(ola_gather_kernel, dim3(nblk(left)), dim3(256), 0, st, h->d_rest, 0, dx, B * Ne - h->nrest, h->d_rest, (int) left);
+      TSD_HIP(hipGetLastError());
+    }
+    if ((rc = finish_out(y, (size_t) nout * sizeof(cpx), dyv, staged, st))) return rc;
+    if (dxv != x && !staged) TSD_HIP(hipStreamSynchronize(st));    // (a staged input must outlive its kernels)
+    h->nrest = (int) left;
+    h->cnt_ech += B * Ne;
     if (n_out) *n_out = nout;
     return TSDGPU_OK;
   }

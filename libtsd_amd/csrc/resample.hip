@@ -52,7 +52,8 @@ struct RsParams {
 
 struct RsCk { uint32_t phase_bits; uint32_t cum; };
 constexpr int RS_KMAX = 256;                   // longest interpolator (taps); LUTs beyond RS_LUT_LDS_BYTES stay in global memory
-constexpr int RS_LUT_LDS_BYTES = 48 * 1024;
+constexpr int RS_LUT_LDS_BYTES = 48 * 1024;      // tables up to this size leave room for RS_WAVES waves per workgroup
+constexpr size_t RS_LDS_LIMIT = 158 * 1024;
 __host__ __device__ inline int rs_tile_elems(int K) { return RS_TI + (K <= 32 ? 32 : (K + 31) / 32 * 32) + 2; }   // cum = outputs before this input (canonical index space)
 
 __host__ __device__ inline float bits2f(uint32_t b)
@@ -116,9 +117,11 @@ __global__ __launch_bounds__(RS_THREADS) void resample_kernel(const T *__restric
 {
   // the workgroup after the persistent ones writes the stream's next window history (the last K - 1 inputs of
   // history ++ x) into the handle's other buffer: one launch per step
+  // waves per workgroup: RS_WAVES, or fewer when a long interpolator's table takes most of the LDS (rs_geometry)
+  const int NT = blockDim.x, NW = NT >> 6;
   if (blockIdx.x == gridDim.x - 1) {
     const int H = P.K - 1;
-    for (int i = threadIdx.x; i < H; i += RS_THREADS) {
+    for (int i = threadIdx.x; i < H; i += NT) {
       const int64_t g = P.n - H + i;
       hist_next[i] = g < 0 ? (hist ? hist[H + g] : zero_of(T{})) : x[g];
     }
@@ -138,14 +141,14 @@ __global__ __launch_bounds__(RS_THREADS) void resample_kernel(const T *__restric
 
   // ---- stage the LUT once per (persistent) workgroup (a LUT too large for LDS is read in place)
   const int lut_n = P.lut_in_lds ? (P.nph + 1) * K : 0;
-  for (int i = threadIdx.x; i < lut_n; i += RS_THREADS) {
+  for (int i = threadIdx.x; i < lut_n; i += NT) {
     const int c = i / K, k = i - c * K;
     lut_s[c * lstride + k] = lut[c * P.gl + k];
   }
   const float *lutp = P.lut_in_lds ? lut_s : lut;
   const int lrow = P.lut_in_lds ? lstride : P.gl;         // both multiples of 4: rows are read 16 B at a time
   if (KT == 15)
-    for (int c = threadIdx.x; c <= P.nph; c += RS_THREADS) lut_s[c * lstride + 15] = 0.f;   // 16th tap
+    for (int c = threadIdx.x; c <= P.nph; c += NT) lut_s[c * lstride + 15] = 0.f;   // 16th tap
   __syncthreads();
 
   auto wave_sync = []() {
@@ -156,8 +159,8 @@ __global__ __launch_bounds__(RS_THREADS) void resample_kernel(const T *__restric
 
   // canonical (cycle-folded) index of this wave's first tile: ONE 64-bit division per wave;
   // afterwards the index advances by a constant and is folded by subtraction
-  const int wtile0 = blockIdx.x * RS_WAVES + wv;
-  const int wstep = (gridDim.x - 1) * RS_WAVES;
+  const int wtile0 = blockIdx.x * NW + wv;
+  const int wstep = (gridDim.x - 1) * NW;
   int64_t icT = P.tile0 + (int64_t) wtile0 * RS_TI, qT = 0;
   if (P.lambda > 0 && icT >= P.mu + P.lambda) {
     const int64_t d = icT - P.mu;
@@ -276,6 +279,7 @@ __global__ __launch_bounds__(RS_THREADS) void resample_kernel(const T *__restric
       } else if (P.mode == 0) {
         // taps 16 B at a time (a row per lane: scalar reads cost one cache line or LDS access per tap)
         const int K4 = K & ~3;
+#pragma unroll 4
         for (int k = 0; k < K4; k += 4) {
           const float4 q4 = *reinterpret_cast<const float4 *>(h + k);
           acc = tap_mac(acc, q4.x, w[k]);
@@ -750,15 +754,34 @@ int sync_table(tsdgpu_resampler *r, hipStream_t st)
 // LDS bytes per workgroup of the generic kernel for this handle (the arithmetic of tsdgpu_resampler_step):
 // checked at creation so that a configuration no step could launch -- a large ratio with wide complex
 // tiles -- is refused there instead of failing at every step
-static size_t rs_lds_need(const tsdgpu_resampler *r, int mode)
+// Geometry of the generic kernel for this handle: is the table staged in LDS, and how many waves share it.  A table of up to
+// 48 KiB leaves room for RS_WAVES waves; a LONG interpolator's table (itrp_sinc{127, 256, ...} of the reference's test_ra_unit:
+// 257 rows of 132 floats = 133 KiB) is staged too when at least two waves' tiles still fit beside it -- read through L2
+// instead (a row per lane per tap quadruple: 64 cache lines per wave instruction) it cost 5.7 ms per 2^26 inputs.
+struct RsGeom {
+  bool lut_in_lds;
+  int waves;
+  size_t lds;
+};
+static RsGeom rs_geometry(const tsdgpu_resampler *r, int mode)
 {
   const size_t sz = dtype_size(r->data_type);
   const int rec_cap = ((int) ((double) RS_TI * (double) r->ratio * 1.0001) + 32 + 3) / 4 * 4;
   const size_t wbytes = ((size_t) rs_tile_elems(r->K) * sz + (size_t) rec_cap * (mode ? 8 : 4) + 15) / 16 * 16;
   const int lstride = r->K == 15 ? 20 : r->lstride;
-  const bool in_lds = (size_t) (r->nph + 1) * lstride * 4 <= (size_t) RS_LUT_LDS_BYTES;
-  return (size_t) (in_lds ? (r->nph + 1) * lstride + 4 : 8) * 4 + RS_WAVES * wbytes + 64;
+  const size_t lut = ((size_t) (r->nph + 1) * lstride + 4) * 4;
+  RsGeom g;
+  g.lut_in_lds = lut - 16 <= (size_t) RS_LUT_LDS_BYTES;
+  g.waves = RS_WAVES;
+  static const bool no_big = getenv("TSDGPU_RS_LUT_L2") != nullptr;          // A/B switch: long tables through L2 as before
+  if (!g.lut_in_lds && !no_big && mode == 0 && lut + 64 + 2 * wbytes <= RS_LDS_LIMIT) {
+    g.lut_in_lds = true;
+    g.waves = (int) std::min<size_t>(RS_WAVES, (RS_LDS_LIMIT - lut - 64) / wbytes);
+  }
+  g.lds = (g.lut_in_lds ? lut : 32) + (size_t) g.waves * wbytes + 64;
+  return g;
 }
+static size_t rs_lds_need(const tsdgpu_resampler *r, int mode) { return rs_geometry(r, mode).lds; }
 
 extern "C" {
 
@@ -930,15 +953,14 @@ int tsdgpu_resampler_step(tsdgpu_resampler *r, const void *x, int64_t n, void *y
   P.rec_cap = ((int) ((double) RS_TI * (double) r->ratio * 1.0001) + 32 + 3) / 4 * 4;
   const int64_t tiles = cdiv(r->pos + n - P.tile0, RS_TI);
   TSD_CHECK(tiles <= 0x7fffffff, "resampler_step: n too large for one launch");
-  const int lstride = r->K == 15 ? 20 : r->lstride;
-  const size_t wbytes = ((size_t) rs_tile_elems(r->K) * sz + (size_t) P.rec_cap * (r->mode ? 8 : 4) + 15) / 16 * 16;
-  P.lut_in_lds = (size_t) (r->nph + 1) * lstride * 4 <= (size_t) RS_LUT_LDS_BYTES ? 1 : 0;
-  const size_t lds = (size_t) (P.lut_in_lds ? (r->nph + 1) * lstride + 4 : 8) * 4 + RS_WAVES * wbytes + 64;
-  TSD_CHECK(lds <= 158 * 1024, "resampler_step: configuration needs %zu bytes of LDS", lds);
+  const RsGeom geo = rs_geometry(r, r->mode);
+  P.lut_in_lds = geo.lut_in_lds ? 1 : 0;
+  const size_t lds = geo.lds;
+  TSD_CHECK(lds <= RS_LDS_LIMIT, "resampler_step: configuration needs %zu bytes of LDS", lds);
   // persistent workgroups (the LUT is staged once per workgroup): as many as stay resident
   static const int PG = getenv("TSDGPU_RS_WG_PER_CU") ? atoi(getenv("TSDGPU_RS_WG_PER_CU")) : 0;
   int per_cu = PG > 0 ? PG : (int) std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (lds + 1024)));
-  const int64_t pgrid = std::min<int64_t>(cdiv(tiles, RS_WAVES), (int64_t) 256 * per_cu);
+  const int64_t pgrid = std::min<int64_t>(cdiv(tiles, geo.waves), (int64_t) 256 * per_cu);
   const size_t wb15 = ((size_t) (RS15_LATE_STORE ? RS15_TILE_PAD + P.rec_cap : std::max(RS15_TILE_PAD, P.rec_cap)) * sz + 15) / 16 * 16;
   const size_t lds15 = (size_t) ((r->nph + 1) * 20 + 4) * 4 + RS15_WAVES * wb15 + 64;
   const void *hcur = r->hist_zero ? nullptr : r->d_hist[r->cur];
@@ -970,7 +992,7 @@ int tsdgpu_resampler_step(tsdgpu_resampler *r, const void *x, int64_t n, void *y
                          (const float *) hcur, (float *) dy, r->d_lut, r->d_ck, P, (int) tiles, (float *) r->d_hist[r->cur ^ 1], dyn);
   } else {
 #define RS_LAUNCH(T, KT)                                                                                            \
-  hipLaunchKernelGGL((resample_kernel<T, KT>), dim3((unsigned) pgrid + 1), dim3(RS_THREADS), lds, st, (const T *) dx, \
+  hipLaunchKernelGGL((resample_kernel<T, KT>), dim3((unsigned) pgrid + 1), dim3(64 * geo.waves), lds, st, (const T *) dx, \
                      (const T *) hcur, (T *) dy, r->d_lut, r->d_ck, P, (int) tiles, (T *) r->d_hist[r->cur ^ 1])
   if (r->data_type == TSDGPU_C64) RS_LAUNCH(float2, 0); else RS_LAUNCH(float, 0);
 #undef RS_LAUNCH

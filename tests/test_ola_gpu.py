@@ -243,3 +243,50 @@ def test_fused_other_geometries_long_runs(Ne, K):
         g3.set_response(H)
         xi = x.clone()
         assert torch.equal(g3.step(xi, xi), y)
+
+
+@pytest.mark.parametrize("Ne,nz", [(512, 0), (512, 127), (64, 64), (2048, 500), (1000, 24), (4096, 0), (100, 20)])
+def test_fused_windowed_long_runs(Ne, nz):
+    """The windowed mode as ONE kernel (ola.hip, olaw_run_kernel: a run of blocks emulated statement by statement, runs past the
+    first recompute two blocks of warm-up): long calls -- many runs, the last one cut short -- against the multi-kernel
+    engine (TSDGPU_OLA_UNFUSED cannot be flipped inside a process: the analyse / synthese pair IS that engine), the stream in
+    ragged calls and in place; and against the numpy restatement on a stream short enough for it."""
+    import torch
+    rng = np.random.default_rng(Ne + nz)
+    win = ola_oracle.fen_hann_periodique(Ne)
+    g = t.Ola(Ne, nz, win)
+    H, _ = response(g.N, rng)
+    Hd = torch.from_numpy(H).cuda()
+    n = (3 << 20) // Ne * Ne + Ne
+    x = torch.view_as_complex(torch.randn(n, 2, device="cuda", generator=torch.Generator(device="cuda").manual_seed(n)))
+    g.set_response(H)
+    y = g.step(x)
+    assert y.shape[0] == n - Ne                               # the very first block gives no output (fourier.cc:899-901)
+    # the multi-kernel engine on the same stream: analyse -> spectra x H -> synthese
+    m = t.Ola(Ne, nz, win)
+    sp, nf = m.analyse(x)
+    spectra = torch.empty((nf, m.N), dtype=torch.complex64, device="cuda")
+    t.lib().tsdgpu_memcpy(spectra.data_ptr(), sp, nf * m.N * 8, None)
+    spectra *= Hd
+    t.lib().tsdgpu_memcpy(sp, spectra.data_ptr(), nf * m.N * 8, None)
+    torch.cuda.synchronize()
+    ym = m.synthese()
+    assert ym.shape == y.shape
+    assert float((y - ym).abs().max() / ym.abs().max()) <= 2e-6
+    # ragged calls (waiting samples in front of a call, runs falling elsewhere) and in place
+    g2 = t.Ola(Ne, nz, win)
+    g2.set_response(H)
+    cut = (n // Ne // 2) * Ne + Ne // 3
+    y2 = torch.cat([g2.step(x[:cut]), g2.step(x[cut:n - Ne + 7]), g2.step(x[n - Ne + 7:])])
+    assert y2.shape == y.shape and float((y2 - y).abs().max() / y.abs().max()) <= 1e-6
+    g3 = t.Ola(Ne, nz, win)
+    g3.set_response(H)
+    xi = x.clone()
+    y3 = g3.step(xi, xi)
+    assert torch.equal(y3, y)
+    # the numpy restatement on the first 40 blocks
+    ref = ola_oracle.Ola(Ne, nz, win, lambda X: X * H)
+    g4 = t.Ola(Ne, nz, win)
+    g4.set_response(H)
+    xs = x[:40 * Ne + 11].cpu().numpy()
+    assert relerr(g4.step(xs), ref.step(xs)) <= TOL
