@@ -241,28 +241,33 @@ __device__ __forceinline__ void ols_body(cv *lds, const cv *ltab, const void *__
   // nb: the block prefetched while `blk` is transformed; inrun: nb = blk + 1 inside the same run
   auto process = [&](cv (&cur)[16], cv (&nxt)[16], int64_t blk, int64_t nb, bool inrun) {
     const bool more = !EDGE && nb < b_hi;
-    if (more) {
+    // the prefetch of block nb into `nxt`: the rows reused from this block are copied NOW (cur still holds the raw samples),
+    // the loads are issued at `prefetch_loads()` -- before the forward transform, or (-DOLS_LATE_PREFETCH=1, experiment) after it
+    if (more && R0 > 0 && inrun) {
+#pragma unroll
+      for (int r = 0; r < R0; r++) nxt[r] = REAL ? mkv(cur[(16 - R0 + r) & 15].y, 0.f) : cur[(16 - R0 + r) & 15];
+    }
+    auto prefetch_loads = [&]() {
+      if (!more) return;
       if (R0 > 0 && inrun) {
         if (!REAL) {
           const cv *xb = x + (nb * (int64_t) L - Km1);
 #pragma unroll
-          for (int r = 0; r < 16; r++) {
-            if (r < R0) nxt[r] = cur[(16 - R0 + r) & 15];                // (cur still holds the raw samples)
-            else nxt[r] = NT ? ntload(xb + 64 * r + lane) : xb[64 * r + lane];
-          }
+          for (int r = R0; r < 16; r++) nxt[r] = NT ? ntload(xb + 64 * r + lane) : xb[64 * r + lane];
         } else {
           // pair (2 nb, 2 nb + 1): the first block's overlap is the tail of this pair's second block; the second block's
           // overlap is the tail of the first block being loaded now -- filled in once the loads have landed (below)
           const float *xa = xr + (2 * nb * (int64_t) L - Km1), *xb = xa + L;
 #pragma unroll
-          for (int r = 0; r < 16; r++) {
-            if (r < R0) nxt[r] = mkv(cur[(16 - R0 + r) & 15].y, 0.f);
-            else nxt[r] = mkv(xa[64 * r + lane], xb[64 * r + lane]);
-          }
+          for (int r = R0; r < 16; r++) nxt[r] = mkv(xa[64 * r + lane], xb[64 * r + lane]);
         }
       } else if (REAL) ols_fetch_real<EDGE>(nxt, xr, histr, histlen, Km1, L, n, nb, lane);
       else ols_fetch<EDGE>(nxt, x, hist, histlen, Km1, L, n, nb, lane);
-    }
+    };
+#ifndef OLS_LATE_PREFETCH
+#define OLS_LATE_PREFETCH 0
+#endif
+    if (!OLS_LATE_PREFETCH || TM != 0) prefetch_loads();
 #ifndef OLS_ABLATE   // measurement only: bit 0 drops the forward FFT, bit 1 the product, bit 2 the inverse
 #define OLS_ABLATE 0
 #endif
@@ -295,6 +300,7 @@ __device__ __forceinline__ void ols_body(cv *lds, const cv *ltab, const void *__
       if (!(OLS_ABLATE & 4)) inverse(cur, lds, lane, g1, g2, sync);
     } else {
       if (!(OLS_ABLATE & 1)) forward(cur, lds, lane, tw1r, tw2r, sync);
+      if (OLS_LATE_PREFETCH) prefetch_loads();
       if (!(OLS_ABLATE & 2)) {
 #pragma unroll
         for (int r = 0; r < 16; r++) cur[r] = cmul(cur[r], Hr[r]);
