@@ -206,3 +206,28 @@ def test_fir_very_long_filters(tg, orc, K, cplx_taps):
     hist = np.empty(K - 1, np.complex64)
     g.get_history(hist)
     assert np.array_equal(hist[-min(K - 1, 70000):], x[70000 - min(K - 1, 70000):70000])
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("K", [57, 127, 180, 250, 300, 513])
+def test_ols_dynamic_handout_and_runs(tg, orc, monkeypatch, K, cplx):
+    """Round 3 schedule of the overlap-save kernel, forced on a call that would keep the static partition (the switches are
+    read at every step): blocks pulled from the counters (TSDGPU_OLS_DYN_MIN=0), walked in runs of 2 and 3 with the overlap rows
+    reused from registers (overlaps of 1..4 rows have their own kernel, more rows the generic one), real data packed two
+    blocks per transform; several steps on one handle (the counters are never reset: every launch starts from the base the
+    host tracks), the counter count switched mid-stream, the static partition on the same handle."""
+    if not cplx and K == 57:
+        K = 63
+    h = orc.design_rif_fen(K, "lp", 0.05)
+    n = 700001
+    x = rand(n, cplx, K)
+    ref = orc.fir(h, x)
+    f = tg.Fir(h, tg.C64 if cplx else tg.F32, tg.FIR_OVERLAP_SAVE)
+    monkeypatch.setenv("TSDGPU_OLS_DYN_MIN", "0")
+    cuts = [0, 200000, 200003, 470001, n]
+    for run, nc in (("2", "16"), ("3", "8"), ("1", "32"), ("2", "0")):
+        monkeypatch.setenv("TSDGPU_OLS_RUN", run)
+        monkeypatch.setenv("TSDGPU_OLS_DYN", nc)
+        f.reset()
+        y = np.concatenate([f.step(x[a:b].copy()) for a, b in zip(cuts[:-1], cuts[1:])])
+        assert relerr(y, ref) <= TOL, (run, nc, relerr(y, ref))

@@ -238,3 +238,24 @@ def test_short_period_ratios_far_into_a_stream(tg, orc, ratio):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / 5 * 1e3
     perf_guard(ms < 5.0, f"ratio {ratio}: {ms:.1f} ms per 4 M inputs far into the stream")
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+def test_resampler_dynamic_tiles_forced(tg, orc, monkeypatch, cplx):
+    """The fused K = 15 kernel with its tiles pulled from the counters on calls that would keep the static partition
+    (TSDGPU_RS_DYN_MIN=0; the switches are read at every step): bit for bit the static partition's outputs, over several
+    ragged steps of one handle (counters never reset) and with the counter count switched mid-stream."""
+    ratio = np.float32(160.0) / np.float32(147.0)
+    x = rand(300007, cplx, 21)
+    dt = tg.C64 if cplx else tg.F32
+    cuts = [0, 5, 100000, 100001, 222222, len(x)]
+    monkeypatch.setenv("TSDGPU_RS_DYN", "0")
+    ref = tg.Resampler(ratio, dt)
+    y0 = np.concatenate([ref.step(x[a:b].copy()) for a, b in zip(cuts[:-1], cuts[1:])])
+    monkeypatch.setenv("TSDGPU_RS_DYN_MIN", "0")
+    g = tg.Resampler(ratio, dt)
+    out = []
+    for (a, b), nc in zip(zip(cuts[:-1], cuts[1:]), ("16", "16", "32", "8", "16")):
+        monkeypatch.setenv("TSDGPU_RS_DYN", nc)
+        out.append(g.step(x[a:b].copy()))
+    assert np.array_equal(np.concatenate(out), y0)
