@@ -319,11 +319,15 @@ __global__ __launch_bounds__(RS_THREADS) void resample_kernel(const T *__restric
 // four ds_read_b128 of taps and 30 FMAs instead of 15 sample reads + a schedule record.
 // Outputs are staged in a per-wave LDS buffer and stored coalesced.  The reference's
 // accumulation order (tap 0 .. 14 over the oldest .. newest sample) is kept.
+// Round 3: 16 waves per workgroup (the whole CU: 128 VGPRs, 60 B of spills per lane on complex data) with the outputs staged in
+// the sample image again (the late-store buffer of round 2 does not fit 16 waves): 0.567 -> 0.537 ms per 2^27 inputs, three
+// interleaved pairs on one box -- under the dynamic tile hand-out more waves pay, where the static partition's skeleton got
+// slower with them.  -DRS15_NW=12 -DRS15_LATE_STORE=1 is round 2's geometry.
 #ifndef RS15_NW
-#define RS15_NW 12
+#define RS15_NW 16
 #endif
 #ifndef RS15_LATE_STORE
-#define RS15_LATE_STORE 1
+#define RS15_LATE_STORE 0
 #endif
 constexpr int RS15_WAVES = RS15_NW;
 // Dynamic hand-out of the tiles (the scheme of the overlap-save FIR, ols.hip: OlsDyn): a persistent grid with a static
