@@ -1299,6 +1299,10 @@ int plan_init(tsdgpu_fft *p, int n)
       TSD_CHECK(p->logn <= 28, "fft: n = %d exceeds the four-step limit 2^28 (two passes of at most 16384-point columns)", n);
       p->kind = tsdgpu_fft::POW2_4STEP;
       p->logN1 = p->logn / 2;
+      if (const char *e = getenv("TSDGPU_FFT_LOGN1")) {          // experiment: another split (both factors 16 .. 16384)
+        const int l1 = atoi(e);
+        if (l1 >= 4 && l1 <= 14 && p->logn - l1 >= 4 && p->logn - l1 <= 14) p->logN1 = l1;
+      }
       p->logN2 = p->logn - p->logN1;
       p->N1 = 1 << p->logN1;
       p->N2 = 1 << p->logN2;
@@ -1603,8 +1607,12 @@ int step_device(tsdgpu_fft *p, const cpx *x, cpx *y, int batch, int forward, hip
         auto launch = [&](int pass, const cpx *src, cpx *dst, const cpx *tw, int L, int logL, int C, float sc) {
           const int tpt = L / 16;
           static const int CTMIN = getenv("TSDGPU_FFT_CT") ? atoi(getenv("TSDGPU_FFT_CT")) : 16;
+          static const int CTMAX = getenv("TSDGPU_FFT_CTMAX") ? atoi(getenv("TSDGPU_FFT_CTMAX")) : 1 << 20;
           int CT = std::max(CTMIN, 256 / tpt);
-          CT = std::min(CT, C);
+          CT = std::min(std::min(CT, C), std::max(CTMAX, 2));
+          // 2048-point columns: 8 of them fill the LDS of a CU with ONE workgroup (139 KiB) whose load, transform and store phases
+          // nothing overlaps; two workgroups of 4 columns measure 3-5 % faster (profiles/r3_fft_large_ab.txt)
+          if (L == 2048 && !getenv("TSDGPU_FFT_CTMAX")) CT = std::min(CT, 4);
           while ((size_t) CT * (L + L / 16 + 1) * sizeof(cpx) > 150 * 1024) CT >>= 1;
           while (CT * tpt > 1024) CT >>= 1;                                    // L = 2048 -> 8 columns, 4096 -> 4
           const size_t lds = (size_t) CT * (L + L / 16 + 1) * sizeof(cpx);

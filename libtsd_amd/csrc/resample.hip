@@ -81,6 +81,15 @@ __device__ __forceinline__ float2 tap_mac(float2 acc, float h, float2 x)
   return make_float2(fmaf(h, x.x, acc.x), fmaf(h, x.y, acc.y));
 }
 
+// the same two fused multiply-adds as ONE v_pk_fma_f32 (long interpolators: a wave per SIMD, VALU issue counts)
+typedef float rs_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float tap_mac_pk(float acc, float h, float x) { return fmaf(h, x, acc); }
+__device__ __forceinline__ float2 tap_mac_pk(float2 acc, float h, float2 x)
+{
+  const rs_v2f r = __builtin_elementwise_fma(rs_v2f{h, h}, rs_v2f{x.x, x.y}, rs_v2f{acc.x, acc.y});
+  return make_float2(r.x, r.y);
+}
+
 // canonical index of the periodic phase sequence: ic -> mu + (ic - mu) mod lambda, q += the number of periods removed.
 // A few subtractions when the index is a few periods out (the usual case: lambda in the millions, 160/147: 3.85 M); a
 // division otherwise -- ratios whose float recurrence has a SHORT period (1: lambda = 1, 0.5: 2, 2.5: 5 ...) put millions
@@ -309,6 +318,248 @@ __global__ __launch_bounds__(RS_THREADS) void resample_kernel(const T *__restric
       yt[o] = acc;
     }
     wave_sync();          // tile / rec are rewritten by the next iteration
+  }
+}
+
+// ---- long table-driven interpolators (K >= 24 taps, ratio <= 2; e.g. the 127-tap sinc of the reference's test_ra_unit) --------
+// resample_kernel evaluates an output per lane and reads, per tap, a sample (8 B) and a coefficient (4 B) from LDS: 12 B of LDS
+// traffic per tap and output -- at 127 taps the LDS floor alone is 1.4 ms per 2^26 inputs, and with the 130-KiB table in LDS two
+// waves per CU are left to reach it (4.6 ms).  Here the SAMPLES come from registers: a lane owns 8 consecutive inputs (as in
+// the K = 15 kernel), walks the taps in chunks of 16 with the chunk's 23-sample window in registers (statically indexed: the
+// input index s and the tap k are unrolled), and evaluates the FIRST output of each of its inputs -- every input has one when
+// ratio >= 1, most have when it is below.  An input's SECOND output (ratio > 1: 9 % of the outputs at 160/147) would cost a
+// second, mostly idle copy of the whole evaluation: those go to a list and are evaluated one per lane in the old way afterwards.
+// 5.4 B of LDS traffic per tap and output instead of 12; the accumulation order (tap 0 .. K-1, filtrage.hpp:1877-1879) is kept.
+// Outputs are stored straight from registers (a lane's outputs are consecutive; the lines are completed in L2).
+constexpr int RSL_CH = 16;                                  // taps per chunk
+constexpr int RSL_WIN = RSL_CH + RS_SEG - 1;                // samples of a chunk's window: 23
+__host__ __device__ inline int rsl_slot(int p) { return p + (p >> 3); }       // padded sample image: a lane's window starts 9 slots after its neighbour's
+// (the last sample a window read touches: lane 63, last chunk, window entry 22)
+__host__ __device__ inline int rsl_tile_slots(int K) { return rsl_slot(RS_TI - RS_SEG + (K + RSL_CH - 1) / RSL_CH * RSL_CH - RSL_CH + RSL_WIN - 1) + 2; }
+
+template <typename T>
+__global__ __launch_bounds__(256) void resample_long_kernel(const T *__restrict__ x, const T *__restrict__ hist, T *__restrict__ y,
+                                                            const float *__restrict__ lut, const RsCk *__restrict__ ck, RsParams P,
+                                                            int ntiles, T *__restrict__ hist_next, int cap2)
+{
+  const int NT = blockDim.x, NW = NT >> 6;
+  if (blockIdx.x == gridDim.x - 1) {
+    const int H = P.K - 1;
+    for (int i = threadIdx.x; i < H; i += NT) {
+      const int64_t g = P.n - H + i;
+      hist_next[i] = g < 0 ? (hist ? hist[H + g] : zero_of(T{})) : x[g];
+    }
+    return;
+  }
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int K = P.K, lstride = P.lstride;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float *lut_s = reinterpret_cast<float *>(smem_raw);
+  char *wbase = reinterpret_cast<char *>(lut_s + ((P.nph + 1) * lstride + 3) / 4 * 4);
+  const int tile_slots = rsl_tile_slots(K);
+  const size_t wbytes = ((size_t) tile_slots * sizeof(T) + (size_t) cap2 * 8 + 15) / 16 * 16;
+  T *tile = reinterpret_cast<T *>(wbase + wv * wbytes);
+  uint2 *rec2 = reinterpret_cast<uint2 *>(tile + tile_slots);       // second outputs: (input << 13 | column, output index)
+
+  for (int i = threadIdx.x; i < (P.nph + 1) * K; i += NT) {
+    const int c = i / K, k = i - c * K;
+    lut_s[c * lstride + k] = lut[c * P.gl + k];
+  }
+  __syncthreads();
+  auto wave_sync = []() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+
+  const int wtile0 = blockIdx.x * NW + wv;
+  const int wstep = (gridDim.x - 1) * NW;
+  int64_t icT = P.tile0 + (int64_t) wtile0 * RS_TI, qT = 0;
+  rs_wrap(icT, qT, P.mu, P.lambda);
+  const int64_t icStep = (int64_t) wstep * RS_TI;
+
+  constexpr int NPF = (RS_TI + RS_KMAX + 63) / 64;
+  T pf[NPF];
+  RsCk cpf;
+  auto fetch = [&](int tix_, int64_t icT_) {
+    const int64_t T0_ = P.tile0 + (int64_t) tix_ * RS_TI;
+    const int64_t rel0 = T0_ - (K - 1) - P.pos;                     // x index of tile sample 0
+    if (rel0 >= 0 && rel0 + RS_TI + K <= P.n) {
+      const T *xs = x + rel0;
+#pragma unroll
+      for (int j = 0; j < NPF; j++) {
+        const int s_ = lane + j * 64;
+        pf[j] = s_ < RS_TI + K ? xs[s_] : zero_of(T{});
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NPF; j++) {
+        const int64_t rel = rel0 + lane + j * 64;
+        T v = zero_of(T{});
+        if (lane + j * 64 < RS_TI + K) {
+          if (rel < 0) {
+            if (hist && rel >= -(int64_t) (K - 1)) v = hist[(K - 1) + rel];
+          } else if (rel < P.n) {
+            v = x[rel];
+          }
+        }
+        pf[j] = v;
+      }
+    }
+    int64_t ic_ = icT_ + lane * RS_SEG, q_ = 0;
+    rs_wrap(ic_, q_, P.mu, P.lambda);
+    cpf.phase_bits = 0x40000000u;                                   // 2.0f: "emit nothing"
+    cpf.cum = 0;
+    if (T0_ + (int64_t) lane * RS_SEG < P.pos + P.n) cpf = ck[ic_ / RS_CK];
+  };
+
+  const int K16 = K / RSL_CH * RSL_CH, ktail = K - K16;
+  const float fnph = (float) P.nph;
+  if (wtile0 < ntiles) fetch(wtile0, icT);
+  for (int tix = wtile0; tix < ntiles; tix += wstep) {
+    const int64_t T0 = P.tile0 + (int64_t) tix * RS_TI;
+#pragma unroll
+    for (int j = 0; j < NPF; j++) {
+      const int s_ = lane + j * 64;
+      if (s_ < RS_TI + K) tile[rsl_slot(s_)] = pf[j];
+    }
+    const int64_t i_abs = T0 + (int64_t) lane * RS_SEG;
+    int64_t ic = icT + lane * RS_SEG, q = qT;
+    rs_wrap(ic, q, P.mu, P.lambda);
+    const bool in_call = i_abs < P.pos + P.n;
+    const float inc = P.inc;
+    float phase = bits2f(cpf.phase_bits);
+    int64_t cum = (int64_t) cpf.cum + q * P.opp;
+    icT += icStep;
+    rs_wrap(icT, qT, P.mu, P.lambda);
+    if (tix + wstep < ntiles) fetch(tix + wstep, icT);
+
+    if (in_call) {
+      for (int s = (int) (ic % RS_CK); s > 0; s--) {
+        while (phase < 1.f) { phase = phase + inc; cum++; }
+        phase = phase - 1.f;
+      }
+    }
+    const int64_t cum_t0 = ((int64_t) __shfl((int) (cum >> 32), 0) << 32) | (uint32_t) __shfl((int) (uint32_t) cum, 0);
+    // ---- replay: the first output of every input stays with the lane, second ones go to the wave's list
+    int col0[RS_SEG], o0[RS_SEG];
+    unsigned has0 = 0;
+    int n2 = 0;                                            // entries of rec2 so far (wave-uniform)
+#pragma unroll
+    for (int s = 0; s < RS_SEG; s++) {
+      const int64_t i = i_abs + s;
+      const bool live = in_call && i >= P.pos && i < P.pos + P.n;
+      col0[s] = 0;
+      o0[s] = (int) (cum - cum_t0);
+      int cnt = 0, col1 = 0;
+      if (in_call) {
+        while (phase < 1.f) {
+          const int col = (int) (phase * fnph);            // itrp.cc:19
+          if (cnt == 0) col0[s] = col;
+          else col1 = col;                                 // (ratio <= 2: at most two outputs per input)
+          phase = phase + inc;                             // ra.cc:71, float32 add
+          cum++;
+          cnt++;
+        }
+        phase = phase - 1.f;                               // ra.cc:73
+      }
+      if (live && cnt > 0) has0 |= 1u << s;
+      const bool sec = live && cnt > 1;
+      const uint64_t m = __ballot(sec);
+      if (sec) {
+        const int at = n2 + __popcll(m & ((1ull << lane) - 1ull));
+        if (at < cap2) rec2[at] = make_uint2(((uint32_t) (lane * RS_SEG + s) << 13) | (uint32_t) col1, (uint32_t) (o0[s] + 1));
+      }
+      n2 += __popcll(m);
+    }
+    n2 = min(n2, cap2);
+    wave_sync();
+
+    // ---- first outputs: taps in chunks of 16, the chunk's window in registers
+    T acc[RS_SEG];
+#pragma unroll
+    for (int s = 0; s < RS_SEG; s++) acc[s] = zero_of(T{});
+    const T *wl = tile + 9 * lane;                         // slot of sample 8 lane
+    // (every input is evaluated, with column 0 where it has no output: straight-line code whose table reads hipcc can issue ahead
+    // of the multiply-adds of the input before -- with a branch per input every row read was waited for on the spot)
+    for (int k0 = 0; k0 < K16; k0 += RSL_CH) {
+      T X[RSL_WIN];
+      const T *wc = wl + k0 + (k0 >> 3);
+#pragma unroll
+      for (int j = 0; j < RSL_WIN; j++) X[j] = wc[j + (j >> 3)];
+      // all eight rows first, then tap-major over the eight inputs: eight independent accumulation chains (a wave per SIMD has
+      // nobody else to fill the latency of a dependent multiply-add) and one exposed LDS latency per chunk instead of eight
+      float hh[RS_SEG][RSL_CH];
+#pragma unroll
+      for (int s = 0; s < RS_SEG; s++) {
+        const float *h = lut_s + col0[s] * lstride + k0;
+#pragma unroll
+        for (int k4 = 0; k4 < RSL_CH / 4; k4++) {
+          const float4 q4 = *reinterpret_cast<const float4 *>(h + 4 * k4);
+          hh[s][4 * k4] = q4.x; hh[s][4 * k4 + 1] = q4.y; hh[s][4 * k4 + 2] = q4.z; hh[s][4 * k4 + 3] = q4.w;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < RSL_CH; k++) {
+#pragma unroll
+        for (int s = 0; s < RS_SEG; s++) acc[s] = tap_mac_pk(acc[s], hh[s][k], X[s + k]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (ktail > 0) {
+      T X[RSL_WIN];
+      const T *wc = wl + K16 + (K16 >> 3);
+#pragma unroll
+      for (int j = 0; j < RSL_WIN; j++) X[j] = wc[j + (j >> 3)];
+#pragma unroll
+      for (int s = 0; s < RS_SEG; s++) {
+        const float *h = lut_s + col0[s] * lstride + K16;       // (rows are padded to a multiple of 4 floats)
+        float hh[RSL_CH];
+#pragma unroll
+        for (int k4 = 0; k4 < RSL_CH / 4; k4++) {
+          float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (4 * k4 < ktail) q4 = *reinterpret_cast<const float4 *>(h + 4 * k4);
+          hh[4 * k4] = q4.x; hh[4 * k4 + 1] = q4.y; hh[4 * k4 + 2] = q4.z; hh[4 * k4 + 3] = q4.w;
+        }
+#pragma unroll
+        for (int k = 0; k < RSL_CH; k++)
+          if (k < ktail) acc[s] = tap_mac_pk(acc[s], hh[k], X[s + k]);
+      }
+    }
+    T *yt = y + (cum_t0 - P.cum_pos);
+#pragma unroll
+    for (int s = 0; s < RS_SEG; s++)
+      if (has0 & (1u << s)) yt[o0[s]] = acc[s];
+
+    // ---- second outputs: one per lane, samples and taps from LDS
+    // (sample i0 + k sits in slot A + k + ((r + k) >> 3), A = slot of i0, r = i0 mod 8: with k = 8 m + e the run-time part is one of
+    // eight base addresses per output, the rest an immediate offset -- no address arithmetic per tap)
+    for (int e = lane; e < n2; e += 64) {
+      const uint2 r = rec2[e];
+      const int i0 = (int) (r.x >> 13), r8 = i0 & 7;
+      const float *h = lut_s + (r.x & 8191u) * lstride;
+      const T *be[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) be[j] = tile + rsl_slot(i0) + ((r8 + j) >> 3);
+      T a = zero_of(T{});
+      const int K8 = K & ~7;
+      for (int k = 0; k < K8; k += 8) {
+        const float4 qa = *reinterpret_cast<const float4 *>(h + k), qb = *reinterpret_cast<const float4 *>(h + k + 4);
+        const int o9 = k + (k >> 3);
+        a = tap_mac_pk(a, qa.x, be[0][o9]);
+        a = tap_mac_pk(a, qa.y, be[1][o9 + 1]);
+        a = tap_mac_pk(a, qa.z, be[2][o9 + 2]);
+        a = tap_mac_pk(a, qa.w, be[3][o9 + 3]);
+        a = tap_mac_pk(a, qb.x, be[4][o9 + 4]);
+        a = tap_mac_pk(a, qb.y, be[5][o9 + 5]);
+        a = tap_mac_pk(a, qb.z, be[6][o9 + 6]);
+        a = tap_mac_pk(a, qb.w, be[7][o9 + 7]);
+      }
+      for (int k = K8; k < K; k++) a = tap_mac_pk(a, h[k], tile[rsl_slot(i0 + k)]);
+      yt[r.y] = a;
+    }
+    wave_sync();          // the sample image and the list are rewritten by the next iteration
   }
 }
 
@@ -786,6 +1037,28 @@ static RsGeom rs_geometry(const tsdgpu_resampler *r, int mode)
   return g;
 }
 static size_t rs_lds_need(const tsdgpu_resampler *r, int mode) { return rs_geometry(r, mode).lds; }
+// geometry of resample_long_kernel, or waves = 0 when the handle does not qualify (table-driven, 24 taps and more, at most two
+// outputs per input, table + one wave within the LDS); TSDGPU_RS_LONG=0 keeps such handles on resample_kernel
+struct RsLongGeom {
+  int waves, cap2;
+  size_t lds;
+};
+static RsLongGeom rs_long_geometry(const tsdgpu_resampler *r)
+{
+  RsLongGeom g = {0, 0, 0};
+  static const bool off = getenv("TSDGPU_RS_LONG") && atoi(getenv("TSDGPU_RS_LONG")) == 0;
+  static const int kmin = getenv("TSDGPU_RS_LONG_KMIN") ? atoi(getenv("TSDGPU_RS_LONG_KMIN")) : 24;
+  if (off || r->mode != 0 || r->K < kmin || r->K == 15 || !(r->inc >= 0.5f)) return g;
+  const size_t sz = dtype_size(r->data_type);
+  g.cap2 = r->ratio > 1.f ? ((int) ((double) RS_TI * ((double) r->ratio - 1.0) * 1.0001) + 40 + 1) / 2 * 2 : 8;
+  const size_t wbytes = ((size_t) rsl_tile_slots(r->K) * sz + (size_t) g.cap2 * 8 + 15) / 16 * 16;
+  const size_t lut = (size_t) (((r->nph + 1) * r->lstride + 3) / 4 * 4) * 4;
+  if (lut + wbytes + 64 > RS_LDS_LIMIT) return g;
+  g.waves = (int) std::min<size_t>(4, (RS_LDS_LIMIT - lut - 64) / wbytes);
+  g.lds = lut + (size_t) g.waves * wbytes + 64;
+  return g;
+}
+
 
 extern "C" {
 
@@ -843,6 +1116,8 @@ int tsdgpu_resampler_create(tsdgpu_resampler **out, int data_type, float ratio, 
   }
   (void) hipFuncSetAttribute((const void *) resample_kernel<float, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void) hipFuncSetAttribute((const void *) resample_kernel<float2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void) hipFuncSetAttribute((const void *) resample_long_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void) hipFuncSetAttribute((const void *) resample_long_kernel<float2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void) hipFuncSetAttribute((const void *) resample15_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void) hipFuncSetAttribute((const void *) resample15_kernel<float2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void) hipGetLastError();
@@ -994,6 +1269,14 @@ int tsdgpu_resampler_step(tsdgpu_resampler *r, const void *x, int64_t n, void *y
     else
       hipLaunchKernelGGL(resample15_kernel<float>, dim3((unsigned) g15 + 1), dim3(64 * RS15_WAVES), lds15, st, (const float *) dx,
                          (const float *) hcur, (float *) dy, r->d_lut, r->d_ck, P, (int) tiles, (float *) r->d_hist[r->cur ^ 1], dyn);
+  } else if (const RsLongGeom lg = rs_long_geometry(r); lg.waves > 0) {
+    const int64_t lgrid = std::min<int64_t>(cdiv(tiles, lg.waves), 256);
+    if (r->data_type == TSDGPU_C64)
+      hipLaunchKernelGGL(resample_long_kernel<float2>, dim3((unsigned) lgrid + 1), dim3(64 * lg.waves), lg.lds, st, (const float2 *) dx,
+                         (const float2 *) hcur, (float2 *) dy, r->d_lut, r->d_ck, P, (int) tiles, (float2 *) r->d_hist[r->cur ^ 1], lg.cap2);
+    else
+      hipLaunchKernelGGL(resample_long_kernel<float>, dim3((unsigned) lgrid + 1), dim3(64 * lg.waves), lg.lds, st, (const float *) dx,
+                         (const float *) hcur, (float *) dy, r->d_lut, r->d_ck, P, (int) tiles, (float *) r->d_hist[r->cur ^ 1], lg.cap2);
   } else {
 #define RS_LAUNCH(T, KT)                                                                                            \
   hipLaunchKernelGGL((resample_kernel<T, KT>), dim3((unsigned) pgrid + 1), dim3(64 * geo.waves), lds, st, (const T *) dx, \
