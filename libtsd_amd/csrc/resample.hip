@@ -331,16 +331,27 @@ __global__ __launch_bounds__(RS_THREADS) void resample_kernel(const T *__restric
 // second, mostly idle copy of the whole evaluation: those go to a list and are evaluated one per lane in the old way afterwards.
 // 5.4 B of LDS traffic per tap and output instead of 12; the accumulation order (tap 0 .. K-1, filtrage.hpp:1877-1879) is kept.
 // Outputs are stored straight from registers (a lane's outputs are consecutive; the lines are completed in L2).
-constexpr int RSL_CH = 16;                                  // taps per chunk
-constexpr int RSL_WIN = RSL_CH + RS_SEG - 1;                // samples of a chunk's window: 23
+#ifndef RSL_CHUNK
+#define RSL_CHUNK 8
+#endif
+constexpr int RSL_CH = RSL_CHUNK;                           // taps per chunk (8: 64 + 30 registers of rows and window; 16 spills at two waves per SIMD)
+constexpr int RSL_WIN = RSL_CH + RS_SEG - 1;                // samples of a chunk's window
 __host__ __device__ inline int rsl_slot(int p) { return p + (p >> 3); }       // padded sample image: a lane's window starts 9 slots after its neighbour's
 // (the last sample a window read touches: lane 63, last chunk, window entry 22)
 __host__ __device__ inline int rsl_tile_slots(int K) { return rsl_slot(RS_TI - RS_SEG + (K + RSL_CH - 1) / RSL_CH * RSL_CH - RSL_CH + RSL_WIN - 1) + 2; }
 
+// TAP PHASES: a 257 x 127 table takes 133 KiB of the 160 and leaves room for four waves -- one per SIMD, with nobody to
+// fill the latency of its LDS reads and dependent multiply-adds (PMC: VALU 34 % busy, LDS 48 %).  The table is therefore staged
+// in `nphase` slices of `kp` taps (a multiple of 16); a workgroup walks ALL its tiles per slice: phase 0 stores the partial sums
+// of taps [0, kp) as the outputs, every later phase reloads them, continues the same accumulation in the same order (a float
+// stored and reloaded is the same float: the result does not depend on the number of phases) and stores them back.  The static
+// partition gives a tile to the same wave -- and an output to the same lane -- in every phase, so a thread re-reads only what
+// it wrote itself.  The extra traffic (x once more and the outputs out and back per extra phase) is noise at 3-10 % of the
+// HBM roofline; the replay is repeated per phase.
 template <typename T>
-__global__ __launch_bounds__(256) void resample_long_kernel(const T *__restrict__ x, const T *__restrict__ hist, T *__restrict__ y,
+__global__ __launch_bounds__(512) void resample_long_kernel(const T *__restrict__ x, const T *__restrict__ hist, T *__restrict__ y,
                                                             const float *__restrict__ lut, const RsCk *__restrict__ ck, RsParams P,
-                                                            int ntiles, T *__restrict__ hist_next, int cap2)
+                                                            int ntiles, T *__restrict__ hist_next, int cap2, int kp, int nphase)
 {
   const int NT = blockDim.x, NW = NT >> 6;
   if (blockIdx.x == gridDim.x - 1) {
@@ -352,31 +363,25 @@ __global__ __launch_bounds__(256) void resample_long_kernel(const T *__restrict_
     return;
   }
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int K = P.K, lstride = P.lstride;
+  const int K = P.K;
+  const int lsp = kp + 4;                                  // slice pitch: a multiple of 4 floats with an odd number of 16-B units
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   float *lut_s = reinterpret_cast<float *>(smem_raw);
-  char *wbase = reinterpret_cast<char *>(lut_s + ((P.nph + 1) * lstride + 3) / 4 * 4);
+  char *wbase = reinterpret_cast<char *>(lut_s + (P.nph + 1) * lsp);
   const int tile_slots = rsl_tile_slots(K);
   const size_t wbytes = ((size_t) tile_slots * sizeof(T) + (size_t) cap2 * 8 + 15) / 16 * 16;
   T *tile = reinterpret_cast<T *>(wbase + wv * wbytes);
   uint2 *rec2 = reinterpret_cast<uint2 *>(tile + tile_slots);       // second outputs: (input << 13 | column, output index)
 
-  for (int i = threadIdx.x; i < (P.nph + 1) * K; i += NT) {
-    const int c = i / K, k = i - c * K;
-    lut_s[c * lstride + k] = lut[c * P.gl + k];
-  }
-  __syncthreads();
   auto wave_sync = []() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   };
-
   const int wtile0 = blockIdx.x * NW + wv;
   const int wstep = (gridDim.x - 1) * NW;
-  int64_t icT = P.tile0 + (int64_t) wtile0 * RS_TI, qT = 0;
-  rs_wrap(icT, qT, P.mu, P.lambda);
   const int64_t icStep = (int64_t) wstep * RS_TI;
+  const float fnph = (float) P.nph;
 
   constexpr int NPF = (RS_TI + RS_KMAX + 63) / 64;
   T pf[NPF];
@@ -413,153 +418,167 @@ __global__ __launch_bounds__(256) void resample_long_kernel(const T *__restrict_
     if (T0_ + (int64_t) lane * RS_SEG < P.pos + P.n) cpf = ck[ic_ / RS_CK];
   };
 
-  const int K16 = K / RSL_CH * RSL_CH, ktail = K - K16;
-  const float fnph = (float) P.nph;
-  if (wtile0 < ntiles) fetch(wtile0, icT);
-  for (int tix = wtile0; tix < ntiles; tix += wstep) {
-    const int64_t T0 = P.tile0 + (int64_t) tix * RS_TI;
-#pragma unroll
-    for (int j = 0; j < NPF; j++) {
-      const int s_ = lane + j * 64;
-      if (s_ < RS_TI + K) tile[rsl_slot(s_)] = pf[j];
+  for (int ph = 0; ph < nphase; ph++) {
+    // ---- this phase's taps [ka, kb) of every row
+    const int ka = ph * kp, kb = min(K, ka + kp), kn = kb - ka;
+    if (ph > 0) __syncthreads();                             // everybody has left the previous slice
+    for (int i = threadIdx.x; i < (P.nph + 1) * kn; i += NT) {
+      const int c = i / kn, k = i - c * kn;
+      lut_s[c * lsp + k] = lut[c * P.gl + ka + k];
     }
-    const int64_t i_abs = T0 + (int64_t) lane * RS_SEG;
-    int64_t ic = icT + lane * RS_SEG, q = qT;
-    rs_wrap(ic, q, P.mu, P.lambda);
-    const bool in_call = i_abs < P.pos + P.n;
-    const float inc = P.inc;
-    float phase = bits2f(cpf.phase_bits);
-    int64_t cum = (int64_t) cpf.cum + q * P.opp;
-    icT += icStep;
+    __syncthreads();
+    const int nfull = kn / RSL_CH * RSL_CH, ktail = kn - nfull;       // whole chunks of this phase, taps of its last partial one
+
+    int64_t icT = P.tile0 + (int64_t) wtile0 * RS_TI, qT = 0;
     rs_wrap(icT, qT, P.mu, P.lambda);
-    if (tix + wstep < ntiles) fetch(tix + wstep, icT);
-
-    if (in_call) {
-      for (int s = (int) (ic % RS_CK); s > 0; s--) {
-        while (phase < 1.f) { phase = phase + inc; cum++; }
-        phase = phase - 1.f;
-      }
-    }
-    const int64_t cum_t0 = ((int64_t) __shfl((int) (cum >> 32), 0) << 32) | (uint32_t) __shfl((int) (uint32_t) cum, 0);
-    // ---- replay: the first output of every input stays with the lane, second ones go to the wave's list
-    int col0[RS_SEG], o0[RS_SEG];
-    unsigned has0 = 0;
-    int n2 = 0;                                            // entries of rec2 so far (wave-uniform)
+    if (wtile0 < ntiles) fetch(wtile0, icT);
+    for (int tix = wtile0; tix < ntiles; tix += wstep) {
+      const int64_t T0 = P.tile0 + (int64_t) tix * RS_TI;
 #pragma unroll
-    for (int s = 0; s < RS_SEG; s++) {
-      const int64_t i = i_abs + s;
-      const bool live = in_call && i >= P.pos && i < P.pos + P.n;
-      col0[s] = 0;
-      o0[s] = (int) (cum - cum_t0);
-      int cnt = 0, col1 = 0;
+      for (int j = 0; j < NPF; j++) {
+        const int s_ = lane + j * 64;
+        if (s_ < RS_TI + K) tile[rsl_slot(s_)] = pf[j];
+      }
+      const int64_t i_abs = T0 + (int64_t) lane * RS_SEG;
+      int64_t ic = icT + lane * RS_SEG, q = qT;
+      rs_wrap(ic, q, P.mu, P.lambda);
+      const bool in_call = i_abs < P.pos + P.n;
+      const float inc = P.inc;
+      float phase = bits2f(cpf.phase_bits);
+      int64_t cum = (int64_t) cpf.cum + q * P.opp;
+      icT += icStep;
+      rs_wrap(icT, qT, P.mu, P.lambda);
+      if (tix + wstep < ntiles) fetch(tix + wstep, icT);
+
       if (in_call) {
-        while (phase < 1.f) {
-          const int col = (int) (phase * fnph);            // itrp.cc:19
-          if (cnt == 0) col0[s] = col;
-          else col1 = col;                                 // (ratio <= 2: at most two outputs per input)
-          phase = phase + inc;                             // ra.cc:71, float32 add
-          cum++;
-          cnt++;
+        for (int s = (int) (ic % RS_CK); s > 0; s--) {
+          while (phase < 1.f) { phase = phase + inc; cum++; }
+          phase = phase - 1.f;
         }
-        phase = phase - 1.f;                               // ra.cc:73
       }
-      if (live && cnt > 0) has0 |= 1u << s;
-      const bool sec = live && cnt > 1;
-      const uint64_t m = __ballot(sec);
-      if (sec) {
-        const int at = n2 + __popcll(m & ((1ull << lane) - 1ull));
-        if (at < cap2) rec2[at] = make_uint2(((uint32_t) (lane * RS_SEG + s) << 13) | (uint32_t) col1, (uint32_t) (o0[s] + 1));
-      }
-      n2 += __popcll(m);
-    }
-    n2 = min(n2, cap2);
-    wave_sync();
-
-    // ---- first outputs: taps in chunks of 16, the chunk's window in registers
-    T acc[RS_SEG];
-#pragma unroll
-    for (int s = 0; s < RS_SEG; s++) acc[s] = zero_of(T{});
-    const T *wl = tile + 9 * lane;                         // slot of sample 8 lane
-    // (every input is evaluated, with column 0 where it has no output: straight-line code whose table reads hipcc can issue ahead
-    // of the multiply-adds of the input before -- with a branch per input every row read was waited for on the spot)
-    for (int k0 = 0; k0 < K16; k0 += RSL_CH) {
-      T X[RSL_WIN];
-      const T *wc = wl + k0 + (k0 >> 3);
-#pragma unroll
-      for (int j = 0; j < RSL_WIN; j++) X[j] = wc[j + (j >> 3)];
-      // all eight rows first, then tap-major over the eight inputs: eight independent accumulation chains (a wave per SIMD has
-      // nobody else to fill the latency of a dependent multiply-add) and one exposed LDS latency per chunk instead of eight
-      float hh[RS_SEG][RSL_CH];
+      const int64_t cum_t0 = ((int64_t) __shfl((int) (cum >> 32), 0) << 32) | (uint32_t) __shfl((int) (uint32_t) cum, 0);
+      // ---- replay: the first output of every input stays with the lane, second ones go to the wave's list.  Branch-free: an
+      // input has at most two outputs here (1/ratio >= 0.5, host), so the reference's while loop (ra.cc:64-73) is its two
+      // possible turns written out -- the same float additions in the same order; counts relative to the tile in 32 bits.
+      int col0[RS_SEG], o0[RS_SEG];
+      unsigned has0 = 0;
+      int n2 = 0;                                            // entries of rec2 so far (wave-uniform)
+      int crel = (int) (cum - cum_t0);                       // outputs of the tile before the lane's next one
+      // the lane's inputs [s_lo, s_hi) belong to this call
+      const int s_lo = in_call ? (int) max((int64_t) 0, min((int64_t) RS_SEG, P.pos - i_abs)) : RS_SEG;
+      const int s_hi = in_call ? (int) min((int64_t) RS_SEG, P.pos + P.n - i_abs) : 0;
 #pragma unroll
       for (int s = 0; s < RS_SEG; s++) {
-        const float *h = lut_s + col0[s] * lstride + k0;
-#pragma unroll
-        for (int k4 = 0; k4 < RSL_CH / 4; k4++) {
-          const float4 q4 = *reinterpret_cast<const float4 *>(h + 4 * k4);
-          hh[s][4 * k4] = q4.x; hh[s][4 * k4 + 1] = q4.y; hh[s][4 * k4 + 2] = q4.z; hh[s][4 * k4 + 3] = q4.w;
+        const bool live = s >= s_lo && s < s_hi;
+        const bool first = in_call && phase < 1.f;
+        const float ph1 = phase + inc;                       // ra.cc:71, float32 add
+        const bool second = first && ph1 < 1.f;
+        const float ph2 = ph1 + inc;
+        col0[s] = first ? (int) (phase * fnph) : 0;          // itrp.cc:19
+        const int col1 = (int) (ph1 * fnph);
+        o0[s] = crel;
+        if (in_call) phase = (second ? ph2 : first ? ph1 : phase) - 1.f;       // ra.cc:73
+        crel += (first ? 1 : 0) + (second ? 1 : 0);
+        if (live && first) has0 |= 1u << s;
+        const bool sec = live && second;
+        const uint64_t m = __ballot(sec);
+        if (sec) {
+          const int at = n2 + __popcll(m & ((1ull << lane) - 1ull));
+          if (at < cap2) rec2[at] = make_uint2(((uint32_t) (lane * RS_SEG + s) << 13) | (uint32_t) col1, (uint32_t) (o0[s] + 1));
         }
+        n2 += __popcll(m);
       }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int k = 0; k < RSL_CH; k++) {
-#pragma unroll
-        for (int s = 0; s < RS_SEG; s++) acc[s] = tap_mac_pk(acc[s], hh[s][k], X[s + k]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (ktail > 0) {
-      T X[RSL_WIN];
-      const T *wc = wl + K16 + (K16 >> 3);
-#pragma unroll
-      for (int j = 0; j < RSL_WIN; j++) X[j] = wc[j + (j >> 3)];
+      n2 = min(n2, cap2);
+      wave_sync();
+
+      // ---- first outputs: taps in chunks of 16, the chunk's window in registers
+      T *yt = y + (cum_t0 - P.cum_pos);
+      T acc[RS_SEG];
 #pragma unroll
       for (int s = 0; s < RS_SEG; s++) {
-        const float *h = lut_s + col0[s] * lstride + K16;       // (rows are padded to a multiple of 4 floats)
-        float hh[RSL_CH];
+        acc[s] = zero_of(T{});
+        if (ph > 0 && (has0 & (1u << s))) acc[s] = yt[o0[s]];
+      }
+      const T *wl = tile + 9 * lane + ka + (ka >> 3);        // slot of sample 8 lane + ka (ka is a multiple of 16)
+      // (every input is evaluated, with column 0 where it has no output: straight-line code; all eight rows first, then tap-major
+      // over the eight inputs -- eight independent accumulation chains and one exposed LDS latency per chunk)
+      for (int k0 = 0; k0 < nfull; k0 += RSL_CH) {
+        T X[RSL_WIN];
+        const T *wc = wl + k0 + (k0 >> 3);
 #pragma unroll
-        for (int k4 = 0; k4 < RSL_CH / 4; k4++) {
-          float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (4 * k4 < ktail) q4 = *reinterpret_cast<const float4 *>(h + 4 * k4);
-          hh[4 * k4] = q4.x; hh[4 * k4 + 1] = q4.y; hh[4 * k4 + 2] = q4.z; hh[4 * k4 + 3] = q4.w;
+        for (int j = 0; j < RSL_WIN; j++) X[j] = wc[j + (j >> 3)];
+        float hh[RS_SEG][RSL_CH];
+#pragma unroll
+        for (int s = 0; s < RS_SEG; s++) {
+          const float *h = lut_s + col0[s] * lsp + k0;
+#pragma unroll
+          for (int k4 = 0; k4 < RSL_CH / 4; k4++) {
+            const float4 q4 = *reinterpret_cast<const float4 *>(h + 4 * k4);
+            hh[s][4 * k4] = q4.x; hh[s][4 * k4 + 1] = q4.y; hh[s][4 * k4 + 2] = q4.z; hh[s][4 * k4 + 3] = q4.w;
+          }
         }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < RSL_CH; k++)
-          if (k < ktail) acc[s] = tap_mac_pk(acc[s], hh[k], X[s + k]);
+        for (int k = 0; k < RSL_CH; k++) {
+#pragma unroll
+          for (int s = 0; s < RS_SEG; s++) acc[s] = tap_mac_pk(acc[s], hh[s][k], X[s + k]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
-    }
-    T *yt = y + (cum_t0 - P.cum_pos);
+      if (ktail > 0) {
+        T X[RSL_WIN];
+        const T *wc = wl + nfull + (nfull >> 3);
 #pragma unroll
-    for (int s = 0; s < RS_SEG; s++)
-      if (has0 & (1u << s)) yt[o0[s]] = acc[s];
+        for (int j = 0; j < RSL_WIN; j++) X[j] = wc[j + (j >> 3)];
+#pragma unroll
+        for (int s = 0; s < RS_SEG; s++) {
+          const float *h = lut_s + col0[s] * lsp + nfull;       // (the slice pitch is a multiple of 4 floats)
+          float hh[RSL_CH];
+#pragma unroll
+          for (int k4 = 0; k4 < RSL_CH / 4; k4++) {
+            float4 q4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (4 * k4 < ktail) q4 = *reinterpret_cast<const float4 *>(h + 4 * k4);
+            hh[4 * k4] = q4.x; hh[4 * k4 + 1] = q4.y; hh[4 * k4 + 2] = q4.z; hh[4 * k4 + 3] = q4.w;
+          }
+#pragma unroll
+          for (int k = 0; k < RSL_CH; k++)
+            if (k < ktail) acc[s] = tap_mac_pk(acc[s], hh[k], X[s + k]);
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < RS_SEG; s++)
+        if (has0 & (1u << s)) yt[o0[s]] = acc[s];
 
-    // ---- second outputs: one per lane, samples and taps from LDS
-    // (sample i0 + k sits in slot A + k + ((r + k) >> 3), A = slot of i0, r = i0 mod 8: with k = 8 m + e the run-time part is one of
-    // eight base addresses per output, the rest an immediate offset -- no address arithmetic per tap)
-    for (int e = lane; e < n2; e += 64) {
-      const uint2 r = rec2[e];
-      const int i0 = (int) (r.x >> 13), r8 = i0 & 7;
-      const float *h = lut_s + (r.x & 8191u) * lstride;
-      const T *be[8];
+      // ---- second outputs: one per lane, samples and taps from LDS
+      // (sample i0 + k sits in slot A + k + ((r + k) >> 3), A = slot of i0, r = i0 mod 8: with k = 8 m + e the run-time part is one of
+      // eight base addresses per output, the rest an immediate offset -- no address arithmetic per tap)
+      for (int e = lane; e < n2; e += 64) {
+        const uint2 r = rec2[e];
+        const int i0 = (int) (r.x >> 13) + ka, r8 = i0 & 7;
+        const float *h = lut_s + (r.x & 8191u) * lsp;
+        const T *be[8];
 #pragma unroll
-      for (int j = 0; j < 8; j++) be[j] = tile + rsl_slot(i0) + ((r8 + j) >> 3);
-      T a = zero_of(T{});
-      const int K8 = K & ~7;
-      for (int k = 0; k < K8; k += 8) {
-        const float4 qa = *reinterpret_cast<const float4 *>(h + k), qb = *reinterpret_cast<const float4 *>(h + k + 4);
-        const int o9 = k + (k >> 3);
-        a = tap_mac_pk(a, qa.x, be[0][o9]);
-        a = tap_mac_pk(a, qa.y, be[1][o9 + 1]);
-        a = tap_mac_pk(a, qa.z, be[2][o9 + 2]);
-        a = tap_mac_pk(a, qa.w, be[3][o9 + 3]);
-        a = tap_mac_pk(a, qb.x, be[4][o9 + 4]);
-        a = tap_mac_pk(a, qb.y, be[5][o9 + 5]);
-        a = tap_mac_pk(a, qb.z, be[6][o9 + 6]);
-        a = tap_mac_pk(a, qb.w, be[7][o9 + 7]);
+        for (int j = 0; j < 8; j++) be[j] = tile + rsl_slot(i0) + ((r8 + j) >> 3);
+        T a = zero_of(T{});
+        if (ph > 0) a = yt[r.y];
+        const int K8 = kn & ~7;
+        for (int k = 0; k < K8; k += 8) {
+          const float4 qa = *reinterpret_cast<const float4 *>(h + k), qb = *reinterpret_cast<const float4 *>(h + k + 4);
+          const int o9 = k + (k >> 3);
+          a = tap_mac_pk(a, qa.x, be[0][o9]);
+          a = tap_mac_pk(a, qa.y, be[1][o9 + 1]);
+          a = tap_mac_pk(a, qa.z, be[2][o9 + 2]);
+          a = tap_mac_pk(a, qa.w, be[3][o9 + 3]);
+          a = tap_mac_pk(a, qb.x, be[4][o9 + 4]);
+          a = tap_mac_pk(a, qb.y, be[5][o9 + 5]);
+          a = tap_mac_pk(a, qb.z, be[6][o9 + 6]);
+          a = tap_mac_pk(a, qb.w, be[7][o9 + 7]);
+        }
+        for (int k = K8; k < kn; k++) a = tap_mac_pk(a, h[k], tile[rsl_slot(i0 + k)]);
+        yt[r.y] = a;
       }
-      for (int k = K8; k < K; k++) a = tap_mac_pk(a, h[k], tile[rsl_slot(i0 + k)]);
-      yt[r.y] = a;
+      wave_sync();          // the sample image and the list are rewritten by the next iteration
     }
-    wave_sync();          // the sample image and the list are rewritten by the next iteration
   }
 }
 
@@ -1040,25 +1059,45 @@ static size_t rs_lds_need(const tsdgpu_resampler *r, int mode) { return rs_geome
 // geometry of resample_long_kernel, or waves = 0 when the handle does not qualify (table-driven, 24 taps and more, at most two
 // outputs per input, table + one wave within the LDS); TSDGPU_RS_LONG=0 keeps such handles on resample_kernel
 struct RsLongGeom {
-  int waves, cap2;
+  int waves, cap2, kp, nphase;
   size_t lds;
 };
 static RsLongGeom rs_long_geometry(const tsdgpu_resampler *r)
 {
-  RsLongGeom g = {0, 0, 0};
-  static const bool off = getenv("TSDGPU_RS_LONG") && atoi(getenv("TSDGPU_RS_LONG")) == 0;
-  static const int kmin = getenv("TSDGPU_RS_LONG_KMIN") ? atoi(getenv("TSDGPU_RS_LONG_KMIN")) : 24;
+  RsLongGeom g = {0, 0, 0, 0, 0};
+  // (read per call: the tests flip them between handles)
+  const char *e_off = getenv("TSDGPU_RS_LONG"), *e_kmin = getenv("TSDGPU_RS_LONG_KMIN"), *e_w = getenv("TSDGPU_RS_LONG_WAVES"),
+             *e_ph = getenv("TSDGPU_RS_LONG_PHASES");
+  const bool off = e_off && atoi(e_off) == 0;
+  const int kmin = e_kmin ? atoi(e_kmin) : 24;
+  const int want = e_w ? atoi(e_w) : 8;                      // waves per workgroup aimed at
+  const int force_ph = e_ph ? atoi(e_ph) : 0;
   if (off || r->mode != 0 || r->K < kmin || r->K == 15 || !(r->inc >= 0.5f)) return g;
   const size_t sz = dtype_size(r->data_type);
   g.cap2 = r->ratio > 1.f ? ((int) ((double) RS_TI * ((double) r->ratio - 1.0) * 1.0001) + 40 + 1) / 2 * 2 : 8;
   const size_t wbytes = ((size_t) rsl_tile_slots(r->K) * sz + (size_t) g.cap2 * 8 + 15) / 16 * 16;
-  const size_t lut = (size_t) (((r->nph + 1) * r->lstride + 3) / 4 * 4) * 4;
-  if (lut + wbytes + 64 > RS_LDS_LIMIT) return g;
-  g.waves = (int) std::min<size_t>(4, (RS_LDS_LIMIT - lut - 64) / wbytes);
-  g.lds = lut + (size_t) g.waves * wbytes + 64;
+  // as few tap phases as leave room for `want` waves (at most 8: the kernel's bound); a table too large for that takes the phase
+  // count that leaves the most waves, down to one
+  const int kc = (r->K + RSL_CH - 1) / RSL_CH;               // chunks of taps
+  int best_w = 0;
+  for (int nph = 1; nph <= kc; nph++) {
+    if (force_ph > 0 && nph != std::min(force_ph, kc)) continue;
+    const int kp = (kc + nph - 1) / nph * RSL_CH;
+    if ((int64_t) kp * (nph - 1) >= r->K) continue;          // (an empty last phase: the same slices as a smaller count)
+    const size_t lut = (size_t) (r->nph + 1) * (kp + 4) * 4;
+    if (lut + wbytes + 64 > RS_LDS_LIMIT) continue;
+    const int w = (int) std::min<size_t>(8, (RS_LDS_LIMIT - lut - 64) / wbytes);
+    if (w > best_w) {
+      best_w = w;
+      g.waves = w;
+      g.kp = kp;
+      g.nphase = nph;
+      g.lds = lut + (size_t) w * wbytes + 64;
+    }
+    if (w >= std::min(want, 8)) break;
+  }
   return g;
 }
-
 
 extern "C" {
 
@@ -1273,10 +1312,10 @@ int tsdgpu_resampler_step(tsdgpu_resampler *r, const void *x, int64_t n, void *y
     const int64_t lgrid = std::min<int64_t>(cdiv(tiles, lg.waves), 256);
     if (r->data_type == TSDGPU_C64)
       hipLaunchKernelGGL(resample_long_kernel<float2>, dim3((unsigned) lgrid + 1), dim3(64 * lg.waves), lg.lds, st, (const float2 *) dx,
-                         (const float2 *) hcur, (float2 *) dy, r->d_lut, r->d_ck, P, (int) tiles, (float2 *) r->d_hist[r->cur ^ 1], lg.cap2);
+                         (const float2 *) hcur, (float2 *) dy, r->d_lut, r->d_ck, P, (int) tiles, (float2 *) r->d_hist[r->cur ^ 1], lg.cap2, lg.kp, lg.nphase);
     else
       hipLaunchKernelGGL(resample_long_kernel<float>, dim3((unsigned) lgrid + 1), dim3(64 * lg.waves), lg.lds, st, (const float *) dx,
-                         (const float *) hcur, (float *) dy, r->d_lut, r->d_ck, P, (int) tiles, (float *) r->d_hist[r->cur ^ 1], lg.cap2);
+                         (const float *) hcur, (float *) dy, r->d_lut, r->d_ck, P, (int) tiles, (float *) r->d_hist[r->cur ^ 1], lg.cap2, lg.kp, lg.nphase);
   } else {
 #define RS_LAUNCH(T, KT)                                                                                            \
   hipLaunchKernelGGL((resample_kernel<T, KT>), dim3((unsigned) pgrid + 1), dim3(64 * geo.waves), lds, st, (const T *) dx, \

@@ -259,3 +259,34 @@ def test_resampler_dynamic_tiles_forced(tg, orc, monkeypatch, cplx):
         monkeypatch.setenv("TSDGPU_RS_DYN", nc)
         out.append(g.step(x[a:b].copy()))
     assert np.array_equal(np.concatenate(out), y0)
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("K,nph,ratio", [(127, 256, R160), (127, 256, 0.5), (127, 256, 1.999), (100, 64, 1.2), (31, 256, R160),
+                                         (256, 128, 0.77), (24, 300, 1.0)])
+def test_long_interpolator_kernel_bit_for_bit(tg, orc, monkeypatch, K, nph, ratio, cplx):
+    """resample_long_kernel (a lane's 8 inputs against a register window, second outputs of an input from a list, the table
+    staged in tap slices): the same multiply-adds in the same order as resample_kernel, so the outputs must be IDENTICAL -- with
+    one tap phase, with the default geometry and with three and five phases (partial sums stored and reloaded), over ragged
+    steps of one handle; and within the tolerance of the oracle."""
+    x = rand(70001, cplx, K + nph)
+    dt = tg.C64 if cplx else tg.F32
+    ref = orc.Resampler(ratio, K=K, nphases=nph, fcut=0.4)
+    yref = ref.step(x)
+    cuts = [0, 3, 20000, 20001, 51111, len(x)]
+
+    def run():
+        g = tg.Resampler(ratio, dt, K=K, nphases=nph, lut=ref.lut)
+        return np.concatenate([g.step(x[a:b].copy()) for a, b in zip(cuts[:-1], cuts[1:])])
+
+    monkeypatch.setenv("TSDGPU_RS_LONG", "0")
+    y0 = run()
+    monkeypatch.delenv("TSDGPU_RS_LONG")
+    assert len(y0) == len(yref) and relerr(y0, yref) <= TOL
+    for phases in (None, "1", "3", "5"):
+        if phases is None:
+            monkeypatch.delenv("TSDGPU_RS_LONG_PHASES", raising=False)
+        else:
+            monkeypatch.setenv("TSDGPU_RS_LONG_PHASES", phases)
+        y = run()
+        assert np.array_equal(y, y0), (phases, float(np.max(np.abs(y - y0))))
