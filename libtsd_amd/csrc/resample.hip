@@ -334,6 +334,9 @@ __global__ __launch_bounds__(RS_THREADS) void resample_kernel(const T *__restric
 #ifndef RSL_CHUNK
 #define RSL_CHUNK 8
 #endif
+#ifndef RSL_ABLATE          // timing experiments only (wrong outputs): 1 no second outputs, 2 every lane reads table row 0, 4 windows not re-read per chunk
+#define RSL_ABLATE 0
+#endif
 constexpr int RSL_CH = RSL_CHUNK;                           // taps per chunk (8: 64 + 30 registers of rows and window; 16 spills at two waves per SIMD)
 constexpr int RSL_WIN = RSL_CH + RS_SEG - 1;                // samples of a chunk's window
 __host__ __device__ inline int rsl_slot(int p) { return p + (p >> 3); }       // padded sample image: a lane's window starts 9 slots after its neighbour's
@@ -504,13 +507,13 @@ __global__ __launch_bounds__(512) void resample_long_kernel(const T *__restrict_
       // over the eight inputs -- eight independent accumulation chains and one exposed LDS latency per chunk)
       for (int k0 = 0; k0 < nfull; k0 += RSL_CH) {
         T X[RSL_WIN];
-        const T *wc = wl + k0 + (k0 >> 3);
+        const T *wc = wl + ((RSL_ABLATE & 4) ? 0 : k0 + (k0 >> 3));
 #pragma unroll
         for (int j = 0; j < RSL_WIN; j++) X[j] = wc[j + (j >> 3)];
         float hh[RS_SEG][RSL_CH];
 #pragma unroll
         for (int s = 0; s < RS_SEG; s++) {
-          const float *h = lut_s + col0[s] * lsp + k0;
+          const float *h = lut_s + ((RSL_ABLATE & 2) ? 0 : col0[s]) * lsp + k0;
 #pragma unroll
           for (int k4 = 0; k4 < RSL_CH / 4; k4++) {
             const float4 q4 = *reinterpret_cast<const float4 *>(h + 4 * k4);
@@ -552,7 +555,7 @@ __global__ __launch_bounds__(512) void resample_long_kernel(const T *__restrict_
       // ---- second outputs: one per lane, samples and taps from LDS
       // (sample i0 + k sits in slot A + k + ((r + k) >> 3), A = slot of i0, r = i0 mod 8: with k = 8 m + e the run-time part is one of
       // eight base addresses per output, the rest an immediate offset -- no address arithmetic per tap)
-      for (int e = lane; e < n2; e += 64) {
+      for (int e = lane; e < ((RSL_ABLATE & 1) ? 0 : n2); e += 64) {
         const uint2 r = rec2[e];
         const int i0 = (int) (r.x >> 13) + ka, r8 = i0 & 7;
         const float *h = lut_s + (r.x & 8191u) * lsp;
