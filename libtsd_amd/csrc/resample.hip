@@ -1075,7 +1075,7 @@ static RsLongGeom rs_long_geometry(const tsdgpu_resampler *r)
   const int kmin = e_kmin ? atoi(e_kmin) : 24;
   const int want = e_w ? atoi(e_w) : 8;                      // waves per workgroup aimed at
   const int force_ph = e_ph ? atoi(e_ph) : 0;
-  if (off || r->mode != 0 || r->K < kmin || r->K == 15 || !(r->inc >= 0.5f)) return g;
+  if (off || r->mode != 0 || r->K < kmin || !(r->inc >= 0.5f)) return g;
   const size_t sz = dtype_size(r->data_type);
   g.cap2 = r->ratio > 1.f ? ((int) ((double) RS_TI * ((double) r->ratio - 1.0) * 1.0001) + 40 + 1) / 2 * 2 : 8;
   const size_t wbytes = ((size_t) rsl_tile_slots(r->K) * sz + (size_t) g.cap2 * 8 + 15) / 16 * 16;
@@ -1285,7 +1285,8 @@ int tsdgpu_resampler_step(tsdgpu_resampler *r, const void *x, int64_t n, void *y
   const size_t wb15 = ((size_t) (RS15_LATE_STORE ? RS15_TILE_PAD + P.rec_cap : std::max(RS15_TILE_PAD, P.rec_cap)) * sz + 15) / 16 * 16;
   const size_t lds15 = (size_t) ((r->nph + 1) * 20 + 4) * 4 + RS15_WAVES * wb15 + 64;
   const void *hcur = r->hist_zero ? nullptr : r->d_hist[r->cur];
-  if (r->K == 15 && r->mode == 0 && lds15 <= 158 * 1024) {     // fused kernel; larger ratios fall back to the generic one
+  const char *e15 = getenv("TSDGPU_RS15");                     // =0: the K = 15 interpolator through the kernels of the other lengths (A/B)
+  if (r->K == 15 && r->mode == 0 && lds15 <= 158 * 1024 && !(e15 && atoi(e15) == 0)) {     // fused kernel; larger ratios fall back to the generic one
     int64_t g15 = std::min<int64_t>(cdiv(tiles, RS15_WAVES), 256);
     // dynamic hand-out of the tiles when every wave gets several of them (RsDyn); TSDGPU_RS_DYN = counters, 0 = static
     const char *nc_s = getenv("TSDGPU_RS_DYN");

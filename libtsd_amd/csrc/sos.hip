@@ -38,6 +38,19 @@ constexpr int LANE_FLOATS = SOS_LANE_FLOATS;
 constexpr int SUB_FLOATS = 64 * LANE_FLOATS;      // floats per sub-tile (2048)
 constexpr int LDS_LANE_PITCH = LANE_FLOATS + 4;   // floats: + 4 pad -> conflict-free b128 both ways (36: 9 x 16 B, odd; 20: 5 x 16 B, odd)
 constexpr int LANE_QUADS = LANE_FLOATS / 4;
+#ifndef SOS_SWIZZLE
+#define SOS_SWIZZLE 0
+#endif
+// float offset of float p (a multiple of 4) of a sub-tile in the wave's LDS image; row = the lane that owns it
+__device__ __forceinline__ int sos_img(int p)
+{
+#if SOS_SWIZZLE
+  const int row = p / LANE_FLOATS, u = (p % LANE_FLOATS) >> 2;
+  return row * LANE_FLOATS + ((u ^ (row & (LANE_QUADS - 1))) << 2);
+#else
+  return (p / LANE_FLOATS) * LDS_LANE_PITCH + (p % LANE_FLOATS);
+#endif
+}
 
 #ifndef SOS_WARM_FACTOR               // a chunk is at least this many times its warm-up's cost long
 #define SOS_WARM_FACTOR 4
@@ -208,15 +221,25 @@ __device__ __forceinline__ void sos_cascade(float (&v)[LF], const SosSection *__
 //   (sos_carry_scan_kernel turns the E_c into the true start states: S_{c+1} = Phi^L S_c + E_c, S_1 = E_0)
 //   MODE 2  every chunk starts from carry[c] = S_c and stores its outputs: no warm-up.
 // 12 B per sample instead of 8, whatever the pole radius.
+#ifndef SOS_WPE
+#define SOS_WPE 4
+#endif
 template <int NCH, int MODE>
-__global__ __launch_bounds__(64) void sos_kernel(const float *__restrict__ x, float *__restrict__ y,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SOS_WPE, SOS_WPE))) void sos_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                  const SosSection *__restrict__ sec, int nsec, float gain,
                                                  const float *__restrict__ st_in, float *__restrict__ st_out,
                                                  int64_t n_sub, int spc, int warm_sub, int warm_nar, float *__restrict__ carry)
 {
   if (MODE == 1 && blockIdx.x + 1 == gridDim.x) return;       // nobody starts from the last chunk's end state
+#if SOS_SWIZZLE
+  // unpadded image, the 16-B units of a lane's row XOR-ed with the row number (conflict-free b128 both ways like the padded
+  // one), and the running state sized by the handle's section count: 8 KiB + 32 B per section instead of 10 KiB per wave
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float *sst = lds + 64 * LANE_FLOATS;            // running state per (section, channel): 4 floats
+#else
   __shared__ __attribute__((aligned(16))) float lds[64 * LDS_LANE_PITCH];
   __shared__ float sst[SOS_MAX_SEC * 8];          // running state per (section, channel): 4 floats
+#endif
   const int lane = threadIdx.x;
   const int64_t chunk = blockIdx.x;
   const int64_t t_first = chunk * spc;                         // first sub-tile whose output we own
@@ -251,12 +274,12 @@ __global__ __launch_bounds__(64) void sos_kernel(const float *__restrict__ x, fl
     for (int i = 0; i < LANE_QUADS; i++) {
       const int p = 4 * (i * 64 + lane);                       // float index in the sub-tile
       const float4 q = *reinterpret_cast<const float4 *>(xt + p);
-      *reinterpret_cast<float4 *>(&lds[(p / LANE_FLOATS) * LDS_LANE_PITCH + (p % LANE_FLOATS)]) = q;
+      *reinterpret_cast<float4 *>(&lds[sos_img(p)]) = q;
     }
     wave_sync();
 #pragma unroll
     for (int i = 0; i < LANE_QUADS; i++) {
-      const float4 q = *reinterpret_cast<const float4 *>(&lds[lane * LDS_LANE_PITCH + 4 * i]);
+      const float4 q = *reinterpret_cast<const float4 *>(&lds[sos_img(lane * LANE_FLOATS + 4 * i)]);
       v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w;
     }
     wave_sync();
@@ -268,14 +291,14 @@ __global__ __launch_bounds__(64) void sos_kernel(const float *__restrict__ x, fl
 #pragma unroll
       for (int i = 0; i < LANE_QUADS; i++) {
         const float4 q = make_float4(v[4 * i] * gain, v[4 * i + 1] * gain, v[4 * i + 2] * gain, v[4 * i + 3] * gain);
-        *reinterpret_cast<float4 *>(&lds[lane * LDS_LANE_PITCH + 4 * i]) = q;
+        *reinterpret_cast<float4 *>(&lds[sos_img(lane * LANE_FLOATS + 4 * i)]) = q;
       }
       wave_sync();
       float *yt = y + t * SUB_FLOATS;
 #pragma unroll
       for (int i = 0; i < LANE_QUADS; i++) {
         const int p = 4 * (i * 64 + lane);
-        *reinterpret_cast<float4 *>(yt + p) = *reinterpret_cast<const float4 *>(&lds[(p / LANE_FLOATS) * LDS_LANE_PITCH + (p % LANE_FLOATS)]);
+        *reinterpret_cast<float4 *>(yt + p) = *reinterpret_cast<const float4 *>(&lds[sos_img(p)]);
       }
       wave_sync();
     }
@@ -866,6 +889,7 @@ int tsdgpu_sos_step(tsdgpu_sos *s, const void *x, void *y, int64_t n, void *stre
     static const bool no_exact = getenv("TSDGPU_SOS_NO_EXACT_CARRY") != nullptr;
     static const int64_t EX_TARGET = 4096;
     const int64_t spc_ex = std::max<int64_t>(1, n_sub / EX_TARGET), nch_ex = cdiv(n_sub, spc_ex);
+    const size_t sos_dyn_lds = SOS_SWIZZLE ? (size_t) (64 * LANE_FLOATS + s->nsec * 8) * sizeof(float) : 0;
     bool exact = false;
     if (!no_exact && !s->capturable && nch_ex >= 8) {
       // which is cheaper (microseconds, rough): a wave alone takes tw per sub-tile (latency-bound: 1.5 + 0.4 per section,
@@ -904,7 +928,7 @@ int tsdgpu_sos_step(tsdgpu_sos *s, const void *x, void *y, int64_t n, void *stre
       double *ws = s->scan_ws.as<double>(), *gs = ws + img;
       const size_t cl = ((size_t) m * m + 2 * per + (size_t) CARRY_BLOCK * per) * sizeof(double);
 #define SOS_LAUNCH(NCH, MODE)                                                                                              \
-  hipLaunchKernelGGL((sos_kernel<NCH, MODE>), dim3((unsigned) nch_ex), dim3(64), 0, st, (const float *) dx, (float *) dy, s->d_sec, \
+  hipLaunchKernelGGL((sos_kernel<NCH, MODE>), dim3((unsigned) nch_ex), dim3(64), sos_dyn_lds, st, (const float *) dx, (float *) dy, s->d_sec, \
                      s->nsec, s->gain, st_in, st_out, n_sub, (int) spc_ex, 0, 0, carry)
       if (nch == 1) SOS_LAUNCH(1, 1); else SOS_LAUNCH(2, 1);
       const int mp = per > 64 || m > 16 ? 0 : m <= 2 ? 2 : m <= 4 ? 4 : m <= 8 ? 8 : 16;
@@ -922,10 +946,10 @@ int tsdgpu_sos_step(tsdgpu_sos *s, const void *x, void *y, int64_t n, void *stre
 #undef SOS_LAUNCH
       nchunks = nch_ex;
     } else if (nch == 1) {
-      hipLaunchKernelGGL((sos_kernel<1, 0>), dim3((unsigned) nchunks), dim3(64), 0, st, (const float *) dx, (float *) dy,
+      hipLaunchKernelGGL((sos_kernel<1, 0>), dim3((unsigned) nchunks), dim3(64), sos_dyn_lds, st, (const float *) dx, (float *) dy,
                          s->d_sec, s->nsec, s->gain, st_in, st_out, n_sub, (int) spc, (int) warm_sub, (int) warm_nar, (float *) nullptr);
     } else {
-      hipLaunchKernelGGL((sos_kernel<2, 0>), dim3((unsigned) nchunks), dim3(64), 0, st, (const float *) dx, (float *) dy,
+      hipLaunchKernelGGL((sos_kernel<2, 0>), dim3((unsigned) nchunks), dim3(64), sos_dyn_lds, st, (const float *) dx, (float *) dy,
                          s->d_sec, s->nsec, s->gain, st_in, st_out, n_sub, (int) spc, (int) warm_sub, (int) warm_nar, (float *) nullptr);
     }
     TSD_HIP(hipGetLastError());
