@@ -337,5 +337,71 @@ TSD_HD void inverse(C (&v)[16], C *lds, int lane, const TW1 &tw1, const TW2 &tw2
   stageA<true>(v, tw1);
 }
 
+// ---- TWO 512-point transforms in one wave (round 3: the windowed overlap-add engine at its default geometry) ----------------
+// The same three stages and LDS exchanges with one bit of the engine's last digit m2 = 2 sigma + eps standing for the SEQUENCE:
+// 512 = 16 x 16 x 2, v = 32 n1 + 2 m1 + eps, k = k1 + 16 j1 + 256 j2 --
+//   time:  lane n2 = 4 m1 + 2 sigma + eps, reg n1   holds sample v = 32 n1 + 2 m1 + eps of sequence sigma
+//   stage A twiddle W_512^((2 m1 + eps) k1), stage B twiddle W_32^(eps j1), stage C a radix-2 over eps per sequence
+//   freq:  lane 4 k1 + j1lo, reg 4 j1hi + 2 sigma + j2   holds bin k of sequence sigma (both sequences' bin k in one lane)
+// i.e. forward() / inverse() with the tables of fill_twiddles_pair512 and stageC2 in place of stageC.
+inline void fill_twiddles_pair512(cpx *tw1, cpx *tw2)
+{
+  const double PI = 3.14159265358979323846;
+  for (int r = 0; r < 16; r++)
+    for (int lane = 0; lane < 64; lane++) {
+      const int w = 2 * (lane >> 2) + (lane & 1);
+      double a1 = -2.0 * PI * (double) (w * r) / 512.0;
+      tw1[r * 64 + lane] = mk((float) std::cos(a1), (float) std::sin(a1));
+      double a2 = -2.0 * PI * (double) ((lane & 1) * r) / 32.0;
+      tw2[r * 64 + lane] = mk((float) std::cos(a2), (float) std::sin(a2));
+    }
+}
+TSD_HD int pair512_seq_of_lane(int lane) { return (lane >> 1) & 1; }
+TSD_HD int pair512_time_index(int lane, int reg) { return 32 * reg + 2 * (lane >> 2) + (lane & 1); }
+TSD_HD int pair512_seq_of_reg(int reg) { return (reg >> 1) & 1; }
+TSD_HD int pair512_freq_index(int lane, int reg)
+{
+  const int k1 = lane >> 2, j1lo = lane & 3, j1hi = reg >> 2, j2 = reg & 1;
+  return k1 + 16 * (4 * j1hi + j1lo) + 256 * j2;
+}
+template <typename C> TSD_HD void stageC2(C (&v)[16])        // (a radix-2 butterfly is its own inverse)
+{
+#pragma unroll
+  for (int q = 0; q < 8; q++) {
+    const C a = v[2 * q], b = v[2 * q + 1];
+    v[2 * q] = cadd(a, b);
+    v[2 * q + 1] = csub(a, b);
+  }
+}
+template <int S = 1, typename C, typename TW1, typename TW2, typename SYNC>
+TSD_HD void forward_pair512(C (&v)[16], C *lds, int lane, const TW1 &tw1, const TW2 &tw2, SYNC sync)
+{
+  stageA<false>(v, tw1);
+  x1_write_rows<S>(v, lds, lane);
+  sync();
+  x1_read_cols<S>(v, lds, lane);
+  stageB<false>(v, tw2);
+  sync();
+  x2_write_j1<S>(v, lds, lane);
+  sync();
+  x2_read_m2<S>(v, lds, lane);
+  stageC2(v);
+}
+template <int S = 1, typename C, typename TW1, typename TW2, typename SYNC>
+TSD_HD void inverse_pair512(C (&v)[16], C *lds, int lane, const TW1 &tw1, const TW2 &tw2, SYNC sync)
+{
+  stageC2(v);
+  sync();
+  x2_write_m2<S>(v, lds, lane);
+  sync();
+  x2_read_j1<S>(v, lds, lane);
+  stageB<true>(v, tw2);
+  sync();
+  x1_write_cols<S>(v, lds, lane);
+  sync();
+  x1_read_rows<S>(v, lds, lane);
+  stageA<true>(v, tw1);
+}
+
 }  // namespace w1024
 }  // namespace tsdgpu

@@ -49,6 +49,10 @@ void ola1024_tables(const float2 *H_host, float2 *out3);
 int welch1024_launch(const float2 *x, const float *w, const float2 *tw2x1024, float *part, int64_t nseg, int per, hipStream_t st);
 void welch1024_tables(float2 *out2);
 int ola1024_launch(const float2 *x, float2 *y, const float2 *tables3, const float2 *svg_in, float2 *svg_out, int64_t B, hipStream_t st);
+// the windowed engine at Ne = N = 512 on the in-wave pair transform (ols.hip: olaw512_kernel); tables: 512 + 2 x 1024 complex values
+void olaw512_tables(const float2 *H_host, float2 *out);
+int olaw512_launch(const float2 *blk0, int nrest, const float2 *x, float2 *y, const float2 *tables, const float *fen, const float2 *svg_in,
+                   const float2 *last_in, const float2 *prev_half_in, float2 *svg_out, float2 *last_out, int64_t B, int skip_first, hipStream_t st);
 // overlap-save for long filters (514..12289 taps), radix-16 Stockham blocks
 bool ols_long_supported(const tsdgpu_fir *f);
 int ols_long_plan_create(tsdgpu_fir *f);

@@ -24,7 +24,7 @@ struct tsdgpu_ola {
   bool fuse_response = false;              // set by tsdgpu_ola_step: the forward transform applies H itself
   bool response_applied = false;
   tsdgpu::DevBuf frames, spectra, in_stage, out_stage;
-  tsdgpu::cpx *d_fast = nullptr;           // fast path (Ne = 512, N = 1024, no window): response in register order / N + twiddles (3 x 1024)
+  tsdgpu::cpx *d_fast = nullptr;           // in-wave paths: Ne = 512, N = 1024 without window (response in register order / N + twiddles, 3 x 1024); Ne = N = 512 windowed (512 + 2 x 1024)
   tsdgpu::cpx *d_svg_tmp = nullptr;        // Ne: the new tail, written by the last wave while the first one may still read d_svg
   tsdgpu::cpx *d_last_tmp = nullptr;       // Ne: the same for `last` (windowed run kernel)
   tsdgpu::cpx *d_bloc = nullptr;           // ONE allocation behind d_svg, d_svg_tmp, d_last, d_prev_half, d_rest
@@ -968,6 +968,15 @@ int tsdgpu_ola_set_response(tsdgpu_ola *h, const void *H)
     if (!h->d_fast) TSD_HIP(hipMalloc((void **) &h->d_fast, t3.size() * sizeof(cpx)));
     TSD_HIP(hipMemcpy(h->d_fast, t3.data(), t3.size() * sizeof(cpx), hipMemcpyHostToDevice));
   }
+  // the windowed mode at Ne = N = 512 (the engine's defaults with a window): the in-wave pair transform (ols.hip, olaw512_kernel)
+  static const bool no_w512 = getenv("TSDGPU_OLAW512") != nullptr && atoi(getenv("TSDGPU_OLAW512")) == 0;
+  if (!unfused && !no_w512 && h->windowed && h->N == 512 && h->Ne == 512) {
+    std::vector<cpx> Hh(512), tb(512 + 2 * 1024);
+    TSD_HIP(hipMemcpy(Hh.data(), h->d_H, 512 * sizeof(cpx), hipMemcpyDeviceToHost));
+    olaw512_tables(Hh.data(), tb.data());
+    if (!h->d_fast) TSD_HIP(hipMalloc((void **) &h->d_fast, tb.size() * sizeof(cpx)));
+    TSD_HIP(hipMemcpy(h->d_fast, tb.data(), tb.size() * sizeof(cpx), hipMemcpyHostToDevice));
+  }
   if (!unfused && (h->windowed ? olaw_run_fits(h->N, h->Ne) : ola_run_fits(h->N, h->Ne))) {
     // the other geometries whose frame and carried block fit the LDS: one kernel too (ola_run_kernel) -- which also serves the
     // ragged calls of the default geometry (waiting samples in front of x), the in-wave kernel taking the whole-block ones
@@ -1137,7 +1146,7 @@ int tsdgpu_ola_step(tsdgpu_ola *h, const void *x, int64_t n, void *y, int64_t *n
         x, n, sizeof(cpx), y, sizeof(cpx), n_out, Ne, (hipStream_t) stream, [Ne](int64_t c) { return c + Ne; },
         [h](const void *cx, void *cy, int64_t cnt, int64_t, int64_t *got, hipStream_t q) { return tsdgpu_ola_step(h, cx, cnt, cy, got, q); });
   }
-  if (h->d_fast && h->nrest == 0 && n >= h->Ne && h->pending_blocks < 0 && x != nullptr && y != nullptr) {
+  if (h->d_fast && !h->windowed && h->nrest == 0 && n >= h->Ne && h->pending_blocks < 0 && x != nullptr && y != nullptr) {
     // fast path: B whole blocks through ONE kernel, 16 B of HBM traffic per sample (see ols.hip)
     hipStream_t st = (hipStream_t) stream;
     const int Ne = h->Ne;
@@ -1226,9 +1235,13 @@ int tsdgpu_ola_step(tsdgpu_ola *h, const void *x, int64_t n, void *y, int64_t *n
     const cpx *dx = (const cpx *) dxv;
     // block 0 made contiguous: the waiting samples, then the head of x (rest has room for a whole block)
     if (h->nrest > 0 && (rc = copy_small(h->d_rest + h->nrest, dx, Ne - h->nrest, st))) return rc;
-    if ((rc = olaw_run_launch(h->nrest > 0 ? h->d_rest : dx, h->nrest, dx, (cpx *) dyv, h->d_run, h->d_fen, h->d_svg, h->d_last, h->d_prev_half,
-                              h->d_svg_tmp, h->d_last_tmp, Ne, h->N, B, skip, st)))
-      return rc;
+    if (h->d_fast && h->N == 512 && Ne == 512)
+      rc = olaw512_launch(h->nrest > 0 ? h->d_rest : dx, h->nrest, dx, (cpx *) dyv, h->d_fast, h->d_fen, h->d_svg, h->d_last, h->d_prev_half,
+                          h->d_svg_tmp, h->d_last_tmp, B, skip, st);
+    else
+      rc = olaw_run_launch(h->nrest > 0 ? h->d_rest : dx, h->nrest, dx, (cpx *) dyv, h->d_run, h->d_fen, h->d_svg, h->d_last, h->d_prev_half,
+                           h->d_svg_tmp, h->d_last_tmp, Ne, h->N, B, skip, st);
+    if (rc) return rc;
     std::swap(h->d_svg, h->d_svg_tmp);
     std::swap(h->d_last, h->d_last_tmp);
     // the second half of the last block waits for the next call's first frame (:926); then the samples after the last whole block

@@ -793,6 +793,149 @@ int ola1024_launch(const cpx *x, cpx *y, const cpx *tables3, const cpx *svg_in, 
   return TSDGPU_OK;
 }
 
+// ---- the WINDOWED overlap-add engine at its default geometry (Ne = N = 512, fourier.cc:883-927) on the in-wave transform ----
+// Per block b two Hann-windowed frames half a block apart, A_b = [second half of block b-1 | first half of block b] and
+// B_b = block b, each -> FFT -> x H -> IFFT.  Without zero padding the reference's bookkeeping (svg, last; statement by
+// statement in olaw_run_kernel, ola.hip) closes to
+//     y_b = [ B_{b-2}.tail / 2 + A_{b-1}.head / 2  |  A_{b-1}.tail / 2 + B_{b-1}.head / 2 ]
+// (every sum has two terms: the order of the reference's additions does not matter), with the handle's state
+// svg = B_{b-1}, last = [ B_{b-2}.tail / 2 + A_{b-1}.head / 2 | A_{b-1}.tail / 2 ] between calls.
+// A wave transforms the PAIR (A_p, B_p) in one pass of the 1024-point engine (forward_pair512: lanes with bit 1 clear hold A_p,
+// the others B_p; 16 samples per lane) and writes block p + 1 after it: the lanes of A_p the first half -- with the upper half of
+// B_{p-1}, kept from the pass before --, the lanes of B_p the second half with the upper half of A_p; the halves travel between a
+// lane and its partner (lane ^ 2) by DPP.  A run of `per` blocks starts two passes early (the first one only for its B); the
+// runs that start at block 0 or 1 take the handle's state instead, and the last run makes the next state.  16 B of HBM traffic
+// per sample; the same work per sample as the unwindowed default geometry (one 1024-point pair of transforms per 512 samples).
+__global__ __launch_bounds__(64, 2) void olaw512_kernel(const cpx *__restrict__ blk0, int nrest, const cpx *__restrict__ x, cpx *__restrict__ y,
+                                                        const cpx *__restrict__ Hreg, const cpx *__restrict__ TW1, const cpx *__restrict__ TW2,
+                                                        const float *__restrict__ fen, const cpx *__restrict__ svg_in,
+                                                        const cpx *__restrict__ last_in, const cpx *__restrict__ prev_half_in,
+                                                        cpx *__restrict__ svg_out, cpx *__restrict__ last_out, int64_t B, int per,
+                                                        int skip_first)
+{
+  __shared__ cv lds[LDS_ELEMS];
+  const int lane = threadIdx.x;
+  const int64_t b_lo = (int64_t) blockIdx.x * per, b_hi = min(B, b_lo + (int64_t) per);
+  if (b_lo >= B) return;
+  const int sig = (lane >> 1) & 1, c = 2 * (lane >> 2) + (lane & 1);      // this lane's sequence (0: A, 1: B) and sample column
+  cv tw1[16], tw2[16], H[8];
+  float win[16];
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    tw1[r] = ((const cv *) TW1)[r * 64 + lane];
+    tw2[r] = ((const cv *) TW2)[r * 64 + lane];
+    win[r] = fen[32 * r + c];
+  }
+#pragma unroll
+  for (int q = 0; q < 8; q++) H[q] = ((const cv *) Hreg)[q * 64 + lane];         // bin of reg 4 j1hi + 2 sigma + j2: q = 2 j1hi + j2
+  auto sync = []() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  // sample i (-256 <= i) of the stream [rest ++ x]; block 0 was made contiguous by the host, the half block before it is the handle's
+  auto sample = [&](int64_t i) -> cv {
+    if (i < 0) return ((const cv *) prev_half_in)[i + 256];
+    if (i < 512) return ((const cv *) blk0)[i];
+    return ((const cv *) x)[i - nrest];
+  };
+  auto xchg = [&](cv a) -> cv {        // the partner's value (lane ^ 2)
+    return mkv(__shfl_xor(a.x, 2), __shfl_xor(a.y, 2));
+  };
+  cv v[16], keep[8];                   // keep: on the lanes of A the upper half of the B before
+  // the first pass: block 0 or 1 starts from the state (B_{-1} = svg), later runs two blocks early
+  int64_t p = b_lo <= 1 ? 0 : b_lo - 2;
+  if (b_lo <= 1) {
+#pragma unroll
+    for (int r = 0; r < 8; r++) keep[r] = ((const cv *) svg_in)[256 + 32 * r + c];
+    if (b_lo == 0 && !skip_first) {
+      // y_0 = [ last.head | last.tail + svg.head / 2 ]   (:895-899)
+#pragma unroll
+      for (int r = 0; r < 8; r++) {
+        const int i = 32 * r + c;
+        cv o = ((const cv *) last_in)[256 * sig + i];
+        if (sig) {
+          const cv g = ((const cv *) svg_in)[i];
+          o = mkv(o.x + g.x * 0.5f, o.y + g.y * 0.5f);
+        }
+        ((cv *) y)[256 * sig + i] = o;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 8; r++) keep[r] = mkv(0.f, 0.f);
+  }
+  // passes p = first .. b_hi - 2 write block p + 1; the last run adds pass B - 1 for the state
+  const int64_t p_end = b_hi == B ? B : b_hi - 1;      // exclusive
+  for (; p < p_end; p++) {
+    const int64_t base = 512 * p - 256 + 256 * sig;    // first sample of this lane's frame
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const cv a = sample(base + 32 * r + c);
+      v[r] = mkv(a.x * win[r], a.y * win[r]);          // :886 / :910
+    }
+    forward_pair512(v, lds, lane, tw1, tw2, sync);
+#pragma unroll
+    for (int r = 0; r < 16; r++) v[r] = cmul(v[r], H[2 * (r >> 2) + (r & 1)]);
+    inverse_pair512(v, lds, lane, tw1, tw2, sync);
+    sync();
+    cv got[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) got[r] = xchg(v[8 + r]);
+    if (p + 1 < B) {
+      if (p + 1 >= b_lo) {
+        // lanes of A: y.head = B_{p-1}.tail / 2 + A_p.head / 2; lanes of B: y.tail = A_p.tail / 2 + B_p.head / 2
+        cv *yo = (cv *) y + (p + 1 - skip_first) * 512 + 256 * sig + c;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+          const cv o = sig ? got[r] : keep[r];
+          yo[32 * r] = mkv(o.x * 0.5f + v[r].x * 0.5f, o.y * 0.5f + v[r].y * 0.5f);
+        }
+      }
+    } else {
+      // the state after the call's last block: svg = B_p, last = [ B_{p-1}.tail / 2 + A_p.head / 2 | A_p.tail / 2 ]
+      if (sig) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) ((cv *) svg_out)[32 * r + c] = v[r];
+      } else {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+          ((cv *) last_out)[32 * r + c] = mkv(keep[r].x * 0.5f + v[r].x * 0.5f, keep[r].y * 0.5f + v[r].y * 0.5f);
+          ((cv *) last_out)[256 + 32 * r + c] = mkv(v[8 + r].x * 0.5f, v[8 + r].y * 0.5f);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 8; r++) keep[r] = got[r];      // (on the lanes of A: the upper half of B_p)
+  }
+}
+
+// tables of that kernel: the response of the 8 bins a lane holds per sequence, scaled by 1/512, and the two twiddle sets of the
+// pair transform -> 512 + 2 x 1024 complex values
+void olaw512_tables(const cpx *H_host, cpx *out)
+{
+  for (int lane = 0; lane < 64; lane++)
+    for (int q = 0; q < 8; q++) {
+      const cpx h = H_host[pair512_freq_index(lane, 4 * (q >> 1) + (q & 1))];
+      out[q * 64 + lane] = mk(h.x / 512.f, h.y / 512.f);
+    }
+  fill_twiddles_pair512(out + 512, out + 512 + 1024);
+}
+
+int olaw512_launch(const cpx *blk0, int nrest, const cpx *x, cpx *y, const cpx *tables, const float *fen, const cpx *svg_in, const cpx *last_in,
+                   const cpx *prev_half_in, cpx *svg_out, cpx *last_out, int64_t B, int skip_first, hipStream_t st)
+{
+  if (B <= 0) return TSDGPU_OK;
+  // blocks per wave: a run costs per + 2 passes; short calls spread out, long ones amortise the two warm-up passes over 16 blocks
+  const int per = (int) std::min<int64_t>(16, std::max<int64_t>(2, B / 2048));
+  const int64_t grid = cdiv(B, per);
+  if (grid > 0x7fffffff) return set_err(TSDGPU_ERR_UNSUPPORTED, "ola: too many blocks in one call");
+  hipLaunchKernelGGL(olaw512_kernel, dim3((unsigned) grid), dim3(64), 0, st, blk0, nrest, x, y, tables, tables + 512, tables + 512 + 1024, fen, svg_in,
+                     last_in, prev_half_in, svg_out, last_out, B, per, skip_first);
+  TSD_HIP(hipGetLastError());
+  return TSDGPU_OK;
+}
+
 // ---- Welch periodogram sums, N = 1024, on the same in-wave transform (ola.hip: tsdgpu_welch's fast path) -------------
 // psd_welch (freqestim.cc:7-20): segments of N samples every N/2, windowed, |FFT|^2 summed.  A wave runs through `per`
 // consecutive segments: loads (each sample is read by two segments: 16 B of HBM traffic per sample, against the 50 B of

@@ -108,6 +108,59 @@ int main()
   audit([](int l, int r) { return LDS_ROW * (l >> 2) + 17 * (l & 3) + r; }, 32, 32, "x2 j1 read");
   audit([](int l, int r) { return LDS_ROW * (l >> 2) + (l & 3) + 17 * (r & 3) + 4 * (r >> 2); }, 16, 16, "x2 m2 write");
   audit([](int l, int r) { return LDS_ROW * (l >> 2) + (l & 3) + 17 * (r & 3) + 4 * (r >> 2); }, 32, 32, "x2 m2 read");
+  // two 512-point transforms in one wave (forward_pair512 / inverse_pair512: the windowed overlap-add engine): both sequences against
+  // the double-precision DFT, the index maps bijections per sequence, and the round trip
+  {
+    std::vector<cpx> p1(1024), p2(1024);
+    fill_twiddles_pair512(p1.data(), p2.data());
+    std::vector<std::complex<double>> xs[2] = {std::vector<std::complex<double>>(512), std::vector<std::complex<double>>(512)}, Xs[2];
+    for (int q = 0; q < 2; q++) {
+      for (auto &u : xs[q]) u = {rand() / (double) RAND_MAX - 0.5, rand() / (double) RAND_MAX - 0.5};
+      Xs[q].resize(512);
+      for (int k = 0; k < 512; k++) {
+        std::complex<double> a = 0;
+        for (int n = 0; n < 512; n++) a += xs[q][n] * std::polar(1.0, -2 * PI * (double) ((long) k * n % 512) / 512);
+        Xs[q][k] = a;
+      }
+    }
+    cpx w[64][16], u1[64][16], u2[64][16];
+    std::vector<int> seen_t(1024, 0), seen_f(1024, 0);
+    for (int l = 0; l < 64; l++)
+      for (int r = 0; r < 16; r++) {
+        auto a = xs[pair512_seq_of_lane(l)][pair512_time_index(l, r)];
+        seen_t[512 * pair512_seq_of_lane(l) + pair512_time_index(l, r)]++;
+        seen_f[512 * pair512_seq_of_reg(r) + pair512_freq_index(l, r)]++;
+        w[l][r] = mk((float) a.real(), (float) a.imag());
+        u1[l][r] = p1[r * 64 + l];
+        u2[l][r] = p2[r * 64 + l];
+      }
+    for (int i = 0; i < 1024; i++)
+      if (seen_t[i] != 1 || seen_f[i] != 1) { printf("FAIL pair512 index maps are not bijections\n"); return 1; }
+    ALL(stageA<false>(w[l], u1[l]));  ALL(x1_write_rows(w[l], lds.data(), l));
+    ALL(x1_read_cols(w[l], lds.data(), l)); ALL(stageB<false>(w[l], u2[l]));
+    ALL(x2_write_j1(w[l], lds.data(), l)); ALL(x2_read_m2(w[l], lds.data(), l));
+    ALL(stageC2(w[l]));
+    double ep = 0, rp = 0;
+    for (int l = 0; l < 64; l++)
+      for (int r = 0; r < 16; r++) {
+        auto e = Xs[pair512_seq_of_reg(r)][pair512_freq_index(l, r)];
+        ep = std::max(ep, std::abs(std::complex<double>(w[l][r].x, w[l][r].y) - e));
+        rp = std::max(rp, std::abs(e));
+      }
+    printf("pair512 forward: max err %.3e (max |X| %.3e)\n", ep, rp);
+    if (ep > 2e-5 * rp) { printf("FAIL pair512 forward\n"); return 1; }
+    ALL(stageC2(w[l])); ALL(x2_write_m2(w[l], lds.data(), l)); ALL(x2_read_j1(w[l], lds.data(), l));
+    ALL(stageB<true>(w[l], u2[l])); ALL(x1_write_cols(w[l], lds.data(), l)); ALL(x1_read_rows(w[l], lds.data(), l));
+    ALL(stageA<true>(w[l], u1[l]));
+    double er = 0;
+    for (int l = 0; l < 64; l++)
+      for (int r = 0; r < 16; r++) {
+        auto a = xs[pair512_seq_of_lane(l)][pair512_time_index(l, r)] * 512.0;
+        er = std::max(er, std::abs(std::complex<double>(w[l][r].x, w[l][r].y) - a));
+      }
+    printf("pair512 round trip: max err %.3e (scale 512)\n", er);
+    if (er > 1e-5 * 512) { printf("FAIL pair512 inverse\n"); return 1; }
+  }
   printf("OK\n");
   return 0;
 }
