@@ -1006,7 +1006,7 @@ __global__ __launch_bounds__(1024) void fft_bluestein_kernel(const cpx *__restri
                                                              const cpx *__restrict__ chirp, const cpx *__restrict__ xc,
                                                              const cpx *__restrict__ TW, int n, int n2, int tpt, int reverse,
                                                              float g, int P, const cpx *__restrict__ Wn, int conj_out,
-                                                             int64_t ntr)
+                                                             int64_t ntr, int fuse, float s2)
 {
   extern __shared__ __attribute__((aligned(16))) char blu_raw[];
   const int t = threadIdx.x;
@@ -1036,17 +1036,55 @@ __global__ __launch_bounds__(1024) void fft_bluestein_kernel(const cpx *__restri
   }
   sync();
   s16::transform<R0>(v, lds, TW, n2, j, tpt, sync);          // conj of n2 * (unitary inverse of the product)
-  if (!live) return;
+  if (!fuse && !live) return;
+  // fuse = P in {2, 4, 8, 16} (the whole mixed-radix plan in this kernel, round 3): the workgroup holds whole groups of P residues; their
+  // Z[r][k1] stay in the transforms' LDS images and pass 2 -- a P-point DFT over r per column k1, fft_smallcols_kernel's -- follows
+  // a barrier later: 16 B of HBM traffic per point instead of 48
+  if (fuse) sync();                                            // (the image is still being read by the transform's last pass)
 #pragma unroll
   for (int q = 0; q < 16; q++) {
     const int pos = j + q * tpt, kk = pos - (n - 1);
-    if (kk >= 0 && kk < n) {
+    if (live && kk >= 0 && kk < n) {
       const int k = reverse ? (kk == 0 ? 0 : n - kk) : kk;    // tfr2itfr: X^-1[k] = X[(n - k) % n]
       cpx o = cscale(cmul(cmk(v[q].x, -v[q].y), chirp[pos]), g);
       if (conj_out) o.y = -o.y;
       if (Wn) o = cmul(o, Wn[(size_t) r * k]);
-      y[k] = o;
+      if (fuse) lds[k] = o;
+      else y[k] = o;
     }
+  }
+  if (!fuse) return;
+  sync();
+  const int G = T / P;
+  const size_t pitch = (size_t) n2 + (n2 >> 4);
+  for (int idx = t; idx < G * n; idx += (int) blockDim.x) {
+    const int gq = idx / n, k1 = idx - gq * n;
+    const int64_t tr0 = (int64_t) blockIdx.x * T + (int64_t) gq * P;
+    if (tr0 >= ntr) continue;
+    const cpx *zb = reinterpret_cast<const cpx *>(blu_raw) + (size_t) gq * P * pitch + k1;
+    cpx *yb = out + (size_t) (tr0 / P) * n * P + k1;
+    if (P == 16) {
+      cpx e[16];
+#pragma unroll
+      for (int rr = 0; rr < 16; rr++) e[rr] = zb[(size_t) rr * pitch];
+      w1024::dft16<false>(e);
+#pragma unroll
+      for (int k2 = 0; k2 < 16; k2++) yb[(size_t) k2 * n] = cmk(e[k2].x * s2, conj_out ? -e[k2].y * s2 : e[k2].y * s2);
+      continue;
+    }
+    cpx e[8];
+#pragma unroll
+    for (int rr = 0; rr < 8; rr++) e[rr] = rr < P ? zb[(size_t) rr * pitch] : cmk(0.f, 0.f);
+    if (P == 2) {
+      s16::dft2(e[0], e[1]);
+    } else if (P == 4) {
+      w1024::dft4<false>(e[0], e[1], e[2], e[3]);
+    } else {
+      s16::dft8(e);
+    }
+#pragma unroll
+    for (int k2 = 0; k2 < 8; k2++)
+      if (k2 < P) yb[(size_t) k2 * n] = cmk(e[k2].x * s2, conj_out ? -e[k2].y * s2 : e[k2].y * s2);
   }
 }
 
@@ -1442,8 +1480,16 @@ inline unsigned blocks_for(int64_t total) { return (unsigned) cdiv(total, 256); 
 
 // One-kernel Bluestein of `p` (an ODD plan with blu_fused) over ntr = batch * P transforms;
 // P > 1 / Wn: pass 1 of the mixed-radix plan (see fft_bluestein_kernel)
+// fuse: pass 2 of a mixed-radix plan with P = 2, 4, 8, 16 in the same kernel (bluestein_fusable)
+bool bluestein_fusable(const tsdgpu_fft *sub, int P)
+{
+  static const bool off = getenv("TSDGPU_FFT_MIXED_UNFUSED") != nullptr;
+  const int n2 = sub->n2, tpt = n2 / 16;
+  return !off && sub->blu_fused && (P == 2 || P == 4 || P == 8 || P == 16) && P * tpt <= 1024 &&
+         (size_t) std::max(256 / tpt, P) * (n2 + n2 / 16) * sizeof(cpx) <= 158 * 1024;
+}
 int launch_bluestein(const tsdgpu_fft *p, const cpx *x, cpx *y, int64_t ntr, int reverse, int conj_out, int P, const cpx *Wn,
-                     hipStream_t st)
+                     hipStream_t st, bool fuse = false)
 {
   const int n = p->n, n2 = p->n2;
   // unitary FFT, product with the unitary xc, unitary inverse, times sqrt(n2)/sqrt(n): the two
@@ -1452,11 +1498,12 @@ int launch_bluestein(const tsdgpu_fft *p, const cpx *x, cpx *y, int64_t ntr, int
   int l2 = 0;
   while ((1 << l2) < n2) l2++;
   const int r0 = 1 << ((l2 & 3) == 0 ? 4 : (l2 & 3)), tpt = n2 / 16;
-  const int threads = std::max(256, tpt), T = threads / tpt;
+  const int threads = std::max(256, fuse ? P * tpt : tpt), T = threads / tpt;       // (fused: whole groups of P residues per workgroup)
   const size_t lds = (size_t) T * (n2 + n2 / 16) * sizeof(cpx);
   const int64_t grid = cdiv(ntr, T);
   TSD_CHECK(grid <= 0x7fffffff, "fft_step: too many transforms");
-#define BLU_LAUNCH(R) hipLaunchKernelGGL((fft_bluestein_kernel<R>), dim3((unsigned) grid), dim3(threads), lds, st, x, y, p->d_chirp, p->d_xc, p->d_tw, n, n2, tpt, reverse, gf, P, Wn, conj_out, ntr)
+  const float s2 = 1.0f / std::sqrt((float) P);
+#define BLU_LAUNCH(R) hipLaunchKernelGGL((fft_bluestein_kernel<R>), dim3((unsigned) grid), dim3(threads), lds, st, x, y, p->d_chirp, p->d_xc, p->d_tw, n, n2, tpt, reverse, gf, P, Wn, conj_out, ntr, fuse ? P : 0, s2)
   if (r0 == 16) BLU_LAUNCH(16); else if (r0 == 8) BLU_LAUNCH(8); else if (r0 == 4) BLU_LAUNCH(4); else BLU_LAUNCH(2);
 #undef BLU_LAUNCH
   TSD_HIP(hipGetLastError());
@@ -1671,6 +1718,8 @@ int step_device(tsdgpu_fft *p, const cpx *x, cpx *y, int batch, int forward, hip
         if (m <= 8) ODD_LAUNCH(8); else if (m <= 16) ODD_LAUNCH(16); else ODD_LAUNCH(32);
 #undef ODD_LAUNCH
         TSD_HIP(hipGetLastError());
+      } else if (bluestein_fusable(p->sub, P)) {
+        return launch_bluestein(p->sub, x, y, tot1, inverse, inverse, P, p->d_rot, st, true);      // both passes in one kernel
       } else {
         rc = launch_bluestein(p->sub, x, z, tot1, inverse, inverse, P, p->d_rot, st);
         if (rc) return rc;

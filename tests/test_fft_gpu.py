@@ -80,8 +80,10 @@ def test_fft_batched_device(tg, orc):
 
 # n = m * 2^p (m odd <= 8191, 2 <= 2^p <= 4096): the two-pass mixed-radix plan -- direct m-point DFT
 # (m <= 31) or one-kernel Bluestein per residue, then 2^p-point columns (radix-2/4/8 kernel below 16)
-# -- alone and underneath one level of even/odd split (24576 = 2 * 12288); forward, inverse, batched
-@pytest.mark.parametrize("n", [6, 10, 12, 24, 40, 48, 80, 112, 240, 496, 600, 1000, 1536, 3000, 3072, 7168, 8190, 12288, 16000, 24576,
+# -- alone and underneath one level of even/odd split (24576 = 2 * 12288); forward, inverse, batched.  Round 3: both passes in ONE
+# kernel when 2^p <= 16 and the 2^p residues' Bluestein images fit a workgroup (600, 1000, 1008, 2000, 3000, 6000, 8190: 2^p = 8, 8,
+# 16, 16, 8, 16, 2; batches that do not fill the last workgroup)
+@pytest.mark.parametrize("n", [6, 10, 12, 24, 40, 48, 80, 112, 240, 496, 600, 1000, 1008, 1536, 2000, 3000, 3072, 6000, 7168, 8190, 12288, 16000, 24576,
                                31 * 4096, 33 * 64, 125 * 1024, 8191 * 2, 8191 * 512])
 def test_fft_mixed_radix(tg, orc, n):
     import torch
