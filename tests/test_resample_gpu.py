@@ -115,6 +115,25 @@ def test_resample_seek_shards(tg, orc):
     assert relerr(out, yref) <= TOL
 
 
+@pytest.mark.parametrize("K,ratio", [(127, R160), (31, 0.77), (63, 1.999)])
+def test_resample_seek_shards_long_interpolators(tg, orc, K, ratio):
+    """The same hook through resample_long_kernel: shards that seek to odd absolute positions with their K - 1 samples of halo
+    reproduce the single stream bit for bit (the same multiply-adds whichever tile a sample falls in)."""
+    n, cuts = 300000, [0, 77777, 150001, 262144, 300000]
+    x = rand(n, True, K)
+    ref = orc.Resampler(ratio, K=K, nphases=256, fcut=0.4)
+    one = tg.Resampler(ratio, tg.C64, K=K, nphases=256, lut=ref.lut).step(x.copy())
+    assert relerr(one, ref.step(x)) <= TOL
+    out = np.zeros_like(one)
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        g = tg.Resampler(ratio, tg.C64, K=K, nphases=256, lut=ref.lut)
+        g.seek(lo, x[lo - (K - 1):lo].copy() if lo else None)
+        off = g.out_offset
+        yp = g.step(x[lo:hi].copy())
+        out[off:off + len(yp)] = yp
+    assert np.array_equal(out, one)
+
+
 # known-answer counts of the float32 recurrence (SURVEY.md section 7) -- host schedule only
 def test_resample_counts_known_answers(tg):
     g = tg.Resampler(R160, tg.C64)
