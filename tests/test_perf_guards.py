@@ -16,7 +16,8 @@ GUARDED = ["tests/test_sos_gpu.py::test_sos_unaligned_device_views",
            "tests/test_polyphase_gpu.py::test_filtre_rii_order6_2p26_under_2ms",
            "tests/test_polyphase_gpu.py::test_filtre_rii_complex_order6_2p24_under_1ms",
            "tests/test_polyphase_gpu.py::test_filtre_rii_high_order_is_not_a_cliff",
-           "tests/test_resample_gpu.py::test_short_period_ratios_far_into_a_stream"]
+           "tests/test_resample_gpu.py::test_short_period_ratios_far_into_a_stream",
+           "tests/test_fast_paths_gpu.py"]
 
 
 @pytest.mark.gpu_perf
