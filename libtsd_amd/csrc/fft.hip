@@ -1088,6 +1088,74 @@ __global__ __launch_bounds__(1024) void fft_bluestein_kernel(const cpx *__restri
   }
 }
 
+// ---- n = m * P, m odd <= 15, P = 2^p >= 16, n <= 16384 (48, 96 ... 1536, 3072, 5120, 7168, 12288, 15360): ONE kernel, the power of two on
+// the radix-16 Stockham engine (round 3).  Decimation in time over the odd factor: the m sub-sequences x[m i + r] are P-point
+// transforms F_r -- s16::transform, compile-time radix-16 passes, one LDS image each, all m of a transform in one workgroup --
+// and X[k + P q] = sum_r W_m^(r q) (W_n^(r k) F_r[k]) is an m-point DFT over r per column k, evaluated directly a barrier later
+// from the images (the twiddled F_r written back in natural order).  fft_mr_kernel serves the same sizes with one autosort pass per
+// factor and run-time index arithmetic (~180 VALU instructions per point: 28-36 % of 8 TB/s at 1536 ... 15360); here the
+// power-of-two part costs what it costs the power-of-two plans.  Same accuracy class (direct m-point DFT against the
+// reference's float32-chirp Bluestein of m <= 31 points: < 5e-6).  Inverse = conj o forward o conj.
+template <int R0, int MMAX>
+__global__ __launch_bounds__(1024) void fft_oddpow2_kernel(const cpx *__restrict__ in, cpx *__restrict__ out, const cpx *__restrict__ TW,
+                                                           const cpx *__restrict__ Wm, const cpx *__restrict__ Wn, int m, int P, int tpt,
+                                                           int inverse, float scale, int batch)
+{
+  extern __shared__ __attribute__((aligned(16))) char op_raw[];
+  const int t = threadIdx.x, per = m * tpt, T = (int) blockDim.x / per;       // threads per transform, transforms per workgroup
+  const int tl = t / per, u = t - tl * per, r = u / tpt, j = u - r * tpt;
+  const int n = m * P;
+  const size_t pitch = (size_t) P + (P >> 4);
+  cpx *img0 = reinterpret_cast<cpx *>(op_raw) + (size_t) tl * m * pitch;     // the m images of this thread's transform
+  cpx *img = img0 + (size_t) r * pitch;
+  const int64_t b = (int64_t) blockIdx.x * T + tl;
+  const bool live = tl < T && b < batch;
+  const cpx *x = in + (size_t) b * n;
+  cpx v[16];
+#pragma unroll
+  for (int q = 0; q < 16; q++) {
+    v[q] = cmk(0.f, 0.f);
+    if (live) {
+      v[q] = x[(size_t) (j + q * tpt) * m + r];
+      if (inverse) v[q].y = -v[q].y;
+    }
+  }
+  auto sync = []() { __syncthreads(); };
+  if (tl < T) s16::transform<R0>(v, img, TW, P, j, tpt, sync);
+  else {
+    // (threads past the last whole transform of the workgroup only keep the barriers company -- never the case: blockDim = T per)
+  }
+  sync();                                                    // the image is still being read by the transform's last pass
+#pragma unroll
+  for (int q = 0; q < 16; q++) {
+    const int k = j + q * tpt;
+    img[k] = cmul(v[q], Wn[(size_t) r * k]);                 // W_n^(r k) F_r[k], natural order
+  }
+  sync();
+  if (!live) return;
+  cpx *y = out + (size_t) b * n;
+  for (int k = u; k < P; k += per) {
+    cpx e[MMAX];
+#pragma unroll
+    for (int i = 0; i < MMAX; i++) e[i] = i < m ? img0[(size_t) i * pitch + k] : cmk(0.f, 0.f);
+    for (int qq = 0; qq < m; qq++) {
+      cpx acc = e[0];
+      int idx = 0;
+#pragma unroll
+      for (int i = 1; i < MMAX; i++) {
+        idx += qq;
+        if (idx >= m) idx -= m;
+        if (i < m) {
+          const cpx w = Wm[idx];
+          acc.x = fmaf(e[i].x, w.x, fmaf(-e[i].y, w.y, acc.x));
+          acc.y = fmaf(e[i].x, w.y, fmaf(e[i].y, w.x, acc.y));
+        }
+      }
+      y[k + (size_t) P * qq] = cmk(acc.x * scale, inverse ? -acc.y * scale : acc.y * scale);
+    }
+  }
+}
+
 // Pass 2 of the mixed-radix plan when the power-of-two factor is only 2, 4 or 8: one thread per
 // column k1 combines the PP residues, X[k1 + m k2] at [k2][k1] (natural order).
 template <int PP>
@@ -1161,7 +1229,7 @@ using namespace tsdgpu;
 
 struct tsdgpu_fft {
   int n = 0;
-  enum Kind { ONE, POW2_LDS, POW2_S16, POW2_W1024, POW2_W1M, POW2_4STEP, SMOOTH, MIXED, EVEN, ODD } kind = ONE;
+  enum Kind { ONE, POW2_LDS, POW2_S16, POW2_W1024, POW2_W1M, POW2_4STEP, SMOOTH, ODDPOW2, MIXED, EVEN, ODD } kind = ONE;
   // pow2
   int logn = 0;
   cpx *d_tw = nullptr;        // W_n^k, k < n/2 (LDS path) ...
@@ -1238,6 +1306,24 @@ bool mixed_split(int n, int *m, int *P)
 // n = 2^a 3^b 5^c 7^d 11^e 13^f, not a power of two, <= 16384: the one-kernel mixed-radix plan.
 // Radix sequence: 16s and the remaining 8 / 4 / 2, then the odd primes.  Threads per transform:
 // enough for every pass to keep its butterflies' inputs in MR_PTS registers.
+// n = m * P with m odd in 3 .. 15, P a power of two >= 16, m P / 16 <= 1024 threads and m LDS images within the CU: fft_oddpow2_kernel
+bool oddpow2_split(int n, int *m, int *P)
+{
+  if (n < 48 || n > 16384) return false;
+  int pw = n & -n, odd = n / pw;
+  if (odd < 3 || odd > 15 || pw < 16) return false;
+  if ((size_t) odd * (pw + pw / 16) * sizeof(cpx) > 150 * 1024) return false;
+  // where it beats fft_mr_kernel (profiles/r3_perf_fft_oddpow2.txt; TSDGPU_FFT_ODDPOW2_ALL=1: wherever it fits): the direct
+  // m-point combination grows with m^2 and short transforms leave a workgroup little to do per barrier
+  if (getenv("TSDGPU_FFT_ODDPOW2_ALL") == nullptr) {
+    const bool wins = (odd == 3 && pw >= 32) || (odd == 5 && pw >= 32 && pw <= 1024) || (odd == 7 && pw >= 128 && pw <= 512) ||
+                      (odd == 9 && pw >= 256 && pw <= 512);
+    if (!wins) return false;
+  }
+  *m = odd;
+  *P = pw;
+  return true;
+}
 bool smooth_plan(int n, MrFactors *F, int *tpt_out)
 {
   if (n < 3 || n > 16384 || (n & (n - 1)) == 0) return false;
@@ -1367,6 +1453,20 @@ int plan_init(tsdgpu_fft *p, int n)
       (void) hipFuncSetAttribute((const void *) fft_cols_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       (void) hipGetLastError();
     }
+  } else if (oddpow2_split(n, &p->mix_m, &p->mix_P) && getenv("TSDGPU_FFT_GENERIC") == nullptr && getenv("TSDGPU_FFT_NO_SMOOTH") == nullptr &&
+             getenv("TSDGPU_FFT_NO_ODDPOW2") == nullptr) {
+    p->kind = tsdgpu_fft::ODDPOW2;
+    const int m = p->mix_m, P = p->mix_P;
+    p->logn = log2_exact(P);
+    if ((rc = upload(&p->d_wm, twiddle_table(m, m)))) return rc;             // W_m^j
+    if ((rc = upload(&p->d_rot, twiddle_table(n, n)))) return rc;            // W_n^j
+    if ((rc = upload(&p->d_tw, twiddle_table(P, std::max(1, P / 16))))) return rc;
+#define OP_ATTR(R) (void) hipFuncSetAttribute((const void *) fft_oddpow2_kernel<R, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+  (void) hipFuncSetAttribute((const void *) fft_oddpow2_kernel<R, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                    \
+  (void) hipFuncSetAttribute((const void *) fft_oddpow2_kernel<R, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+    OP_ATTR(16); OP_ATTR(8); OP_ATTR(4); OP_ATTR(2);
+#undef OP_ATTR
+    (void) hipGetLastError();
   } else if (smooth_plan(n, &p->mr, &p->mr_tpt) && getenv("TSDGPU_FFT_GENERIC") == nullptr && getenv("TSDGPU_FFT_NO_SMOOTH") == nullptr) {
     p->kind = tsdgpu_fft::SMOOTH;
     if ((rc = upload(&p->d_rot, twiddle_table(n, n)))) return rc;            // W_n^j
@@ -1699,6 +1799,21 @@ int step_device(tsdgpu_fft *p, const cpx *x, cpx *y, int batch, int forward, hip
       const size_t lds = (size_t) T * (n + n / 16 + 1) * sizeof(cpx);
       hipLaunchKernelGGL(fft_mr_kernel, dim3((unsigned) cdiv(batch, T)), dim3(threads), lds, st, x, y, p->d_rot, p->mr, n, tpt,
                          inverse, 1.0f / std::sqrt((float) n), batch);
+      TSD_HIP(hipGetLastError());
+      return TSDGPU_OK;
+    }
+    case tsdgpu_fft::ODDPOW2: {
+      const int m = p->mix_m, P = p->mix_P, tpt = P / 16, per = m * tpt;
+      const int T = std::max(1, 256 / per), threads = T * per;
+      const size_t lds = (size_t) T * m * (P + P / 16) * sizeof(cpx);
+      const int r0 = 1 << ((p->logn & 3) == 0 ? 4 : (p->logn & 3));
+      const unsigned grid = (unsigned) cdiv(batch, T);
+      const float sc = 1.0f / std::sqrt((float) n);
+#define OP_LAUNCH(R, MM) hipLaunchKernelGGL((fft_oddpow2_kernel<R, MM>), dim3(grid), dim3(threads), lds, st, x, y, p->d_tw, p->d_wm, p->d_rot, m, P, tpt, inverse, sc, batch)
+#define OP_PICK(R) do { if (m <= 3) OP_LAUNCH(R, 4); else if (m <= 7) OP_LAUNCH(R, 8); else OP_LAUNCH(R, 16); } while (0)
+      if (r0 == 16) OP_PICK(16); else if (r0 == 8) OP_PICK(8); else if (r0 == 4) OP_PICK(4); else OP_PICK(2);
+#undef OP_PICK
+#undef OP_LAUNCH
       TSD_HIP(hipGetLastError());
       return TSDGPU_OK;
     }

@@ -302,6 +302,27 @@ def test_fft_smooth_sizes(tg, orc, n, batch, forward):
     assert relerr(z, x) <= 3e-5
 
 
+# n = m * 2^p with m = 3, 5, 7, 9 where fft_oddpow2_kernel serves (the power of two on the radix-16 Stockham engine, the odd factor
+# combined directly a barrier later): every first-pass radix of the engine (2^p = 32 ... 4096), several transforms per workgroup with a
+# ragged last one and one transform per workgroup, both directions, in place; and underneath one even / odd split (24576)
+@pytest.mark.parametrize("n,batch", [(96, 19), (192, 50), (384, 7), (768, 33), (1536, 9), (3072, 5), (6144, 3), (12288, 3), (160, 41), (320, 13),
+                                     (640, 10), (1280, 6), (2560, 4), (5120, 3), (896, 7), (1792, 4), (3584, 3), (2304, 3), (4608, 2), (24576, 2)])
+@pytest.mark.parametrize("forward", [True, False])
+def test_fft_odd_times_power_of_two(tg, orc, n, batch, forward):
+    import torch
+    x = crand((batch, n), n + batch)
+    p = tg.Fft(n, batch)
+    y = p.step(x, forward)
+    for b in sorted({0, 1 % batch, batch // 2, batch - 1}):
+        assert relerr(y[b], orc.fft(x[b], forward)) <= TOL, (n, b)
+    z = p.step(y, not forward)
+    assert relerr(z, x) <= 3e-5
+    xd = torch.from_numpy(x).cuda()
+    yd = p.step(xd, forward, xd)                             # in place on the device
+    torch.cuda.synchronize()
+    assert np.array_equal(yd.cpu().numpy(), y)
+
+
 # single transforms beyond 2^24 points (four-step with columns of up to 16384 points)
 @pytest.mark.parametrize("logn", [25, 26])
 def test_fft_very_large(tg, orc, logn):
