@@ -282,7 +282,8 @@ def test_resampler_dynamic_tiles_forced(tg, orc, monkeypatch, cplx):
 
 @pytest.mark.parametrize("cplx", [False, True])
 @pytest.mark.parametrize("K,nph,ratio", [(127, 256, R160), (127, 256, 0.5), (127, 256, 1.999), (100, 64, 1.2), (31, 256, R160),
-                                         (256, 128, 0.77), (24, 300, 1.0)])
+                                         (256, 128, 0.77), (24, 300, 1.0), (127, 256, 2.0), (64, 1024, 0.50001), (255, 128, 1.37),
+                                         (40, 2047, 1.1), (25, 8191, 0.9)])
 def test_long_interpolator_kernel_bit_for_bit(tg, orc, monkeypatch, K, nph, ratio, cplx):
     """resample_long_kernel (a lane's 8 inputs against a register window, second outputs of an input from a list, the table
     staged in tap slices): the same multiply-adds in the same order as resample_kernel, so the outputs must be IDENTICAL -- with
