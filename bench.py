@@ -111,7 +111,8 @@ class FirWorkload:
         if self.dist:
             # one rank per chunk: interior launched before the halo arrives, edge after (sharding.OverlappedFir)
             from libtsd_amd import sharding
-            self.ov = sharding.OverlappedFir(t, self.h, t.C64, method)
+            self.ov = sharding.OverlappedFir(t, self.h, t.C64, method, edge_stream=True)
+            self.ov.input_ready = True            # (the bench's inputs are resident before the timed region)
             self.f = self.ov.main
         else:
             self.f = t.Fir(self.h, t.C64, t.FIR_AUTO if method is None else method)
@@ -126,6 +127,7 @@ class FirWorkload:
                        "sharding": "contiguous chunks, K-1 halo via RCCL send/recv posted before the interior launch, "
                                    "edge (first K-1 outputs) launched behind it" if self.dist else "single GPU"}
         self.ring = args.force_dist and world == 1
+        self.pipe = None                          # sharding.HaloPipe, made at the first distributed step
         self.traffic_ok = self.method == "overlap-save" and args.log2n == LOG2N and not self.dist     # the shape the PMC passes were run on
 
     def step(self):
@@ -133,8 +135,9 @@ class FirWorkload:
             self.f.step(self.x, self.y)   # one GPU: no neighbour; launched on torch's current stream (passed through the C ABI)
             return
         from libtsd_amd import sharding
-        ex = sharding.start_halo_exchange(self.halo_out, self.halo_in, self.rank, self.world, ring=self.ring, result=self.halo_in_c)
-        self.ov.step(self.x, self.y, ex, first=(self.rank == 0 and not self.ring))
+        if self.pipe is None:
+            self.pipe = sharding.HaloPipe(self.halo_in, self.rank, self.world, ring=self.ring, complex_view=True)
+        self.ov.step(self.x, self.y, lambda: self.pipe.post(self.halo_out), first=(self.rank == 0 and not self.ring), consumed=self.pipe.consumed)
 
     def cpu_baseline(self):
         from oracle import pyoracle as orc
@@ -211,13 +214,15 @@ class SosWorkload:
         self.ring = args.force_dist and world == 1
         if self.dist:
             from libtsd_amd import sharding
-            self.ov = sharding.OverlappedSos(t, self.co, 1.0, t.F32)
+            self.ov = sharding.OverlappedSos(t, self.co, 1.0, t.F32, edge_stream=True)
+            self.ov.input_ready = True
             self.f = self.ov.main
         else:
             self.f = t.Sos(self.co, 1.0, t.F32)
         self.halo = int(self.f.halo)
         self.halo_out = self.x[self.n - self.halo:].clone()
         self.halo_in = torch.zeros(self.halo, dtype=self.x.dtype, device=dev)
+        self.pipe = None
         self.units = float(self.n)
         self.alg_bytes = 8.0 * self.n
         self.metric = "Msamples/s, 6-section SOS IIR on 2^%d float stream" % args.log2n
@@ -232,8 +237,9 @@ class SosWorkload:
             self.f.step(self.x, self.y)
             return
         from libtsd_amd import sharding
-        ex = sharding.start_halo_exchange(self.halo_out, self.halo_in, self.rank, self.world, ring=self.ring)
-        self.ov.step(self.x, self.y, ex, first=(self.rank == 0 and not self.ring))
+        if self.pipe is None:
+            self.pipe = sharding.HaloPipe(self.halo_in, self.rank, self.world, ring=self.ring)
+        self.ov.step(self.x, self.y, lambda: self.pipe.post(self.halo_out), first=(self.rank == 0 and not self.ring), consumed=self.pipe.consumed)
 
     def cpu_baseline(self):
         from oracle import pyoracle as orc
@@ -256,7 +262,9 @@ class ResampleWorkload:
         from libtsd_amd import sharding
         self.dist = world > 1 or args.force_dist
         self.ring = args.force_dist and world == 1
-        self.ov = sharding.OverlappedResampler(t, np.float32(160.0) / np.float32(147.0), t.C64) if self.dist else None
+        self.ov = sharding.OverlappedResampler(t, np.float32(160.0) / np.float32(147.0), t.C64, edge_stream=True) if self.dist else None
+        if self.dist:
+            self.ov.input_ready = True
         self.r = self.ov.main if self.dist else t.Resampler(np.float32(160.0) / np.float32(147.0), t.C64)
         g = torch.Generator(device=dev).manual_seed(5 + rank)
         self.x = torch.view_as_complex(torch.randn(self.n, 2, device=dev, generator=g))
@@ -267,6 +275,7 @@ class ResampleWorkload:
         self.halo_out = torch.view_as_real(self.x[self.n - 14:].clone())
         self.halo_in_c = torch.zeros(14, dtype=self.x.dtype, device=dev)
         self.halo_in = torch.view_as_real(self.halo_in_c)
+        self.pipe = None
         self.units = float(self.n)
         self.alg_bytes = 8.0 * self.n + 8.0 * self.nout
         self.metric = "Msamples/s (input), 160/147 resampling of a cfloat stream, 2^27 inputs per GPU"
@@ -283,8 +292,9 @@ class ResampleWorkload:
             self.r.step(self.x, self.y)
             return
         from libtsd_amd import sharding
-        ex = sharding.start_halo_exchange(self.halo_out, self.halo_in, self.rank, self.world, ring=self.ring, result=self.halo_in_c)
-        self.ov.step(self.x, self.y, self.pos, ex, first=(self.rank == 0 and not self.ring))
+        if self.pipe is None:
+            self.pipe = sharding.HaloPipe(self.halo_in, self.rank, self.world, ring=self.ring, complex_view=True)
+        self.ov.step(self.x, self.y, self.pos, lambda: self.pipe.post(self.halo_out), first=(self.rank == 0 and not self.ring), consumed=self.pipe.consumed)
 
     def cpu_baseline(self):
         from oracle import pyoracle as orc
@@ -311,6 +321,11 @@ def main():
     # exchange becomes a self send / receive: a circular stream) -- how ONE GPU exercises the RCCL calls of the N > 1 path.
     # A diagnostic mode: the headline line is the default one.
     args.force_dist = os.environ.get("TSDGPU_BENCH_FORCE_DIST", "0") not in ("", "0")
+    # stdout carries ONE line -- the JSON record: everything else this process or the libraries under it print there (RCCL writes
+    # its version banner to stdout when NCCL_DEBUG=VERSION, which the GPU boxes export) goes to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -338,6 +353,10 @@ def main():
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank)
+    if dist.is_initialized() and backend == "nccl":
+        # the multi-rank steps run on a stream of their own instead of the legacy default stream: beside RCCL's transfer kernels
+        # and the edge stream the default stream's implicit ordering cost 10-30 us per step (scripts/diag_dist_step.py)
+        torch.cuda.set_stream(torch.cuda.Stream(dev))
 
     w = WORKLOADS[args.workload](t, torch, dev, rank, world, args)
 
@@ -430,7 +449,8 @@ def main():
         if not args.no_cpu:
             out["cpu_baseline"] = w.cpu_baseline()
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if in_dist:
         dist.destroy_process_group()
 

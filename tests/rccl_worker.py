@@ -109,6 +109,69 @@ def main():
     if err > 1e-6:
         fails.append(f"overlapped SOS: {err}")
 
+    # ---- the same steps PIPELINED the way bench.py runs them at N > 1: the exchange on its own stream through two alternating halo
+    # buffers (HaloPipe), posted after the interior launch, the edge on a stream of its own -- five steps in a row on a
+    # non-default compute stream, every step's output against the single handle after wait_outputs()
+    comp = torch.cuda.Stream(dev)
+    with torch.cuda.stream(comp):
+        ovp = sharding.OverlappedFir(t, h, t.C64, t.FIR_OVERLAP_SAVE, edge_stream=True)
+        ovp.input_ready = True
+        pipe = sharding.HaloPipe(torch.zeros(K - 1, 2, device=dev), 0, 1, ring=True, complex_view=True)
+        if not pipe.piped:
+            fails.append("HaloPipe did not take its own stream under nccl")
+        xs = [torch.view_as_complex(torch.randn(n, 2, device=dev)) for _ in range(5)]
+        tails = [torch.view_as_real(v[n - (K - 1):].clone()) for v in xs]
+        ys = [torch.empty_like(v) for v in xs]
+        torch.cuda.synchronize()
+        for v, tl, yv in zip(xs, tails, ys):
+            ovp.step(v, yv, lambda tl=tl: pipe.post(tl), first=False, consumed=pipe.consumed)
+        ovp.wait_outputs()
+        comp.synchronize()
+        for i, (v, yv) in enumerate(zip(xs, ys)):
+            one = t.Fir(h, t.C64, t.FIR_OVERLAP_SAVE)
+            one.set_history(v[n - (K - 1):].clone())
+            refp = one.step(v)
+            e = float((yv - refp).abs().max() / refp.abs().max())
+            if e > 2e-6:
+                fails.append(f"pipelined FIR step {i} vs single handle: {e}")
+        rp = sharding.OverlappedResampler(t, ratio, t.C64, edge_stream=True)
+        rp.input_ready = True
+        pipe14 = sharding.HaloPipe(torch.zeros(14, 2, device=dev), 0, 1, ring=True, complex_view=True)
+        posp = 3 << 20
+        outs = []
+        for v in xs[:3]:
+            yv = torch.empty(rp.counts(posp, n)[1], dtype=v.dtype, device=dev)
+            t14 = torch.view_as_real(v[n - 14:].clone())
+            rp.step(v, yv, posp, lambda t14=t14: pipe14.post(t14), first=False, consumed=pipe14.consumed)
+            outs.append((v, yv))
+        rp.wait_outputs()
+        comp.synchronize()
+        for i, (v, yv) in enumerate(outs):
+            ro = t.Resampler(ratio, t.C64)
+            ro.seek(posp, v[n - 14:].clone())
+            refp = ro.step(v)
+            if refp.shape != yv.shape or not torch.equal(refp, yv):
+                fails.append(f"pipelined resampler step {i} differs from the single handle")
+        sp = sharding.OverlappedSos(t, co, 1.0, t.F32, edge_stream=True)
+        sp.input_ready = True
+        pipeW = sharding.HaloPipe(torch.zeros(W, device=dev), 0, 1, ring=True)
+        xrs = [torch.randn(n, device=dev) for _ in range(4)]
+        yrs = [torch.empty_like(v) for v in xrs]
+        torch.cuda.synchronize()
+        for v, yv in zip(xrs, yrs):
+            tw = v[n - W:].clone()
+            sp.step(v, yv, lambda tw=tw: pipeW.post(tw), first=False, consumed=pipeW.consumed)
+        sp.wait_outputs()
+        comp.synchronize()
+        for i, (v, yv) in enumerate(zip(xrs, yrs)):
+            fo = t.Sos(co, 1.0, t.F32)
+            fo.step(v[n - W:].clone(), scratch)
+            refp = fo.step(v)
+            e = float((yv - refp).abs().max() / refp.abs().max())
+            if e > 1e-6:
+                fails.append(f"pipelined SOS step {i}: {e}")
+    torch.cuda.synchronize()
+
     # ---- exact SOS exchange: the two all_gathers (int64 length, float32 state) with one rank
     from oracle import pyoracle as orc
     z, p, mn, md = orc.design_butter_lp(1, 1e-5)
