@@ -119,6 +119,13 @@ int tsdgpu_fir_set_history(tsdgpu_fir *f, const void *src, void *stream);
  * step, and the step can be captured once (hipStreamBeginCapture ... tsdgpu_fir_step ... EndCapture) and
  * replayed per block -- a few microseconds per small block instead of several launches' worth.  Run one
  * ordinary step of that size first (scratch buffers are allocated on first use, which capture forbids). */
+/* The sharding hook without a copy: filters x[lead .. n) into y[lead .. n), taking the delay line from x[lead - L .. lead) itself
+ * (L = tsdgpu_fir_lead(f) >= K - 1: the handle's history length, a whole number of 64-sample rows on the overlap-save plan; lead >= L).
+ * Equivalent to tsdgpu_fir_set_history(f, x + lead - (K - 1)) followed by tsdgpu_fir_step(f, x + lead, y + lead, n - lead) -- what a
+ * rank does with the halo-free interior of its chunk (libtsd: FiltreRIF::step on a chunk whose delay line holds the samples before
+ * it, filtre-rt.cc:67-108) -- minus the history copy and its launch.  Device buffers, x != y, not on the partitioned plan. */
+int tsdgpu_fir_step_after(tsdgpu_fir *f, const void *x, void *y, int64_t n, int64_t lead, void *stream);
+int tsdgpu_fir_lead(const tsdgpu_fir *f);
 int tsdgpu_fir_set_capturable(tsdgpu_fir *f, int on);
 int tsdgpu_fir_method_used(const tsdgpu_fir *f);         /* DIRECT or OVERLAP_SAVE */
 int tsdgpu_fir_destroy(tsdgpu_fir *f);

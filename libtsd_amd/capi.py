@@ -50,6 +50,9 @@ def _declare(L):
     L.tsdgpu_fir_create.argtypes = [C.POINTER(vp), i32, i32, vp, i32, i32]
     L.tsdgpu_fir_step.argtypes = [vp, vp, vp, i64, vp]
     L.tsdgpu_fir_reset.argtypes = [vp]
+    L.tsdgpu_fir_step_after.argtypes = [vp, vp, vp, i64, i64, vp]
+    L.tsdgpu_fir_lead.argtypes = [vp]
+    L.tsdgpu_fir_lead.restype = i32
     L.tsdgpu_fir_reset_on.argtypes = [vp, vp]
     L.tsdgpu_sos_reset_on.argtypes = [vp, vp]
     L.tsdgpu_fir_get_history.argtypes = [vp, vp, vp]
@@ -235,6 +238,18 @@ class Fir:
 
     def set_history(self, src, stream=None):
         _check(lib().tsdgpu_fir_set_history(self._h, _ptr(src), _stream_of(src, stream)))
+
+    @property
+    def lead(self):
+        """History length of the handle (>= K - 1): the smallest `lead` of step_after."""
+        return int(lib().tsdgpu_fir_lead(self._h))
+
+    def step_after(self, x, y, lead, stream=None):
+        """Filters x[lead:] into y[lead:] with the delay line taken from x[lead - self.lead : lead] itself (device tensors, x is not y):
+        set_history + step of the halo-free interior of a chunk without the copy."""
+        assert _dtype_code(x) == self.data_type
+        _check(lib().tsdgpu_fir_step_after(self._h, _ptr(x), _ptr(y), int(x.shape[0]), int(lead), _stream_of(x, stream)))
+        return y
 
     def close(self):
         if self._h:

@@ -205,8 +205,8 @@ static int launch_direct(const tsdgpu_fir *f, const void *x, void *y, int64_t n,
   if (tiles > 0x7fffffff) return set_err(TSDGPU_ERR_UNSUPPORTED, "fir: n too large for one launch");
   // 16-byte global accesses need 16-byte aligned buffers (tile starts are multiples of 64 B)
   const bool fast = (((uintptr_t) x | (uintptr_t) y) & 15) == 0;
-  const T *hp = (const T *) f->hist[f->cur] + (f->HL - KP);
-  const T *oldh = (const T *) f->hist[f->cur];
+  const T *hp = (const T *) fir_hist_read(f) + (f->HL - KP);
+  const T *oldh = (const T *) fir_hist_read(f);
   T *newh = (T *) f->hist[f->cur ^ 1];
   if (fast)
     hipLaunchKernelGGL((fir_direct_kernel<T, TC, R, THREADS, true>), dim3((unsigned) tiles + 1), dim3(THREADS), lds, st,
@@ -236,10 +236,10 @@ int fir_update_history(tsdgpu_fir *f, const void *x, int64_t n, hipStream_t st)
   const int blocks = (int) cdiv(H, 256);
   if (f->data_type == TSDGPU_F32)
     hipLaunchKernelGGL(fir_hist_update_kernel<float>, dim3(blocks), dim3(256), 0, st,
-                       (const float *) x, (const float *) f->hist[f->cur], (float *) f->hist[nxt], H, n);
+                       (const float *) x, (const float *) fir_hist_read(f), (float *) f->hist[nxt], H, n);
   else
     hipLaunchKernelGGL(fir_hist_update_kernel<float2>, dim3(blocks), dim3(256), 0, st,
-                       (const float2 *) x, (const float2 *) f->hist[f->cur], (float2 *) f->hist[nxt], H, n);
+                       (const float2 *) x, (const float2 *) fir_hist_read(f), (float2 *) f->hist[nxt], H, n);
   TSD_HIP(hipGetLastError());
   f->cur = nxt;
   return TSDGPU_OK;
@@ -437,6 +437,23 @@ int tsdgpu_fir_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, void *stre
   rc = fir_settle_history(f, st);
   if (rc) return rc;
   return finish_out(y, bytes, dy, staged, st);
+}
+
+int tsdgpu_fir_lead(const tsdgpu_fir *f) { return f ? f->HL : -1; }
+
+int tsdgpu_fir_step_after(tsdgpu_fir *f, const void *x, void *y, int64_t n, int64_t lead, void *stream)
+{
+  TSD_CHECK(f != nullptr, "fir_step_after: NULL handle");
+  TSD_CHECK(x != nullptr && y != nullptr && x != y, "fir_step_after: NULL or aliased buffers");
+  TSD_CHECK(is_device_ptr(x) && is_device_ptr(y), "fir_step_after: device buffers expected");
+  TSD_CHECK(f->parts.empty(), "fir_step_after: not available on the partitioned plan (more than 12289 taps)");
+  TSD_CHECK(lead >= f->HL && lead <= n, "fir_step_after: lead %lld outside [%d, n = %lld]", (long long) lead, f->HL, (long long) n);
+  const size_t sz = dtype_size(f->data_type);
+  if (lead == n) return TSDGPU_OK;
+  f->hist_ext = (const char *) x + (size_t) (lead - f->HL) * sz;
+  const int rc = tsdgpu_fir_step(f, (const char *) x + (size_t) lead * sz, (char *) y + (size_t) lead * sz, n - lead, stream);
+  f->hist_ext = nullptr;
+  return rc;
 }
 
 int tsdgpu_fir_set_capturable(tsdgpu_fir *f, int on)

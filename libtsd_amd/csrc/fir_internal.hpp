@@ -12,6 +12,7 @@ struct tsdgpu_fir {
   int method = TSDGPU_FIR_DIRECT;
   void *d_hrev = nullptr;   // reversed zero-padded taps, KP entries of tap_type
   void *hist[2] = {nullptr, nullptr};   // last HL input samples (double-buffered), newest last
+  const void *hist_ext = nullptr;       // tsdgpu_fir_step_after: this call reads its HL history samples here instead (the caller's own buffer)
   int cur = 0;
   bool capturable = false;  // tsdgpu_fir_set_capturable: every step reads hist[0] and leaves the new history there
   std::vector<char> taps_host;
@@ -35,6 +36,7 @@ struct tsdgpu_fir {
 };
 
 namespace tsdgpu {
+inline const void *fir_hist_read(const tsdgpu_fir *f) { return f->hist_ext ? f->hist_ext : f->hist[f->cur]; }
 int fir_direct_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, hipStream_t st);
 int fir_update_history(tsdgpu_fir *f, const void *x, int64_t n, hipStream_t st);
 int fir_settle_history(tsdgpu_fir *f, hipStream_t st);

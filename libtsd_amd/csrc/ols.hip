@@ -637,7 +637,7 @@ int ols_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, hipStream_t st)
   const int WPW = f->ols_wpw;
   const unsigned nwg = (unsigned) cdiv(grid + ne + 1, WPW);
 #define OLS_LAUNCH(REAL, R0, DYN, W)                                                                                                  \
-  hipLaunchKernelGGL((ols_kernel<REAL, R0, DYN, W>), dim3(nwg), dim3(64 * W), 0, st, x, (const void *) f->hist[f->cur],                 \
+  hipLaunchKernelGGL((ols_kernel<REAL, R0, DYN, W>), dim3(nwg), dim3(64 * W), 0, st, x, (const void *) fir_hist_read(f),                 \
                      f->hist[nxt], y, d, d + OLS_N, d + 2 * OLS_N, OLS_N - L, f->HL, L, n, b_lo_w, b_hi, nblocks, (int) grid, ne,   \
                      e[0], e[1], R, dyn)
 #define OLS_LAUNCH_R0(REAL, DYN, W)                                        \
@@ -649,7 +649,7 @@ int ols_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, hipStream_t st)
     default: OLS_LAUNCH(REAL, 0, DYN, W); break;                           \
   }
 #define OLS_LAUNCH_G(REAL, R0, DYN)                                                                                                   \
-  hipLaunchKernelGGL((ols_kernel<REAL, R0, DYN, 1, true>), dim3(nwg), dim3(64), 0, st, x, (const void *) f->hist[f->cur],               \
+  hipLaunchKernelGGL((ols_kernel<REAL, R0, DYN, 1, true>), dim3(nwg), dim3(64), 0, st, x, (const void *) fir_hist_read(f),               \
                      f->hist[nxt], y, d, d + OLS_N, d + 2 * OLS_N, OLS_N - L, f->HL, L, n, b_lo_w, b_hi, nblocks, (int) grid, ne,   \
                      e[0], e[1], R, dyn)
 #define OLS_LAUNCH_G_R0(REAL, DYN)                                        \
@@ -662,7 +662,7 @@ int ols_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, hipStream_t st)
   }
 #if OLS_WITH_WPW4 && OLS_WITH_GEN
 #define OLS_LAUNCH_G4(REAL, R0, DYN)                                                                                                  \
-  hipLaunchKernelGGL((ols_kernel<REAL, R0, DYN, 4, true>), dim3(nwg), dim3(256), 0, st, x, (const void *) f->hist[f->cur],              \
+  hipLaunchKernelGGL((ols_kernel<REAL, R0, DYN, 4, true>), dim3(nwg), dim3(256), 0, st, x, (const void *) fir_hist_read(f),              \
                      f->hist[nxt], y, d, d + OLS_N, d + 2 * OLS_N, OLS_N - L, f->HL, L, n, b_lo_w, b_hi, nblocks, (int) grid, ne,   \
                      e[0], e[1], R, dyn)
 #define OLS_LAUNCH_W(REAL, DYN) \

@@ -154,7 +154,7 @@ int ols_long_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, hipStream_t 
   const size_t lds = (size_t) (N + N / 16) * sizeof(cpx);
   const cpx *H = (const cpx *) f->d_H, *TW = H + N;
 #define OLSL_LAUNCH(R, B)                                                                                         \
-  hipLaunchKernelGGL((ols_long_kernel<R, B>), dim3((unsigned) nblocks), dim3(tpt), lds, st, x, (const void *) f->hist[f->cur], \
+  hipLaunchKernelGGL((ols_long_kernel<R, B>), dim3((unsigned) nblocks), dim3(tpt), lds, st, x, (const void *) fir_hist_read(f), \
                      y, H, TW, N, tpt, f->K, f->HL, L, n)
   if (real) {
     if (r0 == 16) OLSL_LAUNCH(16, true); else if (r0 == 8) OLSL_LAUNCH(8, true); else if (r0 == 4) OLSL_LAUNCH(4, true); else OLSL_LAUNCH(2, true);

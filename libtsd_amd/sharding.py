@@ -165,21 +165,28 @@ class OverlappedFir(_EdgeStream):
 
     def __init__(self, t, taps, data_type, method=None, edge_stream=False):
         self.main = t.Fir(taps, data_type, t.FIR_AUTO if method is None else method)
-        self.edge = t.Fir(taps, data_type, t.FIR_DIRECT)        # H outputs: the direct kernel is one small launch
-        self.H = self.main.K - 1
+        self.edge = t.Fir(taps, data_type, t.FIR_DIRECT)        # the edge's outputs: the direct kernel is one small launch
+        self.H = self.main.K - 1                                 # samples of the neighbour a chunk needs (the halo)
+        # the interior starts `lead` samples into the chunk and reads its delay line out of the chunk itself
+        # (tsdgpu_fir_step_after: no history copy, no extra launch): lead = the handle's history length >= H
+        self.lead = max(self.main.lead, self.H)
         self._init_edge_stream(edge_stream)
 
     def interior(self, x, y):
-        H = self.H
-        if x.shape[0] <= H:
-            return False
-        self.main.set_history(x[:H])
-        self.main.step(x[H:], y[H:])
-        return True
+        if x.shape[0] <= self.lead or not getattr(x, "is_cuda", False) or x.data_ptr() == y.data_ptr():
+            H = self.H                                           # host arrays / in place: the copying form, split at H
+            if x.shape[0] <= H:
+                return 0
+            self.main.set_history(x[:H])
+            self.main.step(x[H:], y[H:])
+            return H
+        self.main.step_after(x, y, self.lead)
+        return self.lead
 
-    def edge_step(self, x, y, halo, first):
-        """halo: the H samples before the chunk (ignored when `first`: the stream starts here, zero delay line)."""
-        H = min(self.H, x.shape[0])
+    def edge_step(self, x, y, halo, first, upto=None):
+        """halo: the H samples before the chunk (ignored when `first`: the stream starts here, zero delay line); upto: outputs
+        the edge owes (the interior's split point)."""
+        H = min(self.H if upto is None else upto, x.shape[0])
         if first:
             self.edge.reset_on(x)
         else:
@@ -190,13 +197,13 @@ class OverlappedFir(_EdgeStream):
     def step(self, x, y, exchange, first, consumed=None):
         """exchange: a posted HaloExchange (or None); consumed: called once the launches that read the halo are enqueued
         (HaloPipe.consumed).  Returns y."""
-        split = self.interior(x, y)
+        split = self.interior(x, y)      # -> the first output the interior wrote (0: the chunk is no longer than the halo)
         if callable(exchange):
-            exchange = exchange()        # (posted AFTER the interior launch: see HaloPipe.post_after_interior)
+            exchange = exchange()        # (posted AFTER the interior launch: see HaloPipe.post)
         if split:
             def edge():
                 halo = exchange.finish() if exchange is not None else None
-                self.edge_step(x, y, halo, first)
+                self.edge_step(x, y, halo, first, split)
                 if consumed is not None:
                     consumed()
             self._on_edge(x, edge)

@@ -231,3 +231,42 @@ def test_ols_dynamic_handout_and_runs(tg, orc, monkeypatch, K, cplx):
         f.reset()
         y = np.concatenate([f.step(x[a:b].copy()) for a, b in zip(cuts[:-1], cuts[1:])])
         assert relerr(y, ref) <= TOL, (run, nc, relerr(y, ref))
+
+
+@pytest.mark.parametrize("K", [31, 127, 600, 2048])
+@pytest.mark.parametrize("cplx", [True, False])
+def test_fir_step_after_reads_its_delay_line_from_the_chunk(tg, orc, K, cplx):
+    """tsdgpu_fir_step_after (the interior of a sharded chunk without the history copy) against set_history(x[lead - (K-1) : lead]) +
+    step(x[lead:]) on every plan: bit for bit on the direct kernel; on the overlap-save plans the blocks also hold the row-alignment
+    samples in front of the K - 1 that matter (the chunk's own here, the handle's older ones there), which moves the transforms'
+    rounding, not the result.  The handle's stream state afterwards included (a second, ordinary step continues); and the oracle."""
+    import torch
+    n = 200000
+    x = rand(n + 5000, cplx, K)
+    h = np.hanning(K).astype(np.float32)
+    h /= h.sum()
+    dt = tg.C64 if cplx else tg.F32
+    xd = torch.from_numpy(x).cuda()
+    a, b = tg.Fir(h, dt), tg.Fir(h, dt)
+    lead = a.lead
+    assert lead >= K - 1
+    for extra in (0, 64, 333):                                   # any lead >= the handle's
+        ld = lead + extra
+        ya = torch.zeros(n, dtype=xd.dtype, device="cuda")
+        yb = torch.zeros(n, dtype=xd.dtype, device="cuda")
+        a.step_after(xd[:n], ya, ld)
+        b.set_history(xd[ld - (K - 1):ld].clone())
+        b.step(xd[ld:n], yb[ld:])
+        torch.cuda.synchronize()
+        exact = a.method == tg.FIR_DIRECT
+        close = lambda u, v: torch.equal(u, v) if exact else float((u - v).abs().max() / v.abs().max()) <= 2e-6
+        assert close(ya, yb), (K, cplx, extra)
+        assert float(ya[:ld].abs().max()) == 0.0                 # nothing before `lead` is written
+        ya2, yb2 = a.step(xd[n:]), b.step(xd[n:])                # the stream goes on from the same state
+        assert close(ya2, yb2)
+    ref = orc.Fir(h).step(x[:n])
+    assert relerr(ya[ld:].cpu().numpy(), ref[ld:]) <= TOL
+    with pytest.raises(tg.TsdGpuError):
+        a.step_after(xd[:n], ya, lead - 1)
+    with pytest.raises(tg.TsdGpuError):
+        a.step_after(xd[:n], xd[:n], lead)
