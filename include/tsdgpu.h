@@ -212,6 +212,10 @@ int tsdgpu_sos_create(tsdgpu_sos **out, int data_type, const float *coefs_host, 
 int tsdgpu_sos_step(tsdgpu_sos *s, const void *x, void *y, int64_t n, void *stream);
 int tsdgpu_sos_reset(tsdgpu_sos *s);
 int tsdgpu_sos_reset_on(tsdgpu_sos *s, void *stream);
+/* tsdgpu_sos_step whose first `skip` outputs are not stored (the sections run over all n samples; y[0 .. skip) is left untouched):
+ * the halo-free interior of a sharded chunk warms up on the chunk's own first samples and writes from sample skip on, in ONE launch.
+ * Distinct device buffers; skip * channels must be a multiple of 4 floats. */
+int tsdgpu_sos_step_skip(tsdgpu_sos *s, const void *x, void *y, int64_t n, int64_t skip, void *stream);
 int tsdgpu_sos_set_capturable(tsdgpu_sos *s, int on);   /* see tsdgpu_fir_set_capturable */   /* the same, ordered on `stream` (no host wait) */
 /* number of warm-up samples a chunk needs before its first output for the carried state
  * to be exact to 2^-30 (multi-GPU halo size); -1 if the filter decays too slowly.       */

@@ -65,6 +65,7 @@ def _declare(L):
     L.tsdgpu_sos_set_state.argtypes = [vp, vp, vp]
     L.tsdgpu_sos_propagate_state.argtypes = [vp, i64, vp, vp, vp]
     L.tsdgpu_sos_step.argtypes = [vp, vp, vp, i64, vp]
+    L.tsdgpu_sos_step_skip.argtypes = [vp, vp, vp, i64, i64, vp]
     L.tsdgpu_sos_reset.argtypes = [vp]
     L.tsdgpu_sos_halo.argtypes = [vp]
     L.tsdgpu_sos_halo.restype = i64
@@ -495,6 +496,12 @@ class Sos:
         if y is None:
             y = np.empty_like(x) if isinstance(x, np.ndarray) else x.new_empty(x.shape)
         _check(lib().tsdgpu_sos_step(self._h, _ptr(x), _ptr(y), x.shape[0], _stream_of(x, stream)))
+        return y
+
+    def step_skip(self, x, y, skip, stream=None):
+        """step() whose first `skip` outputs are not stored (y[:skip] untouched): device tensors, x is not y."""
+        assert _dtype_code(x) == self.data_type
+        _check(lib().tsdgpu_sos_step_skip(self._h, _ptr(x), _ptr(y), x.shape[0], int(skip), _stream_of(x, stream)))
         return y
 
     def reset(self):

@@ -228,7 +228,8 @@ template <int NCH, int MODE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SOS_WPE, SOS_WPE))) void sos_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                  const SosSection *__restrict__ sec, int nsec, float gain,
                                                  const float *__restrict__ st_in, float *__restrict__ st_out,
-                                                 int64_t n_sub, int spc, int warm_sub, int warm_nar, float *__restrict__ carry)
+                                                 int64_t n_sub, int spc, int warm_sub, int warm_nar, float *__restrict__ carry,
+                                                 int64_t skip_f)
 {
   if (MODE == 1 && blockIdx.x + 1 == gridDim.x) return;       // nobody starts from the last chunk's end state
 #if SOS_SWIZZLE
@@ -295,10 +296,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SOS_WPE, SOS
       }
       wave_sync();
       float *yt = y + t * SUB_FLOATS;
+      // (tsdgpu_sos_step_skip: the first skip_f floats of the call -- a multiple of 4 -- are filtered but not stored)
+      const int64_t keep_from = skip_f - t * SUB_FLOATS;
 #pragma unroll
       for (int i = 0; i < LANE_QUADS; i++) {
         const int p = 4 * (i * 64 + lane);
-        *reinterpret_cast<float4 *>(yt + p) = *reinterpret_cast<const float4 *>(&lds[sos_img(p)]);
+        if (p >= keep_from) *reinterpret_cast<float4 *>(yt + p) = *reinterpret_cast<const float4 *>(&lds[sos_img(p)]);
       }
       wave_sync();
     }
@@ -420,7 +423,7 @@ __global__ __launch_bounds__(64) void sos_carry_kernel(float *__restrict__ carry
 // of 2048 floats.)  x must be 16-B aligned at float f0 (it is: f0 is a multiple of 2048 floats of an aligned buffer).
 template <int NCH>
 __global__ __launch_bounds__(64) void sos_tail_kernel(const float *__restrict__ x, float *__restrict__ y, const SosSection *__restrict__ sec,
-                                                      int nsec, float gain, float *__restrict__ st, int64_t f0, int64_t f1)
+                                                      int nsec, float gain, float *__restrict__ st, int64_t f0, int64_t f1, int64_t skip_f)
 {
   __shared__ float sst[SOS_MAX_SEC * 8];
   __shared__ float buf[LANE_FLOATS];
@@ -458,7 +461,7 @@ __global__ __launch_bounds__(64) void sos_tail_kernel(const float *__restrict__ 
 #pragma unroll
     for (int i = 0; i < LANE_QUADS; i++) {
       const int p = 4 * (i * 64 + lane);
-      if (p < nf) *reinterpret_cast<float4 *>(y + f + p) = *reinterpret_cast<const float4 *>(&lds[(p / LANE_FLOATS) * LDS_LANE_PITCH + (p % LANE_FLOATS)]);
+      if (p < nf && f + p >= skip_f) *reinterpret_cast<float4 *>(y + f + p) = *reinterpret_cast<const float4 *>(&lds[(p / LANE_FLOATS) * LDS_LANE_PITCH + (p % LANE_FLOATS)]);
     }
     wave_sync();
     f += nf;
@@ -500,7 +503,8 @@ __global__ __launch_bounds__(64) void sos_tail_kernel(const float *__restrict__ 
       }
     }
     wave_sync();
-    for (int i = lane; i < m; i += 64) y[f + i] = buf[i];
+    for (int i = lane; i < m; i += 64)
+      if (f + i >= skip_f) y[f + i] = buf[i];
     if (actif) { ss[0] = d1; ss[1] = d1 - k.sg * d2; ss[2] = x1; ss[3] = x2; }
     wave_sync();
   }
@@ -524,6 +528,7 @@ struct tsdgpu_sos {
   int cur = 0;
   bool capturable = false;      // tsdgpu_sos_set_capturable: the state is back in d_state[0] after every step
   int64_t halo = 0;             // W: samples after which the state transition is below 1e-9
+  int64_t skip_f = 0;           // tsdgpu_sos_step_skip: floats at the start of the current call that are filtered but not stored
   DevBuf in_stage, out_stage;
   // exact carry of the state from chunk to chunk (long-memory filters, see sos_kernel)
   int comps = 2;                // state values per section and channel in the carry: 2 (DF2 chain) or 4 (a DF1 section: + its last two inputs)
@@ -929,7 +934,7 @@ int tsdgpu_sos_step(tsdgpu_sos *s, const void *x, void *y, int64_t n, void *stre
       const size_t cl = ((size_t) m * m + 2 * per + (size_t) CARRY_BLOCK * per) * sizeof(double);
 #define SOS_LAUNCH(NCH, MODE)                                                                                              \
   hipLaunchKernelGGL((sos_kernel<NCH, MODE>), dim3((unsigned) nch_ex), dim3(64), sos_dyn_lds, st, (const float *) dx, (float *) dy, s->d_sec, \
-                     s->nsec, s->gain, st_in, st_out, n_sub, (int) spc_ex, 0, 0, carry)
+                     s->nsec, s->gain, st_in, st_out, n_sub, (int) spc_ex, 0, 0, carry, s->skip_f)
       if (nch == 1) SOS_LAUNCH(1, 1); else SOS_LAUNCH(2, 1);
       const int mp = per > 64 || m > 16 ? 0 : m <= 2 ? 2 : m <= 4 ? 4 : m <= 8 ? 8 : 16;
 #define CARRY_LAUNCH(MP)                                                                                                   \
@@ -947,10 +952,10 @@ int tsdgpu_sos_step(tsdgpu_sos *s, const void *x, void *y, int64_t n, void *stre
       nchunks = nch_ex;
     } else if (nch == 1) {
       hipLaunchKernelGGL((sos_kernel<1, 0>), dim3((unsigned) nchunks), dim3(64), sos_dyn_lds, st, (const float *) dx, (float *) dy,
-                         s->d_sec, s->nsec, s->gain, st_in, st_out, n_sub, (int) spc, (int) warm_sub, (int) warm_nar, (float *) nullptr);
+                         s->d_sec, s->nsec, s->gain, st_in, st_out, n_sub, (int) spc, (int) warm_sub, (int) warm_nar, (float *) nullptr, s->skip_f);
     } else {
       hipLaunchKernelGGL((sos_kernel<2, 0>), dim3((unsigned) nchunks), dim3(64), sos_dyn_lds, st, (const float *) dx, (float *) dy,
-                         s->d_sec, s->nsec, s->gain, st_in, st_out, n_sub, (int) spc, (int) warm_sub, (int) warm_nar, (float *) nullptr);
+                         s->d_sec, s->nsec, s->gain, st_in, st_out, n_sub, (int) spc, (int) warm_sub, (int) warm_nar, (float *) nullptr, s->skip_f);
     }
     TSD_HIP(hipGetLastError());
     s->cur ^= 1;
@@ -961,14 +966,15 @@ int tsdgpu_sos_step(tsdgpu_sos *s, const void *x, void *y, int64_t n, void *stre
     float *stc = s->d_state[s->cur];
     if (nch == 1)
       hipLaunchKernelGGL(sos_tail_kernel<1>, dim3(1), dim3(64), 0, st, (const float *) dx, (float *) dy, s->d_sec, s->nsec,
-                         s->gain, stc, n_sub * SUB_FLOATS, nfl);
+                         s->gain, stc, n_sub * SUB_FLOATS, nfl, s->skip_f);
     else
       hipLaunchKernelGGL(sos_tail_kernel<2>, dim3(1), dim3(64), 0, st, (const float *) dx, (float *) dy, s->d_sec, s->nsec,
-                         s->gain, stc, n_sub * SUB_FLOATS, nfl);
+                         s->gain, stc, n_sub * SUB_FLOATS, nfl, s->skip_f);
     TSD_HIP(hipGetLastError());
   }
   if (dy_user) {
-    TSD_HIP(hipMemcpyAsync(dy_user, dy, bytes, hipMemcpyDeviceToDevice, st));
+    const size_t sk = (size_t) s->skip_f * sizeof(float);      // (tsdgpu_sos_step_skip: nothing before the first stored float)
+    TSD_HIP(hipMemcpyAsync((char *) dy_user + sk, (const char *) dy + sk, bytes - sk, hipMemcpyDeviceToDevice, st));
     dy = dy_user;
   }
   if (s->capturable && s->cur == 1) {
@@ -977,6 +983,20 @@ int tsdgpu_sos_step(tsdgpu_sos *s, const void *x, void *y, int64_t n, void *stre
     s->cur = 0;
   }
   return finish_out(y, bytes, dy, staged, st);
+}
+
+int tsdgpu_sos_step_skip(tsdgpu_sos *s, const void *x, void *y, int64_t n, int64_t skip, void *stream)
+{
+  TSD_CHECK(s != nullptr, "sos_step_skip: NULL handle");
+  TSD_CHECK(skip >= 0 && skip <= n, "sos_step_skip: skip %lld outside [0, n = %lld]", (long long) skip, (long long) n);
+  TSD_CHECK(n == 0 || (x != nullptr && y != nullptr && x != y && is_device_ptr(x) && is_device_ptr(y)), "sos_step_skip: distinct device buffers expected");
+  const int64_t sf = skip * s->nch;
+  if (sf % 4 != 0)
+    return set_err(TSDGPU_ERR_UNSUPPORTED, "sos_step_skip: skip * channels = %lld is not a multiple of 4 floats", (long long) sf);
+  s->skip_f = sf;
+  const int rc = tsdgpu_sos_step(s, x, y, n, stream);
+  s->skip_f = 0;
+  return rc;
 }
 
 int tsdgpu_sos_set_capturable(tsdgpu_sos *s, int on)

@@ -408,3 +408,28 @@ def test_sos_state_vector_and_propagation(tg, orc, cplx, order, fc, forme):
     scale = max(float(np.abs(direct[1:][garde]).max()), 1e-6)
     assert np.abs(via[1:] - direct[1:])[garde].max() <= 5e-5 * scale, np.abs(via[1:] - direct[1:])[garde].max() / scale
     assert np.array_equal(a.propagate_state(0, st), st)   # zero samples: the identity
+
+
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("n,skip", [(300000, 256), (300000, 0), (5000, 256), (1500, 256), (2048 * 3 + 77, 2048 + 512), (300, 300), (70000, 4444)])
+def test_sos_step_skip_filters_everything_and_stores_from_skip_on(tg, orc, n, skip, cplx):
+    """tsdgpu_sos_step_skip (the interior of a sharded chunk: warm-up and interior in one launch): bit for bit step(x) from sample
+    `skip` on, nothing written before it, the stream state afterwards the same -- whole sub-tiles, ragged ends, calls shorter than
+    a sub-tile, skips inside / across / at the end of a sub-tile."""
+    import torch
+    z, p, mn, md = orc.design_butter_lp(6, 0.2)
+    co, gain, r1 = orc.SosChain(z, p, mn, md).coefs()
+    dt = tg.C64 if cplx else tg.F32
+    x = rand(n + 1000, cplx, n + skip)
+    xd = torch.from_numpy(x).cuda()
+    a, b = tg.Sos(co, gain, dt, r1), tg.Sos(co, gain, dt, r1)
+    ya = torch.full((n,), 7.0, dtype=xd.dtype, device="cuda")
+    a.step_skip(xd[:n], ya, skip)
+    yb = b.step(xd[:n])
+    torch.cuda.synchronize()
+    assert torch.equal(ya[skip:], yb[skip:])
+    assert bool((ya[:skip] == 7.0).all())
+    assert torch.equal(a.step(xd[n:]), b.step(xd[n:]))          # same stream state
+    if cplx is False:
+        with pytest.raises(tg.TsdGpuError):
+            a.step_skip(xd[:n], ya, 3)                           # 3 floats: not a multiple of 4
