@@ -743,12 +743,21 @@ static int sharded_step_parts_impl(tsdgpu_sharded *h, const void *const *x_parts
     char *yg = (char *) y_parts[g];
     if (h->kind == K_FIR) {
       tsdgpu_fir *fm = (tsdgpu_fir *) h->handle[g], *fe = (tsdgpu_fir *) h->edge[g];
-      rc = tsdgpu_fir_set_history(fm, xg, st);                                   // interior: primed with the part's own head
-      if (!rc) rc = tsdgpu_fir_step(fm, xg + (size_t) H * esz, yg + (size_t) H * esz, cnt - H, st);
+      // interior: the part's own head is its delay line -- read in place when the part is not filtered in place and is longer
+      // than the handle's history (tsdgpu_fir_step_after: no copy, one launch), copied otherwise; the edge owes the outputs before it
+      const int64_t lead = tsdgpu_fir_lead(fm);
+      int64_t He = H;
+      if (!in_place(g) && cnt > lead && lead >= H) {
+        rc = tsdgpu_fir_step_after(fm, xg, yg, cnt, lead, st);
+        He = lead;
+      } else {
+        rc = tsdgpu_fir_set_history(fm, xg, st);
+        if (!rc) rc = tsdgpu_fir_step(fm, xg + (size_t) H * esz, yg + (size_t) H * esz, cnt - H, st);
+      }
       if (rc) break;
-      TSD_HIP(hipStreamWaitEvent(st, h->ev_halo[g], 0));                         // edge: the first H outputs need the halo
+      TSD_HIP(hipStreamWaitEvent(st, h->ev_halo[g], 0));                         // edge: the first outputs need the halo
       rc = tsdgpu_fir_set_history(fe, h->halo[g].p, st);
-      if (!rc) rc = tsdgpu_fir_step(fe, xg, yg, H, st);
+      if (!rc) rc = tsdgpu_fir_step(fe, xg, yg, He, st);
       got[(size_t) g] = cnt;
     } else {
       tsdgpu_resampler *rm = (tsdgpu_resampler *) h->handle[g], *re = (tsdgpu_resampler *) h->edge[g];
