@@ -23,11 +23,25 @@ run TSDGPU_SOS_CHUNKS=4096 tests/test_sos_gpu.py
 run TSDGPU_SHARD_SOS_HALO=1 tests/test_sharded_gpu.py -k "not long_memory"
 run TSDGPU_SOS_NO_EXACT_CARRY=1 tests/test_sos_gpu.py tests/test_sharded_gpu.py -k "not long_memory"
 # (the tests that assert WHICH path serves a filter, or its speed, are about the default choice)
-run TSDGPU_RII_LITERAL=1 tests/test_polyphase_gpu.py -k "not block_parallel and not under_2ms and not cliff and not literal_fallback and not complex_coefficients"
+run TSDGPU_RII_LITERAL=1 tests/test_polyphase_gpu.py -k "not block_parallel and not under_2ms and not under_1ms and not cliff and not literal_fallback and not complex_coefficients"
 run TSDGPU_NO_BOUNCE=1 tests/test_fir_gpu.py tests/test_sos_gpu.py tests/test_fft_gpu.py
 run TSDGPU_NO_PIPE=1 tests/test_host_pipeline_gpu.py
 run TSDGPU_PIPE_ONE_THREAD=1 tests/test_host_pipeline_gpu.py
 run TSDGPU_PIPE_CHUNK_MB=1 tests/test_host_pipeline_gpu.py
 run TSDGPU_OLS_LONG_MIN=200 tests/test_fir_gpu.py
 run TSDGPU_RS_WG_PER_CU=2 tests/test_resample_gpu.py
+# round 3
+run TSDGPU_OLS_DYN=0 tests/test_fir_gpu.py
+run TSDGPU_OLS_RUN=1 tests/test_fir_gpu.py
+run TSDGPU_RS_DYN=0 tests/test_resample_gpu.py
+run TSDGPU_FFT_DYN=0 tests/test_fft_gpu.py
+run TSDGPU_RS_LONG=0 tests/test_resample_gpu.py -k "not bit_for_bit"
+run TSDGPU_RS_LONG_KMIN=8 tests/test_resample_gpu.py -k "not bit_for_bit"
+run TSDGPU_RS15=0 tests/test_resample_gpu.py -k "not dynamic_tiles"
+run TSDGPU_OLAW512=0 tests/test_ola_gpu.py
+run TSDGPU_FFT_MIXED_UNFUSED=1 tests/test_fft_gpu.py tests/test_fft_sweep_gpu.py
+run TSDGPU_FFT_NO_ODDPOW2=1 tests/test_fft_gpu.py tests/test_fft_sweep_gpu.py
+run TSDGPU_FFT_ODDPOW2_ALL=1 tests/test_fft_gpu.py tests/test_fft_sweep_gpu.py
+run TSDGPU_FFT_CTMAX=8 tests/test_fft_gpu.py
+run TSDGPU_SHARD_NO_OVERLAP=1 tests/test_sharded_gpu.py
 exit $FAILED
