@@ -99,7 +99,7 @@ class FirWorkload:
 
     def __init__(self, t, torch, dev, rank, world, args, method=None):
         self.t, self.rank, self.world = t, rank, world
-        self.n = 1 << args.log2n
+        self.n = _per_rank(1 << args.log2n, world, args)
         self.h = design_lowpass(K_TAPS, 0.02)
         g = torch.Generator(device=dev).manual_seed(2 + rank)
         self.x = torch.view_as_complex(torch.randn(self.n, 2, device=dev, generator=g))
@@ -122,13 +122,13 @@ class FirWorkload:
         self.metric = "Msamples/s, 127-tap FIR on 2^%d cfloat stream" % args.log2n
         self.dtype = "f32 (complex64 data, real f32 taps)"
         self.config = {"workload": "configs[1]: 127-tap FIR (design_rif_fen lp 0.02, real taps via filtrer()) "
-                                   "on 2^%d-sample Veccf per GPU, inputs resident in HBM" % args.log2n,
+                                   "on %s, inputs resident in HBM" % _size_note("Veccf", 1 << args.log2n, world, args),
                        "method": self.method, "samples_per_gpu": self.n,
                        "sharding": "contiguous chunks, K-1 halo via RCCL send/recv posted before the interior launch, "
                                    "edge (first K-1 outputs) launched behind it" if self.dist else "single GPU"}
         self.ring = args.force_dist and world == 1
         self.pipe = None                          # sharding.HaloPipe, made at the first distributed step
-        self.traffic_ok = self.method == "overlap-save" and args.log2n == LOG2N and not self.dist     # the shape the PMC passes were run on
+        self.traffic_ok = self.method == "overlap-save" and self.n == 1 << LOG2N and not self.dist     # the shape the PMC passes were run on
 
     def step(self):
         if not self.dist:
@@ -172,7 +172,7 @@ class FftWorkload:
     unit = "Mpoints/s"
 
     def __init__(self, t, torch, dev, rank, world, args):
-        self.nfft, self.batch = 1 << 20, 256
+        self.nfft, self.batch = 1 << 20, _per_rank(256, world, args)
         g = torch.Generator(device=dev).manual_seed(3 + rank)
         self.x = torch.view_as_complex(torch.randn(self.batch * self.nfft, 2, device=dev, generator=g)).reshape(self.batch, self.nfft)
         self.y = torch.empty_like(self.x)
@@ -181,7 +181,7 @@ class FftWorkload:
         self.alg_bytes = 16.0 * self.units
         self.metric = "Mpoints/s, 2^20-point complex FFT, batch 256"
         self.dtype = "f32 (complex64)"
-        self.config = {"workload": "configs[2]: fft() of 256 x Veccf[2^20] per GPU, unitary scaling, inputs resident in HBM",
+        self.config = {"workload": "configs[2]: fft() of %d x Veccf[2^20] per GPU, unitary scaling, inputs resident in HBM" % self.batch,
                        "sharding": "batch index split, no exchange" if world > 1 else "single GPU"}
         self.traffic_ok = self.batch == 256
 
@@ -204,7 +204,7 @@ class SosWorkload:
     def __init__(self, t, torch, dev, rank, world, args):
         from scipy.signal import butter
         self.rank, self.world = rank, world
-        self.n = 1 << args.log2n
+        self.n = _per_rank(1 << args.log2n, world, args)
         sos = butter(12, 0.5, output="sos")          # fcut 0.25 of fs; coefficients = bench input data
         self.co = np.array([[s[0], s[1], s[2], s[4], s[5]] for s in sos], np.float32)
         g = torch.Generator(device=dev).manual_seed(4 + rank)
@@ -227,10 +227,10 @@ class SosWorkload:
         self.alg_bytes = 8.0 * self.n
         self.metric = "Msamples/s, 6-section SOS IIR on 2^%d float stream" % args.log2n
         self.dtype = "f32"
-        self.config = {"workload": "configs[3]: 6 DF2 biquads (Butterworth order 12, fc 0.25) on 2^%d-sample Vecf per GPU" % args.log2n,
+        self.config = {"workload": "configs[3]: 6 DF2 biquads (Butterworth order 12, fc 0.25) on %s" % _size_note("Vecf", 1 << args.log2n, world, args),
                        "halo_samples": self.halo,
                        "sharding": "contiguous chunks, warm-up halo via RCCL send/recv posted before the interior launch" if self.dist else "single GPU"}
-        self.traffic_ok = args.log2n == LOG2N and not self.dist
+        self.traffic_ok = self.n == 1 << LOG2N and not self.dist
 
     def step(self):
         if not self.dist:
@@ -258,7 +258,7 @@ class ResampleWorkload:
 
     def __init__(self, t, torch, dev, rank, world, args):
         self.rank, self.world = rank, world
-        self.n = 1 << 27
+        self.n = _per_rank(1 << 30, world, args) if args.scaling == "strong" else 1 << 27
         from libtsd_amd import sharding
         self.dist = world > 1 or args.force_dist
         self.ring = args.force_dist and world == 1
@@ -278,12 +278,13 @@ class ResampleWorkload:
         self.pipe = None
         self.units = float(self.n)
         self.alg_bytes = 8.0 * self.n + 8.0 * self.nout
-        self.metric = "Msamples/s (input), 160/147 resampling of a cfloat stream, 2^27 inputs per GPU"
+        self.metric = "Msamples/s (input), 160/147 resampling of a cfloat stream, %d inputs per GPU" % self.n if args.scaling == "strong" \
+            else "Msamples/s (input), 160/147 resampling of a cfloat stream, 2^27 inputs per GPU"
         self.dtype = "f32 (complex64 data, f32 LUT taps)"
-        self.config = {"workload": "configs[4]: filtre_reechan(160/147) interpolator on a 2^27-sample Veccf shard per GPU "
-                                   "(2^30 over 8 GPUs)", "outputs_per_gpu": self.nout,
+        self.config = {"workload": "configs[4]: filtre_reechan(160/147) interpolator on a %d-sample Veccf shard per GPU "
+                                   "(2^30 over %s GPUs)" % (self.n, world if args.scaling == "strong" else 8), "outputs_per_gpu": self.nout,
                        "sharding": "contiguous input chunks, 14-sample halo via RCCL send/recv posted before the interior launch + seek" if self.dist else "single GPU"}
-        self.traffic_ok = not self.dist
+        self.traffic_ok = not self.dist and self.n == 1 << 27
 
     def step(self):
         if not self.dist:
@@ -308,6 +309,43 @@ class ResampleWorkload:
 WORKLOADS = {"fir": FirWorkload, "fft": FftWorkload, "sos": SosWorkload, "resample": ResampleWorkload}
 
 
+def _per_rank(total, world, args):
+    """weak: every rank takes `total`; strong: the total is split over the ranks (it must divide)"""
+    if args.scaling != "strong":
+        return total
+    assert total % world == 0, f"--scaling strong: {total} units do not split over {world} ranks"
+    return total // world
+
+
+def _size_note(kind, total, world, args):
+    if args.scaling == "strong":
+        return "%d-sample %s in total, %d per GPU" % (total, kind, total // world)
+    return "2^%d-sample %s per GPU" % (total.bit_length() - 1, kind)
+
+
+def _self_launch(args):
+    """`python3 bench.py --gpus N` started WITHOUT a launcher (WORLD_SIZE unset): start the N ranks as CHILD processes
+    through torch.distributed.run, relay rank 0's JSON line and return the launcher's exit code.  Called before this
+    process has imported torch or touched the GPU: nothing is exec'ed and no GPU-initialised process is relaunched."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on these hosts
+    env.setdefault("OMP_NUM_THREADS", "1")
+    env["TSDGPU_BENCH_SELF_LAUNCHED"] = "1"
+    p = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+    for ln in p.stdout:
+        # stdout carries the ONE JSON line; anything else the launcher or a library wrote there goes to stderr
+        (sys.stdout if ln.startswith("{") else sys.stderr).write(ln)
+    sys.stdout.flush()
+    return p.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -316,7 +354,15 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="fir")
     ap.add_argument("--log2n", type=int, default=LOG2N, help="fir/sos: samples per GPU = 2^log2n (default: the BASELINE size)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default): the per-GPU size is fixed; strong: the TOTAL is fixed and split over the ranks "
+                         "(resample: the 2^30 inputs of configs[4]; fir/sos: 2^log2n samples; fft: the 256 transforms)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="launcher check for a box without N GPUs: the ranks rendezvous (gloo), run the barrier and the max-over-ranks "
+                         "reduction of the bench and rank 0 prints a record with value null; no GPU work, nothing measured")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(_self_launch(args))
     # TSDGPU_BENCH_FORCE_DIST=1: `--gpus 1` also goes through init_process_group(backend) and the multi-rank step (the halo
     # exchange becomes a self send / receive: a circular stream) -- how ONE GPU exercises the RCCL calls of the N > 1 path.
     # A diagnostic mode: the headline line is the default one.
@@ -336,8 +382,24 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     backend = None
+    if args.rendezvous_only:
+        assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+        t0 = time.perf_counter()
+        dist.barrier()
+        dt = sharding.max_over_ranks(time.perf_counter() - t0 + 1e-3 * rank, None, world, force=True)
+        assert dt >= 1e-3 * (world - 1)       # the slowest rank's time is what every rank holds
+        if rank == 0:
+            os.write(json_fd, (json.dumps({"rendezvous_only": True, "value": None, "n_gpus": world, "scaling": args.scaling,
+                                           "config": {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                                                      "self_launched": os.environ.get("TSDGPU_BENCH_SELF_LAUNCHED") == "1"}}) + "\n").encode())
+        dist.destroy_process_group()
+        return
     if world > 1 or args.gpus > 1 or args.force_dist:
-        assert world == args.gpus, f"launch with torch.distributed.run --nproc-per-node {args.gpus}"
+        assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}: start `python3 bench.py --gpus {args.gpus}` (it launches its own ranks) or torch.distributed.run --nproc-per-node {args.gpus}"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         # TSDGPU_BENCH_BACKEND=gloo: rehearsal of the multi-rank path on a box with fewer GPUs than
@@ -425,11 +487,12 @@ def main():
         # "did the collective library see N ranks" is answerable from the record
         cfg["backend"] = (dist.get_backend() + (" (RCCL)" if dist.get_backend() == "nccl" else "")) if in_dist else "none (one process, one GPU)"
         cfg["world_size"] = dist.get_world_size() if in_dist else 1
+        cfg["self_launched"] = os.environ.get("TSDGPU_BENCH_SELF_LAUNCHED") == "1"
         out = {
             "metric": w.metric, "value": round(value, 1), "unit": w.unit,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": w.dtype, "data": "synthetic", "config": cfg,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4),

@@ -19,7 +19,9 @@ def main():
     rank, world = dist.get_rank(), dist.get_world_size()
     import libtsd_amd as t
     from libtsd_amd import sharding
-    dev = torch.device("cuda", 0)
+    # one device per rank where the box has them (a node: the ranks sit on distinct GPUs); they share device 0 on the one-GPU box
+    dev = torch.device("cuda", rank % max(1, torch.cuda.device_count()))
+    torch.cuda.set_device(dev)
     rng = np.random.default_rng(42)
     n = 600001
     x = (rng.standard_normal(n) + 1j * rng.standard_normal(n)).astype(np.complex64)

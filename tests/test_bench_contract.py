@@ -58,11 +58,68 @@ def test_committed_bench_lines_follow_the_contract():
         assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1
 
 
+def test_bench_launches_its_own_ranks_without_a_launcher():
+    """`python3 bench.py --gpus 2` the way the driver starts `--gpus 1` (no launcher in the command line, WORLD_SIZE unset):
+    bench.py starts the two ranks as CHILD processes before anything touches a GPU, they rendezvous on 127.0.0.1 (gloo here,
+    CPU tier), run the barrier and the max-over-ranks reduction, and the parent relays rank 0's one JSON line and the exit
+    code.  --rendezvous-only stops there (no GPU in this tier); the same command without it is test_bench_two_ranks_rehearsal's
+    self-launched case on the GPU box."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rendezvous-only"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout       # stdout carries the ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["world_size"] == 2 and d["config"]["self_launched"] is True and d["value"] is None
+
+
+def test_bench_self_launch_relays_a_failing_rank():
+    """without a GPU the ranks fail loudly (no CPU fallback): the parent's exit code is the launcher's, and no JSON line appears"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_strong_scaling_sizes():
+    """--scaling strong splits BASELINE.json's totals over the ranks (configs[4]: 2^30 inputs), weak keeps the per-GPU size"""
+    sys.path.insert(0, ROOT)
+    import argparse
+    import bench
+    strong, weak = argparse.Namespace(scaling="strong"), argparse.Namespace(scaling="weak")
+    assert bench._per_rank(1 << 30, 8, strong) == 1 << 27 and bench._per_rank(1 << 30, 1, strong) == 1 << 30
+    assert bench._per_rank(1 << 26, 8, weak) == 1 << 26 and bench._per_rank(256, 4, strong) == 64
+    with pytest.raises(AssertionError):
+        bench._per_rank(256, 3, strong)
+
+
 def _free_port():
     import socket
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         return so.getsockname()[1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_two_ranks_self_launched(scaling):
+    """`python3 bench.py --gpus 2` with NO launcher in the command line (how the driver starts --gpus 1): bench.py launches
+    its two ranks itself; rehearsed on ONE GPU over gloo like the test below.  strong: the 2^26 samples are split in two."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["TSDGPU_BENCH_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--scaling", scaling],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["value"] > 0
+    assert d["config"]["backend"] == "gloo" and d["config"]["world_size"] == 2 and d["config"]["self_launched"] is True
+    assert d["config"]["samples_per_gpu"] == (1 << 25 if scaling == "strong" else 1 << 26)
 
 
 @pytest.mark.gpu

@@ -1,8 +1,9 @@
 """One process, N shards (tsdgpu_sharded_*, row e of SURVEY.md section 8): the concatenated outputs of the
 HIP operators run as N logical shards equal the single-handle run -- bit for bit where the operator
 is chunk-invariant (direct FIR, resampler), to float rounding for the SOS chain (warm-up halo exact to
-1e-9 of the state, tiling shifted) and for the overlap-save FIR (block alignment differs).  All shards name device 0 on the
-one-GPU box; on a node they land on different devices through the same code (peer copies)."""
+1e-9 of the state, tiling shifted) and for the overlap-save FIR (block alignment differs).  The shards are spread round-robin
+over every device the box has (`devs`): all on device 0 on the one-GPU box, and on a node the SAME tests run the peer copies /
+peer access of csrc/sharded.hip (hipMemcpyPeerAsync, hipDeviceEnablePeerAccess) between distinct devices."""
 import numpy as np
 import pytest
 
@@ -21,6 +22,19 @@ def tg():
     import libtsd_amd as t
     assert t.device_count() >= 1
     return t
+
+
+def devs(N):
+    """device ordinal of each of N shards: round-robin over the box's devices (one GPU: all 0)"""
+    import libtsd_amd as t
+    nd = max(1, t.device_count())
+    return [g % nd for g in range(N)]
+
+
+def on_dev(a, g, N):
+    """host array -> resident tensor on the device of shard g of N"""
+    import torch
+    return torch.from_numpy(a).to(f"cuda:{devs(N)[g]}")
 
 
 def calls(n, parts):
@@ -44,7 +58,7 @@ def test_sos_sharded_long_memory_exact(tg, orc, N, cplx, order, fc, forme):
     dt = tg.C64 if cplx else tg.F32
     x = rand(600000, cplx, 13) + np.float32(0.7)
     one = tg.Sos(co, gain, dt, r1, forme=forme)
-    sh = tg.Sharded("sos", dt, N, devices=[0] * N, coefs=co, gain=gain, rii1=r1, forme=forme)
+    sh = tg.Sharded("sos", dt, N, devices=devs(N), coefs=co, gain=gain, rii1=r1, forme=forme)
     assert sh.halo == 0                                    # no halo: the exact scheme
     ref, got = [], []
     for lo, hi in calls(len(x), (0.00001, 0.3, 0.8)):       # (the first call has fewer samples than shards)
@@ -80,9 +94,9 @@ def test_sos_sharded_long_memory_exact(tg, orc, N, cplx, order, fc, forme):
     print(f"sharded vs single handle {vs_one:.2e}, band {bande:.2e}")
     assert vs_one <= max(2e-5, 0.25 * bande), (vs_one, bande)
     # resident parts, the second one filtered in place
-    sh2 = tg.Sharded("sos", dt, 3, devices=[0, 0, 0], coefs=co, gain=gain, rii1=r1, forme=forme)
+    sh2 = tg.Sharded("sos", dt, 3, devices=devs(3), coefs=co, gain=gain, rii1=r1, forme=forme)
     cuts = [0, 150000, 150007, 420000]
-    parts = [torch.from_numpy(x[a:b].copy()).to("cuda:0") for a, b in zip(cuts[:-1], cuts[1:])]
+    parts = [on_dev(x[a:b].copy(), g, 3) for g, (a, b) in enumerate(zip(cuts[:-1], cuts[1:]))]
     outs = [torch.empty_like(parts[0]), parts[1], torch.empty_like(parts[2])]
     ys = sh2.step_parts(parts, outs)
     y2 = np.concatenate([t.cpu().numpy() for t in ys])
@@ -98,7 +112,7 @@ def test_fir_sharded_host_bit_exact(tg, orc, N, cplx):
     dt = tg.C64 if cplx else tg.F32
     x = rand(300001, cplx, 3)
     one = tg.Fir(h, dt, tg.FIR_DIRECT)
-    sh = tg.Sharded("fir", dt, N, devices=[0] * N, taps=h, method=tg.FIR_DIRECT)
+    sh = tg.Sharded("fir", dt, N, devices=devs(N), taps=h, method=tg.FIR_DIRECT)
     assert sh.halo == 126
     ref, got = [], []
     for lo, hi in calls(len(x), (0.37, 0.371, 0.9)):      # streaming contract across calls, incl. a call shorter than the halo
@@ -113,7 +127,7 @@ def test_fir_sharded_host_in_place_and_ols(tg, orc):
     h = orc.design_rif_fen(127, "lp", 0.02)
     x = rand(1 << 20, True, 5)
     ref = tg.Fir(h, tg.C64, tg.FIR_OVERLAP_SAVE).step(x.copy())
-    sh = tg.Sharded("fir", tg.C64, 4, devices=[0] * 4, taps=h, method=tg.FIR_OVERLAP_SAVE)
+    sh = tg.Sharded("fir", tg.C64, 4, devices=devs(4), taps=h, method=tg.FIR_OVERLAP_SAVE)
     y = x.copy()
     out = sh.step_host(y, y)                              # y aliases x: every shard reads its halo before anyone writes
     assert out.ctypes.data == y.ctypes.data
@@ -126,21 +140,21 @@ def test_fir_sharded_parts_resident(tg, orc, N):
     h = orc.design_rif_fen(63, "lp", 0.1)
     x = rand(200000, True, 7)
     ref = tg.Fir(h, tg.C64, tg.FIR_DIRECT).step(x.copy())
-    sh = tg.Sharded("fir", tg.C64, N, devices=[0] * N, taps=h, method=tg.FIR_DIRECT)
+    sh = tg.Sharded("fir", tg.C64, N, devices=devs(N), taps=h, method=tg.FIR_DIRECT)
     outs = []
     for lo, hi in calls(len(x), (0.5,)):
         xs = []
         for g in range(N):
             a, b = sh.bounds(hi - lo, g)
-            xs.append(torch.from_numpy(x[lo + a: lo + b].copy()).to("cuda:0"))
+            xs.append(on_dev(x[lo + a: lo + b].copy(), g, N))
         ys = sh.step_parts(xs)
         outs += [t.cpu().numpy() for t in ys]
     # a shard shorter than the halo: the walk back over several parts
     got = np.concatenate(outs)
     assert np.array_equal(got, ref)
-    tiny = tg.Sharded("fir", tg.C64, 4, devices=[0] * 4, taps=h, method=tg.FIR_DIRECT)
+    tiny = tg.Sharded("fir", tg.C64, 4, devices=devs(4), taps=h, method=tg.FIR_DIRECT)
     parts = [x[:10], x[10:30], x[30:31], x[31:5000]]
-    ys = tiny.step_parts([torch.from_numpy(p.copy()).to("cuda:0") for p in parts])
+    ys = tiny.step_parts([on_dev(p.copy(), g, 4) for g, p in enumerate(parts)])
     assert np.array_equal(np.concatenate([t.cpu().numpy() for t in ys]), ref[:5000])
 
 
@@ -156,18 +170,22 @@ def test_fir_sharded_parts_in_place_behind_an_async_producer(tg, orc, method):
     N = 4
     x = rand(1 << 21, True, 17)
     ref = tg.Fir(h, tg.C64, m).step(x.copy())
-    sh = tg.Sharded("fir", tg.C64, N, devices=[0] * N, taps=h, method=m)
-    side = torch.cuda.Stream("cuda:0")
+    sh = tg.Sharded("fir", tg.C64, N, devices=devs(N), taps=h, method=m)
+    dv = devs(N)
+    sides = {d: torch.cuda.Stream(f"cuda:{d}") for d in set(dv)}      # one busy producer stream per device in use
     got = []
     half = len(x) // 2
     for lo, hi in ((0, half), (half, len(x))):
         host = [torch.from_numpy(x[lo + a: lo + b].copy()).pin_memory() for a, b in (sh.bounds(hi - lo, g) for g in range(N))]
-        with torch.cuda.stream(side):
-            # the producer: asynchronous uploads plus arithmetic that keeps the stream busy while step_parts is enqueued
-            parts = [t.to("cuda:0", non_blocking=True) for t in host]
+        import contextlib
+        with contextlib.ExitStack() as es:
+            for d, sd in sides.items():
+                es.enter_context(torch.cuda.stream(sd))           # (sets the current stream of sd's device)
+            # the producer: asynchronous uploads plus arithmetic that keeps the streams busy while step_parts is enqueued
+            parts = [t.to(f"cuda:{dv[g]}", non_blocking=True) for g, t in enumerate(host)]
             for _ in range(20):
                 parts = [(p * 2.0) * 0.5 for p in parts]
-            ys = sh.step_parts(parts, parts)                     # in place, ordered behind `side` by events
+            ys = sh.step_parts(parts, parts)                     # in place, ordered behind the producers by events
         got += [t.cpu().numpy() for t in ys]
     got = np.concatenate(got)
     if method == "direct":
@@ -175,8 +193,8 @@ def test_fir_sharded_parts_in_place_behind_an_async_producer(tg, orc, method):
     else:
         assert np.abs(got - ref).max() <= 2e-6 * np.abs(ref).max()
     # the plain entry point (waits for the devices) gives the same
-    sh2 = tg.Sharded("fir", tg.C64, N, devices=[0] * N, taps=h, method=m)
-    parts = [torch.from_numpy(x[a:b].copy()).to("cuda:0") for a, b in (sh2.bounds(len(x), g) for g in range(N))]
+    sh2 = tg.Sharded("fir", tg.C64, N, devices=devs(N), taps=h, method=m)
+    parts = [on_dev(x[a:b].copy(), g, N) for g, (a, b) in enumerate(sh2.bounds(len(x), g) for g in range(N))]
     y2 = np.concatenate([t.cpu().numpy() for t in sh2.step_parts(parts, device_sync=True)])
     assert np.array_equal(y2, ref) if method == "direct" else np.abs(y2 - ref).max() <= 2e-6 * np.abs(ref).max()
 
@@ -190,7 +208,7 @@ def test_sos_sharded(tg, orc, N, cplx):
     dt = tg.C64 if cplx else tg.F32
     x = rand(1 << 20, cplx, 11)
     one = tg.Sos(co, 1.0, dt)
-    sh = tg.Sharded("sos", dt, N, devices=[0] * N, coefs=co, gain=1.0)
+    sh = tg.Sharded("sos", dt, N, devices=devs(N), coefs=co, gain=1.0)
     assert 0 < sh.halo <= 4096
     ref, got = [], []
     for lo, hi in calls(len(x), (0.0001, 0.4, 0.75)):      # the first call is shorter than the halo: warm-up = the stream itself
@@ -208,7 +226,7 @@ def test_resampler_sharded_bit_exact(tg, orc, N):
     ratio = np.float32(160.0) / np.float32(147.0)
     x = rand(500000, True, 13)
     one = tg.Resampler(ratio, tg.C64)
-    sh = tg.Sharded("resampler", tg.C64, N, devices=[0] * N, ratio=ratio)
+    sh = tg.Sharded("resampler", tg.C64, N, devices=devs(N), ratio=ratio)
     ref, got = [], []
     for lo, hi in calls(len(x), (0.00001, 0.3, 0.8)):
         ref.append(one.step(x[lo:hi].copy()))
@@ -216,12 +234,12 @@ def test_resampler_sharded_bit_exact(tg, orc, N):
     ref, got = np.concatenate(ref), np.concatenate(got)
     assert len(ref) == len(got) and np.array_equal(ref, got)
     # resident parts: per-shard capacities from the schedule
-    shp = tg.Sharded("resampler", tg.C64, N, devices=[0] * N, ratio=ratio)
+    shp = tg.Sharded("resampler", tg.C64, N, devices=devs(N), ratio=ratio)
     xs, caps = [], []
     probe = tg.Resampler(ratio, tg.C64)
     for g in range(N):
         a, b = shp.bounds(len(x), g)
-        xs.append(torch.from_numpy(x[a:b].copy()).to("cuda:0"))
+        xs.append(on_dev(x[a:b].copy(), g, N))
         probe.seek(a)
         o0 = probe.out_offset
         probe.seek(b)
@@ -236,7 +254,7 @@ def test_sharded_errors(tg, orc):
         tg.Sharded("fir", tg.F32, 2, devices=[0, 99], taps=h)
     with pytest.raises(tg.TsdGpuError):
         tg.Sharded("fir", tg.F32, 0, taps=h)
-    sh = tg.Sharded("fir", tg.F32, 3, devices=[0, 0, 0], taps=h)
+    sh = tg.Sharded("fir", tg.F32, 3, devices=devs(3), taps=h)
     assert len(sh.step_host(np.zeros(0, np.float32))) == 0
     # a call of 2 samples over 3 shards (one of them empty): the single handle's output
     assert np.array_equal(sh.step_host(np.ones(2, np.float32)), tg.Fir(h, tg.F32, tg.FIR_DIRECT).step(np.ones(2, np.float32)))
