@@ -123,7 +123,8 @@ int tsdgpu_fir_set_history(tsdgpu_fir *f, const void *src, void *stream);
  * (L = tsdgpu_fir_lead(f) >= K - 1: the handle's history length, a whole number of 64-sample rows on the overlap-save plan; lead >= L).
  * Equivalent to tsdgpu_fir_set_history(f, x + lead - (K - 1)) followed by tsdgpu_fir_step(f, x + lead, y + lead, n - lead) -- what a
  * rank does with the halo-free interior of its chunk (libtsd: FiltreRIF::step on a chunk whose delay line holds the samples before
- * it, filtre-rt.cc:67-108) -- minus the history copy and its launch.  Device buffers, x != y, not on the partitioned plan. */
+ * it, filtre-rt.cc:67-108) -- minus the history copy and its launch.  Device buffers, x != y, not on the partitioned plan
+ * (more than 12289 taps): tsdgpu_fir_lead returns -1 there (and for a NULL handle), and the caller uses set_history + step. */
 int tsdgpu_fir_step_after(tsdgpu_fir *f, const void *x, void *y, int64_t n, int64_t lead, void *stream);
 int tsdgpu_fir_lead(const tsdgpu_fir *f);
 int tsdgpu_fir_set_capturable(tsdgpu_fir *f, int on);
@@ -137,6 +138,11 @@ int tsdgpu_fir_destroy(tsdgpu_fir *f);
  * (power of two: Stockham passes; even: split recursion; odd: Bluestein).
  * `batch` transforms of length n laid out back to back (the reference has no batch API;
  * batch=1 is the FFTPlan::step equivalent).
+ * hipGraph capture: a step on device buffers is stateless and may be captured (run one ordinary
+ * step of the same batch first: scratch is allocated on first use); while the stream records, the
+ * kernels with dynamic tile hand-out take their static partition (their counter base is a launch
+ * argument and would be frozen).  The same holds for tsdgpu_resampler_step, whose captured launch
+ * replays ONE step (stream position, window buffers and output count are host state of the handle).
  * ------------------------------------------------------------------------------------ */
 typedef struct tsdgpu_fft tsdgpu_fft;
 int tsdgpu_fft_create(tsdgpu_fft **out, int n, int batch_hint);

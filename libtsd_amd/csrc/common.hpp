@@ -32,6 +32,13 @@ int set_err(int code, const char *fmt, ...);
 
 inline size_t dtype_size(int dt) { return dt == TSDGPU_C64 ? 8 : 4; }
 
+// true while `st` records a graph.  A captured launch replays with FROZEN arguments, so the kernels whose work counters are
+// never reset (a host-tracked base goes in as a launch argument: fft1m_cols, OlsDyn, RsDyn) take their static partition there.
+inline bool stream_is_capturing(hipStream_t st) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  return hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+}
+
 // true when p is device or managed memory (treated as resident); page-locked / registered host
 // memory is host memory here: it is staged, its copies being asynchronous
 bool is_device_ptr(const void *p);

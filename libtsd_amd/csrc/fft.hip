@@ -1239,7 +1239,8 @@ struct tsdgpu_fft {
   // in-wave 1024-point FFT paths: lane twiddles (2 x 1024) and, for n = 2^20, TA [1024][64] / TD [1024][16]
   cpx *d_w1 = nullptr, *d_w2 = nullptr, *d_ta = nullptr, *d_td = nullptr;
   unsigned *d_ctr = nullptr;  // n = 2^20: work counter of the dynamic tile hand-out (fft1m_cols_kernel), never reset
-  unsigned ctr_base = 0;      // its value before the next launch
+  unsigned ctr_base = 0;      // its value before the next launch (advanced once a launch pair has been accepted)
+  bool ctr_stale = false;     // a launch that used the counter failed: zero it again before the next use
   // even / odd
   tsdgpu_fft *sub = nullptr;
   cpx *d_rot = nullptr;       // W_n^k, k < n (even split)
@@ -1724,9 +1725,14 @@ int step_device(tsdgpu_fft *p, const cpx *x, cpx *y, int batch, int forward, hip
       const int grid = std::min(ntiles, GRID);
       // dynamic tile hand-out when every workgroup gets several tiles (TSDGPU_FFT_DYN=0: the static partition)
       const char *dyn_s = getenv("TSDGPU_FFT_DYN");
-      unsigned *ctr = (p->d_ctr && ntiles >= 4 * grid && !(dyn_s && atoi(dyn_s) == 0)) ? p->d_ctr : nullptr;
+      // (not while `st` records a graph: the base is a launch argument, a replay would see a spent counter and write nothing)
+      unsigned *ctr = (p->d_ctr && ntiles >= 4 * grid && !(dyn_s && atoi(dyn_s) == 0) && !stream_is_capturing(st)) ? p->d_ctr : nullptr;
+      if (ctr && p->ctr_stale) {
+        TSD_HIP(hipMemsetAsync(p->d_ctr, 0, 256, st));
+        p->ctr_base = 0;
+        p->ctr_stale = false;
+      }
       const unsigned b1 = p->ctr_base, b2 = b1 + (unsigned) ntiles + (unsigned) grid;
-      if (ctr) p->ctr_base = b2 + (unsigned) ntiles + (unsigned) grid;
       if (ctr) {
         hipLaunchKernelGGL((fft1m_cols_kernel<1, true>), dim3(grid), dim3(1024), F1M_LDS, st, x, z, p->d_w1, p->d_w2, p->d_ta,
                            p->d_td, inverse, 1.0f, ZP, ntiles, ctr, b1);
@@ -1738,7 +1744,11 @@ int step_device(tsdgpu_fft *p, const cpx *x, cpx *y, int batch, int forward, hip
         hipLaunchKernelGGL((fft1m_cols_kernel<2, false>), dim3(grid), dim3(1024), F1M_LDS, st, z, y, p->d_w1, p->d_w2, p->d_ta,
                            p->d_td, inverse, 1.0f / 1024.0f, ZP, ntiles, ctr, b2);
       }
-      TSD_HIP(hipGetLastError());
+      if (const hipError_t le = hipGetLastError(); le != hipSuccess) {
+        if (ctr) p->ctr_stale = true;                    // (the device counter and the host base may have parted)
+        return set_err(TSDGPU_ERR_HIP, "fft_step: launch failed: %s", hipGetErrorString(le));
+      }
+      if (ctr) p->ctr_base = b2 + (unsigned) ntiles + (unsigned) grid;
       return TSDGPU_OK;
     }
     case tsdgpu_fft::POW2_4STEP: {

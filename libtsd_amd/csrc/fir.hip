@@ -439,7 +439,9 @@ int tsdgpu_fir_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, void *stre
   return finish_out(y, bytes, dy, staged, st);
 }
 
-int tsdgpu_fir_lead(const tsdgpu_fir *f) { return f ? f->HL : -1; }
+// (-1: no tsdgpu_fir_step_after on this handle -- NULL, or the partitioned plan of more than 12289 taps, whose partial
+// filters each hold a delay line of their own: the callers fall back to set_history + step)
+int tsdgpu_fir_lead(const tsdgpu_fir *f) { return (f && f->parts.empty()) ? f->HL : -1; }
 
 int tsdgpu_fir_step_after(tsdgpu_fir *f, const void *x, void *y, int64_t n, int64_t lead, void *stream)
 {

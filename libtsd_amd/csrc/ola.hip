@@ -1444,13 +1444,17 @@ int tsdgpu_spectrum_create(tsdgpu_spectrum **out, int BS, int nsubs, int nmeans,
 {
   TSD_CHECK(out != nullptr, "spectrum_create: out is NULL");
   *out = nullptr;
-  TSD_CHECK(BS >= 1 && nsubs >= 1 && nmeans >= 1 && BS % nsubs == 0, "spectrum_create: BS = %d, nsubs = %d, nmeans = %d", BS, nsubs, nmeans);
+  // (BS need not be a multiple of nsubs: Nf = BS / nsubs like SpectrumConfig::Nf, :1150-1153, and the trailing BS - nsubs Nf
+  // samples of every block are never read -- `x.segment(i * Nf, Nf)`, :1254)
+  TSD_CHECK(BS >= 1 && nsubs >= 1 && nmeans >= 1 && BS >= nsubs, "spectrum_create: BS = %d, nsubs = %d, nmeans = %d", BS, nsubs, nmeans);
   TSD_CHECK(window_host != nullptr, "spectrum_create: NULL window");
   TSD_CHECK(!sweep_active || sweep_step >= 0, "spectrum_create: sweep step %d", sweep_step);
   tsdgpu_spectrum *h = new tsdgpu_spectrum();
   h->BS = BS; h->nsubs = nsubs; h->nmeans = nmeans;
   const int Nf = h->Nf = BS / nsubs;
-  h->sweep = sweep_active ? 1 : 0;
+  // One sub-block per block takes the reference's `sinon` branch (:1272-1277): no masque, no shifted accumulation, and
+  // mag_cnt = max(masque, 1) = 1 everywhere -- the plain spectrum, sweep.active or not.
+  h->sweep = (sweep_active && nsubs > 1) ? 1 : 0;
   h->step = sweep_step;
   const int Ns = h->Ns = h->sweep ? Nf + (nsubs - 1) * sweep_step : Nf;        // SpectrumConfig::Ns (:1157-1161)
   const int ncls = h->sweep ? nsubs : 1;
@@ -1503,6 +1507,8 @@ int tsdgpu_spectrum_create(tsdgpu_spectrum **out, int BS, int nsubs, int nmeans,
 int tsdgpu_spectrum_bins(const tsdgpu_spectrum *h) { return h ? h->Ns : -1; }
 int tsdgpu_spectrum_pending(const tsdgpu_spectrum *h) { return h ? h->cnt : -1; }
 
+static int spectrum_step_blocks(tsdgpu_spectrum *h, const void *x, int64_t nblocks, float *y, int64_t y_capacity, int64_t *n_spectra, void *stream);
+
 int tsdgpu_spectrum_step(tsdgpu_spectrum *h, const void *x, int64_t nblocks, float *y, int64_t y_capacity, int64_t *n_spectra, void *stream)
 {
   TSD_CHECK(h != nullptr, "spectrum_step: NULL handle");
@@ -1510,6 +1516,23 @@ int tsdgpu_spectrum_step(tsdgpu_spectrum *h, const void *x, int64_t nblocks, flo
   if (n_spectra) *n_spectra = 0;
   if (nblocks == 0) return TSDGPU_OK;
   TSD_CHECK(x != nullptr, "spectrum_step: NULL input");
+  if (nblocks == 1 || h->BS == h->nsubs * h->Nf) return spectrum_step_blocks(h, x, nblocks, y, y_capacity, n_spectra, stream);
+  // BS is not a multiple of nsubs: the segments of a block are contiguous, the blocks are BS apart -- block by block
+  const int64_t nout = (h->cnt + nblocks) / h->nmeans;
+  TSD_CHECK(nout <= y_capacity, "spectrum_step: %lld spectra completed, room for %lld", (long long) nout, (long long) y_capacity);
+  int64_t done = 0;
+  for (int64_t b = 0; b < nblocks; b++) {
+    int64_t got = 0;
+    const int rc = spectrum_step_blocks(h, (const cpx *) x + (size_t) b * h->BS, 1, y ? y + (size_t) done * h->Ns : nullptr, y_capacity - done, &got, stream);
+    if (rc) return rc;
+    done += got;
+  }
+  if (n_spectra) *n_spectra = done;
+  return TSDGPU_OK;
+}
+
+static int spectrum_step_blocks(tsdgpu_spectrum *h, const void *x, int64_t nblocks, float *y, int64_t y_capacity, int64_t *n_spectra, void *stream)
+{
   hipStream_t st = (hipStream_t) stream;
   const int Nf = h->Nf, Ns = h->Ns, nsubs = h->nsubs, nmeans = h->nmeans;
   const int64_t B = nblocks, S = B * nsubs;

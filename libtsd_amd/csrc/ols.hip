@@ -594,8 +594,9 @@ int ols_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, hipStream_t st)
   // dynamic hand-out of the runs (OlsDyn) unless the step must be capturable in a graph (frozen kernel arguments)
   const char *nc_s = getenv("TSDGPU_OLS_DYN");       // number of counters; 0 = the static partition
   int NC = nc_s ? atoi(nc_s) : OLS_DYN_DEFAULT;
-  if (NC < 0 || NC > OLS_MAX_CTR || f->capturable || !f->d_ctr) NC = 0;
+  if (NC < 0 || NC > OLS_MAX_CTR || f->capturable || !f->d_ctr || stream_is_capturing(st)) NC = 0;
   int R = 1;
+  unsigned ctr_add = 0;
   OlsDyn dyn = {f->d_ctr, f->ctr_base, 0u, NC > 0 ? NC : 1, 0};
   if (b_hi > b_lo) {
     const int64_t nint = b_hi - b_lo;
@@ -617,7 +618,7 @@ int ols_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, hipStream_t st)
       }
       dyn.nunits = nruns;
       dyn.Q = (unsigned) cdiv(nruns, NC);
-      f->ctr_base += dyn.Q + (unsigned) (grid / NC);          // what this launch adds to every counter
+      ctr_add = dyn.Q + (unsigned) (grid / NC);               // what this launch adds to every counter (booked once it is accepted)
     } else {
       NC = 0;
       // balance the rounds: every wave gets ceil(nruns/grid) or one fewer runs, no tail round
@@ -687,7 +688,11 @@ int ols_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, hipStream_t st)
 #undef OLS_LAUNCH_G
 #undef OLS_LAUNCH_R0
 #undef OLS_LAUNCH
-  TSD_HIP(hipGetLastError());
+  if (const hipError_t le = hipGetLastError(); le != hipSuccess) {
+    if (NC > 0) f->ctr_nc = 0;       // (device counters and host base may have parted: the next dynamic launch zeroes them)
+    return set_err(TSDGPU_ERR_HIP, "fir_step: overlap-save launch failed: %s", hipGetErrorString(le));
+  }
+  f->ctr_base += ctr_add;
   f->cur = nxt;      // the history update is part of the launch
   return TSDGPU_OK;
 }

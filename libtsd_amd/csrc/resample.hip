@@ -1285,13 +1285,14 @@ int tsdgpu_resampler_step(tsdgpu_resampler *r, const void *x, int64_t n, void *y
   const size_t wb15 = ((size_t) (RS15_LATE_STORE ? RS15_TILE_PAD + P.rec_cap : std::max(RS15_TILE_PAD, P.rec_cap)) * sz + 15) / 16 * 16;
   const size_t lds15 = (size_t) ((r->nph + 1) * 20 + 4) * 4 + RS15_WAVES * wb15 + 64;
   const void *hcur = r->hist_zero ? nullptr : r->d_hist[r->cur];
+  unsigned ctr_add = 0;
   const char *e15 = getenv("TSDGPU_RS15");                     // =0: the K = 15 interpolator through the kernels of the other lengths (A/B)
   if (r->K == 15 && r->mode == 0 && lds15 <= 158 * 1024 && !(e15 && atoi(e15) == 0)) {     // fused kernel; larger ratios fall back to the generic one
     int64_t g15 = std::min<int64_t>(cdiv(tiles, RS15_WAVES), 256);
     // dynamic hand-out of the tiles when every wave gets several of them (RsDyn); TSDGPU_RS_DYN = counters, 0 = static
     const char *nc_s = getenv("TSDGPU_RS_DYN");
     int NC = nc_s ? atoi(nc_s) : 16;
-    if (NC < 0 || NC > RS_MAX_CTR || !r->d_ctr || 256 % (8 * std::max(NC, 1)) != 0) NC = 0;
+    if (NC < 0 || NC > RS_MAX_CTR || !r->d_ctr || 256 % (8 * std::max(NC, 1)) != 0 || stream_is_capturing(st)) NC = 0;
     const char *min_s = getenv("TSDGPU_RS_DYN_MIN");         // tiles per wave from which the hand-out is dynamic (tests: 0)
     if (tiles < (int64_t) (min_s ? atoi(min_s) : 4) * 256 * RS15_WAVES) NC = 0;
     RsDyn dyn = {r->d_ctr, r->ctr_base, 0u, NC};
@@ -1304,7 +1305,7 @@ int tsdgpu_resampler_step(tsdgpu_resampler *r, const void *x, int64_t n, void *y
         dyn.base = 0;
       }
       dyn.Q = (unsigned) cdiv(tiles, NC);
-      r->ctr_base += dyn.Q + (unsigned) (g15 / NC * RS15_WAVES);      // what this launch adds to every counter
+      ctr_add = dyn.Q + (unsigned) (g15 / NC * RS15_WAVES);           // what this launch adds to every counter (booked once accepted)
     }
     if (r->data_type == TSDGPU_C64)
       hipLaunchKernelGGL(resample15_kernel<float2>, dim3((unsigned) g15 + 1), dim3(64 * RS15_WAVES), lds15, st, (const float2 *) dx,
@@ -1327,7 +1328,11 @@ int tsdgpu_resampler_step(tsdgpu_resampler *r, const void *x, int64_t n, void *y
   if (r->data_type == TSDGPU_C64) RS_LAUNCH(float2, 0); else RS_LAUNCH(float, 0);
 #undef RS_LAUNCH
   }
-  TSD_HIP(hipGetLastError());
+  if (const hipError_t le = hipGetLastError(); le != hipSuccess) {
+    if (ctr_add) r->ctr_nc = 0;   // (device counters and host base may have parted: the next dynamic launch zeroes them)
+    return set_err(TSDGPU_ERR_HIP, "resampler_step: launch failed: %s", hipGetErrorString(le));
+  }
+  r->ctr_base += ctr_add;
   if (r->K > 1) r->cur ^= 1;      // (the launch wrote the next window history into the other buffer)
   r->hist_zero = false;
   r->pos += n;

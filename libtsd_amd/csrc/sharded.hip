@@ -747,7 +747,7 @@ static int sharded_step_parts_impl(tsdgpu_sharded *h, const void *const *x_parts
       // than the handle's history (tsdgpu_fir_step_after: no copy, one launch), copied otherwise; the edge owes the outputs before it
       const int64_t lead = tsdgpu_fir_lead(fm);
       int64_t He = H;
-      if (!in_place(g) && cnt > lead && lead >= H) {
+      if (!in_place(g) && lead >= H && cnt > lead) {            // (lead = -1: partitioned plan, the copying form serves it)
         rc = tsdgpu_fir_step_after(fm, xg, yg, cnt, lead, st);
         He = lead;
       } else {

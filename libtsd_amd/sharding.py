@@ -139,12 +139,15 @@ class _EdgeStream:
             self._ready = torch.cuda.Event()
             self.edge_done = torch.cuda.Event()
 
-    def _on_edge(self, x, fn):
+    def _on_edge(self, x, fn, y=None):
         """Runs fn() -- the halo wait and the edge launches -- on the edge stream, ordered after what the current stream holds
-        (the producer of x); without an edge stream: in place."""
+        (the producer of x); without an edge stream: in place.  A chunk filtered IN PLACE (y is x) is always ordered behind
+        the current stream, `input_ready` or not: the edge overwrites x[:H], which the interior's history copy -- enqueued
+        on the current stream just before -- must have read first."""
         if self.edge_stream is None or not x.is_cuda:
             return fn()
-        if not self.input_ready:
+        aliased = y is not None and getattr(y, "is_cuda", False) and y.data_ptr() == x.data_ptr()
+        if not self.input_ready or aliased:
             cur = torch.cuda.current_stream(x.device)
             self._ready.record(cur)
             self.edge_stream.wait_event(self._ready)
@@ -169,11 +172,13 @@ class OverlappedFir(_EdgeStream):
         self.H = self.main.K - 1                                 # samples of the neighbour a chunk needs (the halo)
         # the interior starts `lead` samples into the chunk and reads its delay line out of the chunk itself
         # (tsdgpu_fir_step_after: no history copy, no extra launch): lead = the handle's history length >= H
+        # (lead < 0: the partitioned plan of more than 12289 taps has no step_after -- the copying form serves it)
+        self.after = self.main.lead >= 0
         self.lead = max(self.main.lead, self.H)
         self._init_edge_stream(edge_stream)
 
     def interior(self, x, y):
-        if x.shape[0] <= self.lead or not getattr(x, "is_cuda", False) or x.data_ptr() == y.data_ptr():
+        if not self.after or x.shape[0] <= self.lead or not getattr(x, "is_cuda", False) or x.data_ptr() == y.data_ptr():
             H = self.H                                           # host arrays / in place: the copying form, split at H
             if x.shape[0] <= H:
                 return 0
@@ -206,7 +211,7 @@ class OverlappedFir(_EdgeStream):
                 self.edge_step(x, y, halo, first, split)
                 if consumed is not None:
                     consumed()
-            self._on_edge(x, edge)
+            self._on_edge(x, edge, y)
         else:                                # a chunk no longer than the halo: nothing to overlap
             halo = exchange.finish() if exchange is not None else None
             if first:
@@ -316,7 +321,7 @@ class OverlappedSos(_EdgeStream):
             if consumed is not None:
                 consumed()
         if split:
-            self._on_edge(x, edge)
+            self._on_edge(x, edge, y)      # (in place: the edge overwrites x[:W], which the interior's warm-up reads)
         else:
             edge()
         return y

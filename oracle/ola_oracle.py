@@ -140,7 +140,7 @@ class Spectrum:
             X = orc.fft((x[i * Nf:(i + 1) * Nf] * self.f).astype(c64), True)          # plan->step(x.segment(i * Nf, Nf) * f)
             p = (X.real * X.real + X.imag * X.imag).astype(f32)                       # abs2
             p = np.concatenate([p[Nf - h:], p[:Nf - h]])                              # fftshift (fourier.hpp:232-248)
-            if self.sweep is not None:
+            if self.sweep is not None and self.nsubs > 1:                             # (nsubs == 1: the `sinon` branch, no masque)
                 step = self.sweep[0]
                 self.mag_moy[i * step:i * step + Nf] += (p * self.masque).astype(f32)  # :1265
             else:

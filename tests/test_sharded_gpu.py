@@ -199,6 +199,36 @@ def test_fir_sharded_parts_in_place_behind_an_async_producer(tg, orc, method):
     assert np.array_equal(y2, ref) if method == "direct" else np.abs(y2 - ref).max() <= 2e-6 * np.abs(ref).max()
 
 
+def test_fir_sharded_partitioned_plan(tg, orc):
+    """more than 12289 taps run on the PARTITIONED plan, which has no tsdgpu_fir_step_after (tsdgpu_fir_lead = -1): the
+    resident sharded step and sharding.OverlappedFir.interior fall back to set_history + step there.  Against the single handle."""
+    import torch
+    from libtsd_amd import sharding
+    K = 13001
+    rng = np.random.default_rng(5)
+    h = (rng.standard_normal(K) * np.hanning(K) / 64).astype(np.float32)
+    x = rand(300000, True, 23)
+    one = tg.Fir(h, tg.C64)
+    assert one.lead == -1                                         # the partitioned plan
+    ref = one.step(x.copy())
+    N = 3
+    sh = tg.Sharded("fir", tg.C64, N, devices=devs(N), taps=h)
+    parts = [on_dev(x[a:b].copy(), g, N) for g, (a, b) in enumerate(sh.bounds(len(x), g) for g in range(N))]
+    got = np.concatenate([t.cpu().numpy() for t in sh.step_parts(parts)])
+    assert np.abs(got - ref).max() <= 2e-6 * np.abs(ref).max()
+    # one rank's view: the chunk [lo, hi) with the K - 1 samples before it as the halo
+    lo, hi = 100000, 260000
+    ov = sharding.OverlappedFir(tg, h, tg.C64, edge_stream=True)
+    assert not ov.after
+    xc = torch.from_numpy(x[lo:hi].copy()).cuda()
+    yc = torch.empty_like(xc)
+    halo = torch.from_numpy(x[lo - (K - 1):lo].copy()).cuda()
+    ov.step(xc, yc, sharding.HaloExchange([], halo, None), first=False)
+    ov.wait_outputs()
+    torch.cuda.synchronize()
+    assert np.abs(yc.cpu().numpy() - ref[lo:hi]).max() <= 2e-6 * np.abs(ref).max()
+
+
 @pytest.mark.parametrize("N", [2, 4])
 @pytest.mark.parametrize("cplx", [False, True])
 def test_sos_sharded(tg, orc, N, cplx):

@@ -92,6 +92,35 @@ def test_spectrum_sweep_matches_oracle(tg, BS, nsubs, nmeans, step, bf, hf):
     check_db(np.stack(rows), want, "three calls")
 
 
+@pytest.mark.parametrize("BS,nsubs,nmeans,sweep", [(1024, 1, 2, (300, 2, 20)), (4099, 4, 2, None), (4099, 4, 3, (512, 0, 8)), (1030, 4, 1, None)])
+def test_spectrum_one_sub_block_sweep_and_ragged_block_size(tg, BS, nsubs, nmeans, sweep):
+    """(a) nsubs = 1 takes the reference's `sinon` branch (fourier.cc:1272-1277) -- no masque even with sweep.active and
+    masque_hf > 0, so the masked bins hold the power, not 10 log10(FLT_MIN); (b) BS need not be a multiple of nsubs: Nf = BS / nsubs
+    (:1150-1153) and the trailing samples of every block are ignored (`x.segment(i * Nf, Nf)`, :1254)."""
+    Nf = BS // nsubs
+    w = ola_oracle.fen_hann_periodique(Nf)
+    ref = ola_oracle.Spectrum(BS, nmeans, nsubs, w, sweep=sweep)
+    g = tg.Spectrum(BS, nsubs, nmeans, ref.f, sweep=None if sweep is None else (sweep[0], ref.masque))
+    assert g.Ns == ref.Ns
+    nblocks = 2 * nmeans + 1
+    x = rand(nblocks * BS, 5 * BS + nsubs)
+    want = [ref.step(x[b * BS:(b + 1) * BS]) for b in range(nblocks)]
+    want = np.stack([v for v in want if len(v)])
+    if nsubs == 1:
+        assert want.min() > -200.0                   # (a masked bin would read 10 log10(FLT_MIN) = -379 dB)
+    check_db(g.step(x), want, "one call")
+    g2 = tg.Spectrum(BS, nsubs, nmeans, ref.f, sweep=None if sweep is None else (sweep[0], ref.masque))
+    rows = []
+    for b in range(nblocks):
+        rows += list(g2.step(x[b * BS:(b + 1) * BS]))
+    check_db(np.stack(rows), want, "block by block")
+    import torch
+    g3 = tg.Spectrum(BS, nsubs, nmeans, ref.f, sweep=None if sweep is None else (sweep[0], ref.masque))
+    yd = g3.step(torch.from_numpy(x).cuda())
+    torch.cuda.synchronize()
+    check_db(yd.cpu().numpy(), want, "resident, one call")
+
+
 def test_spectrum_resident_input_many_blocks(tg):
     """2^22 resident samples in one call: 4096 blocks of 1024, nmeans = 16 -> 256 spectra; definition check on a tone
     (a unit tone at bin q through a rectangular window of energy Nf reads 0 dB at that bin: |X|^2 = Nf for the unitary
