@@ -8,6 +8,7 @@
 #include <complex>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 #include "tsdgpu.h"
 
@@ -123,6 +124,49 @@ int main()
       return f;
     };
     rc |= run_case("sos 3 sections, real, 4096-sample steps", 4, n, nblk, make);
+  }
+  // FFT 2^20 x 32: the step is stateless and graph-replayable; its kernels hand their tiles out through a
+  // never-reset counter whose base is a launch argument, so while the stream records they must take the static partition --
+  // a replay with a frozen base would find the counter spent and write nothing.  Two replays on different inputs.
+  {
+    const int nfft = 1 << 20, batch = 32;
+    const size_t tot = (size_t) nfft * batch;
+    std::vector<float> hx(2 * tot);
+    uint32_t s = 7u;
+    for (auto &v : hx) { s = s * 1664525u + 1013904223u; v = (float) ((int32_t) s) * (1.0f / 2147483648.0f); }
+    char *dx = nullptr, *dy1 = nullptr, *dy2 = nullptr;
+    CK(hipMalloc(&dx, tot * 8)); CK(hipMalloc(&dy1, tot * 8)); CK(hipMalloc(&dy2, tot * 8));
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    tsdgpu_fft *p = nullptr;
+    TS(tsdgpu_fft_create(&p, nfft, batch));
+    CK(hipMemcpy(dx, hx.data(), tot * 8, hipMemcpyHostToDevice));
+    TS(tsdgpu_fft_step(p, dx, dy2, batch, 1, st));              // (scratch allocated, counters advanced)
+    CK(hipStreamSynchronize(st));
+    hipGraph_t g;
+    hipGraphExec_t ge;
+    CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    TS(tsdgpu_fft_step(p, dx, dy2, batch, 1, st));
+    CK(hipStreamEndCapture(st, &g));
+    CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    size_t diff = 0;
+    for (int rep = 0; rep < 2; rep++) {
+      for (auto &v : hx) { s = s * 1664525u + 1013904223u; v = (float) ((int32_t) s) * (1.0f / 2147483648.0f); }
+      CK(hipMemcpy(dx, hx.data(), tot * 8, hipMemcpyHostToDevice));
+      TS(tsdgpu_fft_step(p, dx, dy1, batch, 1, st));            // ordinary step (dynamic hand-out)
+      CK(hipMemsetAsync(dy2, 0xff, tot * 8, st));
+      CK(hipGraphLaunch(ge, st));
+      CK(hipStreamSynchronize(st));
+      std::vector<float> y1(2 * tot), y2(2 * tot);
+      CK(hipMemcpy(y1.data(), dy1, tot * 8, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(y2.data(), dy2, tot * 8, hipMemcpyDeviceToHost));
+      for (size_t i = 0; i < y1.size(); i++) diff += std::memcmp(&y1[i], &y2[i], 4) != 0;
+    }
+    printf("%-44s replayed twice: %zu differing floats\n", "fft 2^20 x 32", diff);
+    rc |= diff != 0;
+    CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
+    tsdgpu_fft_destroy(p);
+    CK(hipFree(dx)); CK(hipFree(dy1)); CK(hipFree(dy2));
   }
   printf(rc ? "GRAPH CAPTURE FAILED\n" : "GRAPH CAPTURE OK\n");
   return rc;

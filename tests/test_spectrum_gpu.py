@@ -151,7 +151,8 @@ def test_spectrum_resident_input_many_blocks(tg):
 def test_spectrum_errors(tg):
     w = np.ones(100, np.float32)
     with pytest.raises(tg.TsdGpuError):
-        tg.Spectrum(1000, 3, 1, np.ones(333, np.float32))           # BS not a multiple of nsubs
+        tg.Spectrum(2, 3, 1, np.ones(1, np.float32))                # fewer samples than sub-blocks (Nf = 0)
+    assert tg.Spectrum(1000, 3, 1, np.ones(333, np.float32)).Ns == 333       # BS not a multiple of nsubs: Nf = BS / nsubs, like the reference
     g = tg.Spectrum(100, 1, 2, w)
     assert g.step(np.zeros(0, np.complex64)).shape == (0, 100)
     y = g.step(np.zeros(200, np.complex64))
