@@ -847,6 +847,324 @@ __global__ __launch_bounds__(64 * RS15_WAVES) void resample15_kernel(const T *__
 #endif
 }
 
+// ---- K = 15, at most two outputs per input (ratio < 2): first outputs from registers, second outputs from a list -------------
+// The kernel above runs the reference's `while (phase < 1)` loop per lane: whenever ONE of the 64 lanes has a second output on an
+// input (ratio 160/147: 9 % of the inputs, i.e. practically always somewhere in the wave) the whole wave takes the second turn --
+// 16 table rows and 16 x 15 multiply-adds per lane for 8.7 outputs.  Here the replay is branch-free and runs first (1/ratio > 0.5:
+// an input has 0, 1 or 2 outputs), a wave scan of the per-lane counts gives every output its place in the tile -- so the per-lane
+// checkpoint is the PHASE alone (4 B per 8 inputs instead of 8: the schedule table is the kernel's only traffic beyond its
+// samples) --, the FIRST output of each input is evaluated straight-line from the 22-sample register window, and the second
+// outputs go to a per-wave list and are evaluated one per lane from the sample image.  Same arithmetic per output (taps 0 .. 14
+// in the reference's order), so the outputs are bit for bit the other kernel's.
+// The samples come in by LDS-DMA (global_load_lds): no prefetch registers, no ds_write pass.  The padded image (lane stride 9
+// slots: sample s at slot s + (s >> 3)) is filled by giving every lane the SOURCE address of its 16 image bytes (the destination
+// of an LDS-DMA is lane-linear): a chunk that starts on a pad slot starts one sample early, and whatever lands on a pad is never
+// read.  The image is free again once the window is in registers and the second outputs are done: the next tile's DMA is issued
+// there and lands under the first-output pass.  Tiles that touch the ends of the call (history before it, nothing behind it) are
+// loaded through registers with bounds checks.
+template <typename T> struct Rs15sDma;
+template <> struct Rs15sDma<float2> {
+  static constexpr int SPC = 2;       // image slots per DMA lane (16 B)
+  static __device__ __forceinline__ void issue(const float2 *src, unsigned lds_dst)
+  {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+  }
+};
+template <> struct Rs15sDma<float> {
+  static constexpr int SPC = 1;       // 4 B
+  static __device__ __forceinline__ void issue(const float *src, unsigned lds_dst)
+  {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(src), "s"(lds_dst) : "memory");
+  }
+};
+constexpr int RS15S_CKB = 272;        // bytes of a wave's checkpoint area in LDS: 64 phases + the output count, 16-B granular
+constexpr int RS15S_SRC_SPAN = 8 * ((RS15_TILE_PAD - 1) / 9) + 8 + 1;      // samples a full image fill may read (from the tile's first)
+
+template <typename T>
+__global__ __launch_bounds__(1024) void resample15s_kernel(const T *__restrict__ x, const T *__restrict__ hist, T *__restrict__ y,
+                                                           const float *__restrict__ lut, const RsCk *__restrict__ ck,
+                                                           const uint32_t *__restrict__ phs, RsParams P, int ntiles,
+                                                           T *__restrict__ hist_next, RsDyn dyn, int lcap)
+{
+  const int NW = (int) (blockDim.x >> 6);
+  if (blockIdx.x == gridDim.x - 1) {      // (see resample_kernel: the next window history rides in this launch)
+    for (int i = threadIdx.x; i < 14; i += (int) blockDim.x) {
+      const int64_t g = P.n - 14 + i;
+      hist_next[i] = g < 0 ? (hist ? hist[14 + g] : zero_of(T{})) : x[g];
+    }
+    return;
+  }
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int K = 15, LS = 20, IMG = RS15_TILE_PAD, SPC = Rs15sDma<T>::SPC;
+  constexpr int NCH = (IMG + SPC - 1) / SPC, NDMA = (NCH + 63) / 64;
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));     // (the wave index in an SGPR: what follows from it is scalar)
+  float *lut_s = reinterpret_cast<float *>(smem_raw);
+  char *wbase = reinterpret_cast<char *>(lut_s + ((P.nph + 1) * LS + 3) / 4 * 4);
+  const size_t wbytes = ((size_t) (IMG + P.rec_cap) * sizeof(T) + (size_t) lcap * sizeof(uint2) + RS15S_CKB + 15) / 16 * 16;
+  uint32_t *ckl = reinterpret_cast<uint32_t *>(wbase + wv * wbytes);     // the tile's checkpoint: 64 phases, then the outputs before it
+  T *img = reinterpret_cast<T *>(ckl + RS15S_CKB / 4);       // padded: sample s at s + (s >> 3)
+  T *obuf = img + IMG;                                       // the tile's outputs, in order
+  uint2 *list = reinterpret_cast<uint2 *>(obuf + P.rec_cap); // second outputs: (image sample | column << 16, place)
+  const unsigned img_lds = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) (size_t) img);
+  const unsigned ckl_lds = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) (size_t) ckl);
+
+  for (int i = threadIdx.x; i < (P.nph + 1) * K; i += (int) blockDim.x) {
+    const int c = i / K, k = i - c * K;
+    lut_s[c * LS + k] = lut[c * P.gl + k];
+  }
+  for (int c = threadIdx.x; c <= P.nph; c += (int) blockDim.x) lut_s[c * LS + 15] = 0.f;
+  __syncthreads();
+
+  auto wave_sync = []() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
+  const int wtile0 = blockIdx.x * NW + wv;
+  const int wstep = (gridDim.x - 1) * NW;
+  int64_t ic0 = P.tile0, q0 = 0;
+  rs_wrap(ic0, q0, P.mu, P.lambda);
+  auto tile_ic = [&](int tix_, int64_t &ic_, int64_t &q_) {
+    ic_ = ic0 + (int64_t) tix_ * RS_TI;
+    q_ = q0;
+    if (P.lambda > 0) {
+      const int64_t lim = P.mu + P.lambda;
+      if (ic_ >= lim) {
+        if (ic_ - lim < 64 * P.lambda) {
+          do { ic_ -= P.lambda; q_++; } while (ic_ >= lim);       // (wave-uniform: scalar instructions)
+        } else {
+          const int64_t d = ic_ - P.mu, k = d / P.lambda;
+          q_ += k;
+          ic_ = P.mu + (d - k * P.lambda);
+        }
+      }
+    }
+  };
+  const int ctr_c = dyn.NC > 0 ? (int) ((blockIdx.x / 8) % dyn.NC) : 0;
+  // the next tile of this wave: the pull is ISSUED early and its value TAKEN a tile's evaluation later (dynamic: from the wave's
+  // counter, -1 once the quota is spent -- exactly one failing pull per wave; static: prev + waves)
+  auto pull_issue = [&]() -> unsigned {
+    unsigned v = 0;
+    if (dyn.NC > 0 && lane == 0) v = __hip_atomic_fetch_add(dyn.ctr + ctr_c * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return v;
+  };
+  auto pull_take = [&](unsigned v, int prev) -> int {
+    if (dyn.NC == 0) {
+      const int t = prev < 0 ? wtile0 : prev + wstep;
+      return t < ntiles ? t : -1;
+    }
+    for (;;) {
+      v = (unsigned) __builtin_amdgcn_readfirstlane((int) v) - dyn.base;
+      if (v >= dyn.Q) return -1;
+      const int64_t t = (int64_t) v * dyn.NC + ctr_c;
+      if (t < ntiles) return (int) t;
+      v = pull_issue();
+    }
+  };
+
+  // what the tile being loaded brings besides its samples: the lane's phase at its first input, the outputs before the tile
+  // (the checkpoint comes in by LDS-DMA like the samples: a register load would be counted by hipcc, whose waits for it --
+  // wherever it schedules a copy of the register -- also wait for the DMA in flight)
+  bool pf_in = false;       // the lane has inputs inside the call
+  int pf_lead = 0;          // inputs between the lane's checkpoint and its first input (a period that is no multiple of 8 shifts the grid)
+  int64_t pf_cum0 = 0;      // whole periods' outputs before the tile (the checkpoint's own count is in ckl[64])
+  // per-lane element offsets of the DMA sources inside a tile's sample range (loop-invariant: 32-bit, one register each)
+  unsigned doff[NDMA];
+#pragma unroll
+  for (int d = 0; d < NDMA; d++) {
+    const int c = d * 64 + lane, p0 = c * SPC, g = p0 / 9, r = p0 - 9 * g;
+    doff[d] = (unsigned) (8 * g + min(r, 7));
+  }
+  auto fetch = [&](int tix_) {
+    int64_t icT_, qT_;
+    tile_ic(tix_, icT_, qT_);
+    const int64_t T0_ = P.tile0 + (int64_t) tix_ * RS_TI;
+    const int64_t rel0 = T0_ - (K - 1) - P.pos;              // image sample 0, relative to x
+    if (rel0 >= 0 && rel0 + RS15S_SRC_SPAN <= P.n) {
+      const T *xs = x + rel0;                                // (wave-uniform)
+#pragma unroll
+      for (int d = 0; d < NDMA; d++) {
+        unsigned off = doff[d];
+        asm volatile("" : "+v"(off));                          // (keeps the hoisted form 32 bits wide: one register per DMA, not two)
+        if (d * 64 + lane < NCH) Rs15sDma<T>::issue(xs + off, img_lds + (unsigned) (d * 64 * SPC * (int) sizeof(T)));
+      }
+    } else {
+      // (an end of the call: one or two tiles per launch -- a plain loop, two live registers)
+#pragma unroll 1
+      for (int s_ = lane; s_ < RS_TI + K; s_ += 64) {
+        const int64_t rel = rel0 + s_;
+        T v = zero_of(T{});
+        if (rel < 0) {
+          if (hist && rel >= -(int64_t) (K - 1)) v = hist[(K - 1) + rel];
+        } else if (rel < P.n) {
+          v = x[rel];
+        }
+        img[s_ + (s_ >> 3)] = v;
+      }
+    }
+    // the lane's phase at its first input: table index = canonical index / 8 -- the tile's plus the lane, unless the period of
+    // the phase sequence ends inside the tile (then lane by lane)
+    const int64_t left_ = P.pos + P.n - T0_;                  // inputs from the tile's first to the call's end (wave-uniform)
+    const int lefti = left_ > RS_TI ? RS_TI : (int) left_;
+    pf_in = RS_SEG * lane < lefti;
+    const uint32_t *psrc = phs;                               // (lanes behind the call's end read entry 0 and ignore it)
+    pf_lead = 0;
+    if (pf_in) {
+      if (P.lambda <= 0 || icT_ + RS_TI <= P.mu + P.lambda) {
+        psrc = phs + (icT_ / RS_CK + lane);
+        pf_lead = (int) (icT_ % RS_CK);
+      } else {
+        int64_t ic_ = icT_ + lane * RS_SEG, q_ = 0;
+        rs_wrap(ic_, q_, P.mu, P.lambda);
+        psrc = phs + ic_ / RS_CK;
+        pf_lead = (int) (ic_ % RS_CK);
+      }
+    }
+    Rs15sDma<float>::issue(reinterpret_cast<const float *>(psrc), ckl_lds);
+    if (lane == 0) Rs15sDma<float>::issue(reinterpret_cast<const float *>(&ck[icT_ / RS_CK].cum), ckl_lds + 256u);
+    pf_cum0 = qT_ * P.opp;
+  };
+
+  // three tiles are known at any time: the one evaluated, the one being loaded, and the one after -- whose pull is issued at
+  // the top of an iteration and taken at the top of the next, behind the wait for the samples that comes there anyway
+  int tix = pull_take(pull_issue(), -1);
+  int ntix = tix >= 0 ? pull_take(pull_issue(), tix) : -1;
+  unsigned pulled = ntix >= 0 ? pull_issue() : 0u;
+  if (tix >= 0) fetch(tix);
+  const float inc = P.inc, fnph = (float) P.nph;
+  while (tix >= 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the tile's DMA has landed (hipcc does not count asm loads)
+    wave_sync();
+    const int64_t T0 = P.tile0 + (int64_t) tix * RS_TI;
+    int64_t cum_t0 = pf_cum0 + (int64_t) (uint32_t) __builtin_amdgcn_readfirstlane((int) ckl[64]);
+    // inputs of this lane inside the call's end (an input behind it produces nothing here: it belongs to the next call)
+    const int64_t left = P.pos + P.n - T0;                   // (wave-uniform)
+    const int nlive = min(RS_SEG, max(0, (left > RS_TI ? RS_TI : (int) left) - RS_SEG * lane));
+    const int n2tix = ntix >= 0 ? pull_take(pulled, ntix) : -1;
+    pulled = n2tix >= 0 ? pull_issue() : 0u;
+
+    // ---- branch-free replay (ra.cc:64-73 with at most two turns of the while loop: inc > 0.5 and phase >= 0)
+    float ph[RS_SEG];
+    unsigned m1 = 0, m2 = 0;
+    {
+      float p = pf_in ? bits2f(ckl[lane]) : 2.0f;             // (2.0f: no output)
+      // from the checkpoint to the lane's first input (nothing when the tile sits on the checkpoint grid); lane 0's outputs
+      // on the way come before the tile
+      int led = 0;
+      for (int r = pf_lead; r > 0; r--) {
+        const bool a0 = p < 1.f;
+        const float p1 = p + inc;
+        const bool a1 = a0 && (p1 < 1.f);
+        led += (a0 ? 1 : 0) + (a1 ? 1 : 0);
+        p = a0 ? (a1 ? p1 + inc : p1) : p;
+        p = p - 1.f;
+      }
+      cum_t0 += __builtin_amdgcn_readfirstlane(led);
+#pragma unroll
+      for (int s = 0; s < RS_SEG; s++) {
+        ph[s] = p;
+        const bool e0 = (p < 1.f) && (s < nlive);
+        const float p1 = p + inc;
+        const bool e1 = e0 && (p1 < 1.f);
+        const float p2 = p1 + inc;
+        m1 |= e0 ? (1u << s) : 0u;
+        m2 |= e1 ? (1u << s) : 0u;
+        p = (p < 1.f) ? ((p1 < 1.f) ? p2 : p1) : p;           // phase after the loop ...
+        p = p - 1.f;                                         // ... ra.cc:73
+      }
+    }
+    // places: exclusive wave scan of (outputs, second outputs) per lane, packed
+    const unsigned mine = ((unsigned) (__builtin_popcount(m1) + __builtin_popcount(m2)) << 16) | (unsigned) __builtin_popcount(m2);
+    unsigned incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const unsigned o_ = (unsigned) __shfl_up((int) incl, d);
+      if (lane >= d) incl += o_;
+    }
+    const unsigned tot = (unsigned) __builtin_amdgcn_readlane((int) incl, 63);
+    const int total = (int) (tot >> 16), nsec = (int) (tot & 0xffffu);
+    const unsigned excl = incl - mine;
+    const int o_base = (int) (excl >> 16);
+    // the list of second outputs
+    {
+      int o_run = o_base, e_run = (int) (excl & 0xffffu);
+#pragma unroll
+      for (int s = 0; s < RS_SEG; s++) {
+        o_run += (m1 >> s) & 1u;
+        if ((m2 >> s) & 1u) {
+          const int col2 = (int) ((ph[s] + inc) * fnph);
+          list[e_run] = make_uint2((unsigned) (RS_SEG * lane + s) | ((unsigned) col2 << 16), (unsigned) o_run);
+          e_run++;
+          o_run++;
+        }
+      }
+    }
+    wave_sync();
+    // ---- second outputs, one per lane: window from the image (sample m + k at slot(m + e) + 9 * (k >> 3), e = k & 7)
+    for (int e = lane; e < nsec; e += 64) {
+      const uint2 rc = list[e];
+      const int m = (int) (rc.x & 0xffffu);
+      const float *h = lut_s + (int) (rc.x >> 16) * LS;
+      float hh[16];
+#pragma unroll
+      for (int k4 = 0; k4 < 4; k4++) {
+        const float4 q4 = *reinterpret_cast<const float4 *>(h + 4 * k4);
+        hh[4 * k4] = q4.x; hh[4 * k4 + 1] = q4.y; hh[4 * k4 + 2] = q4.z; hh[4 * k4 + 3] = q4.w;
+      }
+      const T *be[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++) be[j] = img + (m + j) + ((m + j) >> 3);
+      T acc = zero_of(T{});
+#pragma unroll
+      for (int k = 0; k < 15; k++) acc = tap_mac(acc, hh[k], be[k & 7][9 * (k >> 3)]);
+      obuf[rc.y] = acc;
+    }
+    // register window (read AFTER the second outputs: their 15 sample reads and the window need not be live together): W[j] = sample 8*lane + j of the image (slot 9*lane + j + (j >> 3))
+    T W[22];
+    {
+      const T *wl = img + 9 * lane;
+#pragma unroll
+      for (int j = 0; j < 22; j++) W[j] = wl[j + (j >> 3)];
+    }
+    // ---- the image is free: the next tile's samples start coming in
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wave_sync();
+    if (ntix >= 0) fetch(ntix);
+    // ---- first outputs from the register window (filtrage.hpp:1877-1879 order)
+    {
+      int o_run = o_base;
+#pragma unroll
+      for (int s = 0; s < RS_SEG; s++) {
+        if ((m1 >> s) & 1u) {
+          const float *h = lut_s + (int) (ph[s] * fnph) * LS;                    // itrp.cc:19
+          float hh[16];
+#pragma unroll
+          for (int k4 = 0; k4 < 4; k4++) {
+            const float4 q4 = *reinterpret_cast<const float4 *>(h + 4 * k4);
+            hh[4 * k4] = q4.x; hh[4 * k4 + 1] = q4.y; hh[4 * k4 + 2] = q4.z; hh[4 * k4 + 3] = q4.w;
+          }
+          T acc = zero_of(T{});
+#pragma unroll
+          for (int k = 0; k < 15; k++) acc = tap_mac(acc, hh[k], W[s + k]);
+          obuf[o_run] = acc;
+        }
+        o_run += ((m1 >> s) & 1u) + ((m2 >> s) & 1u);
+        __builtin_amdgcn_sched_barrier(0);       // (one table row in flight: hoisting all eight costs 128 registers)
+      }
+    }
+    wave_sync();
+    const int o_begin = (int) max((int64_t) 0, P.cum_pos - cum_t0);
+    T *yt = y + (cum_t0 - P.cum_pos);
+    for (int oo = o_begin + lane; oo < total; oo += 64) yt[oo] = obuf[oo];
+    tix = ntix;
+    ntix = n2tix;
+  }
+}
+
 
 }  // namespace tsdgpu
 
@@ -912,6 +1230,7 @@ struct tsdgpu_resampler {
         tort_bits(sch->tort_bits), brent_power(sch->brent_power), brent_lam(sch->brent_lam), cyc(sch->cyc), mu(sch->mu),
         lambda(sch->lambda), opp(sch->opp) {}
   RsCk *d_ck = nullptr;
+  uint32_t *d_ph = nullptr;     // the phases alone (resample15s_kernel: 4 B per checkpoint), behind d_ck in its allocation
   size_t d_ck_cap = 0, d_ck_n = 0;
   DevBuf in_stage, out_stage;
   // work counters of the fused kernel's dynamic tile hand-out (RsDyn), behind the histories in d_lut's allocation
@@ -1011,17 +1330,21 @@ int sync_table(tsdgpu_resampler *r, hipStream_t st)
   if (r->ck.size() > r->d_ck_cap) {
     RsCk *nd = nullptr;
     const size_t cap = r->ck.size() + r->ck.size() / 2 + 1024;
-    if (hipMalloc((void **) &nd, cap * sizeof(RsCk)) != hipSuccess)
+    if (hipMalloc((void **) &nd, cap * (sizeof(RsCk) + sizeof(uint32_t))) != hipSuccess)
       return set_err(TSDGPU_ERR_ALLOC, "resampler: schedule table alloc failed");
     TSD_HIP(hipStreamSynchronize(st));
     if (r->d_ck) (void) hipFree(r->d_ck);
     r->d_ck = nd;
+    r->d_ph = reinterpret_cast<uint32_t *>(nd + cap);
     r->d_ck_cap = cap;
     r->d_ck_n = 0;
   }
-  TSD_HIP(hipMemcpyAsync(r->d_ck + r->d_ck_n, r->ck.data() + r->d_ck_n, (r->ck.size() - r->d_ck_n) * sizeof(RsCk),
-                         hipMemcpyHostToDevice, st));
-  TSD_HIP(hipStreamSynchronize(st));    // the vector may grow (reallocate) before the copy has run
+  const size_t fresh = r->ck.size() - r->d_ck_n;
+  std::vector<uint32_t> phases(fresh);
+  for (size_t i = 0; i < fresh; i++) phases[i] = r->ck[r->d_ck_n + i].phase_bits;
+  TSD_HIP(hipMemcpyAsync(r->d_ck + r->d_ck_n, r->ck.data() + r->d_ck_n, fresh * sizeof(RsCk), hipMemcpyHostToDevice, st));
+  TSD_HIP(hipMemcpyAsync(r->d_ph + r->d_ck_n, phases.data(), fresh * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  TSD_HIP(hipStreamSynchronize(st));    // the vectors may grow (reallocate) / go away before the copies have run
   r->d_ck_n = r->ck.size();
   return TSDGPU_OK;
 }
@@ -1287,7 +1610,42 @@ int tsdgpu_resampler_step(tsdgpu_resampler *r, const void *x, int64_t n, void *y
   const void *hcur = r->hist_zero ? nullptr : r->d_hist[r->cur];
   unsigned ctr_add = 0;
   const char *e15 = getenv("TSDGPU_RS15");                     // =0: the K = 15 interpolator through the kernels of the other lengths (A/B)
-  if (r->K == 15 && r->mode == 0 && lds15 <= 158 * 1024 && !(e15 && atoi(e15) == 0)) {     // fused kernel; larger ratios fall back to the generic one
+  // K = 15 at a ratio below 2 (at most two outputs per input): the split kernel, as many waves per workgroup as its LDS allows
+  const int rec15 = ((int) ((double) RS_TI * (double) r->ratio * 1.0001) + 8 + 3) / 4 * 4;
+  const int lcap15 = (int) ((double) RS_TI * std::max(0.0, (double) r->ratio - 1.0) * 1.0001) + 8;
+  const size_t wb15s = ((size_t) (RS15_TILE_PAD + rec15) * sz + (size_t) lcap15 * 8 + RS15S_CKB + 15) / 16 * 16;
+  const size_t lut15 = (size_t) ((r->nph + 1) * 20 + 4) * 4;
+  const int nw15s = (int) std::min<size_t>(16, (RS_LDS_LIMIT - lut15 - 64) / wb15s);
+  const char *e15s = getenv("TSDGPU_RS15S");                   // =0: the one-pass K = 15 kernel (A/B)
+  if (r->K == 15 && r->mode == 0 && r->inc >= 0.5f && nw15s >= 4 && !(e15 && atoi(e15) == 0) && !(e15s && atoi(e15s) == 0)) {
+    const int NW = nw15s;
+    P.rec_cap = rec15;
+    int64_t g15 = std::min<int64_t>(cdiv(tiles, NW), 256);
+    const char *nc_s = getenv("TSDGPU_RS_DYN");
+    int NC = nc_s ? atoi(nc_s) : 16;
+    if (NC < 0 || NC > RS_MAX_CTR || !r->d_ctr || 256 % (8 * std::max(NC, 1)) != 0 || stream_is_capturing(st)) NC = 0;
+    const char *min_s = getenv("TSDGPU_RS_DYN_MIN");
+    if (tiles < (int64_t) (min_s ? atoi(min_s) : 4) * 256 * NW) NC = 0;
+    RsDyn dyn = {r->d_ctr, r->ctr_base, 0u, NC};
+    if (NC > 0) {
+      g15 = 256;
+      if (NC != r->ctr_nc) {
+        TSD_HIP(hipMemsetAsync(r->d_ctr, 0, (size_t) RS_MAX_CTR * 128, st));
+        r->ctr_base = 0;
+        r->ctr_nc = NC;
+        dyn.base = 0;
+      }
+      dyn.Q = (unsigned) cdiv(tiles, NC);
+      ctr_add = dyn.Q + (unsigned) (g15 / NC * NW);
+    }
+    const size_t lds15s = lut15 + (size_t) NW * wb15s + 64;
+    if (r->data_type == TSDGPU_C64)
+      hipLaunchKernelGGL(resample15s_kernel<float2>, dim3((unsigned) g15 + 1), dim3(64 * NW), lds15s, st, (const float2 *) dx,
+                         (const float2 *) hcur, (float2 *) dy, r->d_lut, r->d_ck, r->d_ph, P, (int) tiles, (float2 *) r->d_hist[r->cur ^ 1], dyn, lcap15);
+    else
+      hipLaunchKernelGGL(resample15s_kernel<float>, dim3((unsigned) g15 + 1), dim3(64 * NW), lds15s, st, (const float *) dx,
+                         (const float *) hcur, (float *) dy, r->d_lut, r->d_ck, r->d_ph, P, (int) tiles, (float *) r->d_hist[r->cur ^ 1], dyn, lcap15);
+  } else if (r->K == 15 && r->mode == 0 && lds15 <= 158 * 1024 && !(e15 && atoi(e15) == 0)) {     // fused kernel; larger ratios fall back to the generic one
     int64_t g15 = std::min<int64_t>(cdiv(tiles, RS15_WAVES), 256);
     // dynamic hand-out of the tiles when every wave gets several of them (RsDyn); TSDGPU_RS_DYN = counters, 0 = static
     const char *nc_s = getenv("TSDGPU_RS_DYN");
