@@ -904,11 +904,11 @@ __global__ __launch_bounds__(1024) void resample15s_kernel(const T *__restrict__
   const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));     // (the wave index in an SGPR: what follows from it is scalar)
   float *lut_s = reinterpret_cast<float *>(smem_raw);
   char *wbase = reinterpret_cast<char *>(lut_s + ((P.nph + 1) * LS + 3) / 4 * 4);
-  const size_t wbytes = ((size_t) (IMG + P.rec_cap) * sizeof(T) + (size_t) lcap * sizeof(uint2) + RS15S_CKB + 15) / 16 * 16;
+  const size_t wbytes = ((size_t) (IMG + P.rec_cap) * sizeof(T) + (size_t) lcap * sizeof(uint32_t) + RS15S_CKB + 15) / 16 * 16;
   uint32_t *ckl = reinterpret_cast<uint32_t *>(wbase + wv * wbytes);     // the tile's checkpoint: 64 phases, then the outputs before it
   T *img = reinterpret_cast<T *>(ckl + RS15S_CKB / 4);       // padded: sample s at s + (s >> 3)
   T *obuf = img + IMG;                                       // the tile's outputs, in order
-  uint2 *list = reinterpret_cast<uint2 *>(obuf + P.rec_cap); // second outputs: (image sample | column << 16, place)
+  uint32_t *list = reinterpret_cast<uint32_t *>(obuf + P.rec_cap);       // second outputs: image sample (9 bits) | column << 9 (9) | place << 18
   const unsigned img_lds = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) (size_t) img);
   const unsigned ckl_lds = (unsigned) __builtin_amdgcn_readfirstlane((int) (unsigned) (size_t) ckl);
 
@@ -1036,6 +1036,15 @@ __global__ __launch_bounds__(1024) void resample15s_kernel(const T *__restrict__
   unsigned pulled = ntix >= 0 ? pull_issue() : 0u;
   if (tix >= 0) fetch(tix);
   const float inc = P.inc, fnph = (float) P.nph;
+  // The outputs of a tile are stored at the START of the next iteration (before its second outputs go to the staging buffer):
+  // vmcnt retires in issue order, so stores issued behind the next tile's DMA would stand between it and the wait at the loop
+  // top -- every tile would pay a store round trip.  Issued here they are a whole first-output pass old when that wait comes.
+  int pend_begin = 0, pend_end = 0;
+  T *pend_y = y;
+  auto flush = [&]() {
+    for (int oo = pend_begin + lane; oo < pend_end; oo += 64) pend_y[oo] = obuf[oo];
+    pend_end = 0;
+  };
   while (tix >= 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the tile's DMA has landed (hipcc does not count asm loads)
     wave_sync();
@@ -1097,35 +1106,72 @@ __global__ __launch_bounds__(1024) void resample15s_kernel(const T *__restrict__
         o_run += (m1 >> s) & 1u;
         if ((m2 >> s) & 1u) {
           const int col2 = (int) ((ph[s] + inc) * fnph);
-          list[e_run] = make_uint2((unsigned) (RS_SEG * lane + s) | ((unsigned) col2 << 16), (unsigned) o_run);
+          list[e_run] = (unsigned) (RS_SEG * lane + s) | ((unsigned) col2 << 9) | ((unsigned) o_run << 18);
           e_run++;
           o_run++;
         }
       }
     }
     wave_sync();
+    flush();                                                 // the previous tile's outputs (see above)
     // ---- second outputs, one per lane: window from the image (sample m + k at slot(m + e) + 9 * (k >> 3), e = k & 7)
     for (int e = lane; e < nsec; e += 64) {
-      const uint2 rc = list[e];
-      const int m = (int) (rc.x & 0xffffu);
-      const float *h = lut_s + (int) (rc.x >> 16) * LS;
+      const uint32_t rc = list[e];
+      const int m = (int) (rc & 511u);
+      const float *h = lut_s + (int) ((rc >> 9) & 511u) * LS;
       float hh[16];
 #pragma unroll
       for (int k4 = 0; k4 < 4; k4++) {
         const float4 q4 = *reinterpret_cast<const float4 *>(h + 4 * k4);
         hh[4 * k4] = q4.x; hh[4 * k4 + 1] = q4.y; hh[4 * k4 + 2] = q4.z; hh[4 * k4 + 3] = q4.w;
       }
+      asm volatile("" :: "v"(hh[15]));
       const T *be[8];
 #pragma unroll
       for (int j = 0; j < 8; j++) be[j] = img + (m + j) + ((m + j) >> 3);
+      T sv[15];
+      if constexpr (sizeof(T) == 8) {
+        // (one statement for the same reason as the window's: no ds_read2_b64)
+        asm volatile(
+            "ds_read_b64 %0, %15\n\tds_read_b64 %1, %16\n\tds_read_b64 %2, %17\n\tds_read_b64 %3, %18\n\t"
+            "ds_read_b64 %4, %19\n\tds_read_b64 %5, %20\n\tds_read_b64 %6, %21\n\tds_read_b64 %7, %22\n\t"
+            "ds_read_b64 %8, %15 offset:72\n\tds_read_b64 %9, %16 offset:72\n\tds_read_b64 %10, %17 offset:72\n\tds_read_b64 %11, %18 offset:72\n\t"
+            "ds_read_b64 %12, %19 offset:72\n\tds_read_b64 %13, %20 offset:72\n\tds_read_b64 %14, %21 offset:72\n\ts_waitcnt lgkmcnt(0)"
+            : "=&v"(sv[0]), "=&v"(sv[1]), "=&v"(sv[2]), "=&v"(sv[3]), "=&v"(sv[4]), "=&v"(sv[5]), "=&v"(sv[6]), "=&v"(sv[7]),
+              "=&v"(sv[8]), "=&v"(sv[9]), "=&v"(sv[10]), "=&v"(sv[11]), "=&v"(sv[12]), "=&v"(sv[13]), "=&v"(sv[14])
+            : "v"((unsigned) (size_t) be[0]), "v"((unsigned) (size_t) be[1]), "v"((unsigned) (size_t) be[2]), "v"((unsigned) (size_t) be[3]),
+              "v"((unsigned) (size_t) be[4]), "v"((unsigned) (size_t) be[5]), "v"((unsigned) (size_t) be[6]), "v"((unsigned) (size_t) be[7])
+            : "memory");
+      } else {
+#pragma unroll
+        for (int k = 0; k < 15; k++) sv[k] = be[k & 7][9 * (k >> 3)];
+      }
       T acc = zero_of(T{});
 #pragma unroll
-      for (int k = 0; k < 15; k++) acc = tap_mac(acc, hh[k], be[k & 7][9 * (k >> 3)]);
-      obuf[rc.y] = acc;
+      for (int k = 0; k < 15; k++) acc = tap_mac(acc, hh[k], sv[k]);
+      obuf[rc >> 18] = acc;
     }
     // register window (read AFTER the second outputs: their 15 sample reads and the window need not be live together): W[j] = sample 8*lane + j of the image (slot 9*lane + j + (j >> 3))
     T W[22];
-    {
+    if constexpr (sizeof(T) == 8) {
+      // 22 ds_read_b64 and their wait in ONE statement: hipcc pairs adjacent 8-byte reads into ds_read2_b64, which moves half
+      // the bytes per LDS cycle (MI355X_MICROARCH.md, LDS table: 8 cycles for 16 B per lane against 2 x 2)
+      const unsigned wa = (unsigned) (size_t) (img + 9 * lane);
+#define RS_W(j) "ds_read_b64 %" #j ", %22 offset:%c" 
+      asm volatile(
+          "ds_read_b64 %0, %22 offset:0\n\tds_read_b64 %1, %22 offset:8\n\tds_read_b64 %2, %22 offset:16\n\tds_read_b64 %3, %22 offset:24\n\t"
+          "ds_read_b64 %4, %22 offset:32\n\tds_read_b64 %5, %22 offset:40\n\tds_read_b64 %6, %22 offset:48\n\tds_read_b64 %7, %22 offset:56\n\t"
+          "ds_read_b64 %8, %22 offset:72\n\tds_read_b64 %9, %22 offset:80\n\tds_read_b64 %10, %22 offset:88\n\tds_read_b64 %11, %22 offset:96\n\t"
+          "ds_read_b64 %12, %22 offset:104\n\tds_read_b64 %13, %22 offset:112\n\tds_read_b64 %14, %22 offset:120\n\tds_read_b64 %15, %22 offset:128\n\t"
+          "ds_read_b64 %16, %22 offset:144\n\tds_read_b64 %17, %22 offset:152\n\tds_read_b64 %18, %22 offset:160\n\tds_read_b64 %19, %22 offset:168\n\t"
+          "ds_read_b64 %20, %22 offset:176\n\tds_read_b64 %21, %22 offset:184\n\ts_waitcnt lgkmcnt(0)"
+          : "=&v"(W[0]), "=&v"(W[1]), "=&v"(W[2]), "=&v"(W[3]), "=&v"(W[4]), "=&v"(W[5]), "=&v"(W[6]), "=&v"(W[7]), "=&v"(W[8]),
+            "=&v"(W[9]), "=&v"(W[10]), "=&v"(W[11]), "=&v"(W[12]), "=&v"(W[13]), "=&v"(W[14]), "=&v"(W[15]), "=&v"(W[16]),
+            "=&v"(W[17]), "=&v"(W[18]), "=&v"(W[19]), "=&v"(W[20]), "=&v"(W[21])
+          : "v"(wa)
+          : "memory");
+#undef RS_W
+    } else {
       const T *wl = img + 9 * lane;
 #pragma unroll
       for (int j = 0; j < 22; j++) W[j] = wl[j + (j >> 3)];
@@ -1147,6 +1193,7 @@ __global__ __launch_bounds__(1024) void resample15s_kernel(const T *__restrict__
             const float4 q4 = *reinterpret_cast<const float4 *>(h + 4 * k4);
             hh[4 * k4] = q4.x; hh[4 * k4 + 1] = q4.y; hh[4 * k4 + 2] = q4.z; hh[4 * k4 + 3] = q4.w;
           }
+          asm volatile("" :: "v"(hh[15]));                    // (keeps the row four ds_read_b128: a b96 takes 8 LDS cycles, a b128 4)
           T acc = zero_of(T{});
 #pragma unroll
           for (int k = 0; k < 15; k++) acc = tap_mac(acc, hh[k], W[s + k]);
@@ -1156,13 +1203,14 @@ __global__ __launch_bounds__(1024) void resample15s_kernel(const T *__restrict__
         __builtin_amdgcn_sched_barrier(0);       // (one table row in flight: hoisting all eight costs 128 registers)
       }
     }
-    wave_sync();
-    const int o_begin = (int) max((int64_t) 0, P.cum_pos - cum_t0);
-    T *yt = y + (cum_t0 - P.cum_pos);
-    for (int oo = o_begin + lane; oo < total; oo += 64) yt[oo] = obuf[oo];
+    pend_begin = (int) max((int64_t) 0, P.cum_pos - cum_t0);
+    pend_end = total;
+    pend_y = y + (cum_t0 - P.cum_pos);
     tix = ntix;
     ntix = n2tix;
   }
+  wave_sync();
+  flush();
 }
 
 
@@ -1613,11 +1661,11 @@ int tsdgpu_resampler_step(tsdgpu_resampler *r, const void *x, int64_t n, void *y
   // K = 15 at a ratio below 2 (at most two outputs per input): the split kernel, as many waves per workgroup as its LDS allows
   const int rec15 = ((int) ((double) RS_TI * (double) r->ratio * 1.0001) + 8 + 3) / 4 * 4;
   const int lcap15 = (int) ((double) RS_TI * std::max(0.0, (double) r->ratio - 1.0) * 1.0001) + 8;
-  const size_t wb15s = ((size_t) (RS15_TILE_PAD + rec15) * sz + (size_t) lcap15 * 8 + RS15S_CKB + 15) / 16 * 16;
+  const size_t wb15s = ((size_t) (RS15_TILE_PAD + rec15) * sz + (size_t) lcap15 * 4 + RS15S_CKB + 15) / 16 * 16;
   const size_t lut15 = (size_t) ((r->nph + 1) * 20 + 4) * 4;
   const int nw15s = (int) std::min<size_t>(16, (RS_LDS_LIMIT - lut15 - 64) / wb15s);
   const char *e15s = getenv("TSDGPU_RS15S");                   // =0: the one-pass K = 15 kernel (A/B)
-  if (r->K == 15 && r->mode == 0 && r->inc >= 0.5f && nw15s >= 4 && !(e15 && atoi(e15) == 0) && !(e15s && atoi(e15s) == 0)) {
+  if (r->K == 15 && r->mode == 0 && r->inc >= 0.5f && r->nph <= 511 && nw15s >= 4 && !(e15 && atoi(e15) == 0) && !(e15s && atoi(e15s) == 0)) {
     const int NW = nw15s;
     P.rec_cap = rec15;
     int64_t g15 = std::min<int64_t>(cdiv(tiles, NW), 256);
