@@ -40,7 +40,7 @@ TRAFFIC_KERNELS = {
     "fir": ["ols_kernel<false"],
     "fft": ["fft1m_cols_kernel<1", "fft1m_cols_kernel<2"],
     "sos": ["sos_kernel"],
-    "resample": ["resample15_kernel"],
+    "resample": ["resample15"],          # (resample15s_kernel; resample15_kernel in the files of rounds 1-3)
 }
 
 
