@@ -76,6 +76,22 @@ def design_lowpass(n, fc):
     return (h / h.sum()).astype(np.float32)
 
 
+def design_riia_butter_sos(order, fc):
+    """Butterworth low-pass of even `order` as libtsd's design_riia(order, "lp", "butt", fc) -> filtre_sois builds it: analogue
+    prototype poles on the unit circle, pre-warped bilinear transform, all zeros at -1; conjugate poles paired into DF2
+    sections [1, 2, 1] / [1, a1, a2] (b0 = 1) and ONE gain = numer.mlt / denom.mlt applied to the last section's output
+    (filtre-rt.cc:467-559).  Coefficients are bench input data (the oracle's design_butter_lp + SosChain.coefs() give the
+    same table; the bench's GPU legs import nothing from oracle/).  -> ([nsec, 5] float32 (b0, b1, b2, a1, a2), gain)"""
+    assert order % 2 == 0
+    k = np.arange(order // 2)
+    pa = np.exp(1j * np.pi * (2 * k + order + 1) / (2 * order))              # left half plane, upper half
+    w = np.tan(np.pi * fc)
+    pz = (1 + w * pa) / (1 - w * pa)                                        # bilinear transform, fs = 1
+    co = np.array([[1.0, 2.0, 1.0, -2 * p.real, abs(p) ** 2] for p in pz], np.float64)
+    gain = float(np.prod([(1 + c[3] + c[4]) / 4.0 for c in co]))            # unit gain at DC
+    return co.astype(np.float32), gain
+
+
 def _time_cpu(fn, units_per_call, unit, what, seconds_target=12.0):
     t0 = time.perf_counter()
     fn()
@@ -202,11 +218,11 @@ class SosWorkload:
     unit = "Msamples/s"
 
     def __init__(self, t, torch, dev, rank, world, args):
-        from scipy.signal import butter
         self.rank, self.world = rank, world
         self.n = _per_rank(1 << args.log2n, world, args)
-        sos = butter(12, 0.5, output="sos")          # fcut 0.25 of fs; coefficients = bench input data
-        self.co = np.array([[s[0], s[1], s[2], s[4], s[5]] for s in sos], np.float32)
+        # design_riia(12, "lp", "butt", 0.25) -> filtre_sois: six DF2 sections with b0 = 1 and the gain applied at the end
+        # (filtre-rt.cc:467-559) -- the form the reference builds, not scipy's (b0 != 1, gain folded into the first section)
+        self.co, self.gain = design_riia_butter_sos(12, 0.25)
         g = torch.Generator(device=dev).manual_seed(4 + rank)
         self.x = torch.randn(self.n, device=dev, generator=g)
         self.y = torch.empty_like(self.x)
@@ -214,11 +230,11 @@ class SosWorkload:
         self.ring = args.force_dist and world == 1
         if self.dist:
             from libtsd_amd import sharding
-            self.ov = sharding.OverlappedSos(t, self.co, 1.0, t.F32, edge_stream=True)
+            self.ov = sharding.OverlappedSos(t, self.co, self.gain, t.F32, edge_stream=True)
             self.ov.input_ready = True
             self.f = self.ov.main
         else:
-            self.f = t.Sos(self.co, 1.0, t.F32)
+            self.f = t.Sos(self.co, self.gain, t.F32)
         self.halo = int(self.f.halo)
         self.halo_out = self.x[self.n - self.halo:].clone()
         self.halo_in = torch.zeros(self.halo, dtype=self.x.dtype, device=dev)

@@ -68,6 +68,10 @@ struct SosSection {
   // the same tables for the narrow warm-up steps (L = NARROW_FLOATS / channels samples per lane)
   float An[6][4];
   float c1n[NARROW_FLOATS], c2n[NARROW_FLOATS];
+  // Levels of the Kogge-Stone scan that matter: after K levels a lane's sum holds the terms of the 2^K lanes before it, and
+  // the first term left out is (M^L)^(2^K) Z = A[K] Z -- below 1e-9 of the states for a damped section long before the sixth
+  // level (pole radius 0.88: three levels; 0.67: two; 0.5 and less: one).  The bound of the chunk warm-ups (||Phi^W|| <= 1e-9).
+  int nlev, nlevn;
 };
 
 // state buffer layout (floats): [0] = seeded flag, then per (section, channel) four values:
@@ -181,9 +185,11 @@ __device__ __forceinline__ void sos_cascade(float (&v)[LF], const SosSection *__
         p1 = fmaf(A[0][0], sin1, fmaf(A[0][1], sin0, p1));
         p0 = fmaf(A[0][2], sin1, fmaf(A[0][3], sin0, p0));
       }
-      // inclusive Kogge-Stone scan over the 64 lanes: P_l = sum_j (M^L)^(l-j) Z_j
+      // inclusive Kogge-Stone scan over the 64 lanes: P_l = sum_j (M^L)^(l-j) Z_j, cut where the powers have died out (nlev)
+      const int nlev = NARROW ? k.nlevn : k.nlev;
 #pragma unroll
       for (int kk = 0; kk < 6; kk++) {
+        if (kk >= nlev) break;
         const int dd = 1 << kk;
         const float q1 = __shfl_up(p1, dd), q0 = __shfl_up(p0, dd);
         if (lane >= dd) {
@@ -671,12 +677,15 @@ bool carry_tables(const std::vector<double> &phi, int m, int64_t L, std::vector<
 }
 
 void fill_tables_for(SosSection &k, int L, int NF, float *c1, float *c2, float (*Aout)[4]);
+int scan_levels(const float (*A)[4]);
 void fill_tables(SosSection &k, int L)
 {
   k.sg = k.a1 <= 0.f ? 1.f : -1.f;          // poles' real part = -a1 / 2
   fill_tables_for(k, L, LANE_FLOATS, k.c1, k.c2, k.A);
   // narrow warm-up steps: NARROW_FLOATS floats per lane = L * NARROW_FLOATS / LANE_FLOATS samples per channel
   fill_tables_for(k, L * NARROW_FLOATS / LANE_FLOATS, NARROW_FLOATS, k.c1n, k.c2n, k.An);
+  k.nlev = scan_levels(k.A);
+  k.nlevn = scan_levels(k.An);
 }
 void fill_tables_for(SosSection &k, int L, int NF, float *c1o, float *c2o, float (*Aout)[4])
 {
@@ -715,6 +724,17 @@ void fill_tables_for(SosSection &k, int L, int NF, float *c1o, float *c2o, float
                          A[2] * A[1] + A[3] * A[3]};
     for (int j = 0; j < 4; j++) A[j] = t[j];
   }
+}
+// scan levels that matter for this table (see SosSection::nlev): the first K whose power is below 1e-9 in the row-sum norm
+int scan_levels(const float (*A)[4])
+{
+  static const bool full = getenv("TSDGPU_SOS_FULL_SCAN") != nullptr;      // A/B and test switch: all six levels
+  if (full) return 6;
+  for (int K = 0; K < 6; K++) {
+    const double n0 = std::fabs((double) A[K][0]) + std::fabs((double) A[K][1]), n1 = std::fabs((double) A[K][2]) + std::fabs((double) A[K][3]);
+    if (std::isfinite(n0) && std::isfinite(n1) && std::max(n0, n1) <= 1e-9) return K;
+  }
+  return 6;
 }
 
 }  // namespace

@@ -7,7 +7,7 @@ cd "$(dirname "$0")/../libtsd_amd/csrc"
 name=$1; unit=$2; flags=$3
 make -s
 mkdir -p build/variants ../lib/variants
-base="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result -ffp-contract=off"
+base="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result -ffp-contract=off -mllvm -amdgpu-atomic-optimizer-strategy=None"
 case $unit in ols.hip|fft.hip|ols_long.hip) base="$base -fno-slp-vectorize -ffp-contract=fast";; esac
 /opt/rocm/bin/hipcc $base $flags -c $unit -o build/variants/${name}.o
 objs=""
