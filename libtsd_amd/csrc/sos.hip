@@ -123,7 +123,16 @@ __device__ __forceinline__ void sos_cascade(float (&v)[LF], const SosSection *__
   for (int s = 0; s < nsec; s++) {
     const SosSection &k = sec[s];
     const float b0 = k.b0, b1 = k.b1, b2 = k.b2, a1 = k.a1, a2 = k.a2;
-    const float(*A)[4] = NARROW ? k.An : k.A;
+    // (the scan's tables loaded here, beside the coefficients -- one scalar-cache round trip for both; read level by level
+    // inside the scan, each level waited for its own)
+    float A[6][4];
+    {
+      const float(*Ag)[4] = NARROW ? k.An : k.A;
+#pragma unroll
+      for (int q = 0; q < 6; q++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) A[q][j] = Ag[q][j];
+    }
     const float *c1 = NARROW ? k.c1n : k.c1, *c2 = NARROW ? k.c2n : k.c2;
 #pragma unroll
     for (int c = 0; c < NCH; c++) {
