@@ -73,16 +73,20 @@ __global__ __launch_bounds__(THREADS) void fir_direct_kernel(
   const int64_t tile0 = (int64_t) blockIdx.x * TILE;
   const int H = KP;
   const int total = TILE + H;                        // samples 0 .. total-1 (sample 0 unused)
-  const bool interior = FAST && tile0 - H >= 0 && tile0 + TILE <= n;
+  const bool interior = FAST && tile0 - H >= 0 && tile0 + TILE + VEC <= n;      // (the chunked load reads up to VEC - 1 samples past the tile)
 
   if (interior) {
-    // 16-B global loads: chunk c = samples [c*VEC, c*VEC + VEC)
-    const float4 *xs = reinterpret_cast<const float4 *>(x + (tile0 - H));
+    // 16-B global loads that start ONE sample into the tile's range: chunk c = samples [c*VEC + 1, c*VEC + 1 + VEC), i.e.
+    // positions q = c*VEC .. c*VEC + VEC - 1 -- a whole 16-B unit of one segment, so a chunk goes to LDS as one ds_write_b128
+    // (loaded from the range's first sample the chunks straddled the units: two ds_write_b64 each, 2-way bank conflicts).
+    // The loads are sizeof(T) off the 16-B grid, which global memory does not mind.
+    struct __attribute__((aligned(4))) f4u { float x, y, z, w; };
+    const f4u *xs = reinterpret_cast<const f4u *>(x + (tile0 - H + 1));
     // four loads in flight per thread (the tile is 4..5 chunks per thread: one load per
     // iteration exposed the HBM latency that many times per workgroup)
-    const int nchunks = total / VEC;
+    const int nchunks = (total - 1 + VEC - 1) / VEC;
     for (int c0 = threadIdx.x; c0 < nchunks; c0 += 4 * THREADS) {
-      float4 q4[4];
+      f4u q4[4];
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const int c = c0 + u * THREADS;
@@ -92,12 +96,8 @@ __global__ __launch_bounds__(THREADS) void fir_direct_kernel(
       for (int u = 0; u < 4; u++) {
         const int c = c0 + u * THREADS;
         if (c < nchunks) {
-          const T *e = reinterpret_cast<const T *>(&q4[u]);
-#pragma unroll
-          for (int k = 0; k < VEC; k++) {
-            const int q = c * VEC + k - 1;
-            if (q >= 0) L[q + (q / R) * P] = e[k];
-          }
+          const int q = c * VEC;
+          *reinterpret_cast<float4 *>(L + q + (q / R) * P) = make_float4(q4[u].x, q4[u].y, q4[u].z, q4[u].w);
         }
       }
     }
@@ -132,6 +132,7 @@ __global__ __launch_bounds__(THREADS) void fir_direct_kernel(
   load_seg(A, Lw);
 
   const int nchunk = KP / R;  // even by construction
+#pragma unroll 2
   for (int c = 0; c < nchunk; c += 2) {
     const TC *h0 = hrev + c * R;
     load_seg(B, Lw + (c + 1) * SP);
@@ -159,21 +160,19 @@ __global__ __launch_bounds__(THREADS) void fir_direct_kernel(
   }
 
   if (interior) {
-    // outputs go back through LDS so that every global store is a coalesced 16-B access
-    __syncthreads();
-    T *Lo = L + threadIdx.x * SP;
+    // a lane's R outputs are 64 contiguous bytes: four 16-B stores straight from the registers.  A wave instruction covers 32
+    // cache lines half a line at a time and the next one completes them (L2 merges the halves); staged back through LDS for
+    // fully coalesced stores the tile cost two more barriers, eight LDS instructions per lane and their index arithmetic --
+    // in a kernel whose vector ALUs are 92 % busy that is time, and the stores are 1/16 of its memory traffic per tap.
+    float4 *ys = reinterpret_cast<float4 *>(y + tile0 + (int64_t) threadIdx.x * R);
 #pragma unroll
     for (int v4 = 0; v4 < R / VEC; v4++) {
       float4 q4;
       T *e = reinterpret_cast<T *>(&q4);
 #pragma unroll
       for (int k = 0; k < VEC; k++) e[k] = acc[v4 * VEC + k];
-      *reinterpret_cast<float4 *>(Lo + v4 * VEC) = q4;
+      ys[v4] = q4;
     }
-    __syncthreads();
-    float4 *ys = reinterpret_cast<float4 *>(y + tile0);
-    for (int c = threadIdx.x; c < TILE / VEC; c += THREADS)
-      ys[c] = *reinterpret_cast<const float4 *>(L + (c / (R / VEC)) * SP + (c % (R / VEC)) * VEC);
   } else {
     const int64_t o0 = tile0 + (int64_t) threadIdx.x * R;
 #pragma unroll
