@@ -166,7 +166,7 @@ class FirWorkload:
         # single-threaded: one stateful filter per chunk) -- informative extra, not the baseline
         try:
             from concurrent.futures import ThreadPoolExecutor
-            nthr = max(1, min(16, len(os.sched_getaffinity(0))))
+            nthr = max(1, len(os.sched_getaffinity(0)))      # every core this process may run on; the count is in `cores`
             firs = [orc.Fir(self.h) for _ in range(nthr)]
             xs = [x.copy() for _ in range(nthr)]
             with ThreadPoolExecutor(nthr) as ex:
@@ -177,7 +177,8 @@ class FirWorkload:
                     list(ex.map(lambda i: firs[i].step(xs[i]), range(nthr)))
                 dt = time.perf_counter() - t0
             res["parallel"] = {"value": round(reps * nthr * n0 / dt / 1e6, 3), "unit": "Msamples/s", "cores": nthr,
-                               "sample": f"{reps} x {nthr} chunks of 2^20 samples, one oracle filter per thread"}
+                               "sample": f"{reps} x {nthr} chunks of 2^20 samples, one oracle filter per thread, "
+                                         f"{nthr} threads = the affinity mask of this process ({os.cpu_count()} cores on the host)"}
         except Exception as e:      # never let the informative leg break the bench line
             res["parallel"] = {"error": str(e)}
         return res

@@ -25,6 +25,10 @@ static int exemple_anglais()
     bruit_y += (y(i) - ref) * (y(i) - ref);
   }
   std::printf("english API: %d taps, %d samples, residual noise power %.4f -> %.4f\n", h.rows(), y.rows(), bruit_x / (n - 100), bruit_y / (n - 100));
+  // resampling through an interpolator, English names (dsp/filter.hpp:1755-1805,1910)
+  let z = dsp::filter::filter_itrp<float>(1.5f, dsp::filter::itrp_sinc<float>(15, 0.4f, "hn"))->step(y);
+  std::printf("english API: filter_itrp(1.5, itrp_sinc(15, 0.4, \"hn\")): %d -> %d samples\n", y.rows(), z.rows());
+  if (std::abs(z.rows() - 750) > 2) return 1;
   return (h.rows() == 31 && y.rows() == n && bruit_y < 0.7 * bruit_x) ? 0 : 1;
 }
 

@@ -29,8 +29,24 @@ template <typename T> sptr<FilterGen<T>> filter_sois(const FRat<cfloat> &h, RIIS
 template <typename T> sptr<FilterGen<T>> filter_sois(const FRat<float> &h, RIIStructure s = FormeDirecte2) { return tsd::filtrage::filtre_sois<T>(h, s); }
 template <typename T> sptr<Filter<T, T, float>> filter_resample(float ratio) { return tsd::filtrage::filtre_reechan<T>(ratio); }
 // interpolators (dsp/filter.hpp:1762-1805): linear, Lagrange, cubic spline, windowed sinc
+template <typename T> using Interpolator = tsd::filtrage::Interpolateur<T>;
+template <typename T> using InterpolatorFIR = tsd::filtrage::InterpolateurRIF<T>;
+template <typename T> sptr<InterpolatorFIR<T>> itrp_cspline() { return tsd::filtrage::itrp_cspline<T>(); }                 // :1755-1758
 template <typename T> auto itrp_linear() { return tsd::filtrage::itrp_lineaire<T>(); }
 template <typename T> auto itrp_lagrange(int degree) { return tsd::filtrage::itrp_lagrange<T>(degree); }
+// (:1801-1805.  The reference's forwarder passes these three positional arguments to tsd::filtrage::itrp_sinc, which takes an
+// InterpolateurSincConfig -- it does not compile once instantiated.  This one builds the structure.)
+template <typename T> sptr<InterpolatorFIR<T>> itrp_sinc(int ncoefs, float fcut = 0.5, const std::string &window_type = "hn")
+{
+  tsd::filtrage::InterpolateurSincConfig c;
+  c.ncoefs = ncoefs;
+  c.fcut = fcut;
+  c.fenetre = window_type;
+  return tsd::filtrage::itrp_sinc<T>(c);
+}
+// resampling at an arbitrary ratio through an interpolator (:1910): filtre_itrp
+template <typename T> sptr<FilterGen<T>> filter_itrp(float ratio, sptr<Interpolator<T>> itrp = itrp_cspline<T>())
+{ return tsd::filtrage::filtre_itrp<T>(ratio, itrp); }
 // dsp/filter.hpp:1128-1164,1288-1292,1354-1358,1407-1411,1578-1631,1827-1883,1910
 using Frequency = tsd::filtrage::Fréquence;
 inline float ema_coef(Frequency fc) { return tsd::filtrage::lexp_coef(fc); }

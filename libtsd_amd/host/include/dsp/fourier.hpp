@@ -20,6 +20,7 @@ template <typename T> Vector<T> fftshift(const Vector<T> &X) { return tsd::fouri
 template <typename T> void force_csym(Vector<T> &X) { tsd::fourier::csym_forçage(X); }
 // "next" rows (dsp/fourier.hpp:140-143,251-355,397-457,488-505,623-672): same objects, English names
 inline Vecf resample_freq(const Vecf &x, float ratio) { return tsd::fourier::rééchan_freq(x, ratio); }
+inline Veccf czt(const Veccf &x, int m, cfloat W, cfloat z0 = 1.0f) { return tsd::fourier::czt(x, m, W, z0); }        // dsp/fourier.hpp: czt
 struct FFTFilterConfig : tsd::fourier::FiltreFFTConfig {
   int &time_blocks_length = dim_blocs_temporel;
   int &minimum_zeros_count = nb_zeros_min;

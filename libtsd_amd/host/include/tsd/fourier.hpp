@@ -76,6 +76,10 @@ std::tuple<Vecf, Veccf> xcorrb(const Veccf &x, const Veccf &y = Veccf(), entier 
 std::tuple<Vecf, Veccf> xcorr(const Veccf &x, const Veccf &y = Veccf(), entier m = -1);
 // rééchan_freq (fourier.cc:1391-1419): resampling by zero-padding / truncating the spectrum
 Vecf rééchan_freq(const Vecf &x, float lom);
+// czt (fourier.hpp:424, fourier.cc:1347-1389): the reference's chirp-z evaluation -- its chirp sequence, pre-multiplication,
+// fft(hc) * fft(gc), ifft and post-division statement for statement, the transforms on the GPU plan.  As in the reference the
+// two sequences it multiplies have m + n - 1 and 2m - 1 points, so only n == m is served (anything else fails there too).
+Veccf czt(const Veccf &x, entier m, cfloat W, cfloat z0 = 1.0f);
 // filtre_fft (fourier.cc:737-940; include/tsd/fourier.hpp:304-366): frequency-domain block
 // processing by overlap-add with a user callback on every spectrum.  Returns the filter and
 // the FFT size N.  Blocks of Ne = dim_blocs_temporel inputs (512 if <= 0), N = pp2(Ne +

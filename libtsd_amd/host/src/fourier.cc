@@ -109,6 +109,32 @@ Vecf rééchan_freq(const Vecf &x, float lom)
   return hote ? y.vers_hote() : y;
 }
 
+// ---- czt (fourier.cc:1347-1389) ----------------------------------------------------------------------
+// The sequences are built on the host exactly as the reference builds them (float pow of complex numbers, its index
+// arithmetic included -- a transliteration of a 1-based script that the reference left as it is), the three transforms run
+// on the device plan through fft() / ifft(), i.e. 2m - 1 points: an odd size, the one-kernel Bluestein.
+Veccf czt(const Veccf &x, entier m, cfloat W, cfloat z0)
+{
+  const entier n = x.rows(), nm = std::max(n, m);
+  if (n < 1 || m < 1) échec("czt: n = {}, m = {}", n, m);
+  if (m + n - 1 != 2 * m - 1) échec("czt: {} samples, {} points: the reference multiplies transforms of {} and {} points -- only n == m is served", n, m, m + n - 1, 2 * m - 1);
+  const Veccf xh = x.est_sur_gpu() ? x.vers_hote() : x;
+  Veccf h(2 * nm - 1);
+  for (entier i = 0; i < nm; i++) h(i) = std::pow(W, -0.5f * i * i);                                 // :1356-1357
+  for (entier i = nm; i < 2 * nm - 1; i++) h(i) = h(nm - 1 - (i - nm));                              // :1358-1359
+  Veccf g(n);
+  for (entier i = 0; i < n; i++) g(i) = xh(i) * std::pow(z0, (float) -i) / h(nm + i - 1);           // :1364-1368
+  Veccf hc(m + n - 1);                                                                               // :1374-1376
+  hc.head(m) = h.segment(nm - 1, m);
+  if (n > 1) hc.tail(n - 1) = h.segment(nm - n, n - 1);
+  Veccf gc = Veccf::zeros(m + m - 1);                                                                // :1378-1379
+  gc.head(n) = g;
+  const Veccf hcg = ifft(fft(hc) * fft(gc));                                                         // :1384
+  Veccf y(m);                                                                                        // :1389 (element-wise division)
+  for (entier i = 0; i < m; i++) y(i) = hcg(i) / h(nm - 1 + i);
+  return y;
+}
+
 // ---- délais (fourier.cc:607-698) ----------------------------------------------------------------
 // Fractional delay = a linear phase on the spectrum of the vector zero-padded to twice its length (a quarter
 // of the padded length on either side): bin k of the padded transform, at signed frequency f_k = k/n for

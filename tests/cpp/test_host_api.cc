@@ -559,6 +559,17 @@ static void test_reechan()   // test-ra.cc:55-160 style checks on rééchan / fi
   // dsp::resample spelling
   dsp::Veccf xc = randcn(2000);
   CHECK(dsp::resample(xc, 1.25f).rows() == rééchan(xc, 1.25f).rows(), "dsp::resample");
+  // dsp::filter interpolators and filter_itrp (dsp/filter.hpp:1755-1805,1910): the same objects as the French names; itrp_sinc
+  // takes (ncoefs, fcut, window) -- the reference's own forwarder does not compile once instantiated, this one builds the structure
+  {
+    auto fa = dsp::filter::filter_itrp<cfloat>(1.25f, dsp::filter::itrp_sinc<cfloat>(15, 0.4f, "hn"));
+    auto fb = filtre_itrp<cfloat>(1.25f, itrp_sinc<cfloat>({15, 256, 0.4f, "hn"}));
+    Veccf ya = fa->step(xc), yb = fb->step(xc);
+    CHECK(ya.rows() == yb.rows() && maxabs(ya - yb) == 0.f, "dsp::filter::filter_itrp(itrp_sinc(15, 0.4, hn)) == filtre_itrp(itrp_sinc{15,256,0.4,hn})");
+    Veccf yc = dsp::filter::filter_itrp<cfloat>(0.8f)->step(xc), yd = filtre_itrp<cfloat>(0.8f, itrp_cspline<cfloat>())->step(xc);
+    CHECK(yc.rows() == yd.rows() && maxabs(yc - yd) == 0.f, "dsp::filter::filter_itrp default interpolator = itrp_cspline");
+    CHECK(dsp::filter::itrp_linear<float>()->K == 2 && dsp::filter::itrp_lagrange<float>(3)->K == 4 && dsp::filter::itrp_cspline<float>()->K == 4, "dsp interpolator lengths");
+  }
 }
 
 static void test_polyphase()
@@ -630,6 +641,38 @@ static void test_xcorr(bool biais)
 }
 
 // test_reechan (test-fourier.cc:122-159): x2 by spectrum padding then every other sample == x
+// czt (fourier.cc:1347-1389): no reference test holds a value ("parity unpinned"); the check is the reference's own statements
+// evaluated in double with a direct O(N^2) circular convolution in place of ifft(fft * fft) (unitary transforms: the product of
+// the two spectra comes back as the circular convolution over sqrt(N))
+static void test_czt()
+{
+  for (int n : {8, 13, 64, 500}) {
+    const int m = n, nm = n, N = 2 * m - 1;
+    Veccf x = randcn(n);
+    const cfloat W = std::polar(0.999f, -2 * π_f / n * 0.7f), z0 = std::polar(0.98f, 0.3f);
+    Veccf y = czt(x, m, W, z0);
+    std::vector<std::complex<double>> h(2 * nm - 1), g(N, 0.0), hc(N);
+    for (int i = 0; i < nm; i++) h[i] = (std::complex<double>) std::pow(W, -0.5f * i * i);     // (the float powers of the reference)
+    for (int i = nm; i < 2 * nm - 1; i++) h[i] = h[nm - 1 - (i - nm)];
+    for (int i = 0; i < n; i++) g[i] = (std::complex<double>) (x(i) * std::pow(z0, (float) -i)) / h[nm + i - 1];
+    for (int i = 0; i < m; i++) hc[i] = h[nm - 1 + i];
+    for (int i = 0; i < n - 1; i++) hc[m + i] = h[nm - n + i];
+    double err = 0, ref = 0;
+    for (int k = 0; k < m; k++) {
+      std::complex<double> s = 0;
+      for (int j = 0; j < N; j++) s += hc[j] * g[((k - j) % N + N) % N];
+      const std::complex<double> want = s / std::sqrt((double) N) / h[nm - 1 + k];
+      err = std::max(err, std::abs(want - (std::complex<double>) y(k)));
+      ref = std::max(ref, std::abs(want));
+    }
+    CHECK(y.rows() == m && err <= 2e-5 * ref, "czt n = m = %d: err %g of %g", n, err, ref);
+  }
+  bool jete = false;
+  try { (void) czt(randcn(8), 12, cfloat(1, 0)); } catch (const std::exception &) { jete = true; }
+  CHECK(jete, "czt with n != m fails like the reference (sizes m + n - 1 and 2m - 1 multiplied)");
+  CHECK(dsp::fourier::czt(randcn(4), 4, cfloat(1, 0)).rows() == 4, "dsp::fourier::czt");
+}
+
 static void test_reechan_freq()
 {
   const int n = 16;
@@ -1422,6 +1465,7 @@ int main(int argc, char **argv)
   test_xcorr(true);
   test_xcorr(false);
   test_reechan_freq();
+  test_czt();
   test_pad_zeros();
   for (float f : {0.f, 250.f, 1.f, 10.f, -10.f, 0.5f, 0.1f, 1.5f}) {
     test_delais_fractionnaire<cfloat>(f);
