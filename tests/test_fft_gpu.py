@@ -46,7 +46,7 @@ def test_fft_ones_and_impulse(tg):
         X = tg.fft(np.ones(n, np.complex64))
         ref = np.zeros(n, np.complex64)
         ref[0] = np.sqrt(n)
-        assert np.abs(X - ref).max() <= 2e-5 * np.sqrt(n)
+        assert np.abs(X - ref).max() <= 1e-5 * np.sqrt(n)
         x = np.zeros(n, np.complex64)
         x[0] = 1
         assert np.abs(tg.fft(x) - np.float32(1 / np.sqrt(n))).max() <= 1e-6
@@ -94,8 +94,9 @@ def test_fft_mixed_radix(tg, orc, n):
     yd = p.step(xd)
     torch.cuda.synchronize()
     y = yd.cpu().numpy()
-    # (odd parts above 31 inherit the reference's float32 chirp: 2e-5 like the odd sizes)
-    tol = TOL if (n & -n) * 31 >= n else 2e-5
+    # (odd parts above 31 reproduce the reference's float32 chirp: the same 1e-5 band around the oracle, which itself sits
+    # 1e-4 ... 3e-3 from the float64 transform there -- profiles/r4_tolerance_audit.txt)
+    tol = TOL
     for b in range(batch):
         assert relerr(y[b], orc.fft(x[b])) <= tol
     zd = p.step(yd, False, yd)
@@ -103,7 +104,8 @@ def test_fft_mixed_radix(tg, orc, n):
     # the reference's own round trip is only good to ~1e-4 when the odd part is large (float32 chirp angle)
     # (chirp angle ~ pi m rounded to float32: the error grows like 6e-8 * pi * m per transform)
     m_odd = n // (n & -n)
-    assert relerr(zd.cpu().numpy(), x) <= (2 * TOL if tol == TOL else max(3e-4, 1e-6 * m_odd))
+    # (a property of the transform pair, not a parity band: the oracle's own round trip shows the same figure)
+    assert relerr(zd.cpu().numpy(), x) <= (2 * TOL if m_odd <= 31 else max(3e-4, 1e-6 * m_odd))
     assert relerr(tg.fft(x[0], False), orc.fft(x[0], False)) <= tol
 
 
@@ -120,12 +122,12 @@ def test_fft_odd_fused(tg, orc, n):
     torch.cuda.synchronize()
     y = yd.cpu().numpy()
     for b in range(batch):
-        assert relerr(y[b], orc.fft(x[b])) <= 2e-5
+        assert relerr(y[b], orc.fft(x[b])) <= TOL
     zd = p.step(yd, False, yd)
     torch.cuda.synchronize()
     z = zd.cpu().numpy()
     for b in range(batch):
-        assert relerr(z[b], orc.fft(y[b], False)) <= 2e-5
+        assert relerr(z[b], orc.fft(y[b], False)) <= TOL
 
 
 # plans that put the batch in gridDim.y (four-step, mixed radix) slice batches above 65535

@@ -1,6 +1,6 @@
 """A random sweep of FFT sizes -- the plan-selection boundaries of every round included -- against the oracle's restatement of the
 reference's plan (radix-2, even / odd split, float32-chirp Bluestein): whatever kernel a size lands on, the result is the
-reference's within the tolerance of the path (2e-5 where an odd part inherits the chirp's rounding)."""
+reference's within the tolerance of the path (1e-5, the sizes that reproduce the reference's float32 chirp included)."""
 import numpy as np
 import pytest
 
@@ -27,7 +27,7 @@ def test_fft_random_sizes_against_the_oracle():
         z = p.step(y, False)
         zr = np.stack([orc.fft(ref[b], False) for b in range(batch)])
         e2 = float(np.abs(z - zr).max() / np.abs(zr).max())
-        if e > 2e-5 or e2 > 4e-5:
+        if e > 1e-5 or e2 > 1e-5:
             bad.append((n, e, e2))
         p.close()
     assert not bad, bad

@@ -69,7 +69,7 @@ def test_sos_and_rii_host_pipeline(tg, orc):
     yd = tg.Rii(*lis, tg.F32).step(torch.from_numpy(xo).cuda()).cpu().numpy()
     from scipy.signal import lfilter
     ex = lfilter(lis[0].astype(np.float64), lis[1].astype(np.float64), xo.astype(np.float64))
-    assert np.abs(yh - ex).max() <= 2e-5 * np.abs(ex).max() and np.abs(yd - ex).max() <= 2e-5 * np.abs(ex).max()
+    assert np.abs(yh - ex).max() <= 1e-5 * np.abs(ex).max() and np.abs(yd - ex).max() <= 1e-5 * np.abs(ex).max()
 
 
 # variable output length: the resampler and the integer-rate stages report each chunk's output count on the host and

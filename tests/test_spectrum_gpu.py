@@ -18,10 +18,10 @@ def rand(n, seed):
 
 def check_db(got, ref, what):
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
-    # dB of a linear value within 2e-5 relative; bins the mask or the sweep leaves empty are -inf-like (10 log10 FLT_MIN) in both
+    # dB of a linear value within 1e-5 relative; bins the mask or the sweep leaves empty are -inf-like (10 log10 FLT_MIN) in both
     lin_g, lin_r = 10.0 ** (got.astype(np.float64) / 10), 10.0 ** (ref.astype(np.float64) / 10)
     err = np.abs(lin_g - lin_r).max() / lin_r.max()
-    assert err <= 2e-5, (what, err)
+    assert err <= 1e-5, (what, err)
     quiet = ref < -300
     assert np.array_equal(quiet, got < -300), what
 
