@@ -22,8 +22,6 @@ struct tsdgpu_fir {
   int ols_N = 0;            // FFT block size
   int ols_L = 0;            // valid outputs per block = N - (K-1)
   int ols_grid = 0;         // persistent grid size (waves)
-  bool ols_gen = false;     // twiddles generated from 2 x 4 table entries per lane (3 waves per SIMD)
-  int ols_wpw = 1;          // waves per workgroup of the overlap-save kernel (1: tables in registers, 4: in LDS)
   unsigned *d_ctr = nullptr;   // work counters of the dynamic block hand-out (ols.hip: OlsDyn), behind d_H
   int ctr_nc = 0;              // how many of them the launches so far have used
   unsigned ctr_base = 0;       // their common value before the next launch (every launch advances all of them alike)

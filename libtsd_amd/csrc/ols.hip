@@ -25,9 +25,6 @@ constexpr int OLS_N = 1024;
 // packed (VOP3P) flavour of fft1024_wave.hpp -- half the VALU instructions, parity-green, but
 // measured 2 % SLOWER (0.2313 vs 0.2260 ms, three interleaved runs): the kernel runs at the
 // speed of its memory skeleton, so the arithmetic is not what it waits for
-#ifndef OLS_SCALAR
-#define OLS_SCALAR 1
-#endif
 #ifndef OLS_RUN_DEFAULT   // blocks per run of a wave (ols_body): 1 = every block loads its whole overlap again
 #define OLS_RUN_DEFAULT 2
 #endif
@@ -35,38 +32,18 @@ constexpr int OLS_N = 1024;
 #define OLS_DYN_DEFAULT 16
 #endif
 constexpr int OLS_MAX_CTR = 32;
-// waves per workgroup: 1 (tables in registers, 8 waves per CU) or 4 (tables in an LDS image, 139 VGPRs, 12 waves per CU).
-// Measured with the dynamic hand-out (profiles/r3_ols_schedule_ab.txt): 0.2017-0.2032 ms against 0.2081-0.2087 -- at equal
-// wave counts the 46 table reads per block cost 10 %, which the four extra waves do not win back.  The 4-wave flavour is
-// compiled only with -DOLS_WITH_WPW4=1 (scripts/build_variant.sh) and selected with TSDGPU_OLS_WPW=4.
-#ifndef OLS_WITH_WPW4
-#define OLS_WITH_WPW4 0
-#endif
-// Twiddles generated from 2 x 4 table entries per lane (fft1024_wave.hpp: PowGen; 168 VGPRs, 3 waves per SIMD) instead of 2 x 15
-// held in registers (200 VGPRs, 2 waves per SIMD).  Measured (profiles/r3_ols_schedule_ab.txt): with H in registers too the
-// kernel spills 31-45 dwords and takes 0.267 ms against 0.2036; with H in a 4-wave workgroup's LDS image (no spill worth the
-// name) 0.2154 ms -- the four extra waves per CU do not pay for the 11 generated products per stage and the H reads.
-// Compiled only with -DOLS_WITH_GEN=1 (scripts/build_variant.sh), selected with TSDGPU_OLS_GEN=1.
-#ifndef OLS_WITH_GEN
-#define OLS_WITH_GEN 0
-#endif
-#ifndef OLS_WIDE   // experiment: 16-B global accesses (layout NOT the FFT's: ablation only)
-#define OLS_WIDE 0
-#endif
-#if OLS_SCALAR
+// One wave per workgroup, the block's 46 per-lane constants (twiddles of the two radix-16 stages, the response H) in registers for
+// the wave's lifetime: 200 VGPRs, 2 waves per SIMD.  Measured against it and not kept (profiles/EXPERIMENTS.md, round 3): four
+// waves per workgroup with the tables in an LDS image (0.2081-0.2087 against 0.2017-0.2032 ms), twiddles generated from four
+// table entries per stage (0.2154-0.267), the packed VOP3P arithmetic of fft1024_wave.hpp (2 % slower), 16-B and non-temporal
+// global accesses.
 using cv = cpx;
-#else
-using cv = v2f;
-#endif
 __device__ __forceinline__ cv mkv(float a, float b) { return Make<cv>::of(a, b); }
 
 // EDGE = false: block fully inside [0, n) on both the input and the output side -- no guards,
 // straight-line code (lets hipcc use counted vmcnt waits so the prefetch and the previous
 // block's stores stay in flight).  EDGE = true: guarded loads (history / zero fill) and stores.
-#ifndef OLS_NT
-#define OLS_NT 0
-#endif
-constexpr bool NT = OLS_NT != 0;
+constexpr bool NT = false;      // (non-temporal accesses: measured slower, the helpers below stay for the ragged paths' signature)
 __device__ __forceinline__ cv ntload(const cv *p)
 {
   v2f t = __builtin_nontemporal_load(reinterpret_cast<const v2f *>(p));
@@ -104,16 +81,8 @@ __device__ __forceinline__ void ols_fetch(cv (&v)[16], const cv *__restrict__ x,
   const int64_t g0 = b * (int64_t) L - Km1;   // first input of block b
   if (!EDGE) {
     const cv *xb = x + g0;
-#if OLS_WIDE
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-      const float4 q = *reinterpret_cast<const float4 *>(xb + 128 * r + 2 * lane);
-      v[2 * r] = mkv(q.x, q.y); v[2 * r + 1] = mkv(q.z, q.w);
-    }
-#else
 #pragma unroll
     for (int r = 0; r < 16; r++) v[r] = NT ? ntload(xb + 64 * r + lane) : xb[64 * r + lane];
-#endif
   } else {
 #pragma unroll
     for (int r = 0; r < 16; r++) {
@@ -150,27 +119,13 @@ struct OlsDyn {
   int NC;
   int64_t nunits;
 };
-// The per-lane constants of a block -- twiddles of the two radix-16 stages and the response H, 46 complex values -- either
-// live in registers for the wave's lifetime (LT = false: 96 VGPRs, 200 in all, 2 waves per SIMD) or are read from an LDS
-// image shared by the workgroup's waves at every use (LT = true: 3 waves per SIMD; the kernel wants occupancy:
-// profiles/r3_ols_schedule_ab.txt, 5 / 6 / 7 / 8 waves per CU = 0.245 / 0.225 / 0.216 / 0.205 ms).  The LDS accessors take
-// the lane through an opaque copy made per block: with a loop-invariant address hipcc hoists all 46 reads out of the
-// block loop, back into registers.
 struct RegTab {
   cv v[16];
   __device__ __forceinline__ const cv &operator[](int r) const { return v[r]; }
 };
-struct LdsTab {
-  const cv *p;      // p[r * pitch] is this lane's entry r
-  int pitch;
-  __device__ __forceinline__ cv operator[](int r) const { return p[r * pitch]; }
-};
-constexpr int OLS_TAB_ELEMS = 64 * 16 * 2 + 4 * 16;      // tw1 [16][64] | H [16][64] | tw2 [16][4] (tw2 depends on lane & 3 only)
 
-// TM: where the twiddles come from -- 0: 2 x 15 table entries per lane in registers; 1: an LDS image shared by the workgroup;
-// 2: GENERATED from the table's entries 1, 2, 4, 8 (fft1024_wave.hpp: PowGen), 16 VGPRs instead of 60: 3 waves per SIMD
-template <bool EDGE, bool REAL, int R0, bool DYN, int TM>
-__device__ __forceinline__ void ols_body(cv *lds, const cv *ltab, const void *__restrict__ xv, const void *__restrict__ histv,
+template <bool EDGE, bool REAL, int R0, bool DYN>
+__device__ __forceinline__ void ols_body(cv *lds, const void *__restrict__ xv, const void *__restrict__ histv,
                                          void *__restrict__ yv, const cv *__restrict__ Hreg,
                                          const cv *__restrict__ TW1, const cv *__restrict__ TW2, int Km1,
                                          int histlen, int L, int64_t n, int64_t b_lo, int64_t b_hi, int64_t G,
@@ -181,23 +136,12 @@ __device__ __forceinline__ void ols_body(cv *lds, const cv *ltab, const void *__
   cv *y = (cv *) yv;
   const float *xr = (const float *) xv, *histr = (const float *) histv;
   float *yr = (float *) yv;
-  constexpr bool LT = TM == 1 || TM == 3;          // (3: twiddles generated, H from the workgroup's LDS image)
   RegTab tw1r, tw2r, Hr;
-  PowGen<cv> g1, g2;
-  if (TM == 0) {
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      tw1r.v[r] = TW1[r * 64 + lane];
-      tw2r.v[r] = TW2[r * 64 + lane];
-    }
-  }
-  if (TM == 0 || TM == 2) {
-#pragma unroll
-    for (int r = 0; r < 16; r++) Hr.v[r] = Hreg[r * 64 + lane];
-  }
-  if (TM >= 2) {
-    g1 = PowGen<cv>{TW1[64 + lane], TW1[128 + lane], TW1[256 + lane], TW1[512 + lane]};
-    g2 = PowGen<cv>{TW2[64 + lane], TW2[128 + lane], TW2[256 + lane], TW2[512 + lane]};
+  for (int r = 0; r < 16; r++) {
+    tw1r.v[r] = TW1[r * 64 + lane];
+    tw2r.v[r] = TW2[r * 64 + lane];
+    Hr.v[r] = Hreg[r * 64 + lane];
   }
   // One wave per workgroup: its LDS operations execute in order, so exchanging data between
   // lanes needs no s_barrier and -- crucially -- no vmcnt(0) drain (a __syncthreads() would
@@ -214,9 +158,11 @@ __device__ __forceinline__ void ols_body(cv *lds, const cv *ltab, const void *__
   // over the 8 XCDs, so w % 8 labels its XCD -- takes block (w % 8) * G/8 + w / 8: blocks that
   // share their K-1 overlap samples run on the same XCD at the same time and the second
   // reader hits that XCD's L2.  Placement only affects speed, never results.
-  const int64_t slot = (!LT && G % 8 == 0) ? (w % 8) * (G / 8) + w / 8 : w;
+  const int64_t slot = (G % 8 == 0) ? (w % 8) * (G / 8) + w / 8 : w;
   const int ctr_c = DYN ? (int) (cgrp % dyn.NC) : 0;     // cgrp: rounds of 8 workgroups (one per XCD)
   // -> the next unit of this wave's counter, or -1 once its quota is spent (exactly one failing pull per wave)
+  // (measured, round 4: issuing the pull a block earlier than its value is taken -- what pays in the resampler, whose loop
+  // otherwise drains its LDS-DMA at the pull -- costs 2 % here: 0.2057 against 0.2015 ms, three interleaved pairs)
   auto pull = [&]() -> int64_t {
     for (;;) {
       unsigned v = 0;
@@ -242,7 +188,7 @@ __device__ __forceinline__ void ols_body(cv *lds, const cv *ltab, const void *__
   auto process = [&](cv (&cur)[16], cv (&nxt)[16], int64_t blk, int64_t nb, bool inrun) {
     const bool more = !EDGE && nb < b_hi;
     // the prefetch of block nb into `nxt`: the rows reused from this block are copied NOW (cur still holds the raw samples),
-    // the loads are issued at `prefetch_loads()` -- before the forward transform, or (-DOLS_LATE_PREFETCH=1, experiment) after it
+    // the loads are issued at `prefetch_loads()` -- before the forward transform
     if (more && R0 > 0 && inrun) {
 #pragma unroll
       for (int r = 0; r < R0; r++) nxt[r] = REAL ? mkv(cur[(16 - R0 + r) & 15].y, 0.f) : cur[(16 - R0 + r) & 15];
@@ -264,49 +210,11 @@ __device__ __forceinline__ void ols_body(cv *lds, const cv *ltab, const void *__
       } else if (REAL) ols_fetch_real<EDGE>(nxt, xr, histr, histlen, Km1, L, n, nb, lane);
       else ols_fetch<EDGE>(nxt, x, hist, histlen, Km1, L, n, nb, lane);
     };
-#ifndef OLS_LATE_PREFETCH
-#define OLS_LATE_PREFETCH 0
-#endif
-    if (!OLS_LATE_PREFETCH || TM != 0) prefetch_loads();
-#ifndef OLS_ABLATE   // measurement only: bit 0 drops the forward FFT, bit 1 the product, bit 2 the inverse
-#define OLS_ABLATE 0
-#endif
-    if (TM == 3) {
-      int ol = lane;
-      asm volatile("" : "+v"(ol));               // opaque per block: the table reads stay inside the loop
-      const LdsTab H = {ltab + 1024 + ol, 64};
-      if (!(OLS_ABLATE & 1)) forward(cur, lds, lane, g1, g2, sync);
-      if (!(OLS_ABLATE & 2)) {
+    prefetch_loads();
+    forward(cur, lds, lane, tw1r, tw2r, sync);
 #pragma unroll
-        for (int r = 0; r < 16; r++) cur[r] = cmul(cur[r], H[r]);
-      }
-      if (!(OLS_ABLATE & 4)) inverse(cur, lds, lane, g1, g2, sync);
-    } else if (LT) {
-      int ol = lane;
-      asm volatile("" : "+v"(ol));               // opaque per block: the table reads stay inside the loop
-      const LdsTab tw1 = {ltab + ol, 64}, H = {ltab + 1024 + ol, 64}, tw2 = {ltab + 2048 + (ol & 3), 4};
-      if (!(OLS_ABLATE & 1)) forward(cur, lds, lane, tw1, tw2, sync);
-      if (!(OLS_ABLATE & 2)) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) cur[r] = cmul(cur[r], H[r]);
-      }
-      if (!(OLS_ABLATE & 4)) inverse(cur, lds, lane, tw1, tw2, sync);
-    } else if (TM == 2) {
-      if (!(OLS_ABLATE & 1)) forward(cur, lds, lane, g1, g2, sync);
-      if (!(OLS_ABLATE & 2)) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) cur[r] = cmul(cur[r], Hr[r]);
-      }
-      if (!(OLS_ABLATE & 4)) inverse(cur, lds, lane, g1, g2, sync);
-    } else {
-      if (!(OLS_ABLATE & 1)) forward(cur, lds, lane, tw1r, tw2r, sync);
-      if (OLS_LATE_PREFETCH) prefetch_loads();
-      if (!(OLS_ABLATE & 2)) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) cur[r] = cmul(cur[r], Hr[r]);
-      }
-      if (!(OLS_ABLATE & 4)) inverse(cur, lds, lane, tw1r, tw2r, sync);
-    }
+    for (int r = 0; r < 16; r++) cur[r] = cmul(cur[r], Hr[r]);
+    inverse(cur, lds, lane, tw1r, tw2r, sync);
     sync();   // LDS is reused by the next block
     if (more) {
 #pragma unroll
@@ -321,13 +229,6 @@ __device__ __forceinline__ void ols_body(cv *lds, const cv *ltab, const void *__
     if (!REAL) {
       const int64_t o0 = blk * (int64_t) L;
       cv *yb = y + (o0 - Km1);
-#if OLS_WIDE
-      if (!EDGE) {
-#pragma unroll
-        for (int r = 0; r < 8; r++)
-          if (2 * r >= r0) *reinterpret_cast<float4 *>(yb + 128 * r + 2 * lane) = make_float4(cur[2 * r].x, cur[2 * r].y, cur[2 * r + 1].x, cur[2 * r + 1].y);
-      } else
-#endif
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int t = 64 * r + lane;
@@ -398,42 +299,27 @@ __device__ __forceinline__ void ols_body(cv *lds, const cv *ltab, const void *__
 
 // One launch per step: waves [0, G) walk the interior blocks, the next `ne` waves take one edge block each (block 0 with the
 // history halo, the ragged last block), and the wave after them writes the new history (the last `histlen` samples of
-// history ++ x) into the handle's other history buffer.  WPW waves per workgroup: 1 = tables in registers, 2 waves per
-// SIMD; 4 = tables in an LDS image per workgroup, 3 workgroups per CU = 3 waves per SIMD.
-template <bool REAL, int R0, bool DYN, int WPW, bool GEN = false>
-__global__ __launch_bounds__(64 * WPW, (WPW == 1 && !GEN) ? 2 : 3) void ols_kernel(const void *__restrict__ x, const void *__restrict__ hist,
+// history ++ x) into the handle's other history buffer.  One wave per workgroup (tables in registers, 2 waves per SIMD).
+template <bool REAL, int R0, bool DYN>
+__global__ __launch_bounds__(64, 2) void ols_kernel(const void *__restrict__ x, const void *__restrict__ hist,
                                                     void *__restrict__ hist_next, void *__restrict__ y,
                                                     const cpx *__restrict__ Hreg, const cpx *__restrict__ TW1,
                                                     const cpx *__restrict__ TW2, int Km1, int histlen, int L,
                                                     int64_t n, int64_t b_lo, int64_t b_hi, int64_t nblocks, int G,
                                                     int ne, int64_t n_lo, int64_t b_tail, int R, OlsDyn dyn)
 {
-  constexpr bool LT = WPW > 1;
-  __shared__ cv smem[WPW * LDS_ELEMS + (LT ? OLS_TAB_ELEMS : 0)];
-  const int wv = WPW == 1 ? 0 : __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
-  cv *lds = smem + wv * LDS_ELEMS;
-  const cv *ltab = smem + WPW * LDS_ELEMS;
-  if (LT) {
-    cv *t = smem + WPW * LDS_ELEMS;
-    for (int i = threadIdx.x; i < 1024; i += 64 * WPW) {
-      t[i] = ((const cv *) TW1)[i];
-      t[1024 + i] = ((const cv *) Hreg)[i];
-    }
-    if (threadIdx.x < 64) t[2048 + threadIdx.x] = ((const cv *) TW2)[(threadIdx.x >> 2) * 64 + (threadIdx.x & 3)];      // [r][lane & 3]
-    __syncthreads();          // the only workgroup barrier: from here on the waves are independent
-  }
-  // wave index: workgroups are dealt round-robin over the XCDs, so the waves of workgroups g, g + 8, ... share an XCD; w / (8 WPW)
-  // numbers the rounds of 8 workgroups (the counter choice of the dynamic hand-out), w % 8 ... the static slot map is kept
-  // for WPW = 1 only
-  const int64_t w = (int64_t) blockIdx.x * WPW + wv;
+  __shared__ cv lds[LDS_ELEMS];
+  // wave index: workgroups are dealt round-robin over the XCDs, so the waves of workgroups g, g + 8, ... share an XCD; w / 8
+  // numbers the rounds of 8 workgroups (the counter choice of the dynamic hand-out)
+  const int64_t w = (int64_t) blockIdx.x;
   const int lane = threadIdx.x & 63;
   if (w < G) {
-    ols_body<false, REAL, R0, DYN, LT ? (GEN ? 3 : 1) : (GEN ? 2 : 0)>(lds, ltab, x, hist, y, (const cv *) Hreg, (const cv *) TW1, (const cv *) TW2, Km1, histlen, L, n, b_lo, b_hi, G,
+    ols_body<false, REAL, R0, DYN>(lds, x, hist, y, (const cv *) Hreg, (const cv *) TW1, (const cv *) TW2, Km1, histlen, L, n, b_lo, b_hi, G,
                                        w, (int64_t) blockIdx.x / 8, R, dyn);
   } else if (w < G + ne) {
     // edge items: [0, n_lo) need the history halo, [b_tail, nblocks) are ragged at the end
     const int64_t b = (w - G) < n_lo ? (int64_t) (w - G) : b_tail + (w - G - n_lo);
-    ols_body<true, REAL, 0, false, LT ? (GEN ? 3 : 1) : (GEN ? 2 : 0)>(lds, ltab, x, hist, y, (const cv *) Hreg, (const cv *) TW1, (const cv *) TW2, Km1, histlen, L, n, b, nblocks, 1, 0, 0, 1, dyn);
+    ols_body<true, REAL, 0, false>(lds, x, hist, y, (const cv *) Hreg, (const cv *) TW1, (const cv *) TW2, Km1, histlen, L, n, b, nblocks, 1, 0, 0, 1, dyn);
   } else if (w == G + ne) {
     for (int i = lane; i < histlen; i += 64) {
       const int64_t g = n - histlen + i;
@@ -528,42 +414,19 @@ int ols_plan_create(tsdgpu_fir *f)
   f->d_ctr = (unsigned *) ((char *) f->d_H + 3 * bytes);
   f->ctr_base = 0;
   // persistent grid: as many waves as the device keeps resident (asked once per process: the devices of a node are alike)
-  // waves per workgroup: 4 = tables in LDS, 3 workgroups of 4 waves per CU; 1 = tables in registers, 8 one-wave workgroups
-  const char *wpw_s = getenv("TSDGPU_OLS_WPW");
-  f->ols_wpw = (OLS_WITH_WPW4 && wpw_s && atoi(wpw_s) == 4) ? 4 : 1;
-  // twiddles generated from 2 x 4 table entries per lane (3 waves per SIMD) instead of 2 x 15 held (2 waves per SIMD)
-  const char *gen_s = getenv("TSDGPU_OLS_GEN");
-  f->ols_gen = OLS_WITH_GEN && gen_s && atoi(gen_s) != 0;
-  static const std::pair<int, std::pair<int, int>> occ = []() {
-    int dev = 0, cus = 256, per_cu1 = 8, per_cu4 = 3;
+  static const std::pair<int, int> occ = []() {
+    int dev = 0, cus = 256, per_cu = 8;
     (void) hipGetDevice(&dev);
     (void) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu1, ols_kernel<false, 2, true, 1>, 64, 0) != hipSuccess || per_cu1 < 1) {
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, ols_kernel<false, 2, true>, 64, 0) != hipSuccess || per_cu < 1) {
       (void) hipGetLastError();
-      per_cu1 = 8;
+      per_cu = 8;
     }
-#if OLS_WITH_WPW4
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu4, ols_kernel<false, 2, true, 4>, 256, 0) != hipSuccess || per_cu4 < 1) {
-      (void) hipGetLastError();
-      per_cu4 = 3;
-    }
-#endif
-    return std::make_pair(cus, std::make_pair(per_cu1, 4 * per_cu4));
+    return std::make_pair(cus, per_cu);
   }();
-  static const int per_cu_gen = []() {
-    int v = 12;
-#if OLS_WITH_GEN
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, ols_kernel<false, 2, true, 1, true>, 64, 0) != hipSuccess || v < 1) {
-      (void) hipGetLastError();
-      v = 12;
-    }
-#endif
-    return v;
-  }();
-  const int cus = occ.first, per_cu = f->ols_wpw == 4 ? occ.second.second : (f->ols_gen ? per_cu_gen : occ.second.first);    // waves per CU
+  const int cus = occ.first, per_cu = occ.second;      // waves per CU
   f->ols_grid = cus * per_cu;
-  if (const char *g = getenv("TSDGPU_OLS_WAVES_PER_CU")) f->ols_grid = cus * atoi(g);
-  if (getenv("TSDGPU_DEBUG")) fprintf(stderr, "[tsdgpu] ols plan: N=%d K=%d L=%d cus=%d waves/workgroup=%d waves/CU=%d grid=%d waves\n", N, K, f->ols_L, cus, f->ols_wpw, per_cu, f->ols_grid);
+  if (getenv("TSDGPU_DEBUG")) fprintf(stderr, "[tsdgpu] ols plan: N=%d K=%d L=%d cus=%d waves/CU=%d grid=%d waves\n", N, K, f->ols_L, cus, per_cu, f->ols_grid);
   return TSDGPU_OK;
 }
 
@@ -606,7 +469,7 @@ int ols_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, hipStream_t st)
     const int64_t dyn_min = min_s ? atoi(min_s) : 4;
     if (NC > 0 && nruns >= dyn_min * (int64_t) f->ols_grid) {
       // whole groups of 8 * NC workgroups, so that every counter has the same number of pullers
-      const int64_t grp = (int64_t) 8 * NC * f->ols_wpw;
+      const int64_t grp = (int64_t) 8 * NC;
       grid = std::max<int64_t>(grp, (f->ols_grid / grp) * grp);
       if (NC != f->ctr_nc) {
         // another counter count than the launches before (a tuning switch flipped mid-stream): the counters beyond the
@@ -635,57 +498,24 @@ int ols_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, hipStream_t st)
   const int ne = (int) (n_lo + (nblocks - b_tail));
   int64_t e[2] = {n_lo, b_tail};
   const int nxt = f->cur ^ 1;
-  const int WPW = f->ols_wpw;
-  const unsigned nwg = (unsigned) cdiv(grid + ne + 1, WPW);
-#define OLS_LAUNCH(REAL, R0, DYN, W)                                                                                                  \
-  hipLaunchKernelGGL((ols_kernel<REAL, R0, DYN, W>), dim3(nwg), dim3(64 * W), 0, st, x, (const void *) fir_hist_read(f),                 \
+  const unsigned nwg = (unsigned) (grid + ne + 1);
+#define OLS_LAUNCH(REAL, R0, DYN)                                                                                                     \
+  hipLaunchKernelGGL((ols_kernel<REAL, R0, DYN>), dim3(nwg), dim3(64), 0, st, x, (const void *) fir_hist_read(f),                        \
                      f->hist[nxt], y, d, d + OLS_N, d + 2 * OLS_N, OLS_N - L, f->HL, L, n, b_lo_w, b_hi, nblocks, (int) grid, ne,   \
                      e[0], e[1], R, dyn)
-#define OLS_LAUNCH_R0(REAL, DYN, W)                                        \
-  switch (R > 1 ? r0 : 0) {                                                \
-    case 1: OLS_LAUNCH(REAL, 1, DYN, W); break;                            \
-    case 2: OLS_LAUNCH(REAL, 2, DYN, W); break;                            \
-    case 3: OLS_LAUNCH(REAL, 3, DYN, W); break;                            \
-    case 4: OLS_LAUNCH(REAL, 4, DYN, W); break;                            \
-    default: OLS_LAUNCH(REAL, 0, DYN, W); break;                           \
+#define OLS_LAUNCH_R0(REAL, DYN)                                        \
+  switch (R > 1 ? r0 : 0) {                                             \
+    case 1: OLS_LAUNCH(REAL, 1, DYN); break;                            \
+    case 2: OLS_LAUNCH(REAL, 2, DYN); break;                            \
+    case 3: OLS_LAUNCH(REAL, 3, DYN); break;                            \
+    case 4: OLS_LAUNCH(REAL, 4, DYN); break;                            \
+    default: OLS_LAUNCH(REAL, 0, DYN); break;                           \
   }
-#define OLS_LAUNCH_G(REAL, R0, DYN)                                                                                                   \
-  hipLaunchKernelGGL((ols_kernel<REAL, R0, DYN, 1, true>), dim3(nwg), dim3(64), 0, st, x, (const void *) fir_hist_read(f),               \
-                     f->hist[nxt], y, d, d + OLS_N, d + 2 * OLS_N, OLS_N - L, f->HL, L, n, b_lo_w, b_hi, nblocks, (int) grid, ne,   \
-                     e[0], e[1], R, dyn)
-#define OLS_LAUNCH_G_R0(REAL, DYN)                                        \
-  switch (R > 1 ? r0 : 0) {                                               \
-    case 1: OLS_LAUNCH_G(REAL, 1, DYN); break;                            \
-    case 2: OLS_LAUNCH_G(REAL, 2, DYN); break;                            \
-    case 3: OLS_LAUNCH_G(REAL, 3, DYN); break;                            \
-    case 4: OLS_LAUNCH_G(REAL, 4, DYN); break;                            \
-    default: OLS_LAUNCH_G(REAL, 0, DYN); break;                           \
-  }
-#if OLS_WITH_WPW4 && OLS_WITH_GEN
-#define OLS_LAUNCH_G4(REAL, R0, DYN)                                                                                                  \
-  hipLaunchKernelGGL((ols_kernel<REAL, R0, DYN, 4, true>), dim3(nwg), dim3(256), 0, st, x, (const void *) fir_hist_read(f),              \
-                     f->hist[nxt], y, d, d + OLS_N, d + 2 * OLS_N, OLS_N - L, f->HL, L, n, b_lo_w, b_hi, nblocks, (int) grid, ne,   \
-                     e[0], e[1], R, dyn)
-#define OLS_LAUNCH_W(REAL, DYN) \
-  if (WPW == 4 && f->ols_gen) { if (R > 1 && r0 == 2) { OLS_LAUNCH_G4(REAL, 2, DYN); } else { OLS_LAUNCH_G4(REAL, 0, DYN); } } \
-  else if (f->ols_gen) { OLS_LAUNCH_G_R0(REAL, DYN) } else if (WPW == 1) { OLS_LAUNCH_R0(REAL, DYN, 1) } else { OLS_LAUNCH_R0(REAL, DYN, 4) }
-#elif OLS_WITH_WPW4
-#define OLS_LAUNCH_W(REAL, DYN) \
-  if (WPW == 1) { OLS_LAUNCH_R0(REAL, DYN, 1) } else { OLS_LAUNCH_R0(REAL, DYN, 4) }
-#elif OLS_WITH_GEN
-#define OLS_LAUNCH_W(REAL, DYN) \
-  if (f->ols_gen) { OLS_LAUNCH_G_R0(REAL, DYN) } else { OLS_LAUNCH_R0(REAL, DYN, 1) }
-#else
-#define OLS_LAUNCH_W(REAL, DYN) { OLS_LAUNCH_R0(REAL, DYN, 1) }
-#endif
   if (real) {
-    if (NC > 0) { OLS_LAUNCH_W(true, true) } else { OLS_LAUNCH_W(true, false) }
+    if (NC > 0) { OLS_LAUNCH_R0(true, true) } else { OLS_LAUNCH_R0(true, false) }
   } else {
-    if (NC > 0) { OLS_LAUNCH_W(false, true) } else { OLS_LAUNCH_W(false, false) }
+    if (NC > 0) { OLS_LAUNCH_R0(false, true) } else { OLS_LAUNCH_R0(false, false) }
   }
-#undef OLS_LAUNCH_W
-#undef OLS_LAUNCH_G_R0
-#undef OLS_LAUNCH_G
 #undef OLS_LAUNCH_R0
 #undef OLS_LAUNCH
   if (const hipError_t le = hipGetLastError(); le != hipSuccess) {
