@@ -461,6 +461,18 @@ int pipelined_host_step_var(const void *x, int64_t n, size_t esz_in, void *y, si
   return TSDGPU_OK;
 }
 
+const char *dev_switch(const char *name)
+{
+  char key[96];
+  snprintf(key, sizeof key, "TSDGPU_%s", name);
+  return getenv(key);
+}
+int dev_switch_int(const char *name, int dflt)
+{
+  const char *v = dev_switch(name);
+  return v ? atoi(v) : dflt;
+}
+
 bool host_pipe_enabled()
 {
   static const bool on = getenv("TSDGPU_NO_PIPE") == nullptr;

@@ -79,6 +79,13 @@ bool host_ranges_overlap(const void *a, size_t na, const void *b, size_t nb);
 // small device-to-device copy as a kernel launch (see common.hip)
 int device_copy_small(void *dst, const void *src, size_t bytes, hipStream_t st);
 bool host_pipe_enabled();     // false with TSDGPU_NO_PIPE=1 (A/B switch: whole-vector staging instead)
+// Developer / test switches: plan overrides and hand-out thresholds that let the tests put an ALTERNATIVE PRODUCT PATH (the static
+// partition of a dynamic kernel, the plan another size would take, the literal recursion ...) under the parity tests at small
+// sizes (scripts/check_switches.sh).  One door for all of them: dev_switch("FFT_NO_SMOOTH") is the environment variable
+// TSDGPU_FFT_NO_SMOOTH, read at every call (the tests flip them between handles).  Not a tuning surface: measured-and-rejected
+// variants are not in the tree (profiles/EXPERIMENTS.md has their numbers); the switches a USER may want are listed in DESIGN.md 6.
+const char *dev_switch(const char *name);                 // nullptr when unset
+int dev_switch_int(const char *name, int dflt);
 
 // Scratch of a STATELESS entry point (xcorr, welch, delay estimate ...): buffers and plans are borrowed for the call from a
 // small free list and go back to it, instead of a hipMalloc / plan construction / hipFree per call (a hipFree also

@@ -1254,8 +1254,6 @@ struct tsdgpu_fft {
   DevBuf work, work2, in_stage, out_stage;
   StepOrder order;            // top-level plans only (sub-plans run under their owner's)
   // grouped schedule of the 2^20 plan (TSDGPU_FFT_GROUP): two side streams and their events
-  hipStream_t gs[2] = {nullptr, nullptr};
-  hipEvent_t ge[2] = {nullptr, nullptr}, ge_in = nullptr;
 };
 
 namespace {
@@ -1316,7 +1314,7 @@ bool oddpow2_split(int n, int *m, int *P)
   if ((size_t) odd * (pw + pw / 16) * sizeof(cpx) > 150 * 1024) return false;
   // where it beats fft_mr_kernel (profiles/r3_perf_fft_oddpow2.txt; TSDGPU_FFT_ODDPOW2_ALL=1: wherever it fits): the direct
   // m-point combination grows with m^2 and short transforms leave a workgroup little to do per barrier
-  if (getenv("TSDGPU_FFT_ODDPOW2_ALL") == nullptr) {
+  if (dev_switch("FFT_ODDPOW2_ALL") == nullptr) {
     const bool wins = (odd == 3 && pw >= 32) || (odd == 5 && pw >= 32 && pw <= 1024) || (odd == 7 && pw >= 128 && pw <= 512) ||
                       (odd == 9 && pw >= 256 && pw <= 512);
     if (!wins) return false;
@@ -1372,9 +1370,8 @@ int plan_init(tsdgpu_fft *p, int n)
     p->kind = tsdgpu_fft::ONE;
   } else if ((n & (n - 1)) == 0) {
     p->logn = log2_exact(n);
-    const bool fast = getenv("TSDGPU_FFT_GENERIC") == nullptr;
-    static const bool w1024_rows = getenv("TSDGPU_FFT_W1024") != nullptr;
-    if (fast && ((n == 1024 && w1024_rows) || n == (1 << 20))) {
+    const bool fast = dev_switch("FFT_GENERIC") == nullptr;
+    if (fast && n == (1 << 20)) {
       p->kind = n == 1024 ? tsdgpu_fft::POW2_W1024 : tsdgpu_fft::POW2_W1M;
       std::vector<cpx> t1(1024), t2(1024);
       w1024::fill_twiddles(t1.data(), t2.data());
@@ -1424,10 +1421,6 @@ int plan_init(tsdgpu_fft *p, int n)
       TSD_CHECK(p->logn <= 28, "fft: n = %d exceeds the four-step limit 2^28 (two passes of at most 16384-point columns)", n);
       p->kind = tsdgpu_fft::POW2_4STEP;
       p->logN1 = p->logn / 2;
-      if (const char *e = getenv("TSDGPU_FFT_LOGN1")) {          // experiment: another split (both factors 16 .. 16384)
-        const int l1 = atoi(e);
-        if (l1 >= 4 && l1 <= 14 && p->logn - l1 >= 4 && p->logn - l1 <= 14) p->logN1 = l1;
-      }
       p->logN2 = p->logn - p->logN1;
       p->N1 = 1 << p->logN1;
       p->N2 = 1 << p->logN2;
@@ -1454,8 +1447,8 @@ int plan_init(tsdgpu_fft *p, int n)
       (void) hipFuncSetAttribute((const void *) fft_cols_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       (void) hipGetLastError();
     }
-  } else if (oddpow2_split(n, &p->mix_m, &p->mix_P) && getenv("TSDGPU_FFT_GENERIC") == nullptr && getenv("TSDGPU_FFT_NO_SMOOTH") == nullptr &&
-             getenv("TSDGPU_FFT_NO_ODDPOW2") == nullptr) {
+  } else if (oddpow2_split(n, &p->mix_m, &p->mix_P) && dev_switch("FFT_GENERIC") == nullptr && dev_switch("FFT_NO_SMOOTH") == nullptr &&
+             dev_switch("FFT_NO_ODDPOW2") == nullptr) {
     p->kind = tsdgpu_fft::ODDPOW2;
     const int m = p->mix_m, P = p->mix_P;
     p->logn = log2_exact(P);
@@ -1468,12 +1461,12 @@ int plan_init(tsdgpu_fft *p, int n)
     OP_ATTR(16); OP_ATTR(8); OP_ATTR(4); OP_ATTR(2);
 #undef OP_ATTR
     (void) hipGetLastError();
-  } else if (smooth_plan(n, &p->mr, &p->mr_tpt) && getenv("TSDGPU_FFT_GENERIC") == nullptr && getenv("TSDGPU_FFT_NO_SMOOTH") == nullptr) {
+  } else if (smooth_plan(n, &p->mr, &p->mr_tpt) && dev_switch("FFT_GENERIC") == nullptr && dev_switch("FFT_NO_SMOOTH") == nullptr) {
     p->kind = tsdgpu_fft::SMOOTH;
     if ((rc = upload(&p->d_rot, twiddle_table(n, n)))) return rc;            // W_n^j
     (void) hipFuncSetAttribute((const void *) fft_mr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void) hipGetLastError();
-  } else if ((n & 1) == 0 && mixed_split(n, &p->mix_m, &p->mix_P) && getenv("TSDGPU_FFT_GENERIC") == nullptr) {
+  } else if ((n & 1) == 0 && mixed_split(n, &p->mix_m, &p->mix_P) && dev_switch("FFT_GENERIC") == nullptr) {
     p->kind = tsdgpu_fft::MIXED;
     const int m = p->mix_m, P = p->mix_P;
     p->logn = log2_exact(P);
@@ -1532,7 +1525,7 @@ int plan_init(tsdgpu_fft *p, int n)
     rc = tsdgpu_fft_step(p->sub, d_icp, p->d_xc, 1, 1, nullptr);
     (void) hipDeviceSynchronize();
     (void) hipFree(d_icp);
-    if (!rc && p->n2 >= 16 && p->n2 <= S16_MAX_N && getenv("TSDGPU_FFT_GENERIC") == nullptr) {
+    if (!rc && p->n2 >= 16 && p->n2 <= S16_MAX_N && dev_switch("FFT_GENERIC") == nullptr) {
       p->blu_fused = true;
       rc = upload(&p->d_tw, twiddle_table(p->n2, p->n2 / 16));
       (void) hipFuncSetAttribute((const void *) fft_bluestein_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1561,11 +1554,6 @@ void plan_destroy(tsdgpu_fft *p)
 {
   if (!p) return;
   if (p->sub) plan_destroy(p->sub);
-  for (int i = 0; i < 2; i++) {
-    if (p->gs[i]) (void) hipStreamDestroy(p->gs[i]);
-    if (p->ge[i]) (void) hipEventDestroy(p->ge[i]);
-  }
-  if (p->ge_in) (void) hipEventDestroy(p->ge_in);
   if (p->d_ctr) (void) hipFree(p->d_ctr);
   for (cpx *q : {p->d_tw, p->d_tw1, p->d_tw2, p->d_thi, p->d_tlo, p->d_rot, p->d_chirp, p->d_xc, p->d_w1, p->d_w2, p->d_ta, p->d_td, p->d_wm})
     if (q) (void) hipFree(q);
@@ -1584,7 +1572,7 @@ inline unsigned blocks_for(int64_t total) { return (unsigned) cdiv(total, 256); 
 // fuse: pass 2 of a mixed-radix plan with P = 2, 4, 8, 16 in the same kernel (bluestein_fusable)
 bool bluestein_fusable(const tsdgpu_fft *sub, int P)
 {
-  static const bool off = getenv("TSDGPU_FFT_MIXED_UNFUSED") != nullptr;
+  static const bool off = dev_switch("FFT_MIXED_UNFUSED") != nullptr;
   const int n2 = sub->n2, tpt = n2 / 16;
   return !off && sub->blu_fused && (P == 2 || P == 4 || P == 8 || P == 16) && P * tpt <= 1024 &&
          (size_t) std::max(256 / tpt, P) * (n2 + n2 / 16) * sizeof(cpx) <= 158 * 1024;
@@ -1644,7 +1632,7 @@ int step_device(tsdgpu_fft *p, const cpx *x, cpx *y, int batch, int forward, hip
       const int r0 = 1 << ((p->logn & 3) == 0 ? 4 : (p->logn & 3));
       // one transform per workgroup and more transforms than the chip holds at once: persistent
       // workgroups that prefetch their next transform
-      static const int PERSIST_MIN = getenv("TSDGPU_FFT_PERSIST_MIN") ? atoi(getenv("TSDGPU_FFT_PERSIST_MIN")) : 16384;   // measured: 16384 0.292 -> 0.252 ms per 2^26 points; 8192 and 4096 lose 1-10 %
+      constexpr int PERSIST_MIN = 16384;   // measured: 16384 0.292 -> 0.252 ms per 2^26 points; 8192 and 4096 lose 1-10 %
       if (n >= PERSIST_MIN && T == 1) {
         static const int NCU = [] {
           int dev = 0, c = 256;
@@ -1677,7 +1665,7 @@ int step_device(tsdgpu_fft *p, const cpx *x, cpx *y, int batch, int forward, hip
     case tsdgpu_fft::POW2_W1M: {
       // the transposed intermediate gets a padded row pitch: its columns are read back by
       // pass 2 with a stride that is no longer a power of two (spreads the HBM channels)
-      static const int ZP = getenv("TSDGPU_FFT_ZP") ? atoi(getenv("TSDGPU_FFT_ZP")) : 1024 + 16;
+      constexpr int ZP = 1024 + 16;
       int rc = p->work.reserve((size_t) batch * 1024 * ZP * sizeof(cpx));
       if (rc) return rc;
       cpx *z = p->work.as<cpx>();
@@ -1688,43 +1676,10 @@ int step_device(tsdgpu_fft *p, const cpx *x, cpx *y, int batch, int forward, hip
         if (hipGetDevice(&dev) == hipSuccess) (void) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
         return n > 0 ? n : 256;
       }();
-      static const int GRID = getenv("TSDGPU_FFT_GRID") ? atoi(getenv("TSDGPU_FFT_GRID")) : NCU;
-      // Grouped schedule (experiment, off by default: DESIGN.md section 3.3): the batch is cut in groups of G
-      // transforms whose intermediate (G x 8 MiB) is small enough to stay in the 256 MiB Infinity Cache between
-      // its pass 1 and its pass 2; consecutive groups alternate between two side streams with a slot of the
-      // intermediate buffer each, so that the head of one group's launch fills the tail of the previous one's.
-      static const int GROUP = getenv("TSDGPU_FFT_GROUP") ? atoi(getenv("TSDGPU_FFT_GROUP")) : 0;
-      if (GROUP > 0 && batch > GROUP && x != y) {
-        if (!p->gs[0]) {
-          for (int i = 0; i < 2; i++) {
-            TSD_HIP(hipStreamCreateWithFlags(&p->gs[i], hipStreamNonBlocking));
-            TSD_HIP(hipEventCreateWithFlags(&p->ge[i], hipEventDisableTiming));
-          }
-          TSD_HIP(hipEventCreateWithFlags(&p->ge_in, hipEventDisableTiming));
-        }
-        const size_t slot = (size_t) GROUP * 1024 * ZP;           // elements of z per stream
-        TSD_HIP(hipEventRecord(p->ge_in, st));
-        for (int i = 0; i < 2; i++) TSD_HIP(hipStreamWaitEvent(p->gs[i], p->ge_in, 0));
-        int gi = 0;
-        for (int b0 = 0; b0 < batch; b0 += GROUP, gi++) {
-          const int nb = std::min(GROUP, batch - b0), nt = 64 * nb, grd = std::min(nt, GRID);
-          hipStream_t s2 = p->gs[gi & 1];
-          cpx *zz = z + (size_t) (gi & 1) * slot;
-          hipLaunchKernelGGL((fft1m_cols_kernel<1, false>), dim3(grd), dim3(1024), F1M_LDS, s2, x + (size_t) b0 * n, zz, p->d_w1, p->d_w2, p->d_ta,
-                             p->d_td, inverse, 1.0f, ZP, nt, (unsigned *) nullptr, 0u);
-          hipLaunchKernelGGL((fft1m_cols_kernel<2, false>), dim3(grd), dim3(1024), F1M_LDS, s2, zz, y + (size_t) b0 * n, p->d_w1, p->d_w2, p->d_ta,
-                             p->d_td, inverse, 1.0f / 1024.0f, ZP, nt, (unsigned *) nullptr, 0u);
-        }
-        TSD_HIP(hipGetLastError());
-        for (int i = 0; i < 2; i++) {
-          TSD_HIP(hipEventRecord(p->ge[i], p->gs[i]));
-          TSD_HIP(hipStreamWaitEvent(st, p->ge[i], 0));
-        }
-        return TSDGPU_OK;
-      }
+      const int GRID = NCU;
       const int grid = std::min(ntiles, GRID);
       // dynamic tile hand-out when every workgroup gets several tiles (TSDGPU_FFT_DYN=0: the static partition)
-      const char *dyn_s = getenv("TSDGPU_FFT_DYN");
+      const char *dyn_s = dev_switch("FFT_DYN");
       // (not while `st` records a graph: the base is a launch argument, a replay would see a spent counter and write nothing)
       unsigned *ctr = (p->d_ctr && ntiles >= 4 * grid && !(dyn_s && atoi(dyn_s) == 0) && !stream_is_capturing(st)) ? p->d_ctr : nullptr;
       if (ctr && p->ctr_stale) {
@@ -1759,17 +1714,14 @@ int step_device(tsdgpu_fft *p, const cpx *x, cpx *y, int batch, int forward, hip
       const float scale = 1.0f / std::sqrt((float) n);
       // x viewed [N1][N2]: pass 1 = column FFTs (length N1) + twiddle, stored transposed [N2][N1];
       // z viewed [N2][N1]: pass 2 = column FFTs (length N2), natural store y[k2 * N1 + k1]
-      static const bool generic = getenv("TSDGPU_FFT_GENERIC") != nullptr;
+      static const bool generic = dev_switch("FFT_GENERIC") != nullptr;
       if (!generic) {
         auto launch = [&](int pass, const cpx *src, cpx *dst, const cpx *tw, int L, int logL, int C, float sc) {
           const int tpt = L / 16;
-          static const int CTMIN = getenv("TSDGPU_FFT_CT") ? atoi(getenv("TSDGPU_FFT_CT")) : 16;
-          static const int CTMAX = getenv("TSDGPU_FFT_CTMAX") ? atoi(getenv("TSDGPU_FFT_CTMAX")) : 1 << 20;
-          int CT = std::max(CTMIN, 256 / tpt);
-          CT = std::min(std::min(CT, C), std::max(CTMAX, 2));
+          int CT = std::min(std::max(16, 256 / tpt), C);
           // 2048-point columns: 8 of them fill the LDS of a CU with ONE workgroup (139 KiB) whose load, transform and store phases
           // nothing overlaps; two workgroups of 4 columns measure 3-5 % faster (profiles/r3_fft_large_ab.txt)
-          if (L == 2048 && !getenv("TSDGPU_FFT_CTMAX")) CT = std::min(CT, 4);
+          if (L == 2048) CT = std::min(CT, 4);
           while ((size_t) CT * (L + L / 16 + 1) * sizeof(cpx) > 150 * 1024) CT >>= 1;
           while (CT * tpt > 1024) CT >>= 1;                                    // L = 2048 -> 8 columns, 4096 -> 4
           const size_t lds = (size_t) CT * (L + L / 16 + 1) * sizeof(cpx);
@@ -2060,7 +2012,7 @@ static int rfft_device(tsdgpu_rfft *p, const void *dx, void *dy, int batch, hipS
 {
   const int n = p->n;
   int rc = TSDGPU_OK;
-  if ((n & 1) == 0 && p->sub->kind == tsdgpu_fft::POW2_S16 && getenv("TSDGPU_RFFT_TWO_PASS") == nullptr) {
+  if ((n & 1) == 0 && p->sub->kind == tsdgpu_fft::POW2_S16 && dev_switch("RFFT_TWO_PASS") == nullptr) {
     // half-size Stockham transform with the untangling fused into its store: one pass over HBM
     const int h = n / 2, tpt = h / 16, threads = std::max(256, tpt), T = threads / tpt;
     const size_t lds = (size_t) T * (h + h / 16) * sizeof(cpx);

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(1024) void framed_fft_kernel(FrameSrc S, const cpx 
 bool framed_fft_launch(const tsdgpu_fft *plan, const FrameSrc &S, int64_t nfr, const cpx *H, cpx *outc, float *outp, hipStream_t st)
 {
   const cpx *TW = fft_s16_twiddles(plan);
-  static const bool off = getenv("TSDGPU_OLA_UNFUSED") != nullptr;
+  static const bool off = dev_switch("OLA_UNFUSED") != nullptr;
   if (!TW || off || nfr <= 0) return false;
   const int N = S.N, tpt = N / 16, threads = std::max(256, tpt), T = threads / tpt;
   const size_t lds = (size_t) T * (N + N / 16) * sizeof(cpx);
@@ -960,7 +960,7 @@ int tsdgpu_ola_set_response(tsdgpu_ola *h, const void *H)
   if (!h->d_H) TSD_HIP(hipMalloc((void **) &h->d_H, (size_t) h->N * sizeof(cpx)));
   TSD_HIP(hipMemcpy(h->d_H, H, (size_t) h->N * sizeof(cpx), hipMemcpyDefault));
   // the reference's default geometry without window: one fused kernel (ols.hip, ola1024_kernel) serves whole-block calls
-  static const bool unfused = getenv("TSDGPU_OLA_UNFUSED") != nullptr;
+  static const bool unfused = dev_switch("OLA_UNFUSED") != nullptr;
   if (!unfused && !h->windowed && h->N == 1024 && h->Ne == 512) {
     std::vector<cpx> Hh(1024), t3(3 * 1024);
     TSD_HIP(hipMemcpy(Hh.data(), h->d_H, 1024 * sizeof(cpx), hipMemcpyDeviceToHost));
@@ -969,7 +969,7 @@ int tsdgpu_ola_set_response(tsdgpu_ola *h, const void *H)
     TSD_HIP(hipMemcpy(h->d_fast, t3.data(), t3.size() * sizeof(cpx), hipMemcpyHostToDevice));
   }
   // the windowed mode at Ne = N = 512 (the engine's defaults with a window): the in-wave pair transform (ols.hip, olaw512_kernel)
-  static const bool no_w512 = getenv("TSDGPU_OLAW512") != nullptr && atoi(getenv("TSDGPU_OLAW512")) == 0;
+  static const bool no_w512 = dev_switch("OLAW512") != nullptr && atoi(dev_switch("OLAW512")) == 0;
   if (!unfused && !no_w512 && h->windowed && h->N == 512 && h->Ne == 512) {
     std::vector<cpx> Hh(512), tb(512 + 2 * 1024);
     TSD_HIP(hipMemcpy(Hh.data(), h->d_H, 512 * sizeof(cpx), hipMemcpyDeviceToHost));
@@ -1299,7 +1299,7 @@ int tsdgpu_welch(const void *x, int64_t n, int N, const float *window, float *S,
   if (!rc) rc = stage_in(window, (size_t) N * sizeof(float), wbuf, st, &dwv);
   if (!rc) rc = stage_out(S, (size_t) N * sizeof(float), sout, &dS, &staged);
   tsdgpu_fft *plan = nullptr;
-  static const bool multi = getenv("TSDGPU_OLA_UNFUSED") != nullptr;
+  static const bool multi = dev_switch("OLA_UNFUSED") != nullptr;
   if (!rc && nseg > 0 && N == 1024 && !multi) {
     // N = 1024: ONE kernel on the in-wave transform keeps the running sums in registers (ols.hip, welch1024_kernel)
     if (c->tw_N != 1024) {
@@ -1458,7 +1458,7 @@ int tsdgpu_spectrum_create(tsdgpu_spectrum **out, int BS, int nsubs, int nmeans,
   h->step = sweep_step;
   const int Ns = h->Ns = h->sweep ? Nf + (nsubs - 1) * sweep_step : Nf;        // SpectrumConfig::Ns (:1157-1161)
   const int ncls = h->sweep ? nsubs : 1;
-  h->run_kernel = Nf >= 16 && (Nf & (Nf - 1)) == 0 && ola_run_fits(Nf, Nf / 2) && getenv("TSDGPU_OLA_UNFUSED") == nullptr;
+  h->run_kernel = Nf >= 16 && (Nf & (Nf - 1)) == 0 && ola_run_fits(Nf, Nf / 2) && dev_switch("OLA_UNFUSED") == nullptr;
   // ONE allocation, ONE upload of its host image
   const size_t ntw = h->run_kernel ? (size_t) Nf / 16 : 0;
   std::vector<float> img((size_t) 2 * Nf + Ns + 2 * (size_t) ncls * Nf + 2 * ntw, 0.f);

@@ -452,10 +452,10 @@ int ols_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, hipStream_t st)
   // runs of R consecutive blocks per wave (ols_body): only with whole-row overlaps the kernel is specialised for, and only
   // when there are blocks enough for every wave to get several runs
   const int r0 = (int) (ovl / 64);
-  const char *run_s = getenv("TSDGPU_OLS_RUN");      // (read per step: scripts/perf_ols_run.py interleaves values in one process)
+  const char *run_s = dev_switch("OLS_RUN");      // (read per step: scripts/perf_ols_run.py interleaves values in one process)
   const int run_env = run_s ? atoi(run_s) : OLS_RUN_DEFAULT;
   // dynamic hand-out of the runs (OlsDyn) unless the step must be capturable in a graph (frozen kernel arguments)
-  const char *nc_s = getenv("TSDGPU_OLS_DYN");       // number of counters; 0 = the static partition
+  const char *nc_s = dev_switch("OLS_DYN");       // number of counters; 0 = the static partition
   int NC = nc_s ? atoi(nc_s) : OLS_DYN_DEFAULT;
   if (NC < 0 || NC > OLS_MAX_CTR || f->capturable || !f->d_ctr || stream_is_capturing(st)) NC = 0;
   int R = 1;
@@ -465,7 +465,7 @@ int ols_step(tsdgpu_fir *f, const void *x, void *y, int64_t n, hipStream_t st)
     const int64_t nint = b_hi - b_lo;
     if (r0 >= 1 && r0 <= 4 && run_env > 1 && nint >= (int64_t) f->ols_grid * run_env * 2) R = run_env;
     const int64_t nruns = cdiv(nint, R);
-    const char *min_s = getenv("TSDGPU_OLS_DYN_MIN");        // runs per wave from which the hand-out is dynamic (tests: 0)
+    const char *min_s = dev_switch("OLS_DYN_MIN");        // runs per wave from which the hand-out is dynamic (tests: 0)
     const int64_t dyn_min = min_s ? atoi(min_s) : 4;
     if (NC > 0 && nruns >= dyn_min * (int64_t) f->ols_grid) {
       // whole groups of 8 * NC workgroups, so that every counter has the same number of pullers

@@ -106,7 +106,7 @@ void host_fft(std::vector<std::complex<double>> &a)
 
 bool ols_long_supported(const tsdgpu_fir *f)
 {
-  static const int KMIN = getenv("TSDGPU_OLS_LONG_MIN") ? atoi(getenv("TSDGPU_OLS_LONG_MIN")) : 514;
+  static const int KMIN = dev_switch("OLS_LONG_MIN") ? atoi(dev_switch("OLS_LONG_MIN")) : 514;
   return f->K >= KMIN && f->K <= 12289;
 }
 
@@ -114,7 +114,7 @@ int ols_long_plan_create(tsdgpu_fir *f)
 {
   const int K = f->K;
   int N = 2048;
-  static const int RATIO = getenv("TSDGPU_OLS_LONG_RATIO") ? atoi(getenv("TSDGPU_OLS_LONG_RATIO")) : 4;
+  static const int RATIO = dev_switch("OLS_LONG_RATIO") ? atoi(dev_switch("OLS_LONG_RATIO")) : 4;
   // measured on 2^26 complex samples (scripts/perf_long_fir.py): blocks of about 4 K are the
   // optimum (K = 1024: N = 2048 / 4096 / 8192 -> 0.42 / 0.32 / 0.36 ms), i.e. overlap <= 25 % up to
   // K = 4097, growing to 75 % at the 12289-tap limit of the 16384-point block

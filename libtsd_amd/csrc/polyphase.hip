@@ -485,7 +485,7 @@ int fused_setup(tsdgpu_polyfir *p, const std::vector<float> &g, int NPH, int W, 
   // ... and preferably within ~PF_SPAN_TARGET samples (17 KiB: several workgroups per CU overlap their load and compute phases)
   int64_t to = std::min<int64_t>(PF_TO, ((int64_t) (PF_MAX_SPAN - W) / stride - 1) * NPH);
   to = std::min<int64_t>(to, std::max<int64_t>(256, (int64_t) (PF_SPAN_TARGET / stride) * NPH));
-  if (getenv("TSDGPU_POLY_COMPOSED") || to < 256 || (size_t) NPH * W > 4096 || W < 1) return TSDGPU_OK;
+  if (dev_switch("POLY_COMPOSED") || to < 256 || (size_t) NPH * W > 4096 || W < 1) return TSDGPU_OK;
   p->TO = (int) (to / 256 * 256);
   p->NPH = NPH;
   p->W = W;
@@ -511,7 +511,7 @@ int fused_setup(tsdgpu_polyfir *p, const std::vector<float> &g, int NPH, int W, 
 template <typename T>
 int fused_step(tsdgpu_polyfir *p, const void *dx, void *dy, int stride, int64_t start, int64_t n, int64_t nout, hipStream_t st)
 {
-  static const bool sans_rangs = getenv("TSDGPU_POLY_NO_ROWS") != nullptr;
+  static const bool sans_rangs = dev_switch("POLY_NO_ROWS") != nullptr;
   if (nout > 0 && !sans_rangs && p->NPH == 1 && stride >= 2 && stride <= PF_ROWS_MAXR && p->W >= 32) {
     // decimators of small rate and at least 32 taps: polyphase rows (decim_rows_kernel).  (Shorter filters are bound by the
     // staging, which the phase-major scatter makes dearer: 15 taps at R = 2, 2^26 samples: 0.22 against 0.18 ms.)
@@ -991,7 +991,7 @@ int tsdgpu_rii_create2(tsdgpu_rii **out, int data_type, int coef_type, const voi
   r->Ky = Kd - 1;
   r->Kx = Kx;
   int rc = TSDGPU_OK;
-  static const bool litteral = getenv("TSDGPU_RII_LITERAL") != nullptr;
+  static const bool litteral = dev_switch("RII_LITERAL") != nullptr;
   if (reel && !litteral) {
     std::vector<std::array<float, 2>> poles;
     if (factor_denominator(dr.data(), Kd, poles) && (int) poles.size() <= 32) {

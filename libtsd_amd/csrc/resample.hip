@@ -334,9 +334,6 @@ __global__ __launch_bounds__(RS_THREADS) void resample_kernel(const T *__restric
 #ifndef RSL_CHUNK
 #define RSL_CHUNK 8
 #endif
-#ifndef RSL_ABLATE          // timing experiments only (wrong outputs): 1 no second outputs, 2 every lane reads table row 0, 4 windows not re-read per chunk
-#define RSL_ABLATE 0
-#endif
 constexpr int RSL_CH = RSL_CHUNK;                           // taps per chunk (8: 64 + 30 registers of rows and window; 16 spills at two waves per SIMD)
 constexpr int RSL_WIN = RSL_CH + RS_SEG - 1;                // samples of a chunk's window
 __host__ __device__ inline int rsl_slot(int p) { return p + (p >> 3); }       // padded sample image: a lane's window starts 9 slots after its neighbour's
@@ -507,13 +504,13 @@ __global__ __launch_bounds__(512) void resample_long_kernel(const T *__restrict_
       // over the eight inputs -- eight independent accumulation chains and one exposed LDS latency per chunk)
       for (int k0 = 0; k0 < nfull; k0 += RSL_CH) {
         T X[RSL_WIN];
-        const T *wc = wl + ((RSL_ABLATE & 4) ? 0 : k0 + (k0 >> 3));
+        const T *wc = wl + (k0 + (k0 >> 3));
 #pragma unroll
         for (int j = 0; j < RSL_WIN; j++) X[j] = wc[j + (j >> 3)];
         float hh[RS_SEG][RSL_CH];
 #pragma unroll
         for (int s = 0; s < RS_SEG; s++) {
-          const float *h = lut_s + ((RSL_ABLATE & 2) ? 0 : col0[s]) * lsp + k0;
+          const float *h = lut_s + col0[s] * lsp + k0;
 #pragma unroll
           for (int k4 = 0; k4 < RSL_CH / 4; k4++) {
             const float4 q4 = *reinterpret_cast<const float4 *>(h + 4 * k4);
@@ -555,7 +552,7 @@ __global__ __launch_bounds__(512) void resample_long_kernel(const T *__restrict_
       // ---- second outputs: one per lane, samples and taps from LDS
       // (sample i0 + k sits in slot A + k + ((r + k) >> 3), A = slot of i0, r = i0 mod 8: with k = 8 m + e the run-time part is one of
       // eight base addresses per output, the rest an immediate offset -- no address arithmetic per tap)
-      for (int e = lane; e < ((RSL_ABLATE & 1) ? 0 : n2); e += 64) {
+      for (int e = lane; e < n2; e += 64) {
         const uint2 r = rec2[e];
         const int i0 = (int) (r.x >> 13) + ka, r8 = i0 & 7;
         const float *h = lut_s + (r.x & 8191u) * lsp;
@@ -585,24 +582,6 @@ __global__ __launch_bounds__(512) void resample_long_kernel(const T *__restrict_
   }
 }
 
-// ---- K = 15 (the filtre_reechan interpolator): replay and evaluation FUSED per lane --------
-// A lane replays the recurrence for its 8 inputs and evaluates each output on the spot from
-// a 22-sample REGISTER window (samples 8*lane .. 8*lane+21 of the wave's tile, read once from
-// a padded LDS image: lane stride 9 samples, conflict-free ds_read_b64), so an output costs
-// four ds_read_b128 of taps and 30 FMAs instead of 15 sample reads + a schedule record.
-// Outputs are staged in a per-wave LDS buffer and stored coalesced.  The reference's
-// accumulation order (tap 0 .. 14 over the oldest .. newest sample) is kept.
-// Round 3: 16 waves per workgroup (the whole CU: 128 VGPRs, 60 B of spills per lane on complex data) with the outputs staged in
-// the sample image again (the late-store buffer of round 2 does not fit 16 waves): 0.567 -> 0.537 ms per 2^27 inputs, three
-// interleaved pairs on one box -- under the dynamic tile hand-out more waves pay, where the static partition's skeleton got
-// slower with them.  -DRS15_NW=12 -DRS15_LATE_STORE=1 is round 2's geometry.
-#ifndef RS15_NW
-#define RS15_NW 16
-#endif
-#ifndef RS15_LATE_STORE
-#define RS15_LATE_STORE 0
-#endif
-constexpr int RS15_WAVES = RS15_NW;
 // Dynamic hand-out of the tiles (the scheme of the overlap-save FIR, ols.hip: OlsDyn): a persistent grid with a static
 // partition streams 6-9 % below the same bytes handed out in order (scripts/ubench/copy_shapes.hip).  NC counters on their
 // own 128-B lines, workgroup g pulls from counter (g / 8) % NC (its pullers sit on all 8 XCDs), a pulled value v stands for
@@ -613,244 +592,15 @@ struct RsDyn {
   unsigned base, Q;
   int NC;            // 0: static partition (tile = wave + k * waves)
 };
-constexpr int RS15_TILE_PAD = (RS_TI + 16) + (RS_TI + 16) / 8 + 2;      // padded sample slots per wave
-template <typename T>
-__global__ __launch_bounds__(64 * RS15_WAVES) void resample15_kernel(const T *__restrict__ x, const T *__restrict__ hist,
-                                                                     T *__restrict__ y, const float *__restrict__ lut,
-                                                                     const RsCk *__restrict__ ck, RsParams P, int ntiles,
-                                                                     T *__restrict__ hist_next, RsDyn dyn)
-{
-  if (blockIdx.x == gridDim.x - 1) {      // (see resample_kernel: the next window history rides in this launch)
-    for (int i = threadIdx.x; i < 14; i += 64 * RS15_WAVES) {
-      const int64_t g = P.n - 14 + i;
-      hist_next[i] = g < 0 ? (hist ? hist[14 + g] : zero_of(T{})) : x[g];
-    }
-    return;
-  }
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  constexpr int K = 15, LS = 20;
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  float *lut_s = reinterpret_cast<float *>(smem_raw);
-  char *wbase = reinterpret_cast<char *>(lut_s + ((P.nph + 1) * LS + 3) / 4 * 4);
-#if RS15_LATE_STORE
-  // The outputs of a tile are stored at the START of the next iteration, right after that tile's samples have gone
-  // to LDS and BEFORE its own prefetch is issued.  vmcnt retires in issue order: stored at the end of their own
-  // iteration, the stores sat between the prefetch and its consumer, and the wait for the prefetch at the loop
-  // top (`s_waitcnt vmcnt(0)` at the latch in the ISA) waited for the stores' acknowledgement as well -- every tile
-  // paid a full store round trip.  Stored here, they are a whole evaluation old when that wait comes.  The staging
-  // buffer therefore keeps its contents across the loop top and has its own room beside the sample image.
-  const size_t wbytes = ((size_t) (RS15_TILE_PAD + P.rec_cap) * sizeof(T) + 15) / 16 * 16;
-  T *tile = reinterpret_cast<T *>(wbase + wv * wbytes);      // padded: sample s at s + (s >> 3)
-  T *obuf = tile + RS15_TILE_PAD;                            // outputs of the tile, in order
-#else
-  // The output staging buffer ALIASES the sample image: every lane has its 22-sample window in
-  // registers before the first output of the wave is written (one wave: program order is LDS
-  // order), and the image is only rewritten after the outputs have been flushed.
-  const size_t wbytes = ((size_t) max(RS15_TILE_PAD, P.rec_cap) * sizeof(T) + 15) / 16 * 16;
-  T *tile = reinterpret_cast<T *>(wbase + wv * wbytes);      // padded: sample s at s + (s >> 3)
-  T *obuf = tile;                                            // outputs of the tile, in order
-#endif
+constexpr int RS15_TILE_PAD = (RS_TI + 16) + (RS_TI + 16) / 8 + 2;      // padded sample slots per wave (lane stride 9: sample s at s + (s >> 3))
 
-  for (int i = threadIdx.x; i < (P.nph + 1) * K; i += 64 * RS15_WAVES) {
-    const int c = i / K, k = i - c * K;
-    lut_s[c * LS + k] = lut[c * P.gl + k];
-  }
-  for (int c = threadIdx.x; c <= P.nph; c += 64 * RS15_WAVES) lut_s[c * LS + 15] = 0.f;
-  __syncthreads();
-
-  auto wave_sync = []() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  };
-  const int wtile0 = blockIdx.x * RS15_WAVES + wv;
-  const int wstep = (gridDim.x - 1) * RS15_WAVES;
-  // canonical schedule index of tile 0 of this call (inside the tabulated prefix + one period) and its period count
-  int64_t ic0 = P.tile0, q0 = 0;
-  rs_wrap(ic0, q0, P.mu, P.lambda);
-  // -> (canonical index, periods) of tile tix: the tile's absolute index folded back into the table
-  auto tile_ic = [&](int tix_, int64_t &ic_, int64_t &q_) {
-    ic_ = ic0 + (int64_t) tix_ * RS_TI;
-    q_ = q0;
-    if (P.lambda > 0) {
-      const int64_t lim = P.mu + P.lambda;
-      if (ic_ >= lim) {
-        if (ic_ - lim < 64 * P.lambda) {
-          do { ic_ -= P.lambda; q_++; } while (ic_ >= lim);       // (wave-uniform: scalar instructions)
-        } else {
-          const int64_t d = ic_ - P.mu, k = d / P.lambda;
-          q_ += k;
-          ic_ = P.mu + (d - k * P.lambda);
-        }
-      }
-    }
-  };
-  const int ctr_c = dyn.NC > 0 ? (int) ((blockIdx.x / 8) % dyn.NC) : 0;
-  // -> the next tile of this wave (dynamic: from its counter, -1 once the quota is spent -- exactly one failing pull per
-  // wave; static: prev + waves)
-  auto next_tile = [&](int prev) -> int {
-    if (dyn.NC == 0) {
-      const int t = prev < 0 ? wtile0 : prev + wstep;
-      return t < ntiles ? t : -1;
-    }
-    for (;;) {
-      unsigned v = 0;
-      if (lane == 0) v = __hip_atomic_fetch_add(dyn.ctr + ctr_c * 32, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      v = (unsigned) __builtin_amdgcn_readfirstlane((int) v) - dyn.base;
-      if (v >= dyn.Q) return -1;
-      const int64_t t = (int64_t) v * dyn.NC + ctr_c;
-      if (t < ntiles) return (int) t;
-    }
-  };
-  int64_t icT = 0, qT = 0;
-
-  constexpr int NPF = (RS_TI + K + 63) / 64;       // 9 samples per lane per tile
-  T pf[NPF];
-  RsCk cpf;
-  auto fetch = [&](int tix_, int64_t icT_) {
-    const int64_t T0_ = P.tile0 + (int64_t) tix_ * RS_TI;
-    const int64_t rel0 = T0_ - (K - 1) - P.pos;
-    if (rel0 >= 0 && rel0 + RS_TI + K <= P.n) {
-      const T *xs = x + rel0;
-#pragma unroll
-      for (int j = 0; j < NPF; j++) {
-        const int s_ = lane + j * 64;
-        pf[j] = s_ < RS_TI + K ? xs[s_] : zero_of(T{});
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < NPF; j++) {
-        const int64_t rel = rel0 + lane + j * 64;
-        T v = zero_of(T{});
-        if (lane + j * 64 < RS_TI + K) {
-          if (rel < 0) {
-            if (hist && rel >= -(int64_t) (K - 1)) v = hist[(K - 1) + rel];
-          } else if (rel < P.n) {
-            v = x[rel];
-          }
-        }
-        pf[j] = v;
-      }
-    }
-    int64_t ic_ = icT_ + lane * RS_SEG;
-    {
-      int64_t q_ = 0;
-      rs_wrap(ic_, q_, P.mu, P.lambda);
-    }
-    cpf.phase_bits = 0x40000000u;
-    cpf.cum = 0;
-    if (T0_ + (int64_t) lane * RS_SEG < P.pos + P.n) cpf = ck[ic_ / RS_CK];
-  };
-
-  // the tile being evaluated, the one being prefetched, and (requested a tile ahead) the one after it
-  int tix = next_tile(-1);
-  int ntix = tix >= 0 ? next_tile(tix) : -1;
-  if (tix >= 0) {
-    tile_ic(tix, icT, qT);
-    fetch(tix, icT);
-  }
-#if RS15_LATE_STORE
-  int pend_begin = 0, pend_last = 0;       // outputs [pend_begin, pend_last) of the previous tile wait in obuf
-  T *pend_y = y;
-  auto flush = [&]() {
-    for (int oo = pend_begin + lane; oo < pend_last; oo += 64) pend_y[oo] = obuf[oo];
-    pend_last = 0;
-  };
-#endif
-  while (tix >= 0) {
-    const int64_t T0 = P.tile0 + (int64_t) tix * RS_TI;
-#pragma unroll
-    for (int j = 0; j < NPF; j++) {
-      const int s_ = lane + j * 64;
-      if (s_ < RS_TI + K) tile[s_ + (s_ >> 3)] = pf[j];
-    }
-#if RS15_LATE_STORE
-    flush();                               // the previous tile's outputs (see above)
-#endif
-    const int64_t i_abs = T0 + (int64_t) lane * RS_SEG;
-    int64_t ic = icT + lane * RS_SEG, q = qT;
-    rs_wrap(ic, q, P.mu, P.lambda);
-    const bool in_call = i_abs < P.pos + P.n;
-    const float inc = P.inc;
-    float phase = bits2f(cpf.phase_bits);
-    int64_t cum = (int64_t) cpf.cum + q * P.opp;
-    const int nntix = ntix >= 0 ? next_tile(ntix) : -1;      // (its latency hides under this tile's evaluation)
-    if (ntix >= 0) {
-      tile_ic(ntix, icT, qT);
-      fetch(ntix, icT);
-    }
-
-    if (in_call) {
-      for (int s = (int) (ic % RS_CK); s > 0; s--) {
-        while (phase < 1.f) { phase = phase + inc; cum++; }
-        phase = phase - 1.f;
-      }
-    }
-    const int64_t cum_t0 = ((int64_t) __shfl((int) (cum >> 32), 0) << 32) | (uint32_t) __shfl((int) (uint32_t) cum, 0);
-    wave_sync();
-    // register window: W[j] = sample 8*lane + j of the tile (slot 9*lane + j + (j >> 3))
-    T W[22];
-    const T *wl = tile + 9 * lane;
-#pragma unroll
-    for (int j = 0; j < 22; j++) W[j] = wl[j + (j >> 3)];
-    const float fnph = (float) P.nph;
-    int last = 0;
-    int o = (int) (cum - cum_t0);
-#pragma unroll
-    for (int s = 0; s < RS_SEG; s++) {
-      const int64_t i = i_abs + s;
-      const bool live = in_call && i >= P.pos && i < P.pos + P.n;
-      while (in_call && phase < 1.f) {
-        if (live) {
-          const float *h = lut_s + (int) (phase * fnph) * LS;                  // itrp.cc:19
-          float hh[16];
-#pragma unroll
-          for (int k4 = 0; k4 < 4; k4++) {
-            const float4 q4 = *reinterpret_cast<const float4 *>(h + 4 * k4);
-            hh[4 * k4] = q4.x; hh[4 * k4 + 1] = q4.y; hh[4 * k4 + 2] = q4.z; hh[4 * k4 + 3] = q4.w;
-          }
-          T acc = zero_of(T{});
-#ifndef RS15_ABLATE   // measurement only: 1 = no taps, no MACs (the replay, the loads and the stores remain)
-#define RS15_ABLATE 0
-#endif
-          if (RS15_ABLATE & 1) acc = W[s + 7];
-          else {
-#pragma unroll
-            for (int k = 0; k < 15; k++) acc = tap_mac(acc, hh[k], W[s + k]);     // filtrage.hpp:1877-1879 order
-          }
-          obuf[o] = acc;
-          last = o + 1;
-        }
-        phase = phase + inc;                                                   // ra.cc:71
-        o++;
-      }
-      if (in_call) phase = phase - 1.f;                                        // ra.cc:73
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) last = max(last, __shfl_xor(last, d));
-    wave_sync();
-    const int o_begin = (int) max((int64_t) 0, P.cum_pos - cum_t0);
-    T *yt = y + (cum_t0 - P.cum_pos);
-#if RS15_LATE_STORE
-    pend_begin = o_begin;
-    pend_last = last;
-    pend_y = yt;
-#else
-    for (int oo = o_begin + lane; oo < last; oo += 64) yt[oo] = obuf[oo];
-    wave_sync();
-#endif
-    tix = ntix;
-    ntix = nntix;
-  }
-#if RS15_LATE_STORE
-  flush();
-#endif
-}
-
-// ---- K = 15, at most two outputs per input (ratio < 2): first outputs from registers, second outputs from a list -------------
-// The kernel above runs the reference's `while (phase < 1)` loop per lane: whenever ONE of the 64 lanes has a second output on an
-// input (ratio 160/147: 9 % of the inputs, i.e. practically always somewhere in the wave) the whole wave takes the second turn --
-// 16 table rows and 16 x 15 multiply-adds per lane for 8.7 outputs.  Here the replay is branch-free and runs first (1/ratio > 0.5:
+// ---- K = 15 (the filtre_reechan interpolator), at most two outputs per input (ratio <= 2) ----------------------------------------
+// Every wave owns 512-input tiles: a lane replays the phase recurrence for its 8 inputs, evaluates the FIRST output of each
+// from a 22-sample register window (taps: four ds_read_b128 of a table row of pitch 20 floats) and hands the second outputs to
+// a per-wave list.  (Rounds 1-3 ran the reference's `while (phase < 1)` loop per lane: whenever ONE of the 64 lanes has a second
+// output on an input -- ratio 160/147: 9 % of the inputs, i.e. practically always somewhere in the wave -- the whole wave took
+// the second turn: 16 table rows and 16 x 15 multiply-adds per lane for 8.7 outputs; 0.527 ms per 2^27 inputs against 0.462 now.)
+// The replay is branch-free and runs first (1/ratio > 0.5:
 // an input has 0, 1 or 2 outputs), a wave scan of the per-lane counts gives every output its place in the tile -- so the per-lane
 // checkpoint is the PHASE alone (4 B per 8 inputs instead of 8: the schedule table is the kernel's only traffic beyond its
 // samples) --, the FIRST output of each input is evaluated straight-line from the 22-sample register window, and the second
@@ -1421,8 +1171,7 @@ static RsGeom rs_geometry(const tsdgpu_resampler *r, int mode)
   RsGeom g;
   g.lut_in_lds = lut - 16 <= (size_t) RS_LUT_LDS_BYTES;
   g.waves = RS_WAVES;
-  static const bool no_big = getenv("TSDGPU_RS_LUT_L2") != nullptr;          // A/B switch: long tables through L2 as before
-  if (!g.lut_in_lds && !no_big && mode == 0 && lut + 64 + 2 * wbytes <= RS_LDS_LIMIT) {
+  if (!g.lut_in_lds && mode == 0 && lut + 64 + 2 * wbytes <= RS_LDS_LIMIT) {
     g.lut_in_lds = true;
     g.waves = (int) std::min<size_t>(RS_WAVES, (RS_LDS_LIMIT - lut - 64) / wbytes);
   }
@@ -1440,8 +1189,8 @@ static RsLongGeom rs_long_geometry(const tsdgpu_resampler *r)
 {
   RsLongGeom g = {0, 0, 0, 0, 0};
   // (read per call: the tests flip them between handles)
-  const char *e_off = getenv("TSDGPU_RS_LONG"), *e_kmin = getenv("TSDGPU_RS_LONG_KMIN"), *e_w = getenv("TSDGPU_RS_LONG_WAVES"),
-             *e_ph = getenv("TSDGPU_RS_LONG_PHASES");
+  const char *e_off = dev_switch("RS_LONG"), *e_kmin = dev_switch("RS_LONG_KMIN"), *e_w = dev_switch("RS_LONG_WAVES"),
+             *e_ph = dev_switch("RS_LONG_PHASES");
   const bool off = e_off && atoi(e_off) == 0;
   const int kmin = e_kmin ? atoi(e_kmin) : 24;
   const int want = e_w ? atoi(e_w) : 8;                      // waves per workgroup aimed at
@@ -1531,8 +1280,8 @@ int tsdgpu_resampler_create(tsdgpu_resampler **out, int data_type, float ratio, 
   (void) hipFuncSetAttribute((const void *) resample_kernel<float2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void) hipFuncSetAttribute((const void *) resample_long_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void) hipFuncSetAttribute((const void *) resample_long_kernel<float2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void) hipFuncSetAttribute((const void *) resample15_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  (void) hipFuncSetAttribute((const void *) resample15_kernel<float2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void) hipFuncSetAttribute((const void *) resample15s_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  (void) hipFuncSetAttribute((const void *) resample15s_kernel<float2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   (void) hipGetLastError();
   *out = r;
   return TSDGPU_OK;
@@ -1650,29 +1399,25 @@ int tsdgpu_resampler_step(tsdgpu_resampler *r, const void *x, int64_t n, void *y
   const size_t lds = geo.lds;
   TSD_CHECK(lds <= RS_LDS_LIMIT, "resampler_step: configuration needs %zu bytes of LDS", lds);
   // persistent workgroups (the LUT is staged once per workgroup): as many as stay resident
-  static const int PG = getenv("TSDGPU_RS_WG_PER_CU") ? atoi(getenv("TSDGPU_RS_WG_PER_CU")) : 0;
-  int per_cu = PG > 0 ? PG : (int) std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (lds + 1024)));
+  int per_cu = (int) std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / (lds + 1024)));
   const int64_t pgrid = std::min<int64_t>(cdiv(tiles, geo.waves), (int64_t) 256 * per_cu);
-  const size_t wb15 = ((size_t) (RS15_LATE_STORE ? RS15_TILE_PAD + P.rec_cap : std::max(RS15_TILE_PAD, P.rec_cap)) * sz + 15) / 16 * 16;
-  const size_t lds15 = (size_t) ((r->nph + 1) * 20 + 4) * 4 + RS15_WAVES * wb15 + 64;
   const void *hcur = r->hist_zero ? nullptr : r->d_hist[r->cur];
   unsigned ctr_add = 0;
-  const char *e15 = getenv("TSDGPU_RS15");                     // =0: the K = 15 interpolator through the kernels of the other lengths (A/B)
+  const char *e15 = dev_switch("RS15");                     // =0: the K = 15 interpolator through the kernels of the other lengths (parity tests)
   // K = 15 at a ratio below 2 (at most two outputs per input): the split kernel, as many waves per workgroup as its LDS allows
   const int rec15 = ((int) ((double) RS_TI * (double) r->ratio * 1.0001) + 8 + 3) / 4 * 4;
   const int lcap15 = (int) ((double) RS_TI * std::max(0.0, (double) r->ratio - 1.0) * 1.0001) + 8;
   const size_t wb15s = ((size_t) (RS15_TILE_PAD + rec15) * sz + (size_t) lcap15 * 4 + RS15S_CKB + 15) / 16 * 16;
   const size_t lut15 = (size_t) ((r->nph + 1) * 20 + 4) * 4;
   const int nw15s = (int) std::min<size_t>(16, (RS_LDS_LIMIT - lut15 - 64) / wb15s);
-  const char *e15s = getenv("TSDGPU_RS15S");                   // =0: the one-pass K = 15 kernel (A/B)
-  if (r->K == 15 && r->mode == 0 && r->inc >= 0.5f && r->nph <= 511 && nw15s >= 4 && !(e15 && atoi(e15) == 0) && !(e15s && atoi(e15s) == 0)) {
+  if (r->K == 15 && r->mode == 0 && r->inc >= 0.5f && r->nph <= 511 && nw15s >= 4 && !(e15 && atoi(e15) == 0)) {
     const int NW = nw15s;
     P.rec_cap = rec15;
     int64_t g15 = std::min<int64_t>(cdiv(tiles, NW), 256);
-    const char *nc_s = getenv("TSDGPU_RS_DYN");
+    const char *nc_s = dev_switch("RS_DYN");
     int NC = nc_s ? atoi(nc_s) : 16;
     if (NC < 0 || NC > RS_MAX_CTR || !r->d_ctr || 256 % (8 * std::max(NC, 1)) != 0 || stream_is_capturing(st)) NC = 0;
-    const char *min_s = getenv("TSDGPU_RS_DYN_MIN");
+    const char *min_s = dev_switch("RS_DYN_MIN");
     if (tiles < (int64_t) (min_s ? atoi(min_s) : 4) * 256 * NW) NC = 0;
     RsDyn dyn = {r->d_ctr, r->ctr_base, 0u, NC};
     if (NC > 0) {
@@ -1693,32 +1438,6 @@ int tsdgpu_resampler_step(tsdgpu_resampler *r, const void *x, int64_t n, void *y
     else
       hipLaunchKernelGGL(resample15s_kernel<float>, dim3((unsigned) g15 + 1), dim3(64 * NW), lds15s, st, (const float *) dx,
                          (const float *) hcur, (float *) dy, r->d_lut, r->d_ck, r->d_ph, P, (int) tiles, (float *) r->d_hist[r->cur ^ 1], dyn, lcap15);
-  } else if (r->K == 15 && r->mode == 0 && lds15 <= 158 * 1024 && !(e15 && atoi(e15) == 0)) {     // fused kernel; larger ratios fall back to the generic one
-    int64_t g15 = std::min<int64_t>(cdiv(tiles, RS15_WAVES), 256);
-    // dynamic hand-out of the tiles when every wave gets several of them (RsDyn); TSDGPU_RS_DYN = counters, 0 = static
-    const char *nc_s = getenv("TSDGPU_RS_DYN");
-    int NC = nc_s ? atoi(nc_s) : 16;
-    if (NC < 0 || NC > RS_MAX_CTR || !r->d_ctr || 256 % (8 * std::max(NC, 1)) != 0 || stream_is_capturing(st)) NC = 0;
-    const char *min_s = getenv("TSDGPU_RS_DYN_MIN");         // tiles per wave from which the hand-out is dynamic (tests: 0)
-    if (tiles < (int64_t) (min_s ? atoi(min_s) : 4) * 256 * RS15_WAVES) NC = 0;
-    RsDyn dyn = {r->d_ctr, r->ctr_base, 0u, NC};
-    if (NC > 0) {
-      g15 = 256;                                             // whole groups of 8 * NC workgroups: equal pullers per counter
-      if (NC != r->ctr_nc) {
-        TSD_HIP(hipMemsetAsync(r->d_ctr, 0, (size_t) RS_MAX_CTR * 128, st));      // (a tuning switch flipped mid-stream)
-        r->ctr_base = 0;
-        r->ctr_nc = NC;
-        dyn.base = 0;
-      }
-      dyn.Q = (unsigned) cdiv(tiles, NC);
-      ctr_add = dyn.Q + (unsigned) (g15 / NC * RS15_WAVES);           // what this launch adds to every counter (booked once accepted)
-    }
-    if (r->data_type == TSDGPU_C64)
-      hipLaunchKernelGGL(resample15_kernel<float2>, dim3((unsigned) g15 + 1), dim3(64 * RS15_WAVES), lds15, st, (const float2 *) dx,
-                         (const float2 *) hcur, (float2 *) dy, r->d_lut, r->d_ck, P, (int) tiles, (float2 *) r->d_hist[r->cur ^ 1], dyn);
-    else
-      hipLaunchKernelGGL(resample15_kernel<float>, dim3((unsigned) g15 + 1), dim3(64 * RS15_WAVES), lds15, st, (const float *) dx,
-                         (const float *) hcur, (float *) dy, r->d_lut, r->d_ck, P, (int) tiles, (float *) r->d_hist[r->cur ^ 1], dyn);
   } else if (const RsLongGeom lg = rs_long_geometry(r); lg.waves > 0) {
     const int64_t lgrid = std::min<int64_t>(cdiv(tiles, lg.waves), 256);
     if (r->data_type == TSDGPU_C64)

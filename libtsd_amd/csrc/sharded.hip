@@ -318,7 +318,7 @@ int tsdgpu_sos_sharded_create(tsdgpu_sharded **out, int data_type, const float *
     rc = with_device(h->dev[g], [&] { return tsdgpu_sos_create((tsdgpu_sos **) &h->handle[g], data_type, coefs_host, nsec, gain, rii1_host, forme); });
   if (!rc) {
     h->H = tsdgpu_sos_halo((tsdgpu_sos *) h->handle[0]);
-    static const bool toujours_halo = getenv("TSDGPU_SHARD_SOS_HALO") != nullptr;
+    static const bool toujours_halo = dev_switch("SHARD_SOS_HALO") != nullptr;
     if (h->H < 0 || (h->H > 65536 && !toujours_halo) || h->H > ((int64_t) 1 << 24)) {
       // a warm-up of more than 2^16 samples per shard (or no decay at all): the exact scheme
       h->exact = true;
@@ -721,7 +721,7 @@ static int sharded_step_parts_impl(tsdgpu_sharded *h, const void *const *x_parts
   }
   // (2) the shards, concurrently (one stream each; the enqueue itself is cheap)
   std::vector<int64_t> got((size_t) N, 0);
-  static const bool no_split = getenv("TSDGPU_SHARD_NO_OVERLAP") != nullptr;     // A/B switch: wait for the halo, one launch
+  static const bool no_split = dev_switch("SHARD_NO_OVERLAP") != nullptr;     // A/B switch: wait for the halo, one launch
   for (int g = 0; g < N && !rc; g++) {
     TSD_HIP(hipSetDevice(h->dev[g]));
     hipStream_t st = h->stream[g];

@@ -31,30 +31,17 @@
 namespace tsdgpu {
 
 constexpr int SOS_MAX_SEC = 32;
-#ifndef SOS_LANE_FLOATS               // floats a lane holds per sub-tile: 32 (default), 16 (build option: half the LDS and VGPRs per wave)
-#define SOS_LANE_FLOATS 32
-#endif
-constexpr int LANE_FLOATS = SOS_LANE_FLOATS;
+constexpr int LANE_FLOATS = 32;                   // floats a lane holds per sub-tile (16 was measured: twice the scans and LDS work per sample)
 constexpr int SUB_FLOATS = 64 * LANE_FLOATS;      // floats per sub-tile (2048)
 constexpr int LDS_LANE_PITCH = LANE_FLOATS + 4;   // floats: + 4 pad -> conflict-free b128 both ways (36: 9 x 16 B, odd; 20: 5 x 16 B, odd)
 constexpr int LANE_QUADS = LANE_FLOATS / 4;
-#ifndef SOS_SWIZZLE
-#define SOS_SWIZZLE 0
-#endif
 // float offset of float p (a multiple of 4) of a sub-tile in the wave's LDS image; row = the lane that owns it
 __device__ __forceinline__ int sos_img(int p)
 {
-#if SOS_SWIZZLE
-  const int row = p / LANE_FLOATS, u = (p % LANE_FLOATS) >> 2;
-  return row * LANE_FLOATS + ((u ^ (row & (LANE_QUADS - 1))) << 2);
-#else
   return (p / LANE_FLOATS) * LDS_LANE_PITCH + (p % LANE_FLOATS);
-#endif
 }
 
-#ifndef SOS_WARM_FACTOR               // a chunk is at least this many times its warm-up's cost long
-#define SOS_WARM_FACTOR 4
-#endif
+constexpr int SOS_WARM_FACTOR = 4;    // a chunk is at least this many times its warm-up's cost long
 constexpr int NARROW_FLOATS = 4;      // floats per lane of a warm-up step (one 16-B load, no transposition)
 
 struct SosSection {
@@ -236,9 +223,7 @@ __device__ __forceinline__ void sos_cascade(float (&v)[LF], const SosSection *__
 //   (sos_carry_scan_kernel turns the E_c into the true start states: S_{c+1} = Phi^L S_c + E_c, S_1 = E_0)
 //   MODE 2  every chunk starts from carry[c] = S_c and stores its outputs: no warm-up.
 // 12 B per sample instead of 8, whatever the pole radius.
-#ifndef SOS_WPE
-#define SOS_WPE 4
-#endif
+constexpr int SOS_WPE = 4;            // waves per SIMD the kernel is compiled for (a fifth costs spills: profiles/EXPERIMENTS.md)
 template <int NCH, int MODE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SOS_WPE, SOS_WPE))) void sos_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                  const SosSection *__restrict__ sec, int nsec, float gain,
@@ -247,15 +232,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SOS_WPE, SOS
                                                  int64_t skip_f)
 {
   if (MODE == 1 && blockIdx.x + 1 == gridDim.x) return;       // nobody starts from the last chunk's end state
-#if SOS_SWIZZLE
-  // unpadded image, the 16-B units of a lane's row XOR-ed with the row number (conflict-free b128 both ways like the padded
-  // one), and the running state sized by the handle's section count: 8 KiB + 32 B per section instead of 10 KiB per wave
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  float *sst = lds + 64 * LANE_FLOATS;            // running state per (section, channel): 4 floats
-#else
   __shared__ __attribute__((aligned(16))) float lds[64 * LDS_LANE_PITCH];
   __shared__ float sst[SOS_MAX_SEC * 8];          // running state per (section, channel): 4 floats
-#endif
   const int lane = threadIdx.x;
   const int64_t chunk = blockIdx.x;
   const int64_t t_first = chunk * spc;                         // first sub-tile whose output we own
@@ -737,7 +715,7 @@ void fill_tables_for(SosSection &k, int L, int NF, float *c1o, float *c2o, float
 // scan levels that matter for this table (see SosSection::nlev): the first K whose power is below 1e-9 in the row-sum norm
 int scan_levels(const float (*A)[4])
 {
-  static const bool full = getenv("TSDGPU_SOS_FULL_SCAN") != nullptr;      // A/B and test switch: all six levels
+  static const bool full = dev_switch("SOS_FULL_SCAN") != nullptr;      // A/B and test switch: all six levels
   if (full) return 6;
   for (int K = 0; K < 6; K++) {
     const double n0 = std::fabs((double) A[K][0]) + std::fabs((double) A[K][1]), n1 = std::fabs((double) A[K][2]) + std::fabs((double) A[K][3]);
@@ -895,20 +873,15 @@ int tsdgpu_sos_step(tsdgpu_sos *s, const void *x, void *y, int64_t n, void *stre
     } else {
       // warm-up of `halo` samples: whole sub-tiles for the bulk of a long halo, then narrow steps of
       // 64 * NARROW_FLOATS floats (a fifth of a sub-tile's work each) for the rest
-      static const bool narrow = getenv("TSDGPU_SOS_WIDE_WARMUP") == nullptr;
       const int64_t nar_samples = 64 * NARROW_FLOATS / nch;
-      if (narrow) {
-        warm_sub = s->halo / sub_samples;
-        warm_nar = cdiv(s->halo - warm_sub * sub_samples, nar_samples);
-        if (warm_nar * nar_samples >= sub_samples) { warm_sub++; warm_nar = 0; }
-      } else {
-        warm_sub = cdiv(s->halo, sub_samples);
-      }
+      warm_sub = s->halo / sub_samples;
+      warm_nar = cdiv(s->halo - warm_sub * sub_samples, nar_samples);
+      if (warm_nar * nar_samples >= sub_samples) { warm_sub++; warm_nar = 0; }
       // chunk length: enough chunks to fill the chip, but the warm-up never more than a quarter of the
       // chunk's work (a narrow step counts as a fifth of a sub-tile)
       // (with the quarter rule above: 8192 chunks of four sub-tiles at 2^26 samples, 0.1267 ms against 0.1317 with 4096 chunks of
       // eight -- measured twice, interleaved)
-      static const int64_t TARGET = getenv("TSDGPU_SOS_CHUNKS") ? atoll(getenv("TSDGPU_SOS_CHUNKS")) : 16384;
+      constexpr int64_t TARGET = 16384;                 // (flat from 8192 up: profiles/EXPERIMENTS.md, round 4)
       const int64_t warm_cost = warm_sub + cdiv(warm_nar, 5);
       spc = std::max<int64_t>({2, SOS_WARM_FACTOR * warm_cost, warm_sub + 1, n_sub / TARGET});
       // ... unless the call is short of filling the chip anyway: then the shortest chunks finish first (a wave alone takes
@@ -920,10 +893,10 @@ int tsdgpu_sos_step(tsdgpu_sos *s, const void *x, void *y, int64_t n, void *stre
     TSD_CHECK(nchunks <= 0x7fffffff, "sos_step: too many chunks");
     // a memory that is long against the call leaves few chunks (one, without decay): carry the state exactly from chunk
     // to chunk instead -- two passes over x and a scan of the chunks' end states (see sos_kernel)
-    static const bool no_exact = getenv("TSDGPU_SOS_NO_EXACT_CARRY") != nullptr;
+    static const bool no_exact = dev_switch("SOS_NO_EXACT_CARRY") != nullptr;
     static const int64_t EX_TARGET = 4096;
     const int64_t spc_ex = std::max<int64_t>(1, n_sub / EX_TARGET), nch_ex = cdiv(n_sub, spc_ex);
-    const size_t sos_dyn_lds = SOS_SWIZZLE ? (size_t) (64 * LANE_FLOATS + s->nsec * 8) * sizeof(float) : 0;
+    const size_t sos_dyn_lds = 0;
     bool exact = false;
     if (!no_exact && !s->capturable && nch_ex >= 8) {
       // which is cheaper (microseconds, rough): a wave alone takes tw per sub-tile (latency-bound: 1.5 + 0.4 per section,

@@ -1,6 +1,6 @@
 #!/bin/bash
-# The tuning / debugging switches of DESIGN section 5b select alternative code paths that must stay parity-green:
-# runs the test files that exercise each path with the switch set.  usage (GPU box, repo root): scripts/check_switches.sh
+# The developer / test switches (csrc/common.hpp: dev_switch) and the user switches of DESIGN.md select ALTERNATIVE PRODUCT PATHS that
+# must stay parity-green: runs the test files that exercise each path with the switch set.  usage (GPU box, repo root): scripts/check_switches.sh
 set -u
 run() {   # run "ENV=1 [ENV2=..]" files...
   local envs=$1; shift
@@ -11,15 +11,11 @@ run() {   # run "ENV=1 [ENV2=..]" files...
 }
 FAILED=0
 run TSDGPU_FFT_GENERIC=1 tests/test_fft_gpu.py tests/test_ola_gpu.py
-run TSDGPU_FFT_W1024=1 tests/test_fft_gpu.py
 run TSDGPU_FFT_NO_SMOOTH=1 tests/test_fft_gpu.py
-run TSDGPU_FFT_GROUP=8 tests/test_fft_gpu.py
 run TSDGPU_OLA_UNFUSED=1 tests/test_ola_gpu.py tests/test_detect_gpu.py
 run TSDGPU_RFFT_TWO_PASS=1 tests/test_fft_gpu.py
 run TSDGPU_POLY_COMPOSED=1 tests/test_polyphase_gpu.py
 run TSDGPU_POLY_NO_ROWS=1 tests/test_polyphase_gpu.py tests/test_host_pipeline_gpu.py
-run TSDGPU_SOS_WIDE_WARMUP=1 tests/test_sos_gpu.py tests/test_sharded_gpu.py
-run TSDGPU_SOS_CHUNKS=4096 tests/test_sos_gpu.py
 run TSDGPU_SHARD_SOS_HALO=1 tests/test_sharded_gpu.py -k "not long_memory"
 run TSDGPU_SOS_NO_EXACT_CARRY=1 tests/test_sos_gpu.py tests/test_sharded_gpu.py -k "not long_memory"
 # (the tests that assert WHICH path serves a filter, or its speed, are about the default choice)
@@ -29,7 +25,6 @@ run TSDGPU_NO_PIPE=1 tests/test_host_pipeline_gpu.py
 run TSDGPU_PIPE_ONE_THREAD=1 tests/test_host_pipeline_gpu.py
 run TSDGPU_PIPE_CHUNK_MB=1 tests/test_host_pipeline_gpu.py
 run TSDGPU_OLS_LONG_MIN=200 tests/test_fir_gpu.py
-run TSDGPU_RS_WG_PER_CU=2 tests/test_resample_gpu.py
 # round 3
 run TSDGPU_OLS_DYN=0 tests/test_fir_gpu.py
 run TSDGPU_OLS_RUN=1 tests/test_fir_gpu.py
@@ -42,6 +37,8 @@ run TSDGPU_OLAW512=0 tests/test_ola_gpu.py
 run TSDGPU_FFT_MIXED_UNFUSED=1 tests/test_fft_gpu.py tests/test_fft_sweep_gpu.py
 run TSDGPU_FFT_NO_ODDPOW2=1 tests/test_fft_gpu.py tests/test_fft_sweep_gpu.py
 run TSDGPU_FFT_ODDPOW2_ALL=1 tests/test_fft_gpu.py tests/test_fft_sweep_gpu.py
-run TSDGPU_FFT_CTMAX=8 tests/test_fft_gpu.py
 run TSDGPU_SHARD_NO_OVERLAP=1 tests/test_sharded_gpu.py
+# round 4
+run TSDGPU_SOS_FULL_SCAN=1 tests/test_sos_gpu.py tests/test_sharded_gpu.py
+run "TSDGPU_RS_DYN_MIN=0 TSDGPU_OLS_DYN_MIN=0" tests/test_resample_gpu.py tests/test_fir_gpu.py
 exit $FAILED
