@@ -771,6 +771,8 @@ struct F1mCtx {
   LdsTw1 tw1;
   LdsTw2 tw2;
   int ipitch, opitch, inverse, t, lane, wv, rr, cc, k0, grid;
+  int tshift;          // log2 of the column tiles per transform (6: 1024 columns; pass 1 of a 1024 x C plan: log2(C / 16))
+  int orows;           // rows of a transform's output block (pass 1: its columns, i.e. C; pass 2: 1024)
   float scale;
 };
 
@@ -786,13 +788,14 @@ __device__ __forceinline__ unsigned opaque(unsigned v)
 template <int PASS>
 __device__ __forceinline__ void f1m_issue(const F1mCtx &k, int id, float4 (&q)[8], cpx &ta, cpx &td)
 {
-  const char *x = reinterpret_cast<const char *>(k.in + (size_t) (id >> 6) * 1024 * k.ipitch + (id & 63) * 16);
+  const int ct = id & ((1 << k.tshift) - 1);
+  const char *x = reinterpret_cast<const char *>(k.in + (size_t) (id >> k.tshift) * 1024 * k.ipitch + ct * 16);
   const unsigned o = opaque(((unsigned) k.rr * k.ipitch + k.cc) * 8u), step = 128u * 8u * k.ipitch;
 #pragma unroll
   for (int i = 0; i < 8; i++) q[i] = *reinterpret_cast<const float4 *>(x + (o + step * i));
   if (PASS == 1) {
-    ta = k.TA[((id & 63) * 16 + k.wv) * 64 + k.lane];
-    td = k.TD[(id & 63) * 256 + (k.t & 255)];              // [column][r] of the 16 columns
+    ta = k.TA[(ct * 16 + k.wv) * 64 + k.lane];
+    td = k.TD[ct * 256 + (k.t & 255)];                     // [column][r] of the 16 columns
   }
 }
 
@@ -821,8 +824,8 @@ __device__ __forceinline__ void f1m_tile(const F1mCtx &k, int id, int nid, float
 #pragma unroll
   for (int r = 0; r < 16; r++) v[r] = colc[(64 * r + lane) * P];
   w1024::forward<P>(v, colc, lane, k.tw1, k.tw2, wave_fence);
-  const int c0 = (id & 63) * 16, c = c0 + k.wv;
-  cpx *y = k.out + (size_t) (id >> 6) * 1024 * k.opitch;
+  const int c0 = (id & ((1 << k.tshift) - 1)) * 16, c = c0 + k.wv;
+  cpx *y = k.out + (size_t) (id >> k.tshift) * k.orows * k.opitch;
   wave_fence();
   if (PASS == 1) {
     // row c of the transposed intermediate.  The spectrum leaves the wave through its own LDS
@@ -867,7 +870,8 @@ template <int PASS, bool DYN>
 __global__ __launch_bounds__(1024) void fft1m_cols_kernel(const cpx *__restrict__ in, cpx *__restrict__ out,
                                                           const cpx *__restrict__ TW1, const cpx *__restrict__ TW2,
                                                           const cpx *__restrict__ TA, const cpx *__restrict__ TD,
-                                                          int inverse, float scale, int zp, int ntiles, unsigned *ctr, unsigned base)
+                                                          int inverse, float scale, int zp, int ntiles, unsigned *ctr, unsigned base,
+                                                          int tshift)
 {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   cpx *tile = reinterpret_cast<cpx *>(smem_raw);
@@ -880,7 +884,9 @@ __global__ __launch_bounds__(1024) void fft1m_cols_kernel(const cpx *__restrict_
   k.in = in; k.out = out; k.TA = TA; k.TD = TD;
   k.tile = tile; k.col = tile + wv; k.ltd = ltd;           // this wave's column: slots e*P + wv
   k.tw1 = LdsTw1{reinterpret_cast<const f1c *>(ltw1) + lane}; k.tw2 = LdsTw2{reinterpret_cast<const f1c *>(ltw2) + (lane & 3)};
-  k.ipitch = PASS == 1 ? 1024 : zp; k.opitch = PASS == 1 ? zp : 1024;
+  // (pass 1 of a 1024 x C plan: C = 16 << tshift columns of 1024 points, input rows C apart, C transposed output rows of pitch zp)
+  k.ipitch = PASS == 1 ? (16 << tshift) : zp; k.opitch = PASS == 1 ? zp : 1024;
+  k.tshift = tshift; k.orows = PASS == 1 ? (16 << tshift) : 1024;
   k.inverse = inverse; k.t = t; k.lane = lane; k.wv = wv;
   k.rr = t >> 3; k.cc = 2 * (t & 7);                       // 8 threads x 16 B per 128-B row segment
   k.k0 = (lane >> 2) + 16 * (lane & 3);
@@ -936,6 +942,144 @@ __global__ __launch_bounds__(1024) void fft1m_cols_kernel(const cpx *__restrict_
     }
   }
   f1m_tile<PASS, false>(k, id, -1, q, ta, td);
+}
+
+// ---- 2048-point columns, sixteen per tile: fft2k_cols_kernel (pass 2 of n = 2^21 and 2^22) ----------------------------------
+// A column of 2048 points times a 128-B row segment (16 columns) is 256 KiB: more than the LDS, so fft_cols16_kernel takes 4-8
+// columns per tile -- 32- and 64-B row segments, and the pass runs at half the rate of the 1024-point plans.  Here the tile lives
+// in the REGISTER FILE: one wave per column as in fft1m_cols_kernel, the column split by decimation in time: the even rows
+// (1024 x 16: the image of the 2^20 kernel) go through LDS into the waves, which keep E = FFT_1024(even) in registers (16 complex
+// per lane), then the odd rows take the same way and give O; X(k) = E(k) + W_2048^k O(k), X(k + 1024) = E(k) - W_2048^k O(k) is
+// formed in registers (k = the engine's frequency of (lane, register): W_2048^k = W_2048^k0(lane) times one of 16 constants) and
+// leaves through the image in two slices of 1024 rows x 128 B.  One persistent 1024-thread workgroup per CU, tiles handed out
+// from a counter like the 2^20 kernel's; the loads of the next half tile are in flight while a half is transformed.
+// Inverse transforms: conj at the last store (pass 1 conjugated its input).
+template <bool DYN>
+__global__ __launch_bounds__(1024) void fft2k_cols_kernel(const cpx *__restrict__ in, cpx *__restrict__ out,
+                                                          const cpx *__restrict__ TW1, const cpx *__restrict__ TW2,
+                                                          const cpx *__restrict__ W2K, int C, int ipitch, int opitch,
+                                                          int inverse, float scale, int ntiles, unsigned *ctr, unsigned base)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int P = F1M_PITCH;
+  cpx *tile = reinterpret_cast<cpx *>(smem_raw);
+  cpx *ltw1 = tile + F1M_TILE_ELEMS, *ltw2 = ltw1 + 15 * 64;
+  int *lnext = reinterpret_cast<int *>(ltw2 + 16 * 4 + 256);
+  const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  if (t < 15 * 64) ltw1[t] = TW1[64 + t];
+  if (t < 64) ltw2[t] = TW2[(t >> 2) * 64 + (t & 3)];
+  const LdsTw1 tw1{reinterpret_cast<const f1c *>(ltw1) + lane};
+  const LdsTw2 tw2{reinterpret_cast<const f1c *>(ltw2) + (lane & 3)};
+  f1c *colc = reinterpret_cast<f1c *>(tile + wv);          // this wave's column: slots e * P + wv
+  const cpx *col = tile + wv;
+  const int rr = t >> 3, cc = 2 * (t & 7);                 // 8 threads x 16 B per 128-B row segment
+  const int k0 = (lane >> 2) + 16 * (lane & 3);            // the engine's frequency of (lane, r): k0 + 64 (r >> 2) + 256 (r & 3)
+  const cpx wl = W2K[k0];                                  // W_2048^k0
+  const int tpt = C >> 4;                                  // column tiles per transform
+  const size_t tstride_i = (size_t) 2048 * ipitch, tstride_o = (size_t) 2048 * opitch;
+
+  float4 q[8];
+  // loads of half `h` (rows 2 j + h, j = rr + 128 i) of tile `id`
+  auto issue = [&](int id, int h) {
+    const int b = id / tpt, ct = id - b * tpt;
+    const char *x = reinterpret_cast<const char *>(in + (size_t) b * tstride_i + (size_t) ct * 16);
+    const unsigned o = opaque(((unsigned) (2 * rr + h) * (unsigned) ipitch + (unsigned) cc) * 8u), step = 256u * 8u * (unsigned) ipitch;
+#pragma unroll
+    for (int i = 0; i < 8; i++) q[i] = *reinterpret_cast<const float4 *>(x + (o + step * i));      // (< 2^32 bytes inside a transform)
+  };
+  auto rows_to_lds = [&]() {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int row = rr + 128 * i;
+      tile[row * P + cc] = cmk(q[i].x, q[i].y);
+      tile[row * P + cc + 1] = cmk(q[i].z, q[i].w);
+    }
+  };
+  auto column_fft = [&](f1c (&v)[16]) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) v[r] = colc[(64 * r + lane) * P];
+    w1024::forward<P>(v, colc, lane, tw1, tw2, wave_fence);
+    wave_fence();
+  };
+  // the slice held in the image (frequencies `slice` * 1024 + row) goes out as 128-B row segments
+  auto store_slice = [&](int id, int slice) {
+    const int b = id / tpt, ct = id - b * tpt;
+    char *yb = reinterpret_cast<char *>(out + (size_t) b * tstride_o + (size_t) ct * 16);
+    const unsigned o = opaque(((unsigned) (1024 * slice + rr) * (unsigned) opitch + (unsigned) cc) * 8u), step = 128u * 8u * (unsigned) opitch;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int row = rr + 128 * i;
+      const cpx a = tile[row * P + cc], bb = tile[row * P + cc + 1];
+      *reinterpret_cast<float4 *>(yb + (o + step * i)) = make_float4(a.x, a.y, bb.x, bb.y);
+    }
+  };
+  auto pull = [&]() -> int {
+    const unsigned v = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base;
+    return v < (unsigned) ntiles ? (int) v : -1;
+  };
+  int id, nid;
+  if (DYN) {
+    if (t == 0) {
+      const int a = pull();
+      lnext[0] = a;
+      lnext[1] = a >= 0 ? pull() : -1;
+    }
+    __syncthreads();
+    id = lnext[0];
+    nid = lnext[1];
+    __syncthreads();
+  } else {
+    __syncthreads();
+    id = blockIdx.x < (unsigned) ntiles ? (int) blockIdx.x : -1;
+    nid = id >= 0 && id + (int) gridDim.x < ntiles ? id + (int) gridDim.x : -1;
+  }
+  if (id < 0) return;
+  issue(id, 0);
+  (void) col;
+  while (id >= 0) {
+    int pulled = -1;
+    if (DYN && t == 0 && nid >= 0) pulled = pull();         // the tile after next: its latency hides under this tile
+    rows_to_lds();                                          // even rows
+    issue(id, 1);
+    lds_barrier();
+    f1c E[16], O[16];
+    column_fft(E);
+    lds_barrier();                                          // every wave is done with its column of the image
+    rows_to_lds();                                          // odd rows
+    lds_barrier();
+    column_fft(O);
+    // X(k) = E + w O, X(k + 1024) = E - w O, w = W_2048^k = wl * W_2048^(64 a + 256 b), k = k0 + 64 a + 256 b, a = r >> 2, b = r & 3
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+      const f1c tw = f1mul(O[r], cmul(wl, W2K[64 + r]));     // (W2K[64 + r] = W_2048^(64 a + 256 b): wave-uniform)
+      O[r] = w1024::csub(E[r], tw);
+      E[r] = w1024::cadd(E[r], tw);
+      if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    }
+    // slice 0 (k < 1024) through the wave's own column, then out as rows
+#pragma unroll
+    for (int r = 0; r < 16; r++) colc[(k0 + 64 * (r >> 2) + 256 * (r & 3)) * P] = f1out(E[r], scale, inverse);
+    __builtin_amdgcn_sched_barrier(0);                      // (the loads below must not be hoisted over the combination: E, O and q would all be live)
+    if (nid >= 0) issue(nid, 0);                            // (E is dead: the prefetch registers are free again)
+    lds_barrier();
+    store_slice(id, 0);
+    lds_barrier();
+#pragma unroll
+    for (int r = 0; r < 16; r++) colc[(k0 + 64 * (r >> 2) + 256 * (r & 3)) * P] = f1out(O[r], scale, inverse);
+    lds_barrier();
+    store_slice(id, 1);
+    if (DYN) {
+      if (t == 0) lnext[0] = pulled;
+      lds_barrier();
+      id = nid;
+      nid = id >= 0 ? lnext[0] : -1;
+      lds_barrier();                                        // (lnext[0] is rewritten at the next tile's end)
+    } else {
+      lds_barrier();
+      id = nid;
+      nid = id >= 0 && id + (int) gridDim.x < ntiles ? id + (int) gridDim.x : -1;
+    }
+  }
 }
 
 // ---- helpers for the non power-of-two paths ------------------------------------------------
@@ -1237,8 +1381,9 @@ struct tsdgpu_fft {
   int N1 = 0, N2 = 0, logN1 = 0, logN2 = 0;
   cpx *d_tw1 = nullptr, *d_tw2 = nullptr, *d_thi = nullptr, *d_tlo = nullptr;
   // in-wave 1024-point FFT paths: lane twiddles (2 x 1024) and, for n = 2^20, TA [1024][64] / TD [1024][16]
-  cpx *d_w1 = nullptr, *d_w2 = nullptr, *d_ta = nullptr, *d_td = nullptr;
+  cpx *d_w1 = nullptr, *d_w2 = nullptr, *d_ta = nullptr, *d_td = nullptr, *d_w2k = nullptr;
   unsigned *d_ctr = nullptr;  // n = 2^20: work counter of the dynamic tile hand-out (fft1m_cols_kernel), never reset
+  bool cols2k = false;        // four-step plan whose pass 2 (2048-point columns) runs on fft2k_cols_kernel
   unsigned ctr_base = 0;      // its value before the next launch (advanced once a launch pair has been accepted)
   bool ctr_stale = false;     // a launch that used the counter failed: zero it again before the next use
   // even / odd
@@ -1439,6 +1584,46 @@ int plan_init(tsdgpu_fft *p, int n)
       }
       if ((rc = upload(&p->d_thi, hi))) return rc;
       if ((rc = upload(&p->d_tlo, lo))) return rc;
+      if (p->N2 == 2048 && (p->N1 & 15) == 0 && dev_switch("FFT_NO_2K") == nullptr) {
+        // pass 2 on fft2k_cols_kernel: the in-wave engine's tables, W_2048^k0 (64 entries) and the 16 constants W_2048^(64 a + 256 b)
+        std::vector<cpx> t1(1024), t2(1024), w2k(80);
+        w1024::fill_twiddles(t1.data(), t2.data());
+        for (int i = 0; i < 80; i++) {
+          const int m = i < 64 ? i : 64 * ((i - 64) >> 2) + 256 * ((i - 64) & 3);
+          const double ang = -2.0 * PI * (double) m / 2048.0;
+          w2k[i] = make_float2((float) std::cos(ang), (float) std::sin(ang));
+        }
+        if ((rc = upload(&p->d_w1, t1))) return rc;
+        if ((rc = upload(&p->d_w2, t2))) return rc;
+        if ((rc = upload(&p->d_w2k, w2k))) return rc;
+        if (p->N1 == 1024) {
+          // pass 1 on fft1m_cols_kernel<1>: 1024-point columns of the N2 = 2048 columns, four-step twiddle W_n^(c k) as TA[c][lane] TD[c][r]
+          std::vector<cpx> ta((size_t) p->N2 * 64), td((size_t) p->N2 * 16);
+          for (int c = 0; c < p->N2; c++) {
+            for (int lane = 0; lane < 64; lane++) {
+              const int64_t m = ((int64_t) c * ((lane >> 2) + 16 * (lane & 3))) % n;
+              const double a = -2.0 * PI * (double) m / (double) n;
+              ta[(size_t) c * 64 + lane] = make_float2((float) std::cos(a), (float) std::sin(a));
+            }
+            for (int r = 0; r < 16; r++) {
+              const int64_t m = ((int64_t) c * (64 * (r >> 2) + 256 * (r & 3))) % n;
+              const double a = -2.0 * PI * (double) m / (double) n;
+              td[(size_t) c * 16 + r] = make_float2((float) std::cos(a), (float) std::sin(a));
+            }
+          }
+          if ((rc = upload(&p->d_ta, ta))) return rc;
+          if ((rc = upload(&p->d_td, td))) return rc;
+          (void) hipFuncSetAttribute((const void *) fft1m_cols_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+          (void) hipFuncSetAttribute((const void *) fft1m_cols_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        }
+        if (hipMalloc((void **) &p->d_ctr, 256) != hipSuccess || hipMemset(p->d_ctr, 0, 256) != hipSuccess) {
+          (void) hipGetLastError();
+          p->d_ctr = nullptr;                                // (the static partition then)
+        }
+        (void) hipFuncSetAttribute((const void *) fft2k_cols_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void) hipFuncSetAttribute((const void *) fft2k_cols_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        p->cols2k = true;
+      }
       // the column tiles use up to ~150 KiB of the CU's 160 KiB LDS
 #define C16_ATTR(P, R) (void) hipFuncSetAttribute((const void *) fft_cols16_kernel<P, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
       C16_ATTR(1, 16); C16_ATTR(1, 8); C16_ATTR(1, 4); C16_ATTR(1, 2); C16_ATTR(2, 16); C16_ATTR(2, 8); C16_ATTR(2, 4); C16_ATTR(2, 2);
@@ -1555,7 +1740,7 @@ void plan_destroy(tsdgpu_fft *p)
   if (!p) return;
   if (p->sub) plan_destroy(p->sub);
   if (p->d_ctr) (void) hipFree(p->d_ctr);
-  for (cpx *q : {p->d_tw, p->d_tw1, p->d_tw2, p->d_thi, p->d_tlo, p->d_rot, p->d_chirp, p->d_xc, p->d_w1, p->d_w2, p->d_ta, p->d_td, p->d_wm})
+  for (cpx *q : {p->d_tw, p->d_tw1, p->d_tw2, p->d_thi, p->d_tlo, p->d_rot, p->d_chirp, p->d_xc, p->d_w1, p->d_w2, p->d_ta, p->d_td, p->d_wm, p->d_w2k})
     if (q) (void) hipFree(q);
   p->work.release();
   p->work2.release();
@@ -1690,14 +1875,14 @@ int step_device(tsdgpu_fft *p, const cpx *x, cpx *y, int batch, int forward, hip
       const unsigned b1 = p->ctr_base, b2 = b1 + (unsigned) ntiles + (unsigned) grid;
       if (ctr) {
         hipLaunchKernelGGL((fft1m_cols_kernel<1, true>), dim3(grid), dim3(1024), F1M_LDS, st, x, z, p->d_w1, p->d_w2, p->d_ta,
-                           p->d_td, inverse, 1.0f, ZP, ntiles, ctr, b1);
+                           p->d_td, inverse, 1.0f, ZP, ntiles, ctr, b1, 6);
         hipLaunchKernelGGL((fft1m_cols_kernel<2, true>), dim3(grid), dim3(1024), F1M_LDS, st, z, y, p->d_w1, p->d_w2, p->d_ta,
-                           p->d_td, inverse, 1.0f / 1024.0f, ZP, ntiles, ctr, b2);
+                           p->d_td, inverse, 1.0f / 1024.0f, ZP, ntiles, ctr, b2, 6);
       } else {
         hipLaunchKernelGGL((fft1m_cols_kernel<1, false>), dim3(grid), dim3(1024), F1M_LDS, st, x, z, p->d_w1, p->d_w2, p->d_ta,
-                           p->d_td, inverse, 1.0f, ZP, ntiles, ctr, b1);
+                           p->d_td, inverse, 1.0f, ZP, ntiles, ctr, b1, 6);
         hipLaunchKernelGGL((fft1m_cols_kernel<2, false>), dim3(grid), dim3(1024), F1M_LDS, st, z, y, p->d_w1, p->d_w2, p->d_ta,
-                           p->d_td, inverse, 1.0f / 1024.0f, ZP, ntiles, ctr, b2);
+                           p->d_td, inverse, 1.0f / 1024.0f, ZP, ntiles, ctr, b2, 6);
       }
       if (const hipError_t le = hipGetLastError(); le != hipSuccess) {
         if (ctr) p->ctr_stale = true;                    // (the device counter and the host base may have parted)
@@ -1735,6 +1920,55 @@ int step_device(tsdgpu_fft *p, const cpx *x, cpx *y, int batch, int forward, hip
           }
 #undef C16_LAUNCH
         };
+        if (p->cols2k) {
+          // pass 2 with 2048-point columns: sixteen-column tiles in the register file (fft2k_cols_kernel), persistent grid; when
+          // N1 = 1024 (n = 2^21) pass 1 runs on the 2^20 plan's column kernel and leaves the intermediate at a padded row pitch
+          static const int NCU2 = [] {
+            int dev = 0, nn = 256;
+            if (hipGetDevice(&dev) == hipSuccess) (void) hipDeviceGetAttribute(&nn, hipDeviceAttributeMultiprocessorCount, dev);
+            return nn > 0 ? nn : 256;
+          }();
+          const bool p1w = p->N1 == 1024;
+          const int zp = p1w ? 1024 + 16 : p->N1;
+          if (p1w) {
+            rc = p->work.reserve((size_t) batch * p->N2 * zp * sizeof(cpx));
+            if (rc) return rc;
+            z = p->work.as<cpx>();
+          }
+          const int nt1 = (p->N2 / 16) * batch, g1 = std::min(nt1, NCU2), nt2 = (p->N1 / 16) * batch, g2 = std::min(nt2, NCU2);
+          const bool dyn_ok = p->d_ctr && dev_switch_int("FFT_DYN", 1) != 0 && !stream_is_capturing(st);
+          unsigned *c1 = (p1w && dyn_ok && nt1 >= 4 * g1) ? p->d_ctr : nullptr, *c2 = (dyn_ok && nt2 >= 4 * g2) ? p->d_ctr : nullptr;
+          if ((c1 || c2) && p->ctr_stale) {
+            TSD_HIP(hipMemsetAsync(p->d_ctr, 0, 256, st));
+            p->ctr_base = 0;
+            p->ctr_stale = false;
+          }
+          const unsigned b1 = p->ctr_base, b2 = b1 + (c1 ? (unsigned) nt1 + (unsigned) g1 : 0u);
+          if (p1w) {
+            int tshift = 0;
+            while ((16 << tshift) < p->N2) tshift++;
+            if (c1)
+              hipLaunchKernelGGL((fft1m_cols_kernel<1, true>), dim3(g1), dim3(1024), F1M_LDS, st, x, z, p->d_w1, p->d_w2, p->d_ta, p->d_td, inverse, 1.0f, zp,
+                                 nt1, c1, b1, tshift);
+            else
+              hipLaunchKernelGGL((fft1m_cols_kernel<1, false>), dim3(g1), dim3(1024), F1M_LDS, st, x, z, p->d_w1, p->d_w2, p->d_ta, p->d_td, inverse, 1.0f, zp,
+                                 nt1, (unsigned *) nullptr, 0u, tshift);
+          } else {
+            launch(1, x, z, p->d_tw1, p->N1, p->logN1, p->N2, 1.0f);
+          }
+          if (c2)
+            hipLaunchKernelGGL(fft2k_cols_kernel<true>, dim3(g2), dim3(1024), F1M_LDS, st, z, y, p->d_w1, p->d_w2, p->d_w2k, p->N1, zp, p->N1,
+                               inverse, scale, nt2, c2, b2);
+          else
+            hipLaunchKernelGGL(fft2k_cols_kernel<false>, dim3(g2), dim3(1024), F1M_LDS, st, z, y, p->d_w1, p->d_w2, p->d_w2k, p->N1, zp, p->N1,
+                               inverse, scale, nt2, (unsigned *) nullptr, 0u);
+          if (const hipError_t le = hipGetLastError(); le != hipSuccess) {
+            if (c1 || c2) p->ctr_stale = true;
+            return set_err(TSDGPU_ERR_HIP, "fft_step: launch failed: %s", hipGetErrorString(le));
+          }
+          p->ctr_base = b2 + (c2 ? (unsigned) nt2 + (unsigned) g2 : 0u);
+          return TSDGPU_OK;
+        }
         launch(1, x, z, p->d_tw1, p->N1, p->logN1, p->N2, 1.0f);
         TSD_HIP(hipGetLastError());
         launch(2, z, y, p->d_tw2, p->N2, p->logN2, p->N1, scale);

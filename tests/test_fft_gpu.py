@@ -166,6 +166,36 @@ def test_fft_pow2_batched(tg, orc, logn):
     assert relerr(zd.cpu().numpy(), x) <= TOL
 
 
+# 2^21 and 2^22 points: pass 2 (2048-point columns) on the register-file kernel fft2k_cols_kernel (sixteen-column tiles, two 1024-row
+# half tiles, radix-2 combination in registers), pass 1 of 2^21 on the 2^20 plan's column kernel with a padded intermediate; batches
+# below and above the threshold of the dynamic tile hand-out, the static partition forced, forward / inverse, in place
+@pytest.mark.parametrize("logn,batch,static", [(21, 1, False), (21, 3, False), (21, 20, False), (21, 20, True), (22, 2, False), (22, 17, False)])
+def test_fft_2k_columns(tg, orc, logn, batch, static, monkeypatch):
+    import torch
+    if static:
+        monkeypatch.setenv("TSDGPU_FFT_DYN", "0")
+    n = 1 << logn
+    g = torch.Generator(device="cuda").manual_seed(logn + batch)
+    xd = torch.view_as_complex(torch.randn(batch, n, 2, device="cuda", generator=g))
+    p = tg.Fft(n, batch)
+    yd = p.step(xd)
+    torch.cuda.synchronize()
+    for b in sorted({0, batch // 2, batch - 1}):
+        assert relerr(yd[b].cpu().numpy(), orc.fft(xd[b].cpu().numpy())) <= TOL, b
+    e_in = (xd.abs() ** 2).sum(dim=1)
+    e_out = (yd.abs() ** 2).sum(dim=1)
+    assert torch.allclose(e_in, e_out, rtol=1e-4)                      # Parseval on every transform
+    zd = p.step(yd, False, yd)                                         # inverse, in place
+    torch.cuda.synchronize()
+    assert float((zd - xd).abs().max() / xd.abs().max()) <= TOL
+    # the plan without the 2048-point column kernel gives the same transform (different rounding)
+    monkeypatch.setenv("TSDGPU_FFT_NO_2K", "1")
+    y2 = tg.Fft(n, batch).step(xd)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("TSDGPU_FFT_NO_2K")
+    assert float((y2 - p.step(xd)).abs().max() / y2.abs().max()) <= 2e-6
+
+
 # BASELINE configs[2]: 2^20-point complex FFT, batch (bounded here; the bench runs 256)
 def test_cfg3_fft_2p20(tg, orc):
     import torch
