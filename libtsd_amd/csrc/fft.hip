@@ -947,18 +947,20 @@ __global__ __launch_bounds__(1024) void fft1m_cols_kernel(const cpx *__restrict_
 // ---- 2048-point columns, sixteen per tile: fft2k_cols_kernel (pass 2 of n = 2^21 and 2^22) ----------------------------------
 // A column of 2048 points times a 128-B row segment (16 columns) is 256 KiB: more than the LDS, so fft_cols16_kernel takes 4-8
 // columns per tile -- 32- and 64-B row segments, and the pass runs at half the rate of the 1024-point plans.  Here the tile lives
-// in the REGISTER FILE: one wave per column as in fft1m_cols_kernel, the column split by decimation in time: the even rows
-// (1024 x 16: the image of the 2^20 kernel) go through LDS into the waves, which keep E = FFT_1024(even) in registers (16 complex
-// per lane), then the odd rows take the same way and give O; X(k) = E(k) + W_2048^k O(k), X(k + 1024) = E(k) - W_2048^k O(k) is
-// formed in registers (k = the engine's frequency of (lane, register): W_2048^k = W_2048^k0(lane) times one of 16 constants) and
-// leaves through the image in two slices of 1024 rows x 128 B.  One persistent 1024-thread workgroup per CU, tiles handed out
-// from a counter like the 2^20 kernel's; the loads of the next half tile are in flight while a half is transformed.
-// Inverse transforms: conj at the last store (pass 1 conjugated its input).
-template <bool DYN>
-__global__ __launch_bounds__(1024) void fft2k_cols_kernel(const cpx *__restrict__ in, cpx *__restrict__ out,
-                                                          const cpx *__restrict__ TW1, const cpx *__restrict__ TW2,
-                                                          const cpx *__restrict__ W2K, int C, int ipitch, int opitch,
-                                                          int inverse, float scale, int ntiles, unsigned *ctr, unsigned base)
+// in the REGISTER FILE and goes through the 2^20 kernel's LDS image (1024 rows x 16 columns) as two half tiles, each transformed
+// by the in-wave 1024-point FFT, one column per wave at a time; a radix-2 step joins the halves -- in time for pass 1 (even / odd
+// rows, the combination in registers), in frequency for pass 2 (top / bottom rows, the butterfly at the row loads).
+// EIGHT waves per workgroup, TWO columns per wave: a 512-thread workgroup may hold 256 registers per lane,
+// which is what lets the loads of the next half tile (64 registers) stay in flight beside E (64) and the transform -- with sixteen
+// one-column waves (128 registers) nothing fits beside E and O, and a tile's 46 k cycles of memory time and 35 k of arithmetic ran
+// one after the other (0.300 ms per pass; profiles/EXPERIMENTS.md).  One persistent workgroup per CU (the image is 148 KiB), tiles
+// handed out from a counter like the 2^20 kernel's.  Inverse transforms: conj at the last store (pass 1 conjugated its input).
+template <int PASS, bool DYN>
+__global__ __launch_bounds__(512) void fft2k_cols_kernel(const cpx *__restrict__ in, cpx *__restrict__ out,
+                                                         const cpx *__restrict__ TW1, const cpx *__restrict__ TW2,
+                                                         const cpx *__restrict__ W2K, int C, int ipitch, int opitch,
+                                                         int inverse, float scale, int ntiles, unsigned *ctr, unsigned base,
+                                                         const cpx *__restrict__ TA, const cpx *__restrict__ TD)
 {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int P = F1M_PITCH;
@@ -966,52 +968,40 @@ __global__ __launch_bounds__(1024) void fft2k_cols_kernel(const cpx *__restrict_
   cpx *ltw1 = tile + F1M_TILE_ELEMS, *ltw2 = ltw1 + 15 * 64;
   int *lnext = reinterpret_cast<int *>(ltw2 + 16 * 4 + 256);
   const int t = threadIdx.x, lane = t & 63, wv = __builtin_amdgcn_readfirstlane(t >> 6);
-  if (t < 15 * 64) ltw1[t] = TW1[64 + t];
+  for (int i = t; i < 15 * 64; i += 512) ltw1[i] = TW1[64 + i];
   if (t < 64) ltw2[t] = TW2[(t >> 2) * 64 + (t & 3)];
   const LdsTw1 tw1{reinterpret_cast<const f1c *>(ltw1) + lane};
   const LdsTw2 tw2{reinterpret_cast<const f1c *>(ltw2) + (lane & 3)};
-  f1c *colc = reinterpret_cast<f1c *>(tile + wv);          // this wave's column: slots e * P + wv
-  const cpx *col = tile + wv;
-  const int rr = t >> 3, cc = 2 * (t & 7);                 // 8 threads x 16 B per 128-B row segment
+  f1c *colc = reinterpret_cast<f1c *>(tile + 2 * wv);      // this wave's two columns: slots e * P + 2 wv + u
+  const int rr = t >> 3, cc = 2 * (t & 7);                 // 8 threads x 16 B per 128-B row segment, rows rr + 64 i
   const int k0 = (lane >> 2) + 16 * (lane & 3);            // the engine's frequency of (lane, r): k0 + 64 (r >> 2) + 256 (r & 3)
   const cpx wl = W2K[k0];                                  // W_2048^k0
   const int tpt = C >> 4;                                  // column tiles per transform
-  const size_t tstride_i = (size_t) 2048 * ipitch, tstride_o = (size_t) 2048 * opitch;
+  const size_t tstride_i = (size_t) 2048 * ipitch, tstride_o = (size_t) (PASS == 1 ? C : 2048) * opitch;      // (pass 1 writes C transposed rows)
 
-  float4 q[8];
-  // loads of half `h` (rows 2 j + h, j = rr + 128 i) of tile `id`
+  float4 q[16];
+  // loads of half `h` (rows 2 j + h, j = rr + 64 i) of tile `id`
   auto issue = [&](int id, int h) {
     const int b = id / tpt, ct = id - b * tpt;
     const char *x = reinterpret_cast<const char *>(in + (size_t) b * tstride_i + (size_t) ct * 16);
-    const unsigned o = opaque(((unsigned) (2 * rr + h) * (unsigned) ipitch + (unsigned) cc) * 8u), step = 256u * 8u * (unsigned) ipitch;
+    const unsigned o = opaque(((unsigned) (2 * rr + h) * (unsigned) ipitch + (unsigned) cc) * 8u), step = 128u * 8u * (unsigned) ipitch;
 #pragma unroll
-    for (int i = 0; i < 8; i++) q[i] = *reinterpret_cast<const float4 *>(x + (o + step * i));      // (< 2^32 bytes inside a transform)
+    for (int i = 0; i < 16; i++) q[i] = *reinterpret_cast<const float4 *>(x + (o + step * i));      // (< 2^32 bytes inside a transform)
   };
   auto rows_to_lds = [&]() {
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const int row = rr + 128 * i;
-      tile[row * P + cc] = cmk(q[i].x, q[i].y);
-      tile[row * P + cc + 1] = cmk(q[i].z, q[i].w);
+    for (int i = 0; i < 16; i++) {
+      const int row = rr + 64 * i;
+      const float sg = (PASS == 1 && inverse) ? -1.f : 1.f;      // (inverse = conj o FFT o conj: pass 1 conjugates its input)
+      tile[row * P + cc] = cmk(q[i].x, sg * q[i].y);
+      tile[row * P + cc + 1] = cmk(q[i].z, sg * q[i].w);
     }
   };
-  auto column_fft = [&](f1c (&v)[16]) {
+  auto column_fft = [&](f1c (&v)[16], f1c *cu) {
 #pragma unroll
-    for (int r = 0; r < 16; r++) v[r] = colc[(64 * r + lane) * P];
-    w1024::forward<P>(v, colc, lane, tw1, tw2, wave_fence);
+    for (int r = 0; r < 16; r++) v[r] = cu[(64 * r + lane) * P];
+    w1024::forward<P>(v, cu, lane, tw1, tw2, wave_fence);
     wave_fence();
-  };
-  // the slice held in the image (frequencies `slice` * 1024 + row) goes out as 128-B row segments
-  auto store_slice = [&](int id, int slice) {
-    const int b = id / tpt, ct = id - b * tpt;
-    char *yb = reinterpret_cast<char *>(out + (size_t) b * tstride_o + (size_t) ct * 16);
-    const unsigned o = opaque(((unsigned) (1024 * slice + rr) * (unsigned) opitch + (unsigned) cc) * 8u), step = 128u * 8u * (unsigned) opitch;
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const int row = rr + 128 * i;
-      const cpx a = tile[row * P + cc], bb = tile[row * P + cc + 1];
-      *reinterpret_cast<float4 *>(yb + (o + step * i)) = make_float4(a.x, a.y, bb.x, bb.y);
-    }
   };
   auto pull = [&]() -> int {
     const unsigned v = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - base;
@@ -1034,40 +1024,150 @@ __global__ __launch_bounds__(1024) void fft2k_cols_kernel(const cpx *__restrict_
     nid = id >= 0 && id + (int) gridDim.x < ntiles ? id + (int) gridDim.x : -1;
   }
   if (id < 0) return;
+  if (PASS == 2) {
+    // Pass 2 (natural store) by decimation in FREQUENCY: s(j) = x(j) + x(j + 1024) gives the even bins, d(j) = (x(j) - x(j + 1024))
+    // W_2048^j the odd ones.  The butterfly is done by the threads that loaded the rows (top and bottom half tile in registers), the
+    // even bins leave right after the first pair of transforms -- so each of the tile's two transform phases has a half tile of
+    // stores and a half tile of loads of the NEXT tile in flight beside it (the decimation-in-time form above has all 256 KiB of
+    // stores and a half tile of loads on the first phase and waits for them there).
+    float4 qb[16];
+    auto issue_dif = [&](int id_, int h, float4 (&dst)[16]) {
+      const int b = id_ / tpt, ct = id_ - b * tpt;
+      const char *x = reinterpret_cast<const char *>(in + (size_t) b * tstride_i + (size_t) ct * 16);
+      const unsigned o = opaque(((unsigned) (1024 * h + rr) * (unsigned) ipitch + (unsigned) cc) * 8u), step = 64u * 8u * (unsigned) ipitch;
+#pragma unroll
+      for (int i = 0; i < 16; i++) dst[i] = *reinterpret_cast<const float4 *>(x + (o + step * i));
+    };
+    auto store_dif = [&](int id_, int parity) {
+      const int b = id_ / tpt, ct = id_ - b * tpt;
+      char *yb = reinterpret_cast<char *>(out + (size_t) b * tstride_o + (size_t) ct * 16);
+      const unsigned o = opaque(((unsigned) (2 * rr + parity) * (unsigned) opitch + (unsigned) cc) * 8u), step = 128u * 8u * (unsigned) opitch;
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const int row = rr + 64 * i;
+        const cpx a = tile[row * P + cc], bb = tile[row * P + cc + 1];
+        *reinterpret_cast<float4 *>(yb + (o + step * i)) = make_float4(a.x, a.y, bb.x, bb.y);
+      }
+    };
+    const cpx wr = W2K[rr];                                  // W_2048^rr; row j = rr + 64 i: W_2048^j = wr * W2K[80 + i]
+    issue_dif(id, 0, q);
+    issue_dif(id, 1, qb);
+    while (id >= 0) {
+      int pulled = -1;
+      if (DYN && t == 0 && nid >= 0) pulled = pull();
+      // butterfly: s -> the image, d stays in qb
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const int row = rr + 64 * i;
+        const cpx w = cmul(wr, W2K[80 + i]);
+        const cpx t0 = cmk(q[i].x, q[i].y), t1 = cmk(q[i].z, q[i].w), b0 = cmk(qb[i].x, qb[i].y), b1 = cmk(qb[i].z, qb[i].w);
+        tile[row * P + cc] = cadd(t0, b0);
+        tile[row * P + cc + 1] = cadd(t1, b1);
+        const cpx d0 = cmul(csub(t0, b0), w), d1 = cmul(csub(t1, b1), w);
+        qb[i] = make_float4(d0.x, d0.y, d1.x, d1.y);
+      }
+      if (nid >= 0) issue_dif(nid, 0, q);                     // the next tile's top half: in flight through the first transforms
+      lds_barrier();
+      // (one column at a time: its spectrum goes back into its own column of the image before the next one is read; both
+      // side by side -- two instruction streams for a SIMD that has only two waves -- spilled 37 registers and measured slower)
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        f1c V[16];
+        column_fft(V, colc + u);
+#pragma unroll
+        for (int r = 0; r < 16; r++) colc[(k0 + 64 * (r >> 2) + 256 * (r & 3)) * P + u] = f1out(V[r], scale, inverse);
+        wave_fence();
+      }
+      lds_barrier();
+      store_dif(id, 0);                                       // bins 2 k
+      lds_barrier();
+#pragma unroll
+      for (int i = 0; i < 16; i++) {
+        const int row = rr + 64 * i;
+        tile[row * P + cc] = cmk(qb[i].x, qb[i].y);
+        tile[row * P + cc + 1] = cmk(qb[i].z, qb[i].w);
+      }
+      if (nid >= 0) issue_dif(nid, 1, qb);                    // the next tile's bottom half: in flight through the second transforms
+      lds_barrier();
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
+        f1c V[16];
+        column_fft(V, colc + u);
+#pragma unroll
+        for (int r = 0; r < 16; r++) colc[(k0 + 64 * (r >> 2) + 256 * (r & 3)) * P + u] = f1out(V[r], scale, inverse);
+        wave_fence();
+      }
+      lds_barrier();
+      store_dif(id, 1);                                       // bins 2 k + 1
+      if (DYN) {
+        if (t == 0) lnext[0] = pulled;
+        lds_barrier();
+        id = nid;
+        nid = id >= 0 ? lnext[0] : -1;
+        lds_barrier();
+      } else {
+        lds_barrier();
+        id = nid;
+        nid = id >= 0 && id + (int) gridDim.x < ntiles ? id + (int) gridDim.x : -1;
+      }
+    }
+    return;
+  }
+  // Pass 1 (transposed store) by decimation in TIME: the even rows give E, the odd rows O, X(k) = E(k) + W_2048^k O(k) and
+  // X(k + 1024) = E(k) - W_2048^k O(k) come out as two contiguous halves of the column's spectrum -- what a row of the
+  // transposed intermediate wants (decimation in frequency would interleave them).
   issue(id, 0);
-  (void) col;
   while (id >= 0) {
     int pulled = -1;
     if (DYN && t == 0 && nid >= 0) pulled = pull();         // the tile after next: its latency hides under this tile
     rows_to_lds();                                          // even rows
-    issue(id, 1);
+    issue(id, 1);                                           // in flight through the first transforms
     lds_barrier();
-    f1c E[16], O[16];
-    column_fft(E);
-    lds_barrier();                                          // every wave is done with its column of the image
+    f1c E[2][16], H[2][16];
+    column_fft(E[0], colc);
+    column_fft(E[1], colc + 1);
+    lds_barrier();                                          // every wave is done with its columns of the image
     rows_to_lds();                                          // odd rows
+    if (nid >= 0) issue(nid, 0);                            // the next tile's even rows: in flight through the second transforms
     lds_barrier();
-    column_fft(O);
-    // X(k) = E + w O, X(k + 1024) = E - w O, w = W_2048^k = wl * W_2048^(64 a + 256 b), k = k0 + 64 a + 256 b, a = r >> 2, b = r & 3
+    const int ct_cur = id - (id / tpt) * tpt;
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-      const f1c tw = f1mul(O[r], cmul(wl, W2K[64 + r]));     // (W2K[64 + r] = W_2048^(64 a + 256 b): wave-uniform)
-      O[r] = w1024::csub(E[r], tw);
-      E[r] = w1024::cadd(E[r], tw);
-      if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    for (int u = 0; u < 2; u++) {
+      column_fft(H[u], colc + u);
+      // X(k) = E + w O, X(k + 1024) = E - w O, w = W_2048^k = wl * W_2048^(64 a + 256 b), k = k0 + 64 a + 256 b, a = r >> 2, b = r & 3
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const f1c tw = f1mul(H[u][r], cmul(wl, W2K[64 + r]));     // (W2K[64 + r] = W_2048^(64 a + 256 b): wave-uniform)
+        H[u][r] = w1024::csub(E[u][r], tw);
+        E[u][r] = w1024::cadd(E[u][r], tw);
+      }
+      {
+        // four-step twiddle W_n^(c k), c = this column, k = k0 + 64 a + 256 b (+ 1024): TA[c][lane] = W_n^(c k0), TD[c][r] =
+        // W_n^(c (64 a + 256 b)), TD[c][16] = W_n^(1024 c); then row c of the transposed intermediate, 2048 contiguous values:
+        // the spectrum leaves the wave through its own LDS column so that every lane stores 16 B (two adjacent bins)
+        const int c = ct_cur * 16 + 2 * wv + u;
+        const cpx ta = TA[(size_t) c * 64 + lane], th = TD[(size_t) c * 17 + 16];
+        f1c *cu = colc + u;
+        const cpx *cur = tile + 2 * wv + u;
+        cpx *zrow = out + (size_t) (id / tpt) * tstride_o + (size_t) c * opitch;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+#pragma unroll
+          for (int r = 0; r < 16; r++) {
+            cpx w = cmul(ta, TD[(size_t) c * 17 + r]);
+            if (half) w = cmul(w, th);
+            cu[(k0 + 64 * (r >> 2) + 256 * (r & 3)) * P] = f1mul(half ? H[u][r] : E[u][r], w);
+          }
+          wave_fence();
+#pragma unroll
+          for (int j = 0; j < 8; j++) {
+            const cpx e0 = cur[(128 * j + 2 * lane) * P], e1 = cur[(128 * j + 2 * lane + 1) * P];
+            *reinterpret_cast<float4 *>(zrow + 1024 * half + 128 * j + 2 * lane) = make_float4(e0.x, e0.y, e1.x, e1.y);
+          }
+          wave_fence();
+        }
+      }
     }
-    // slice 0 (k < 1024) through the wave's own column, then out as rows
-#pragma unroll
-    for (int r = 0; r < 16; r++) colc[(k0 + 64 * (r >> 2) + 256 * (r & 3)) * P] = f1out(E[r], scale, inverse);
-    __builtin_amdgcn_sched_barrier(0);                      // (the loads below must not be hoisted over the combination: E, O and q would all be live)
-    if (nid >= 0) issue(nid, 0);                            // (E is dead: the prefetch registers are free again)
-    lds_barrier();
-    store_slice(id, 0);
-    lds_barrier();
-#pragma unroll
-    for (int r = 0; r < 16; r++) colc[(k0 + 64 * (r >> 2) + 256 * (r & 3)) * P] = f1out(O[r], scale, inverse);
-    lds_barrier();
-    store_slice(id, 1);
     if (DYN) {
       if (t == 0) lnext[0] = pulled;
       lds_barrier();
@@ -1383,7 +1483,8 @@ struct tsdgpu_fft {
   // in-wave 1024-point FFT paths: lane twiddles (2 x 1024) and, for n = 2^20, TA [1024][64] / TD [1024][16]
   cpx *d_w1 = nullptr, *d_w2 = nullptr, *d_ta = nullptr, *d_td = nullptr, *d_w2k = nullptr;
   unsigned *d_ctr = nullptr;  // n = 2^20: work counter of the dynamic tile hand-out (fft1m_cols_kernel), never reset
-  bool cols2k = false;        // four-step plan whose pass 2 (2048-point columns) runs on fft2k_cols_kernel
+  bool cols2k = false;        // four-step plan whose pass 2 (2048-point columns, N2 = 2048) runs on fft2k_cols_kernel
+  bool cols2k_p1 = false;     // ... whose pass 1 (N1 = 2048) does
   unsigned ctr_base = 0;      // its value before the next launch (advanced once a launch pair has been accepted)
   bool ctr_stale = false;     // a launch that used the counter failed: zero it again before the next use
   // even / odd
@@ -1584,45 +1685,55 @@ int plan_init(tsdgpu_fft *p, int n)
       }
       if ((rc = upload(&p->d_thi, hi))) return rc;
       if ((rc = upload(&p->d_tlo, lo))) return rc;
-      if (p->N2 == 2048 && (p->N1 & 15) == 0 && dev_switch("FFT_NO_2K") == nullptr) {
-        // pass 2 on fft2k_cols_kernel: the in-wave engine's tables, W_2048^k0 (64 entries) and the 16 constants W_2048^(64 a + 256 b)
-        std::vector<cpx> t1(1024), t2(1024), w2k(80);
+      if ((p->N2 == 2048 || p->N1 == 2048) && (p->N1 & 15) == 0 && dev_switch("FFT_NO_2K") == nullptr) {
+        // 2048-point column passes on fft2k_cols_kernel: the in-wave engine's tables, W_2048^k0 (64 entries) and the 16 constants
+        // W_2048^(64 a + 256 b)
+        std::vector<cpx> t1(1024), t2(1024), w2k(96);       // (... and, for the decimation-in-frequency form, W_2048^(64 i), i < 16)
         w1024::fill_twiddles(t1.data(), t2.data());
-        for (int i = 0; i < 80; i++) {
-          const int m = i < 64 ? i : 64 * ((i - 64) >> 2) + 256 * ((i - 64) & 3);
+        for (int i = 0; i < 96; i++) {
+          const int m = i < 64 ? i : (i < 80 ? 64 * ((i - 64) >> 2) + 256 * ((i - 64) & 3) : 64 * (i - 80));
           const double ang = -2.0 * PI * (double) m / 2048.0;
           w2k[i] = make_float2((float) std::cos(ang), (float) std::sin(ang));
         }
         if ((rc = upload(&p->d_w1, t1))) return rc;
         if ((rc = upload(&p->d_w2, t2))) return rc;
         if ((rc = upload(&p->d_w2k, w2k))) return rc;
+        auto Wn = [&](int64_t m) {
+          const double a = -2.0 * PI * (double) (m % n) / (double) n;
+          return make_float2((float) std::cos(a), (float) std::sin(a));
+        };
         if (p->N1 == 1024) {
           // pass 1 on fft1m_cols_kernel<1>: 1024-point columns of the N2 = 2048 columns, four-step twiddle W_n^(c k) as TA[c][lane] TD[c][r]
           std::vector<cpx> ta((size_t) p->N2 * 64), td((size_t) p->N2 * 16);
           for (int c = 0; c < p->N2; c++) {
-            for (int lane = 0; lane < 64; lane++) {
-              const int64_t m = ((int64_t) c * ((lane >> 2) + 16 * (lane & 3))) % n;
-              const double a = -2.0 * PI * (double) m / (double) n;
-              ta[(size_t) c * 64 + lane] = make_float2((float) std::cos(a), (float) std::sin(a));
-            }
-            for (int r = 0; r < 16; r++) {
-              const int64_t m = ((int64_t) c * (64 * (r >> 2) + 256 * (r & 3))) % n;
-              const double a = -2.0 * PI * (double) m / (double) n;
-              td[(size_t) c * 16 + r] = make_float2((float) std::cos(a), (float) std::sin(a));
-            }
+            for (int lane = 0; lane < 64; lane++) ta[(size_t) c * 64 + lane] = Wn((int64_t) c * ((lane >> 2) + 16 * (lane & 3)));
+            for (int r = 0; r < 16; r++) td[(size_t) c * 16 + r] = Wn((int64_t) c * (64 * (r >> 2) + 256 * (r & 3)));
           }
           if ((rc = upload(&p->d_ta, ta))) return rc;
           if ((rc = upload(&p->d_td, td))) return rc;
           (void) hipFuncSetAttribute((const void *) fft1m_cols_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
           (void) hipFuncSetAttribute((const void *) fft1m_cols_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        } else if (p->N1 == 2048) {
+          // pass 1 on fft2k_cols_kernel<1>: TA[c][lane] = W_n^(c k0), TD[c][r] = W_n^(c (64 a + 256 b)), TD[c][16] = W_n^(1024 c)
+          std::vector<cpx> ta((size_t) p->N2 * 64), td((size_t) p->N2 * 17);
+          for (int c = 0; c < p->N2; c++) {
+            for (int lane = 0; lane < 64; lane++) ta[(size_t) c * 64 + lane] = Wn((int64_t) c * ((lane >> 2) + 16 * (lane & 3)));
+            for (int r = 0; r < 16; r++) td[(size_t) c * 17 + r] = Wn((int64_t) c * (64 * (r >> 2) + 256 * (r & 3)));
+            td[(size_t) c * 17 + 16] = Wn((int64_t) c * 1024);
+          }
+          if ((rc = upload(&p->d_ta, ta))) return rc;
+          if ((rc = upload(&p->d_td, td))) return rc;
+          p->cols2k_p1 = true;
         }
         if (hipMalloc((void **) &p->d_ctr, 256) != hipSuccess || hipMemset(p->d_ctr, 0, 256) != hipSuccess) {
           (void) hipGetLastError();
           p->d_ctr = nullptr;                                // (the static partition then)
         }
-        (void) hipFuncSetAttribute((const void *) fft2k_cols_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void) hipFuncSetAttribute((const void *) fft2k_cols_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        p->cols2k = true;
+        (void) hipFuncSetAttribute((const void *) fft2k_cols_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void) hipFuncSetAttribute((const void *) fft2k_cols_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void) hipFuncSetAttribute((const void *) fft2k_cols_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void) hipFuncSetAttribute((const void *) fft2k_cols_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        p->cols2k = p->N2 == 2048;
       }
       // the column tiles use up to ~150 KiB of the CU's 160 KiB LDS
 #define C16_ATTR(P, R) (void) hipFuncSetAttribute((const void *) fft_cols16_kernel<P, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
@@ -1920,24 +2031,24 @@ int step_device(tsdgpu_fft *p, const cpx *x, cpx *y, int batch, int forward, hip
           }
 #undef C16_LAUNCH
         };
-        if (p->cols2k) {
-          // pass 2 with 2048-point columns: sixteen-column tiles in the register file (fft2k_cols_kernel), persistent grid; when
-          // N1 = 1024 (n = 2^21) pass 1 runs on the 2^20 plan's column kernel and leaves the intermediate at a padded row pitch
+        if (p->cols2k || p->cols2k_p1) {
+          // 2048-point column passes in sixteen-column tiles held in the register file (fft2k_cols_kernel), persistent grids; the
+          // 1024-point pass of 2^21 on the 2^20 plan's column kernel; a padded intermediate when both passes can take one
           static const int NCU2 = [] {
             int dev = 0, nn = 256;
             if (hipGetDevice(&dev) == hipSuccess) (void) hipDeviceGetAttribute(&nn, hipDeviceAttributeMultiprocessorCount, dev);
             return nn > 0 ? nn : 256;
           }();
-          const bool p1w = p->N1 == 1024;
-          const int zp = p1w ? 1024 + 16 : p->N1;
-          if (p1w) {
+          const bool p1w = p->cols2k && p->N1 == 1024, p1k = p->cols2k_p1, p2k = p->cols2k;
+          const int zp = (p2k && (p1w || p1k)) ? p->N1 + 16 : p->N1;
+          if (zp != p->N1) {
             rc = p->work.reserve((size_t) batch * p->N2 * zp * sizeof(cpx));
             if (rc) return rc;
             z = p->work.as<cpx>();
           }
           const int nt1 = (p->N2 / 16) * batch, g1 = std::min(nt1, NCU2), nt2 = (p->N1 / 16) * batch, g2 = std::min(nt2, NCU2);
           const bool dyn_ok = p->d_ctr && dev_switch_int("FFT_DYN", 1) != 0 && !stream_is_capturing(st);
-          unsigned *c1 = (p1w && dyn_ok && nt1 >= 4 * g1) ? p->d_ctr : nullptr, *c2 = (dyn_ok && nt2 >= 4 * g2) ? p->d_ctr : nullptr;
+          unsigned *c1 = ((p1w || p1k) && dyn_ok && nt1 >= 4 * g1) ? p->d_ctr : nullptr, *c2 = (p2k && dyn_ok && nt2 >= 4 * g2) ? p->d_ctr : nullptr;
           if ((c1 || c2) && p->ctr_stale) {
             TSD_HIP(hipMemsetAsync(p->d_ctr, 0, 256, st));
             p->ctr_base = 0;
@@ -1953,15 +2064,26 @@ int step_device(tsdgpu_fft *p, const cpx *x, cpx *y, int batch, int forward, hip
             else
               hipLaunchKernelGGL((fft1m_cols_kernel<1, false>), dim3(g1), dim3(1024), F1M_LDS, st, x, z, p->d_w1, p->d_w2, p->d_ta, p->d_td, inverse, 1.0f, zp,
                                  nt1, (unsigned *) nullptr, 0u, tshift);
+          } else if (p1k) {
+            if (c1)
+              hipLaunchKernelGGL((fft2k_cols_kernel<1, true>), dim3(g1), dim3(512), F1M_LDS, st, x, z, p->d_w1, p->d_w2, p->d_w2k, p->N2, p->N2, zp,
+                                 inverse, 1.0f, nt1, c1, b1, p->d_ta, p->d_td);
+            else
+              hipLaunchKernelGGL((fft2k_cols_kernel<1, false>), dim3(g1), dim3(512), F1M_LDS, st, x, z, p->d_w1, p->d_w2, p->d_w2k, p->N2, p->N2, zp,
+                                 inverse, 1.0f, nt1, (unsigned *) nullptr, 0u, p->d_ta, p->d_td);
           } else {
             launch(1, x, z, p->d_tw1, p->N1, p->logN1, p->N2, 1.0f);
           }
-          if (c2)
-            hipLaunchKernelGGL(fft2k_cols_kernel<true>, dim3(g2), dim3(1024), F1M_LDS, st, z, y, p->d_w1, p->d_w2, p->d_w2k, p->N1, zp, p->N1,
-                               inverse, scale, nt2, c2, b2);
-          else
-            hipLaunchKernelGGL(fft2k_cols_kernel<false>, dim3(g2), dim3(1024), F1M_LDS, st, z, y, p->d_w1, p->d_w2, p->d_w2k, p->N1, zp, p->N1,
-                               inverse, scale, nt2, (unsigned *) nullptr, 0u);
+          if (p2k) {
+            if (c2)
+              hipLaunchKernelGGL((fft2k_cols_kernel<2, true>), dim3(g2), dim3(512), F1M_LDS, st, z, y, p->d_w1, p->d_w2, p->d_w2k, p->N1, zp, p->N1,
+                                 inverse, scale, nt2, c2, b2, (const cpx *) nullptr, (const cpx *) nullptr);
+            else
+              hipLaunchKernelGGL((fft2k_cols_kernel<2, false>), dim3(g2), dim3(512), F1M_LDS, st, z, y, p->d_w1, p->d_w2, p->d_w2k, p->N1, zp, p->N1,
+                                 inverse, scale, nt2, (unsigned *) nullptr, 0u, (const cpx *) nullptr, (const cpx *) nullptr);
+          } else {
+            launch(2, z, y, p->d_tw2, p->N2, p->logN2, p->N1, scale);
+          }
           if (const hipError_t le = hipGetLastError(); le != hipSuccess) {
             if (c1 || c2) p->ctr_stale = true;
             return set_err(TSDGPU_ERR_HIP, "fft_step: launch failed: %s", hipGetErrorString(le));

@@ -166,10 +166,12 @@ def test_fft_pow2_batched(tg, orc, logn):
     assert relerr(zd.cpu().numpy(), x) <= TOL
 
 
-# 2^21 and 2^22 points: pass 2 (2048-point columns) on the register-file kernel fft2k_cols_kernel (sixteen-column tiles, two 1024-row
-# half tiles, radix-2 combination in registers), pass 1 of 2^21 on the 2^20 plan's column kernel with a padded intermediate; batches
-# below and above the threshold of the dynamic tile hand-out, the static partition forced, forward / inverse, in place
-@pytest.mark.parametrize("logn,batch,static", [(21, 1, False), (21, 3, False), (21, 20, False), (21, 20, True), (22, 2, False), (22, 17, False)])
+# 2^21 ... 2^23 points: the 2048-point column passes on the register-file kernel fft2k_cols_kernel (sixteen-column tiles, two 1024-row
+# half tiles, radix-2 combination in registers; pass 2 of 2^21 and 2^22, pass 1 of 2^22 and 2^23), pass 1 of 2^21 on the 2^20 plan's
+# column kernel, a padded intermediate where both passes take one; batches below and above the threshold of the dynamic tile
+# hand-out, the static partition forced, forward / inverse, in place
+@pytest.mark.parametrize("logn,batch,static", [(21, 1, False), (21, 3, False), (21, 20, False), (21, 20, True), (22, 2, False), (22, 17, False),
+                                               (22, 9, True), (23, 1, False), (23, 5, False)])
 def test_fft_2k_columns(tg, orc, logn, batch, static, monkeypatch):
     import torch
     if static:
