@@ -1332,6 +1332,249 @@ __global__ __launch_bounds__(1024) void fft_bluestein_kernel(const cpx *__restri
   }
 }
 
+// ---- the same Bluestein for transforms that fit a WAVE (n2 <= 1024, i.e. odd n <= 512: the odd parts of 1000, 3000, 6000 ...) --------
+// fft_bluestein_kernel spends 72 % of its wave cycles waiting (PMC, n = 1000): every thread fetches its 16 chirp and 16 spectrum
+// values per transform from L2 next to its 16 samples, four waves meet at five barriers per transform, and nothing is in
+// flight while a wave computes.  Here a workgroup is PERSISTENT: chirp, transformed chirp and twiddles are staged in LDS once,
+// the tpt <= 64 threads of a transform synchronise inside their wave only (LDS is in order per wave), and the samples of
+// the next slot are requested before the current one is transformed.  Same arithmetic, same order of operations.
+// FRAME (psd_welch, ola.hip): transform (b, r) reads segment b of a stream -- x[b bstride + r + P i] times the window
+// w[r + P i] -- and the kernel stores |X|^2 only.
+struct BluArgs {
+  const cpx *in;
+  cpx *out;
+  float *pw;
+  const cpx *chirp, *xc, *TW, *Wn;
+  const float *win;
+  int n, n2, tpt, reverse, logP, conj_out, fuse;
+  float g, s2;
+  int64_t ntr, bstride;
+};
+// TPT = threads per transform = n2 / 16, a template parameter: the LDS offsets of the exchanges are then immediates (with a run-time tpt
+// half of the kernel's vector instructions were index arithmetic, or -- hoisted -- 256 registers of addresses)
+constexpr int blu_r0(int tpt) { return tpt == 1 || tpt == 16 ? 16 : tpt == 2 || tpt == 32 ? 2 : tpt == 4 || tpt == 64 ? 4 : 8; }
+// Arithmetic: PACKED (w1024::v2f -- a complex number in a 64-bit register pair, one or two VOP3P instructions per primitive): the
+// kernel is bound by its vector instructions (PMC, n = 125: 72 % VALU busy in the scalar flavour), unlike the memory-bound
+// kernels where the packed flavour changed nothing.
+using bwc = w1024::v2f;
+__device__ __forceinline__ bwc bw_conj_mul(bwc a, bwc w)      // conj(a w) = (a.x w.x - a.y w.y, -a.x w.y - a.y w.x)
+{
+  bwc t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(a), "v"(w));                      // (a.x w.x, -a.x w.y)
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0] neg_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+  return r;
+}
+// pass 0 of a transform whose inputs v[8 .. 15] are ZERO (the padding of the chirp product: n <= n2 / 2 always) -- the first
+// butterfly stage of every radix loses half of its additions; v[8 .. 15] are not read
+template <int R0, typename C> __device__ __forceinline__ void bw_pass0_half(C (&v)[16])
+{
+  using namespace w1024;
+  if (R0 == 16) {
+    constexpr float C1 = 0.92387953251128674f, S1 = 0.38268343236508977f, R2 = 0.70710678118654752f;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {                          // dft4(a, b, 0, 0) = (a + b, a - i b, a - b, a + i b)
+      const C a = v[q], b = v[4 + q];
+      v[q] = cadd(a, b);
+      v[4 + q] = caddrot<false>(a, b);
+      v[8 + q] = csub(a, b);
+      v[12 + q] = csubrot<false>(a, b);
+    }
+    v[5] = cmul(v[5], Make<C>::of(C1, -S1));
+    v[6] = cmul(v[6], Make<C>::of(R2, -R2));
+    v[7] = cmul(v[7], Make<C>::of(S1, -C1));
+    v[9] = cmul(v[9], Make<C>::of(R2, -R2));
+    v[11] = cmul(v[11], Make<C>::of(-R2, -R2));
+    v[13] = cmul(v[13], Make<C>::of(S1, -C1));
+    v[14] = cmul(v[14], Make<C>::of(-R2, -R2));
+    v[15] = cmul(v[15], Make<C>::of(-C1, S1));
+    dft4<false>(v[0], v[1], v[2], v[3]);
+    dft4<false>(v[4], v[5], v[6], v[7]);
+    dft4_crot<false>(v[8], v[9], v[10], v[11]);
+    dft4<false>(v[12], v[13], v[14], v[15]);
+#pragma unroll
+    for (int x = 0; x < 4; x++)
+#pragma unroll
+      for (int y = x + 1; y < 4; y++) {
+        const C t = v[4 * x + y];
+        v[4 * x + y] = v[4 * y + x];
+        v[4 * y + x] = t;
+      }
+  } else if (R0 == 8) {
+    constexpr float R2 = 0.70710678118654752f;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {                          // dft8 of (e0, e1, e2, e3, 0, 0, 0, 0), e[q] = v[i + 2 q]
+      const C e0 = v[i], e1 = v[i + 2], e2 = v[i + 4], e3 = v[i + 6];
+      const C a0 = cadd(e0, e2), a1 = caddrot<false>(e0, e2), a2 = csub(e0, e2), a3 = csubrot<false>(e0, e2);
+      const C b0 = cadd(e1, e3), b1 = caddrot<false>(e1, e3), b2 = csub(e1, e3), b3 = csubrot<false>(e1, e3);
+      const C o1 = cmul(b1, Make<C>::of(R2, -R2)), o2 = rot90<false>(b2), o3 = cmul(b3, Make<C>::of(-R2, -R2));
+      v[i] = cadd(a0, b0); v[i + 8] = csub(a0, b0);
+      v[i + 2] = cadd(a1, o1); v[i + 10] = csub(a1, o1);
+      v[i + 4] = cadd(a2, o2); v[i + 12] = csub(a2, o2);
+      v[i + 6] = cadd(a3, o3); v[i + 14] = csub(a3, o3);
+    }
+  } else if (R0 == 4) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const C a = v[i], b = v[i + 4];
+      v[i] = cadd(a, b);
+      v[i + 4] = caddrot<false>(a, b);
+      v[i + 8] = csub(a, b);
+      v[i + 12] = csubrot<false>(a, b);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i + 8] = v[i];
+  }
+}
+// s16::transform with the pruned first pass
+template <int R0, typename C, typename SYNC>
+__device__ __forceinline__ void bw_transform_half(C (&v)[16], C *s, const C *__restrict__ TW, int n, int j, int tpt, SYNC sync)
+{
+  bw_pass0_half<R0>(v);
+  if (n == R0) return;
+  s16::pass0_store<R0>(s, v, j, tpt);
+  for (int Ns = R0;; Ns <<= 4) {
+    sync();
+#pragma unroll
+    for (int q = 0; q < 16; q++) v[q] = s[s16::pad(j + q * tpt)];
+    const int base = s16::pass16(v, TW, j, tpt, Ns);
+    if (Ns * 16 == n) return;
+    sync();
+#pragma unroll
+    for (int q = 0; q < 16; q++) s[s16::pad(base + q * Ns)] = v[q];
+  }
+}
+template <int TPT, bool FRAME>
+__global__ __launch_bounds__(512) void fft_blu_wave_kernel(const BluArgs A)
+{
+  extern __shared__ __attribute__((aligned(16))) char bw_raw[];
+  constexpr int tpt = TPT, n2 = 16 * TPT, R0 = blu_r0(TPT);
+  const int n = A.n, P = 1 << A.logP;
+  const int t = threadIdx.x, NT = blockDim.x, T = NT / tpt;
+  const int tl = t / tpt, j0 = t - tl * tpt;
+  bwc *chL = reinterpret_cast<bwc *>(bw_raw);                // chirp[n - 1 + i], i < n
+  bwc *xcL = chL + n + 1;
+  bwc *twL = xcL + n2;
+  bwc *img0 = twL + (n2 >> 4);
+  constexpr int pitch = n2 + (n2 >> 4);
+  const bwc *gch = reinterpret_cast<const bwc *>(A.chirp), *gxc = reinterpret_cast<const bwc *>(A.xc), *gtw = reinterpret_cast<const bwc *>(A.TW);
+  for (int i = t; i < n; i += NT) chL[i] = gch[n - 1 + i];
+  for (int i = t; i < n2; i += NT) xcL[i] = gxc[i];
+  for (int i = t; i < (n2 >> 4); i += NT) twL[i] = gtw[i];
+  __syncthreads();
+  const int64_t nslots = (A.ntr + T - 1) / T;
+  // the padding of the chirp product is at least half of n2: registers 8 .. 15 of a thread are zeros, never loaded.  Loads are
+  // unconditional: positions past n (and transforms past the last one) are clamped onto valid elements and masked at the product
+  bwc u[8];
+  float uw[FRAME ? 8 : 1];
+  auto fetch = [&](int64_t slot_) {
+    int j = j0;
+    asm volatile("" : "+v"(j));                               // (opaque: keeps sixteen hoisted addresses and predicates per stage out of the loop's registers)
+    const int64_t tr = min(slot_ * T + tl, A.ntr - 1);
+    const int64_t bb = tr >> A.logP;
+    const int r = (int) (tr - (bb << A.logP));
+    const bwc *x = reinterpret_cast<const bwc *>(A.in + bb * A.bstride + r);
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const int pos = min(j + m * tpt, n - 1);
+      u[m] = x[(size_t) ((unsigned) pos << A.logP)];
+      if (FRAME) uw[m] = A.win[r + (pos << A.logP)];
+    }
+  };
+  int64_t slot = blockIdx.x;
+  if (slot < nslots) fetch(slot);
+  const float rn = 1.0f / (float) n;
+  for (; slot < nslots; slot += gridDim.x) {
+    int j = j0;
+    asm volatile("" : "+v"(j));
+    const int64_t tr = slot * T + tl;
+    const bool live = tr < A.ntr;
+    const int r = (int) (tr & (P - 1));
+    bwc *img = img0 + tl * pitch;
+    bwc v[16];
+#pragma unroll
+    for (int m = 0; m < 8; m++) {
+      const int pos = j + m * tpt;
+      bwc a = u[m];
+      if (FRAME) a = a * uw[m];
+      const bwc c = w1024::cmul(a, chL[pos]);                          // (past n: a value of the next table, masked)
+      v[m] = pos < n ? c : (bwc){0.f, 0.f};
+    }
+    if (slot + gridDim.x < nslots) fetch(slot + gridDim.x);
+    bw_transform_half<R0>(v, img, twL, n2, j, tpt, wave_fence);       // sqrt(n2) * unitary FFT
+#pragma unroll
+    for (int q = 0; q < 16; q++) v[q] = bw_conj_mul(v[q], xcL[j + q * tpt]);
+    wave_fence();
+    s16::transform<R0>(v, img, twL, n2, j, tpt, wave_fence);          // conj of n2 * (unitary inverse of the product)
+    if (A.fuse) wave_fence();                                          // (the image is still being read by the transform's last pass)
+    bwc *y = reinterpret_cast<bwc *>(A.out) + (size_t) tr * n;
+    float *ypw = A.pw + (size_t) tr * n;
+    const bwc *gwn = reinterpret_cast<const bwc *>(A.Wn);
+    const bwc gv = {A.g, A.conj_out ? -A.g : A.g};
+    // outputs n - 1 .. 2 n - 2 of the convolution: positions below 4 tpt never qualify (n - 1 >= n2 / 4)
+#pragma unroll
+    for (int q = 4; q < 16; q++) {
+      const int kk = j + q * tpt - (n - 1);
+      const bool ok = live && (unsigned) kk < (unsigned) n;
+      const int kc = ok ? kk : 0;
+      const int k = A.reverse ? (kc == 0 ? 0 : n - kc) : kc;           // tfr2itfr: X^-1[k] = X[(n - k) % n]
+      bwc o = w1024::cmulc(chL[kc], v[q]) * gv;                        // conj(v) chirp g (conjugated for the inverse of a mixed plan)
+      if (gwn) o = w1024::cmul(o, gwn[r * k]);
+      if (ok) {
+        if (A.fuse) img[k] = o;
+        else if (FRAME) ypw[k] = o.x * o.x + o.y * o.y;
+        else y[k] = o;
+      }
+    }
+    if (!A.fuse) {
+      wave_fence();                                                    // (the next slot's pass 0 rewrites the image)
+      continue;
+    }
+    // the P-point column DFT over the residues of every group of this slot (fft_bluestein_kernel's pass 2)
+    lds_barrier();
+    const int G = T >> A.logP;
+    const float s2 = A.s2;
+    for (int idx = t; idx < G * n; idx += NT) {
+      const int gq = (int) (((float) idx + 0.5f) * rn), k1 = idx - gq * n;       // (idx < 2^15, n <= 511: the quotient is exact)
+      const int64_t tr0 = slot * T + ((int64_t) gq << A.logP);
+      if (tr0 >= A.ntr) continue;
+      const bwc *zb = img0 + (gq << A.logP) * pitch + k1;
+      const size_t ob = (size_t) (tr0 >> A.logP) * n * P + k1;
+      bwc e[16];
+      if (P == 16) {
+#pragma unroll
+        for (int rr = 0; rr < 16; rr++) e[rr] = zb[rr * pitch];
+        w1024::dft16<false>(e);
+      } else {
+#pragma unroll
+        for (int rr = 0; rr < 8; rr++) e[rr] = rr < P ? zb[rr * pitch] : (bwc){0.f, 0.f};
+        if (P == 2) {
+          s16::dft2(e[0], e[1]);
+        } else if (P == 4) {
+          w1024::dft4<false>(e[0], e[1], e[2], e[3]);
+        } else {
+          bwc e8[8];
+#pragma unroll
+          for (int rr = 0; rr < 8; rr++) e8[rr] = e[rr];
+          s16::dft8(e8);
+#pragma unroll
+          for (int rr = 0; rr < 8; rr++) e[rr] = e8[rr];
+        }
+      }
+      bwc *yo = reinterpret_cast<bwc *>(A.out) + ob;
+      const bwc sv = {s2, A.conj_out ? -s2 : s2};
+#pragma unroll
+      for (int k2 = 0; k2 < 16; k2++)
+        if (k2 < P) {
+          const bwc o = e[k2] * sv;
+          if (FRAME) A.pw[ob + (size_t) k2 * n] = o.x * o.x + o.y * o.y;
+          else yo[(size_t) k2 * n] = o;
+        }
+    }
+    lds_barrier();                                                     // the next slot rewrites the images
+  }
+}
+
 // ---- n = m * P, m odd <= 15, P = 2^p >= 16, n <= 16384 (48, 96 ... 1536, 3072, 5120, 7168, 12288, 15360): ONE kernel, the power of two on
 // the radix-16 Stockham engine (round 3).  Decimation in time over the odd factor: the m sub-sequences x[m i + r] are P-point
 // transforms F_r -- s16::transform, compile-time radix-16 passes, one LDS image each, all m of a transform in one workgroup --
@@ -1828,6 +2071,11 @@ int plan_init(tsdgpu_fft *p, int n)
       (void) hipFuncSetAttribute((const void *) fft_bluestein_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       (void) hipFuncSetAttribute((const void *) fft_bluestein_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       (void) hipFuncSetAttribute((const void *) fft_bluestein_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define BW_ATTR(R)                                                                                                                   \
+  (void) hipFuncSetAttribute((const void *) fft_blu_wave_kernel<R, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+  (void) hipFuncSetAttribute((const void *) fft_blu_wave_kernel<R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+      BW_ATTR(1); BW_ATTR(2); BW_ATTR(4); BW_ATTR(8); BW_ATTR(16); BW_ATTR(32); BW_ATTR(64);
+#undef BW_ATTR
       (void) hipGetLastError();
     }
   }
@@ -1873,6 +2121,47 @@ bool bluestein_fusable(const tsdgpu_fft *sub, int P)
   return !off && sub->blu_fused && (P == 2 || P == 4 || P == 8 || P == 16) && P * tpt <= 1024 &&
          (size_t) std::max(256 / tpt, P) * (n2 + n2 / 16) * sizeof(cpx) <= 158 * 1024;
 }
+// the wave-level kernel serves transforms of at most 64 threads (n2 <= 1024); fused groups of P residues within 512 threads
+// (TSDGPU_FFT_BLU_OLD=1: fft_bluestein_kernel everywhere)
+bool blu_wave_fits(const tsdgpu_fft *p, int P, bool fuse)
+{
+  const int tpt = p->n2 / 16;
+  return p->blu_fused && tpt >= 1 && tpt <= 64 && (P & (P - 1)) == 0 && (!fuse || P * tpt <= 512) && dev_switch("FFT_BLU_OLD") == nullptr;
+}
+// x: transform (b, r) starts at x + b * bstride + r (element stride P); pw != NULL: |X|^2 out instead of X, win = the window
+int launch_blu_wave(const tsdgpu_fft *p, const cpx *x, cpx *y, float *pw, const float *win, int64_t bstride, int64_t ntr, int reverse,
+                    int conj_out, int P, const cpx *Wn, hipStream_t st, bool fuse)
+{
+  const int n = p->n, n2 = p->n2, tpt = n2 / 16;
+  const float gf = std::sqrt((float) n2) / std::sqrt((float) n) / (float) n2;
+  int logP = 0;
+  while ((1 << logP) < P) logP++;
+  const int NT = fuse ? std::max(256, P * tpt) : 256, T = NT / tpt;
+  const size_t lds = (size_t) ((n + 1) + n2 + n2 / 16 + (size_t) T * (n2 + n2 / 16)) * sizeof(cpx);
+  TSD_CHECK(lds <= 160 * 1024, "fft_step: Bluestein tables of n = %d do not fit the LDS", n);
+  const int64_t nslots = cdiv(ntr, T);
+  const int per_cu = (int) std::max<size_t>(1, std::min<size_t>(std::min<size_t>(8, (160 * 1024) / (lds + 256)), 2048 / NT));
+  const int64_t grid = std::min<int64_t>(nslots, (int64_t) 256 * per_cu);
+  const BluArgs A{x, y, pw, p->d_chirp, p->d_xc, p->d_tw, Wn, win, n, n2, tpt, reverse, logP, conj_out, fuse ? P : 0, gf,
+                  1.0f / std::sqrt((float) P), ntr, bstride};
+#define BW_LAUNCH(TP)                                                                                                          \
+  do {                                                                                                                         \
+    if (pw) hipLaunchKernelGGL((fft_blu_wave_kernel<TP, true>), dim3((unsigned) grid), dim3(NT), lds, st, A);                  \
+    else hipLaunchKernelGGL((fft_blu_wave_kernel<TP, false>), dim3((unsigned) grid), dim3(NT), lds, st, A);                    \
+  } while (0)
+  switch (tpt) {
+    case 1: BW_LAUNCH(1); break;
+    case 2: BW_LAUNCH(2); break;
+    case 4: BW_LAUNCH(4); break;
+    case 8: BW_LAUNCH(8); break;
+    case 16: BW_LAUNCH(16); break;
+    case 32: BW_LAUNCH(32); break;
+    default: BW_LAUNCH(64); break;
+  }
+#undef BW_LAUNCH
+  TSD_HIP(hipGetLastError());
+  return TSDGPU_OK;
+}
 int launch_bluestein(const tsdgpu_fft *p, const cpx *x, cpx *y, int64_t ntr, int reverse, int conj_out, int P, const cpx *Wn,
                      hipStream_t st, bool fuse = false)
 {
@@ -1883,6 +2172,8 @@ int launch_bluestein(const tsdgpu_fft *p, const cpx *x, cpx *y, int64_t ntr, int
   int l2 = 0;
   while ((1 << l2) < n2) l2++;
   const int r0 = 1 << ((l2 & 3) == 0 ? 4 : (l2 & 3)), tpt = n2 / 16;
+  if (blu_wave_fits(p, P, fuse))
+    return launch_blu_wave(p, x, y, nullptr, nullptr, (int64_t) n * P, ntr, reverse, conj_out, P, Wn, st, fuse);
   const int threads = std::max(256, fuse ? P * tpt : tpt), T = threads / tpt;       // (fused: whole groups of P residues per workgroup)
   const size_t lds = (size_t) T * (n2 + n2 / 16) * sizeof(cpx);
   const int64_t grid = cdiv(ntr, T);
@@ -2229,6 +2520,18 @@ int step_device(tsdgpu_fft *p, const cpx *x, cpx *y, int batch, int forward, hip
 
 namespace tsdgpu {
 const float2 *fft_s16_twiddles(const tsdgpu_fft *p) { return (p && p->kind == tsdgpu_fft::POW2_S16) ? p->d_tw : nullptr; }
+// psd_welch at sizes whose plan is the wave-level Bluestein (odd N <= 511, or N = m 2^p with such an odd part and p <= 4): segment s
+// = x[s pas .. s pas + N) times the window goes through the transform where it is, |X|^2 (unitary scaling) comes out; false: not this plan
+bool fft_blu_framed_launch(const tsdgpu_fft *p, const float2 *x, int64_t pas, const float *win, int64_t nseg, float *pw, void *stream)
+{
+  if (!p || nseg <= 0) return false;
+  hipStream_t st = (hipStream_t) stream;
+  if (p->kind == tsdgpu_fft::ODD && blu_wave_fits(p, 1, false))
+    return launch_blu_wave(p, x, nullptr, pw, win, pas, nseg, 0, 0, 1, nullptr, st, false) == TSDGPU_OK;
+  if (p->kind == tsdgpu_fft::MIXED && p->sub && bluestein_fusable(p->sub, p->mix_P) && blu_wave_fits(p->sub, p->mix_P, true))
+    return launch_blu_wave(p->sub, x, nullptr, pw, win, pas, nseg * p->mix_P, 0, 0, p->mix_P, p->d_rot, st, true) == TSDGPU_OK;
+  return false;
+}
 }
 
 extern "C" {

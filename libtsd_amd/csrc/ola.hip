@@ -1390,6 +1390,8 @@ int tsdgpu_welch(const void *x, int64_t n, int N, const float *window, float *S,
       // fused: segments gathered and windowed by the transform itself, which stores |X|^2 only
       const FrameSrc S{nullptr, (const cpx *) dxv, nullptr, (const float *) dwv, 0, pas, N, 0, 2};
       fused = framed_fft_launch(plan, S, nseg, nullptr, nullptr, seg.as<float>(), st);
+      // (sizes on the wave-level Bluestein -- N = 1000: 8 x 125 -- are framed by that kernel)
+      if (!fused && !multi) fused = fft_blu_framed_launch(plan, (const cpx *) dxv, pas, (const float *) dwv, nseg, seg.as<float>(), st);
     }
     if (!rc && !fused) {
       hipLaunchKernelGGL(welch_frame_kernel, dim3(nblk(total)), dim3(256), 0, st, (const cpx *) dxv, (const float *) dwv,

@@ -24,34 +24,37 @@ __device__ __forceinline__ cpx c_mul(cpx a, cpx b) { return c_mk(a.x * b.x - a.y
 __device__ __forceinline__ int pad(int i) { return i + (i >> 4); }
 __device__ __forceinline__ int padded_size(int n) { return n + (n >> 4); }
 
-__device__ __forceinline__ void dft2(cpx &a, cpx &b)
+// The butterflies below are written on the primitives of fft1024_wave.hpp and templated on the complex type: cpx (two scalar
+// registers) or w1024::v2f (a 64-bit register pair on packed VOP3P arithmetic, half the instructions).
+template <typename C> __device__ __forceinline__ void dft2(C &a, C &b)
 {
-  const cpx t = a;
-  a = c_add(t, b);
-  b = c_sub(t, b);
+  const C t = a;
+  a = w1024::cadd(t, b);
+  b = w1024::csub(t, b);
 }
-__device__ __forceinline__ void dft8(cpx (&e)[8])
+template <typename C> __device__ __forceinline__ void dft8(C (&e)[8])
 {
   constexpr float R2 = 0.70710678118654752f;
   w1024::dft4<false>(e[0], e[2], e[4], e[6]);               // even samples -> E[0..3] in e[0],e[2],e[4],e[6]
   w1024::dft4<false>(e[1], e[3], e[5], e[7]);               // odd samples  -> O[0..3] in e[1],e[3],e[5],e[7]
-  const cpx o0 = e[1], o1 = c_mul(e[3], c_mk(R2, -R2)), o2 = c_mk(e[5].y, -e[5].x), o3 = c_mul(e[7], c_mk(-R2, -R2));
-  const cpx a0 = e[0], a1 = e[2], a2 = e[4], a3 = e[6];
-  e[0] = c_add(a0, o0); e[4] = c_sub(a0, o0);
-  e[1] = c_add(a1, o1); e[5] = c_sub(a1, o1);
-  e[2] = c_add(a2, o2); e[6] = c_sub(a2, o2);
-  e[3] = c_add(a3, o3); e[7] = c_sub(a3, o3);
+  const C o0 = e[1], o1 = w1024::cmul(e[3], w1024::Make<C>::of(R2, -R2)), o2 = w1024::rot90<false>(e[5]),
+          o3 = w1024::cmul(e[7], w1024::Make<C>::of(-R2, -R2));
+  const C a0 = e[0], a1 = e[2], a2 = e[4], a3 = e[6];
+  e[0] = w1024::cadd(a0, o0); e[4] = w1024::csub(a0, o0);
+  e[1] = w1024::cadd(a1, o1); e[5] = w1024::csub(a1, o1);
+  e[2] = w1024::cadd(a2, o2); e[6] = w1024::csub(a2, o2);
+  e[3] = w1024::cadd(a3, o3); e[7] = w1024::csub(a3, o3);
 }
 
 // pass 0 in registers: afterwards v[i + q*(16/R0)] = output q of butterfly jb = j + i*tpt
-template <int R0> __device__ __forceinline__ void pass0(cpx (&v)[16])
+template <int R0, typename C> __device__ __forceinline__ void pass0(C (&v)[16])
 {
   if (R0 == 16) {
     w1024::dft16<false>(v);
   } else if (R0 == 8) {
 #pragma unroll
     for (int i = 0; i < 2; i++) {
-      cpx e[8];
+      C e[8];
 #pragma unroll
       for (int q = 0; q < 8; q++) e[q] = v[i + 2 * q];
       dft8(e);
@@ -67,7 +70,7 @@ template <int R0> __device__ __forceinline__ void pass0(cpx (&v)[16])
   }
 }
 // ... and its write to the (padded) LDS image s of the transform
-template <int R0> __device__ __forceinline__ void pass0_store(cpx *s, const cpx (&v)[16], int j, int tpt)
+template <int R0, typename C> __device__ __forceinline__ void pass0_store(C *s, const C (&v)[16], int j, int tpt)
 {
 #pragma unroll
   for (int i = 0; i < 16 / R0; i++)
@@ -75,19 +78,20 @@ template <int R0> __device__ __forceinline__ void pass0_store(cpx *s, const cpx 
     for (int q = 0; q < R0; q++) s[pad((j + i * tpt) * R0 + q)] = v[i + q * (16 / R0)];
 }
 // v[q] *= w1^q, q = 1..15, from ONE table value: products of depth <= 4
-__device__ __forceinline__ void twiddle_powers(cpx (&v)[16], cpx w1)
+template <typename C> __device__ __forceinline__ void twiddle_powers(C (&v)[16], C w1)
 {
-  const cpx w2 = c_mul(w1, w1), w3 = c_mul(w2, w1), w4 = c_mul(w2, w2);
-  const cpx w5 = c_mul(w4, w1), w6 = c_mul(w4, w2), w7 = c_mul(w4, w3), w8 = c_mul(w4, w4);
-  v[1] = c_mul(v[1], w1); v[2] = c_mul(v[2], w2); v[3] = c_mul(v[3], w3); v[4] = c_mul(v[4], w4);
-  v[5] = c_mul(v[5], w5); v[6] = c_mul(v[6], w6); v[7] = c_mul(v[7], w7); v[8] = c_mul(v[8], w8);
-  v[9] = c_mul(v[9], c_mul(w8, w1)); v[10] = c_mul(v[10], c_mul(w8, w2)); v[11] = c_mul(v[11], c_mul(w8, w3));
-  v[12] = c_mul(v[12], c_mul(w8, w4)); v[13] = c_mul(v[13], c_mul(w8, w5)); v[14] = c_mul(v[14], c_mul(w8, w6));
-  v[15] = c_mul(v[15], c_mul(w8, w7));
+  using w1024::cmul;
+  const C w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
+  const C w5 = cmul(w4, w1), w6 = cmul(w4, w2), w7 = cmul(w4, w3), w8 = cmul(w4, w4);
+  v[1] = cmul(v[1], w1); v[2] = cmul(v[2], w2); v[3] = cmul(v[3], w3); v[4] = cmul(v[4], w4);
+  v[5] = cmul(v[5], w5); v[6] = cmul(v[6], w6); v[7] = cmul(v[7], w7); v[8] = cmul(v[8], w8);
+  v[9] = cmul(v[9], cmul(w8, w1)); v[10] = cmul(v[10], cmul(w8, w2)); v[11] = cmul(v[11], cmul(w8, w3));
+  v[12] = cmul(v[12], cmul(w8, w4)); v[13] = cmul(v[13], cmul(w8, w5)); v[14] = cmul(v[14], cmul(w8, w6));
+  v[15] = cmul(v[15], cmul(w8, w7));
 }
 // One radix-16 pass on registers already read from LDS: twiddle + DFT; returns the base index
 // of the outputs: y[base + q*Ns].  TW[i] = W_n^i, i < n/16.
-__device__ __forceinline__ int pass16(cpx (&v)[16], const cpx *__restrict__ TW, int j, int tpt, int Ns)
+template <typename C> __device__ __forceinline__ int pass16(C (&v)[16], const C *__restrict__ TW, int j, int tpt, int Ns)
 {
   const int k = j & (Ns - 1);
   twiddle_powers(v, TW[k * (tpt / Ns)]);
@@ -98,8 +102,8 @@ __device__ __forceinline__ int pass16(cpx (&v)[16], const cpx *__restrict__ TW, 
 // A whole forward transform of the 16 register values of thread j (input v[m] = x[j + m*tpt]),
 // result X[j + q*tpt] in v[q]; s = the transform's padded LDS image; SYNC = barrier over the
 // threads of the transform.  Unnormalised.
-template <int R0, typename SYNC>
-__device__ __forceinline__ void transform(cpx (&v)[16], cpx *s, const cpx *__restrict__ TW, int n, int j, int tpt, SYNC sync)
+template <int R0, typename C, typename SYNC>
+__device__ __forceinline__ void transform(C (&v)[16], C *s, const C *__restrict__ TW, int n, int j, int tpt, SYNC sync)
 {
   pass0<R0>(v);
   if (n == R0) return;

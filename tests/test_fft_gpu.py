@@ -130,6 +130,36 @@ def test_fft_odd_fused(tg, orc, n):
         assert relerr(z[b], orc.fft(y[b], False)) <= TOL
 
 
+# Bluestein transforms that fit a wave (n2 <= 1024; fft_blu_wave_kernel, round 4): every threads-per-transform count the plans
+# produce (n2 = 64 ... 1024), alone (odd n), with the 2^p-point pass fused (2^p <= 16 within 512 threads) and as pass 1 of the
+# two-kernel plan (2^p = 32 ...), batches that leave the last slot of a persistent workgroup ragged and batches of many slots per
+# workgroup; 16 * 257 and 513 stay on fft_bluestein_kernel.  Forward, inverse, in place.
+@pytest.mark.parametrize("n,batch", [(17, 1), (17, 1000), (37, 77), (67, 5), (125, 3), (125, 40000), (131, 9), (257, 2), (511, 37), (513, 3),
+                                     (2 * 37, 33), (4 * 67, 10), (8 * 125, 1), (8 * 125, 2100), (16 * 125, 7), (16 * 131, 5), (8 * 375, 6),
+                                     (2 * 511, 3), (16 * 257, 2), (32 * 37, 9), (64 * 125, 3), (1024 * 67, 1)])
+def test_fft_bluestein_wave_paths(tg, orc, n, batch):
+    import torch
+    x = crand((batch, n), 7 * n + batch)
+    p = tg.Fft(n, batch)
+    xd = torch.from_numpy(x).cuda()
+    yd = p.step(xd)
+    torch.cuda.synchronize()
+    y = yd.cpu().numpy()
+    rows = sorted(set([0, batch // 2, batch - 1] + list(range(min(batch, 4)))))
+    for b in rows:
+        assert relerr(y[b], orc.fft(x[b])) <= TOL, (n, b)
+    if batch > 8:                    # every row against the (already checked) single-row calls' linearity: rows are independent transforms
+        q = tg.Fft(n, 1)
+        for b in (batch - 2, batch // 3):
+            assert relerr(y[b], q.step(torch.from_numpy(x[b:b + 1]).cuda()).cpu().numpy()[0]) <= 1e-6
+        assert np.isfinite(y).all() and np.abs(y).max() < 1e3
+    zd = p.step(yd, False, yd)       # inverse, in place
+    torch.cuda.synchronize()
+    z = zd.cpu().numpy()
+    for b in rows:
+        assert relerr(z[b], orc.fft(y[b], False)) <= TOL, (n, b, "inverse")
+
+
 # plans that put the batch in gridDim.y (four-step, mixed radix) slice batches above 65535
 @pytest.mark.parametrize("n", [48, 1 << 15])
 def test_fft_huge_batch(tg, orc, n):

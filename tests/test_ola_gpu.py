@@ -136,7 +136,8 @@ def test_errors():
 
 # psd_welch (freqestim.cc:7-20) on the device: framing, one batched FFT, sum of the periodograms
 # (16 ... 8192: one fused kernel on the LDS transform, 1024: on the in-wave transform; the others: framed transform + sums)
-@pytest.mark.parametrize("N", [1, 2, 8, 16, 32, 64, 128, 256, 512, 1000, 1001, 1024, 2048, 4096, 8192, 16384])
+# (125, 250, 375, 1000, 2000, 3000: framed by the wave-level Bluestein kernel; 1001, 4000, 6000: framed transform + sums)
+@pytest.mark.parametrize("N", [1, 2, 8, 16, 32, 64, 125, 128, 250, 256, 375, 512, 1000, 1001, 1024, 2000, 2048, 3000, 4000, 4096, 6000, 8192, 16384])
 def test_welch_matches_oracle(N):
     rng = np.random.default_rng(N)
     w = ola_oracle.fen_hann_periodique(N) if N > 2 else np.ones(N, np.float32)
@@ -150,7 +151,7 @@ def test_welch_matches_oracle(N):
         assert np.max(np.abs(S - ref)) <= TOL * max(np.max(ref), 1e-30), (N, n)
 
 
-@pytest.mark.parametrize("N", [64, 256, 1024, 4096, 8192, 16384])
+@pytest.mark.parametrize("N", [64, 125, 256, 1000, 1024, 4096, 8192, 16384])
 def test_welch_long_device_input(N):
     """2^22 samples resident on the device: runs of several segments per transform; white noise of variance 2 ->
     every bin sums to segments * (window energy) * 2 / N within the statistical spread; the first 50 segments and a
