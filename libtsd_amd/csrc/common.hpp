@@ -147,7 +147,8 @@ namespace tsdgpu {
 // twiddles W_n^i, i < n/16, of a plan served by the radix-16 Stockham kernel (n = 16 .. 16384), else NULL:
 // lets other translation units run s16::transform on the plan's table (ola.hip)
 const float2 *fft_s16_twiddles(const tsdgpu_fft *p);
-bool fft_blu_framed_launch(const tsdgpu_fft *p, const float2 *x, int64_t pas, const float *win, int64_t nseg, float *pw, void *stream);
+int fft_blu_framed_launch(const tsdgpu_fft *p, const float2 *x, int64_t pas, const float *win, int64_t nseg, float *pw, int64_t cap_rows,
+                          int64_t *rows, void *stream);
 
 inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -16,6 +16,8 @@
 #include <cmath>
 #include <memory>
 #include <cstdlib>
+#include <mutex>
+#include <unordered_map>
 
 namespace tsdgpu {
 
@@ -1445,22 +1447,47 @@ __device__ __forceinline__ void bw_transform_half(C (&v)[16], C *s, const C *__r
   }
 }
 template <int TPT, bool FRAME>
-__global__ __launch_bounds__(512) void fft_blu_wave_kernel(const BluArgs A)
+__global__ __launch_bounds__(512, 3) void fft_blu_wave_kernel(const BluArgs A)
 {
   extern __shared__ __attribute__((aligned(16))) char bw_raw[];
   constexpr int tpt = TPT, n2 = 16 * TPT, R0 = blu_r0(TPT);
   const int n = A.n, P = 1 << A.logP;
   const int t = threadIdx.x, NT = blockDim.x, T = NT / tpt;
   const int tl = t / tpt, j0 = t - tl * tpt;
-  bwc *chL = reinterpret_cast<bwc *>(bw_raw);                // chirp[n - 1 + i], i < n
+  // LDS: chirp[n - 1 + i] (i < n) | transformed chirp (n2) | twiddles (n2 / 16) | post-multiplier table (R n) | T images
+  const int R = A.fuse ? P : 1;
+  bwc *chL = reinterpret_cast<bwc *>(bw_raw);
   bwc *xcL = chL + n + 1;
   bwc *twL = xcL + n2;
-  bwc *img0 = twL + (n2 >> 4);
+  bwc *poL = twL + (n2 >> 4);
+  bwc *img0 = poL + R * n + 1;
   constexpr int pitch = n2 + (n2 >> 4);
   const bwc *gch = reinterpret_cast<const bwc *>(A.chirp), *gxc = reinterpret_cast<const bwc *>(A.xc), *gtw = reinterpret_cast<const bwc *>(A.TW);
+  const bwc *gwn = reinterpret_cast<const bwc *>(A.Wn);
   for (int i = t; i < n; i += NT) chL[i] = gch[n - 1 + i];
   for (int i = t; i < n2; i += NT) xcL[i] = gxc[i];
   for (int i = t; i < (n2 >> 4); i += NT) twL[i] = gtw[i];
+  // post-multiplier of output kk of residue r: chirp (conjugated for the inverse of a mixed plan, whose odd part is conjugated
+  // after its forward transform: conj(conj(v) c) = v conj(c)) times g times, when pass 2 is fused (the residue of a thread is
+  // then the same in every slot), the four-step twiddle W_N^(r k) of the bin k the output lands on
+  for (int r = 0; r < R; r++)
+    for (int kk = t; kk < n; kk += NT) {
+      bwc c = gch[n - 1 + kk] * A.g;
+      if (A.conj_out) c.y = -c.y;
+      const int k = A.reverse ? (kk == 0 ? 0 : n - kk) : kk;           // tfr2itfr: X^-1[k] = X[(n - k) % n]
+      if (A.fuse && gwn) c = w1024::cmul(c, gwn[r * k]);
+      poL[r * n + kk] = c;
+    }
+  // FRAME: the powers are summed over the slots of the workgroup (an output bin always belongs to the same thread) and leave as ONE row
+  // of N = n P floats per workgroup: partial sums for the caller's row reduction
+  float *accL = reinterpret_cast<float *>(img0 + T * pitch);         // fused: ONE row of N = n P sums (a thread owns its bins k1 in every group)
+  float accR[FRAME ? 12 : 1];                                          // not fused: a thread's twelve outputs are the same bins in every slot
+  if (FRAME) {
+    if (A.fuse)
+      for (int i = t; i < n * P; i += NT) accL[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < (FRAME ? 12 : 1); i++) accR[i] = 0.f;
+  }
   __syncthreads();
   const int64_t nslots = (A.ntr + T - 1) / T;
   // the padding of the chirp product is at least half of n2: registers 8 .. 15 of a thread are zeros, never loaded.  Loads are
@@ -1484,12 +1511,13 @@ __global__ __launch_bounds__(512) void fft_blu_wave_kernel(const BluArgs A)
   int64_t slot = blockIdx.x;
   if (slot < nslots) fetch(slot);
   const float rn = 1.0f / (float) n;
+  const float sgn = A.conj_out ? 1.f : -1.f;                   // the post-multiplier takes conj(v), or v for the conjugated output
+  const bwc *poT = poL + (A.fuse ? (tl & (P - 1)) * n : 0);
   for (; slot < nslots; slot += gridDim.x) {
     int j = j0;
     asm volatile("" : "+v"(j));
     const int64_t tr = slot * T + tl;
     const bool live = tr < A.ntr;
-    const int r = (int) (tr & (P - 1));
     bwc *img = img0 + tl * pitch;
     bwc v[16];
 #pragma unroll
@@ -1506,39 +1534,63 @@ __global__ __launch_bounds__(512) void fft_blu_wave_kernel(const BluArgs A)
     for (int q = 0; q < 16; q++) v[q] = bw_conj_mul(v[q], xcL[j + q * tpt]);
     wave_fence();
     s16::transform<R0>(v, img, twL, n2, j, tpt, wave_fence);          // conj of n2 * (unitary inverse of the product)
-    if (A.fuse) wave_fence();                                          // (the image is still being read by the transform's last pass)
-    bwc *y = reinterpret_cast<bwc *>(A.out) + (size_t) tr * n;
-    float *ypw = A.pw + (size_t) tr * n;
-    const bwc *gwn = reinterpret_cast<const bwc *>(A.Wn);
-    const bwc gv = {A.g, A.conj_out ? -A.g : A.g};
-    // outputs n - 1 .. 2 n - 2 of the convolution: positions below 4 tpt never qualify (n - 1 >= n2 / 4)
+    // outputs n - 1 .. 2 n - 2 of the convolution: positions below 4 tpt never qualify (n - 1 >= n2 / 4).  o = conj(v) chirp g [W]
+    bwc o[12];
+    int kc[12];
+    bool ok[12];
 #pragma unroll
     for (int q = 4; q < 16; q++) {
       const int kk = j + q * tpt - (n - 1);
-      const bool ok = live && (unsigned) kk < (unsigned) n;
-      const int kc = ok ? kk : 0;
-      const int k = A.reverse ? (kc == 0 ? 0 : n - kc) : kc;           // tfr2itfr: X^-1[k] = X[(n - k) % n]
-      bwc o = w1024::cmulc(chL[kc], v[q]) * gv;                        // conj(v) chirp g (conjugated for the inverse of a mixed plan)
-      if (gwn) o = w1024::cmul(o, gwn[r * k]);
-      if (ok) {
-        if (A.fuse) img[k] = o;
-        else if (FRAME) ypw[k] = o.x * o.x + o.y * o.y;
-        else y[k] = o;
-      }
+      ok[q - 4] = live && (unsigned) kk < (unsigned) n;
+      kc[q - 4] = ok[q - 4] ? kk : 0;
+    }
+#pragma unroll
+    for (int q = 4; q < 16; q++) {
+      bwc w = v[q];
+      w.y *= sgn;
+      o[q - 4] = w1024::cmul(w, poT[kc[q - 4]]);
     }
     if (!A.fuse) {
+      if (gwn) {                                                       // pass 1 of a two-kernel mixed plan: the residue changes with the slot
+        const int r = (int) (tr & (P - 1));
+        bwc wn[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+          const int k = A.reverse ? (kc[i] == 0 ? 0 : n - kc[i]) : kc[i];
+          wn[i] = gwn[r * k];
+        }
+#pragma unroll
+        for (int i = 0; i < 12; i++) o[i] = w1024::cmul(o[i], wn[i]);
+      }
+      bwc *y = reinterpret_cast<bwc *>(A.out) + (size_t) tr * n;
+#pragma unroll
+      for (int i = 0; i < 12; i++) {
+        const int k = A.reverse ? (kc[i] == 0 ? 0 : n - kc[i]) : kc[i];
+        if (FRAME) {
+          if (ok[i]) accR[i] += o[i].x * o[i].x + o[i].y * o[i].y;
+        } else if (ok[i]) {
+          y[k] = o[i];
+        }
+      }
       wave_fence();                                                    // (the next slot's pass 0 rewrites the image)
       continue;
     }
-    // the P-point column DFT over the residues of every group of this slot (fft_bluestein_kernel's pass 2)
+    // fused pass 2: the outputs go to the image at their convolution index kk (slot n: a dump nobody reads); the P-point column DFT
+    // over the residues of every group of this slot (fft_bluestein_kernel's pass 2) fetches bin k1 from kk = (n - k1) % n when reversed
+    wave_fence();                                                      // (the image is still being read by the transform's last pass)
+#pragma unroll
+    for (int i = 0; i < 12; i++) img[ok[i] ? kc[i] : n] = o[i];
     lds_barrier();
     const int G = T >> A.logP;
-    const float s2 = A.s2;
-    for (int idx = t; idx < G * n; idx += NT) {
+    const bwc sv = {A.s2, A.conj_out ? -A.s2 : A.s2};
+    // (FRAME: a thread takes bin k1 of every group in turn -- idx = gq n + k1 with k1 = t, t + NT ... -- so that the sums of a bin have one owner)
+    for (int idx0 = t; idx0 < (FRAME ? n : G * n); idx0 += NT)
+    for (int idx = idx0; idx < G * n; idx += (FRAME ? n : G * n)) {
       const int gq = (int) (((float) idx + 0.5f) * rn), k1 = idx - gq * n;       // (idx < 2^15, n <= 511: the quotient is exact)
       const int64_t tr0 = slot * T + ((int64_t) gq << A.logP);
       if (tr0 >= A.ntr) continue;
-      const bwc *zb = img0 + (gq << A.logP) * pitch + k1;
+      const int kk1 = A.reverse ? (k1 == 0 ? 0 : n - k1) : k1;
+      const bwc *zb = img0 + (gq << A.logP) * pitch + kk1;
       const size_t ob = (size_t) (tr0 >> A.logP) * n * P + k1;
       bwc e[16];
       if (P == 16) {
@@ -1562,16 +1614,39 @@ __global__ __launch_bounds__(512) void fft_blu_wave_kernel(const BluArgs A)
         }
       }
       bwc *yo = reinterpret_cast<bwc *>(A.out) + ob;
-      const bwc sv = {s2, A.conj_out ? -s2 : s2};
 #pragma unroll
       for (int k2 = 0; k2 < 16; k2++)
         if (k2 < P) {
-          const bwc o = e[k2] * sv;
-          if (FRAME) A.pw[ob + (size_t) k2 * n] = o.x * o.x + o.y * o.y;
-          else yo[(size_t) k2 * n] = o;
+          const bwc oo = e[k2] * sv;
+          if (FRAME) accL[k2 * n + k1] += oo.x * oo.x + oo.y * oo.y;
+          else yo[(size_t) k2 * n] = oo;
         }
     }
     lds_barrier();                                                     // the next slot rewrites the images
+  }
+  if (FRAME) {
+    __syncthreads();
+    if (A.fuse) {
+      float *row = A.pw + (size_t) blockIdx.x * n * P;
+      for (int i = t; i < n * P; i += NT) row[i] = accL[i];
+    } else {
+      // the T transforms' register sums meet in LDS (the images are free now) and are added in order
+      float *sub = reinterpret_cast<float *>(img0);
+      for (int i = t; i < T * n; i += NT) sub[i] = 0.f;
+      __syncthreads();
+#pragma unroll
+      for (int q = 4; q < 16; q++) {
+        const int kk = j0 + q * tpt - (n - 1);
+        if ((unsigned) kk < (unsigned) n) sub[tl * n + kk] = accR[q - 4];
+      }
+      __syncthreads();
+      float *row = A.pw + (size_t) blockIdx.x * n;
+      for (int i = t; i < n; i += NT) {
+        float sacc = sub[i];
+        for (int g = 1; g < T; g++) sacc += sub[g * n + i];
+        row[i] = sacc;
+      }
+    }
   }
 }
 
@@ -2121,6 +2196,15 @@ bool bluestein_fusable(const tsdgpu_fft *sub, int P)
   return !off && sub->blu_fused && (P == 2 || P == 4 || P == 8 || P == 16) && P * tpt <= 1024 &&
          (size_t) std::max(256 / tpt, P) * (n2 + n2 / 16) * sizeof(cpx) <= 158 * 1024;
 }
+int cu_count()
+{
+  static const int NCU = [] {
+    int dev = 0, c = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void) hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev);
+    return c > 0 ? c : 256;
+  }();
+  return NCU;
+}
 // the wave-level kernel serves transforms of at most 64 threads (n2 <= 1024); fused groups of P residues within 512 threads
 // (TSDGPU_FFT_BLU_OLD=1: fft_bluestein_kernel everywhere)
 bool blu_wave_fits(const tsdgpu_fft *p, int P, bool fuse)
@@ -2129,23 +2213,47 @@ bool blu_wave_fits(const tsdgpu_fft *p, int P, bool fuse)
   return p->blu_fused && tpt >= 1 && tpt <= 64 && (P & (P - 1)) == 0 && (!fuse || P * tpt <= 512) && dev_switch("FFT_BLU_OLD") == nullptr;
 }
 // x: transform (b, r) starts at x + b * bstride + r (element stride P); pw != NULL: |X|^2 out instead of X, win = the window
+// pw_rows != NULL (psd_welch): the kernel sums |X|^2 over the transforms of each workgroup; pw receives *pw_rows partial rows of
+// n P floats, one per workgroup (at most pw_cap rows, else TSDGPU_ERR_INVALID); pw == NULL with pw_rows: only the row count is computed
 int launch_blu_wave(const tsdgpu_fft *p, const cpx *x, cpx *y, float *pw, const float *win, int64_t bstride, int64_t ntr, int reverse,
-                    int conj_out, int P, const cpx *Wn, hipStream_t st, bool fuse)
+                    int conj_out, int P, const cpx *Wn, hipStream_t st, bool fuse, int64_t *pw_rows = nullptr, int64_t pw_cap = 0)
 {
   const int n = p->n, n2 = p->n2, tpt = n2 / 16;
   const float gf = std::sqrt((float) n2) / std::sqrt((float) n) / (float) n2;
   int logP = 0;
   while ((1 << logP) < P) logP++;
   const int NT = fuse ? std::max(256, P * tpt) : 256, T = NT / tpt;
-  const size_t lds = (size_t) ((n + 1) + n2 + n2 / 16 + (size_t) T * (n2 + n2 / 16)) * sizeof(cpx);
+  const size_t lds = (size_t) ((n + 1) + n2 + n2 / 16 + (size_t) (fuse ? P : 1) * n + 1 + (size_t) T * (n2 + n2 / 16)) * sizeof(cpx) +
+                     (pw_rows && fuse ? (size_t) n * P * sizeof(float) : 0);
   TSD_CHECK(lds <= 160 * 1024, "fft_step: Bluestein tables of n = %d do not fit the LDS", n);
   const int64_t nslots = cdiv(ntr, T);
-  const int per_cu = (int) std::max<size_t>(1, std::min<size_t>(std::min<size_t>(8, (160 * 1024) / (lds + 256)), 2048 / NT));
-  const int64_t grid = std::min<int64_t>(nslots, (int64_t) 256 * per_cu);
+  // persistent grid = the workgroups that are resident at once (registers and LDS: asked from the runtime, remembered per shape)
+  auto resident = [&](const void *fn) {
+    static std::mutex mtx;
+    static std::unordered_map<uint64_t, int> memo;
+    const uint64_t key = ((uint64_t) (uintptr_t) fn << 20) ^ ((uint64_t) (lds / 256) << 2) ^ (uint64_t) (NT / 256);
+    std::lock_guard<std::mutex> lock(mtx);
+    auto it = memo.find(key);
+    if (it != memo.end()) return it->second;
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, NT, lds) != hipSuccess || nb < 1) {
+      (void) hipGetLastError();
+      nb = 1;
+    }
+    memo[key] = nb;
+    return nb;
+  };
   const BluArgs A{x, y, pw, p->d_chirp, p->d_xc, p->d_tw, Wn, win, n, n2, tpt, reverse, logP, conj_out, fuse ? P : 0, gf,
                   1.0f / std::sqrt((float) P), ntr, bstride};
 #define BW_LAUNCH(TP)                                                                                                          \
   do {                                                                                                                         \
+    const void *fn = pw_rows ? (const void *) fft_blu_wave_kernel<TP, true> : (const void *) fft_blu_wave_kernel<TP, false>;   \
+    const int64_t grid = std::min<int64_t>(nslots, (int64_t) cu_count() * resident(fn));                                        \
+    if (pw_rows) {                                                                                                             \
+      *pw_rows = grid;                                                                                                         \
+      if (!pw) return TSDGPU_OK;                                                                                               \
+      TSD_CHECK(*pw_rows <= pw_cap, "welch: %lld partial rows, room for %lld", (long long) *pw_rows, (long long) pw_cap);      \
+    }                                                                                                                          \
     if (pw) hipLaunchKernelGGL((fft_blu_wave_kernel<TP, true>), dim3((unsigned) grid), dim3(NT), lds, st, A);                  \
     else hipLaunchKernelGGL((fft_blu_wave_kernel<TP, false>), dim3((unsigned) grid), dim3(NT), lds, st, A);                    \
   } while (0)
@@ -2521,17 +2629,21 @@ int step_device(tsdgpu_fft *p, const cpx *x, cpx *y, int batch, int forward, hip
 namespace tsdgpu {
 const float2 *fft_s16_twiddles(const tsdgpu_fft *p) { return (p && p->kind == tsdgpu_fft::POW2_S16) ? p->d_tw : nullptr; }
 // psd_welch at sizes whose plan is the wave-level Bluestein (odd N <= 511, or N = m 2^p with such an odd part and p <= 4): segment s
-// = x[s pas .. s pas + N) times the window goes through the transform where it is, |X|^2 (unitary scaling) comes out; false: not this plan
-bool fft_blu_framed_launch(const tsdgpu_fft *p, const float2 *x, int64_t pas, const float *win, int64_t nseg, float *pw, void *stream)
+// = x[s pas .. s pas + N) times the window goes through the transform where it is, and the |X|^2 (unitary scaling) come out summed per
+// workgroup: `rows` partial rows of N floats in pw (pw == NULL: only the count, for the caller's allocation).  0: not this plan.
+int fft_blu_framed_launch(const tsdgpu_fft *p, const float2 *x, int64_t pas, const float *win, int64_t nseg, float *pw, int64_t cap_rows,
+                          int64_t *rows, void *stream)
 {
-  if (!p || nseg <= 0) return false;
+  *rows = 0;
+  if (!p || nseg <= 0) return TSDGPU_OK;
   hipStream_t st = (hipStream_t) stream;
   if (p->kind == tsdgpu_fft::ODD && blu_wave_fits(p, 1, false))
-    return launch_blu_wave(p, x, nullptr, pw, win, pas, nseg, 0, 0, 1, nullptr, st, false) == TSDGPU_OK;
+    return launch_blu_wave(p, x, nullptr, pw, win, pas, nseg, 0, 0, 1, nullptr, st, false, rows, cap_rows);
   if (p->kind == tsdgpu_fft::MIXED && p->sub && bluestein_fusable(p->sub, p->mix_P) && blu_wave_fits(p->sub, p->mix_P, true))
-    return launch_blu_wave(p->sub, x, nullptr, pw, win, pas, nseg * p->mix_P, 0, 0, p->mix_P, p->d_rot, st, true) == TSDGPU_OK;
-  return false;
+    return launch_blu_wave(p->sub, x, nullptr, pw, win, pas, nseg * p->mix_P, 0, 0, p->mix_P, p->d_rot, st, true, rows, cap_rows);
+  return TSDGPU_OK;
 }
+
 }
 
 extern "C" {

@@ -792,6 +792,23 @@ __global__ void welch_sum_kernel(const float *__restrict__ part, float *__restri
   S[i] = acc;
 }
 
+// ... of rows in transform order: bin i of the result is bin src(i) of the rows (the fftshift map above).  64 bins x 4 row lanes per
+// workgroup (a row lane adds every fourth row, the four sums are added in lane order): N / 64 workgroups instead of N / 256
+__global__ __launch_bounds__(256) void welch_sum_shift_kernel(const float *__restrict__ part, float *__restrict__ S, int N, int groups)
+{
+  __shared__ float red[4][64];
+  const int c = threadIdx.x & 63, l = threadIdx.x >> 6, i = blockIdx.x * 64 + c;
+  float acc = 0.f;
+  if (i < N) {
+    const int h = N / 2;
+    const int src = i < h ? N - h + i : i - h;
+    for (int g = l; g < groups; g += 4) acc += part[(size_t) g * N + src];
+  }
+  red[l][c] = acc;
+  __syncthreads();
+  if (l == 0 && i < N) S[i] = ((red[0][c] + red[1][c]) + red[2][c]) + red[3][c];
+}
+
 inline unsigned nblk(int64_t total) { return (unsigned) cdiv(total, 256); }
 
 // ---- rt_spectrum (fourier.cc:1162-1342) -----------------------------------------------------------------------------
@@ -1379,6 +1396,31 @@ int tsdgpu_welch(const void *x, int64_t n, int N, const float *window, float *S,
   if (!rc && nseg == 0) {
     if (hipMemsetAsync(dS, 0, (size_t) N * sizeof(float), st) != hipSuccess) rc = set_err(TSDGPU_ERR_HIP, "welch: memset failed");
   } else if (!rc) {
+    // sizes whose plan is the wave-level Bluestein (N = 1000 = 8 x 125, odd N <= 511 ...): that kernel frames, windows, transforms and
+    // sums |X|^2 per workgroup; what is left is the reduction of its partial rows
+    int64_t rows = 0;
+    if (!multi) rc = fft_blu_framed_launch(plan, (const cpx *) dxv, pas, (const float *) dwv, nseg, nullptr, 0, &rows, st);
+    if (!rc && rows > 0) {
+      // (one row per workgroup of the persistent grid: a few hundred; groups of 8 rows, then 4 row lanes per bin)
+      const int rpg = 8, ngr = (int) cdiv(rows, rpg);
+      rc = part.reserve((size_t) (rows + ngr) * N * sizeof(float));
+      float *p1 = part.as<float>(), *p2 = p1 + (size_t) rows * N;
+      if (!rc) rc = fft_blu_framed_launch(plan, (const cpx *) dxv, pas, (const float *) dwv, nseg, p1, rows, &rows, st);
+      if (!rc) {
+        hipLaunchKernelGGL(welch_sum_groups_kernel, dim3(nblk(N), (unsigned) ngr), dim3(256), 0, st, p1, p2, N, (int) rows, rpg);
+        hipLaunchKernelGGL(welch_sum_shift_kernel, dim3((unsigned) cdiv(N, 64)), dim3(256), 0, st, p2, (float *) dS, N, ngr);
+        if (hipGetLastError() != hipSuccess) rc = set_err(TSDGPU_ERR_HIP, "welch: launch failed");
+      }
+      if (!rc) rc = finish_out(S, (size_t) N * sizeof(float), dS, staged, st);
+      (void) hipStreamSynchronize(st);
+      reserve->rend(c);
+      return rc;
+    }
+    if (rc) {
+      (void) hipStreamSynchronize(st);
+      reserve->rend(c);
+      return rc;
+    }
     const int64_t total = nseg * N;
     // enough groups to fill the chip whatever N: N/256 x groups workgroups, <= 512 partial sums per bin
     const int groups = (int) std::max<int64_t>(1, std::min<int64_t>(512, std::min<int64_t>(cdiv(nseg, 16), cdiv(262144, N))));
@@ -1390,8 +1432,6 @@ int tsdgpu_welch(const void *x, int64_t n, int N, const float *window, float *S,
       // fused: segments gathered and windowed by the transform itself, which stores |X|^2 only
       const FrameSrc S{nullptr, (const cpx *) dxv, nullptr, (const float *) dwv, 0, pas, N, 0, 2};
       fused = framed_fft_launch(plan, S, nseg, nullptr, nullptr, seg.as<float>(), st);
-      // (sizes on the wave-level Bluestein -- N = 1000: 8 x 125 -- are framed by that kernel)
-      if (!fused && !multi) fused = fft_blu_framed_launch(plan, (const cpx *) dxv, pas, (const float *) dwv, nseg, seg.as<float>(), st);
     }
     if (!rc && !fused) {
       hipLaunchKernelGGL(welch_frame_kernel, dim3(nblk(total)), dim3(256), 0, st, (const cpx *) dxv, (const float *) dwv,
