@@ -1428,19 +1428,32 @@ template <int R0, typename C> __device__ __forceinline__ void bw_pass0_half(C (&
     for (int i = 0; i < 8; i++) v[i + 8] = v[i];
   }
 }
-// s16::transform with the pruned first pass
-template <int R0, typename C, typename SYNC>
-__device__ __forceinline__ void bw_transform_half(C (&v)[16], C *s, const C *__restrict__ TW, int n, int j, int tpt, SYNC sync)
+// s16::transform with (HALF) the pruned first pass and the twiddles of the radix-16 passes READ instead of generated: W[i][q] =
+// W_n^(q i), i < n / 16, in rows of 17 (s16::twiddle_powers spends 11 complex products per pass on the powers of one table value)
+constexpr int BW_TWROW = 17, BW_TAB_MAX_TPT = 32;
+// (TAB = false: W[i] = W_n^i, i < n / 16, and generated powers -- where the rows would cost a resident workgroup: n = 1024)
+template <int R0, bool HALF, bool TAB, typename C, typename SYNC>
+__device__ __forceinline__ void bw_transform(C (&v)[16], C *s, const C *__restrict__ W, int n, int j, int tpt, SYNC sync)
 {
-  bw_pass0_half<R0>(v);
+  if (HALF) bw_pass0_half<R0>(v);
+  else s16::pass0<R0>(v);
   if (n == R0) return;
   s16::pass0_store<R0>(s, v, j, tpt);
   for (int Ns = R0;; Ns <<= 4) {
     sync();
 #pragma unroll
     for (int q = 0; q < 16; q++) v[q] = s[s16::pad(j + q * tpt)];
-    const int base = s16::pass16(v, TW, j, tpt, Ns);
-    if (Ns * 16 == n) return;
+    const int k = j & (Ns - 1);
+    if (TAB) {
+      const C *w = W + k * (tpt / Ns) * BW_TWROW;
+#pragma unroll
+      for (int q = 1; q < 16; q++) v[q] = w1024::cmul(v[q], w[q]);
+    } else {
+      s16::twiddle_powers(v, W[k * (tpt / Ns)]);
+    }
+    w1024::dft16<false>(v);
+    if (Ns * 16 == n) return;                                // natural order in registers
+    const int base = (j - k) * 16 + k;
     sync();
 #pragma unroll
     for (int q = 0; q < 16; q++) s[s16::pad(base + q * Ns)] = v[q];
@@ -1451,22 +1464,24 @@ __global__ __launch_bounds__(512, 3) void fft_blu_wave_kernel(const BluArgs A)
 {
   extern __shared__ __attribute__((aligned(16))) char bw_raw[];
   constexpr int tpt = TPT, n2 = 16 * TPT, R0 = blu_r0(TPT);
+  constexpr bool TAB = TPT <= BW_TAB_MAX_TPT;
+  constexpr int TWN = TAB ? TPT * BW_TWROW + (TPT & 1) : TPT;
   const int n = A.n, P = 1 << A.logP;
   const int t = threadIdx.x, NT = blockDim.x, T = NT / tpt;
   const int tl = t / tpt, j0 = t - tl * tpt;
-  // LDS: chirp[n - 1 + i] (i < n) | transformed chirp (n2) | twiddles (n2 / 16) | post-multiplier table (R n) | T images
+  // LDS: chirp[n - 1 + i] (i < n) | transformed chirp (n2) | twiddle rows (17 n2 / 16) | post-multiplier table (R n) | T images
   const int R = A.fuse ? P : 1;
   bwc *chL = reinterpret_cast<bwc *>(bw_raw);
   bwc *xcL = chL + n + 1;
   bwc *twL = xcL + n2;
-  bwc *poL = twL + (n2 >> 4);
+  bwc *poL = twL + TWN;
   bwc *img0 = poL + R * n + 1;
   constexpr int pitch = n2 + (n2 >> 4);
   const bwc *gch = reinterpret_cast<const bwc *>(A.chirp), *gxc = reinterpret_cast<const bwc *>(A.xc), *gtw = reinterpret_cast<const bwc *>(A.TW);
   const bwc *gwn = reinterpret_cast<const bwc *>(A.Wn);
   for (int i = t; i < n; i += NT) chL[i] = gch[n - 1 + i];
   for (int i = t; i < n2; i += NT) xcL[i] = gxc[i];
-  for (int i = t; i < (n2 >> 4); i += NT) twL[i] = gtw[i];
+  for (int i = t; i < TWN; i += NT) twL[i] = gtw[i];
   // post-multiplier of output kk of residue r: chirp (conjugated for the inverse of a mixed plan, whose odd part is conjugated
   // after its forward transform: conj(conj(v) c) = v conj(c)) times g times, when pass 2 is fused (the residue of a thread is
   // then the same in every slot), the four-step twiddle W_N^(r k) of the bin k the output lands on
@@ -1516,6 +1531,7 @@ __global__ __launch_bounds__(512, 3) void fft_blu_wave_kernel(const BluArgs A)
   for (; slot < nslots; slot += gridDim.x) {
     int j = j0;
     asm volatile("" : "+v"(j));
+    j &= tpt - 1;                                                      // (the range is what turns the padded LDS indices into immediates)
     const int64_t tr = slot * T + tl;
     const bool live = tr < A.ntr;
     bwc *img = img0 + tl * pitch;
@@ -1529,11 +1545,11 @@ __global__ __launch_bounds__(512, 3) void fft_blu_wave_kernel(const BluArgs A)
       v[m] = pos < n ? c : (bwc){0.f, 0.f};
     }
     if (slot + gridDim.x < nslots) fetch(slot + gridDim.x);
-    bw_transform_half<R0>(v, img, twL, n2, j, tpt, wave_fence);       // sqrt(n2) * unitary FFT
+    bw_transform<R0, true, TAB>(v, img, twL, n2, j, tpt, wave_fence);       // sqrt(n2) * unitary FFT
 #pragma unroll
     for (int q = 0; q < 16; q++) v[q] = bw_conj_mul(v[q], xcL[j + q * tpt]);
     wave_fence();
-    s16::transform<R0>(v, img, twL, n2, j, tpt, wave_fence);          // conj of n2 * (unitary inverse of the product)
+    bw_transform<R0, false, TAB>(v, img, twL, n2, j, tpt, wave_fence);     // conj of n2 * (unitary inverse of the product)
     // outputs n - 1 .. 2 n - 2 of the convolution: positions below 4 tpt never qualify (n - 1 >= n2 / 4).  o = conj(v) chirp g [W]
     bwc o[12];
     int kc[12];
@@ -1815,6 +1831,7 @@ struct tsdgpu_fft {
   bool blu_fused = false;     // ODD: the one-kernel Bluestein (n2 = 1024 .. 16384)
   cpx *d_wm = nullptr;        // W_m^j, j < m
   cpx *d_chirp = nullptr, *d_xc = nullptr;   // Bluestein chirp (2n-1) and FFT of its conjugate (n2)
+  cpx *d_twf = nullptr;       // n2 <= 1024: W_n2^(q i) in rows [i][17], i < n2 / 16 (fft_blu_wave_kernel)
   DevBuf work, work2, in_stage, out_stage;
   StepOrder order;            // top-level plans only (sub-plans run under their owner's)
   // grouped schedule of the 2^20 plan (TSDGPU_FFT_GROUP): two side streams and their events
@@ -2142,6 +2159,17 @@ int plan_init(tsdgpu_fft *p, int n)
     if (!rc && p->n2 >= 16 && p->n2 <= S16_MAX_N && dev_switch("FFT_GENERIC") == nullptr) {
       p->blu_fused = true;
       rc = upload(&p->d_tw, twiddle_table(p->n2, p->n2 / 16));
+      if (!rc && p->n2 <= 1024) {
+        const int tp = p->n2 / 16;
+        std::vector<cpx> twf((size_t) tp * BW_TWROW, make_float2(1.f, 0.f));
+        const double PI = 3.14159265358979323846;
+        for (int i = 0; i < tp; i++)
+          for (int q = 0; q < 16; q++) {
+            const double a = -2.0 * PI * (double) ((q * i) % p->n2) / (double) p->n2;
+            twf[(size_t) i * BW_TWROW + q] = make_float2((float) std::cos(a), (float) std::sin(a));
+          }
+        rc = upload(&p->d_twf, twf);
+      }
       (void) hipFuncSetAttribute((const void *) fft_bluestein_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       (void) hipFuncSetAttribute((const void *) fft_bluestein_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       (void) hipFuncSetAttribute((const void *) fft_bluestein_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -2174,7 +2202,7 @@ void plan_destroy(tsdgpu_fft *p)
   if (!p) return;
   if (p->sub) plan_destroy(p->sub);
   if (p->d_ctr) (void) hipFree(p->d_ctr);
-  for (cpx *q : {p->d_tw, p->d_tw1, p->d_tw2, p->d_thi, p->d_tlo, p->d_rot, p->d_chirp, p->d_xc, p->d_w1, p->d_w2, p->d_ta, p->d_td, p->d_wm, p->d_w2k})
+  for (cpx *q : {p->d_tw, p->d_tw1, p->d_tw2, p->d_thi, p->d_tlo, p->d_rot, p->d_chirp, p->d_xc, p->d_twf, p->d_w1, p->d_w2, p->d_ta, p->d_td, p->d_wm, p->d_w2k})
     if (q) (void) hipFree(q);
   p->work.release();
   p->work2.release();
@@ -2210,7 +2238,7 @@ int cu_count()
 bool blu_wave_fits(const tsdgpu_fft *p, int P, bool fuse)
 {
   const int tpt = p->n2 / 16;
-  return p->blu_fused && tpt >= 1 && tpt <= 64 && (P & (P - 1)) == 0 && (!fuse || P * tpt <= 512) && dev_switch("FFT_BLU_OLD") == nullptr;
+  return p->blu_fused && p->d_twf && tpt >= 1 && tpt <= 64 && (P & (P - 1)) == 0 && (!fuse || P * tpt <= 512) && dev_switch("FFT_BLU_OLD") == nullptr;
 }
 // x: transform (b, r) starts at x + b * bstride + r (element stride P); pw != NULL: |X|^2 out instead of X, win = the window
 // pw_rows != NULL (psd_welch): the kernel sums |X|^2 over the transforms of each workgroup; pw receives *pw_rows partial rows of
@@ -2223,7 +2251,8 @@ int launch_blu_wave(const tsdgpu_fft *p, const cpx *x, cpx *y, float *pw, const 
   int logP = 0;
   while ((1 << logP) < P) logP++;
   const int NT = fuse ? std::max(256, P * tpt) : 256, T = NT / tpt;
-  const size_t lds = (size_t) ((n + 1) + n2 + n2 / 16 + (size_t) (fuse ? P : 1) * n + 1 + (size_t) T * (n2 + n2 / 16)) * sizeof(cpx) +
+  const bool tab = tpt <= BW_TAB_MAX_TPT;
+  const size_t lds = (size_t) ((n + 1) + n2 + (tab ? tpt * BW_TWROW + (tpt & 1) : tpt) + (size_t) (fuse ? P : 1) * n + 1 + (size_t) T * (n2 + n2 / 16)) * sizeof(cpx) +
                      (pw_rows && fuse ? (size_t) n * P * sizeof(float) : 0);
   TSD_CHECK(lds <= 160 * 1024, "fft_step: Bluestein tables of n = %d do not fit the LDS", n);
   const int64_t nslots = cdiv(ntr, T);
@@ -2243,7 +2272,7 @@ int launch_blu_wave(const tsdgpu_fft *p, const cpx *x, cpx *y, float *pw, const 
     memo[key] = nb;
     return nb;
   };
-  const BluArgs A{x, y, pw, p->d_chirp, p->d_xc, p->d_tw, Wn, win, n, n2, tpt, reverse, logP, conj_out, fuse ? P : 0, gf,
+  const BluArgs A{x, y, pw, p->d_chirp, p->d_xc, tab ? p->d_twf : p->d_tw, Wn, win, n, n2, tpt, reverse, logP, conj_out, fuse ? P : 0, gf,
                   1.0f / std::sqrt((float) P), ntr, bstride};
 #define BW_LAUNCH(TP)                                                                                                          \
   do {                                                                                                                         \
