@@ -775,9 +775,19 @@ struct F1mCtx {
   int ipitch, opitch, inverse, t, lane, wv, rr, cc, k0, grid;
   int tshift;          // log2 of the column tiles per transform (6: 1024 columns; pass 1 of a 1024 x C plan: log2(C / 16))
   int orows;           // rows of a transform's output block (pass 1: its columns, i.e. C; pass 2: 1024)
+  int lc1;             // pass 2 as the LAST pass of a three-pass plan (n = 1024 x C1 x 1024): transform T' = (b, p), p < C1 = 2^lc1,
+                       // stores its row q at y[b n + (C1 q + p) 1024 ..]: row pitch C1 x 1024, base p x 1024 (0: the two-pass plans)
   float scale;
 };
 
+// tile id -> (transform, column tile): consecutive ids are adjacent 128-B column segments of one transform (measured on the three-pass
+// plan, whose rows are 128 KiB apart: spreading the column tiles -- times 17 mod 2^tshift -- or interleaving the transforms changes
+// nothing or costs 2-3 %)
+__device__ __forceinline__ void f1m_decode(const F1mCtx &k, int id, int &tq, int &ct)
+{
+  ct = id & ((1 << k.tshift) - 1);
+  tq = id >> k.tshift;
+}
 // loads of tile `id` into registers: 8 x 16 B of the tile + this tile's share of the TA/TD tables
 // Addresses are formed as (uniform tile base) + (32-bit per-thread byte offset), and the offset
 // is made opaque once per tile: otherwise the 8 row addresses of the loads and of the stores
@@ -790,8 +800,9 @@ __device__ __forceinline__ unsigned opaque(unsigned v)
 template <int PASS>
 __device__ __forceinline__ void f1m_issue(const F1mCtx &k, int id, float4 (&q)[8], cpx &ta, cpx &td)
 {
-  const int ct = id & ((1 << k.tshift) - 1);
-  const char *x = reinterpret_cast<const char *>(k.in + (size_t) (id >> k.tshift) * 1024 * k.ipitch + ct * 16);
+  int tq_, ct;
+  f1m_decode(k, id, tq_, ct);
+  const char *x = reinterpret_cast<const char *>(k.in + (size_t) tq_ * 1024 * k.ipitch + ct * 16);
   const unsigned o = opaque(((unsigned) k.rr * k.ipitch + k.cc) * 8u), step = 128u * 8u * k.ipitch;
 #pragma unroll
   for (int i = 0; i < 8; i++) q[i] = *reinterpret_cast<const float4 *>(x + (o + step * i));
@@ -826,8 +837,11 @@ __device__ __forceinline__ void f1m_tile(const F1mCtx &k, int id, int nid, float
 #pragma unroll
   for (int r = 0; r < 16; r++) v[r] = colc[(64 * r + lane) * P];
   w1024::forward<P>(v, colc, lane, k.tw1, k.tw2, wave_fence);
-  const int c0 = (id & ((1 << k.tshift) - 1)) * 16, c = c0 + k.wv;
-  cpx *y = k.out + (size_t) (id >> k.tshift) * k.orows * k.opitch;
+  int tq_, ct_;
+  f1m_decode(k, id, tq_, ct_);
+  const int c0 = ct_ * 16, c = c0 + k.wv;
+  const size_t tq = (size_t) tq_;
+  cpx *y = PASS == 2 ? k.out + ((tq >> k.lc1) << (20 + k.lc1)) + (tq & ((1u << k.lc1) - 1)) * 1024 : k.out + tq * k.orows * k.opitch;
   wave_fence();
   if (PASS == 1) {
     // row c of the transposed intermediate.  The spectrum leaves the wave through its own LDS
@@ -873,7 +887,7 @@ __global__ __launch_bounds__(1024) void fft1m_cols_kernel(const cpx *__restrict_
                                                           const cpx *__restrict__ TW1, const cpx *__restrict__ TW2,
                                                           const cpx *__restrict__ TA, const cpx *__restrict__ TD,
                                                           int inverse, float scale, int zp, int ntiles, unsigned *ctr, unsigned base,
-                                                          int tshift)
+                                                          int tshift, int lc1)
 {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   cpx *tile = reinterpret_cast<cpx *>(smem_raw);
@@ -887,8 +901,8 @@ __global__ __launch_bounds__(1024) void fft1m_cols_kernel(const cpx *__restrict_
   k.tile = tile; k.col = tile + wv; k.ltd = ltd;           // this wave's column: slots e*P + wv
   k.tw1 = LdsTw1{reinterpret_cast<const f1c *>(ltw1) + lane}; k.tw2 = LdsTw2{reinterpret_cast<const f1c *>(ltw2) + (lane & 3)};
   // (pass 1 of a 1024 x C plan: C = 16 << tshift columns of 1024 points, input rows C apart, C transposed output rows of pitch zp)
-  k.ipitch = PASS == 1 ? (16 << tshift) : zp; k.opitch = PASS == 1 ? zp : 1024;
-  k.tshift = tshift; k.orows = PASS == 1 ? (16 << tshift) : 1024;
+  k.ipitch = PASS == 1 ? (16 << tshift) : zp; k.opitch = PASS == 1 ? zp : (1024 << lc1);
+  k.tshift = tshift; k.orows = PASS == 1 ? (16 << tshift) : 1024; k.lc1 = lc1;
   k.inverse = inverse; k.t = t; k.lane = lane; k.wv = wv;
   k.rr = t >> 3; k.cc = 2 * (t & 7);                       // 8 threads x 16 B per 128-B row segment
   k.k0 = (lane >> 2) + 16 * (lane & 3);
@@ -944,6 +958,73 @@ __global__ __launch_bounds__(1024) void fft1m_cols_kernel(const cpx *__restrict_
     }
   }
   f1m_tile<PASS, false>(k, id, -1, q, ta, td);
+}
+
+// ---- n = 2^23 .. 2^25 in THREE passes: n = 1024 x C1 x 1024 (C1 = 8, 16, 32) -----------------------------------------------------------
+// Two passes need 4096-point columns from 2^23 on: a 128-B row segment of them is 512 KiB, so fft_cols16_kernel takes 32-B
+// segments and runs at a quarter of the 2^20 plan's rate (0.18 of 8 TB/s at 2^24).  Three passes that all move 128-B segments:
+//   pass 1   fft1m_cols_kernel<1>: 1024-point columns of x viewed [1024][C], C = C1 x 1024, four-step twiddle W_n^(c k1), stored
+//            transposed: Z[c][k1], rows of pitch 1040
+//   pass 2a  fft_planes_kernel (here): with c = 1024 a + b, a C1-point DFT over a -- the C1 PLANES of 1024 rows each, element-wise in
+//            (b, k1): pure streaming, in place -- times W_C^(b p):  U[p][b][k1]
+//   pass 2b  fft1m_cols_kernel<2>: for every (p, k1) the 1024-point FFT over b (the rows of plane p), bin q stored at
+//            y[(C1 q + p) 1024 + k1]: X[k1 + 1024 (p + C1 q)]
+// (index algebra: W_C^(c k2) with k2 = p + C1 q is W_C1^(a p) W_C^(b p) W_1024^(b q))
+template <int C1, int VEC>
+__global__ __launch_bounds__(256) void fft_planes_kernel(cpx *__restrict__ z, const cpx *__restrict__ TP, int zp, int64_t total)
+{
+  const int64_t g = (int64_t) blockIdx.x * 256 + threadIdx.x;
+  if (g >= total) return;
+  constexpr int PER_ROW = 1024 / VEC;                       // threads of a row: a wave stays inside one row b
+  const int64_t rowid = g / PER_ROW;                        // batch * 1024 + b
+  const int kq = (int) (g - rowid * PER_ROW) * VEC;
+  const int b = __builtin_amdgcn_readfirstlane((int) (rowid & 1023));
+  const int64_t bt = rowid >> 10;
+  const size_t ps = (size_t) 1024 * zp;                     // plane stride
+  cpx *base = z + ((size_t) bt * C1 * 1024 + b) * zp + kq;
+  cpx e[VEC][C1];
+#pragma unroll
+  for (int a = 0; a < C1; a++) {
+    if (VEC == 2) {
+      const float4 q = *reinterpret_cast<const float4 *>(base + a * ps);
+      e[0][a] = cmk(q.x, q.y);
+      e[VEC - 1][a] = cmk(q.z, q.w);
+    } else {
+      e[0][a] = base[a * ps];
+    }
+  }
+  const cpx *tw = TP + b * C1;                              // W_C^(b p), p < C1: wave-uniform
+#pragma unroll
+  for (int v = 0; v < VEC; v++) {
+    if (C1 == 8) {
+      cpx (&a8)[8] = reinterpret_cast<cpx (&)[8]>(e[v]);
+      s16::dft8(a8);
+    } else if (C1 == 16) {
+      cpx (&a16)[16] = reinterpret_cast<cpx (&)[16]>(e[v]);
+      w1024::dft16<false>(a16);
+    } else {
+      // 32 = 2 x 16, decimation in time: X[k] = E[k] + W_32^k O[k], X[k + 16] = E[k] - W_32^k O[k]
+      cpx ev[16], od[16];
+#pragma unroll
+      for (int i = 0; i < 16; i++) { ev[i] = e[v][2 * i]; od[i] = e[v][2 * i + 1]; }
+      w1024::dft16<false>(ev);
+      w1024::dft16<false>(od);
+#pragma unroll
+      for (int k = 0; k < 16; k++) {
+        const float ang = -6.28318530717958647692f * (float) k / 32.0f;
+        const cpx o = cmul(od[k], cmk(__builtin_cosf(ang), __builtin_sinf(ang)));
+        e[v][k] = cadd(ev[k], o);
+        e[v][k + 16] = csub(ev[k], o);
+      }
+    }
+#pragma unroll
+    for (int pq = 1; pq < C1; pq++) e[v][pq] = cmul(e[v][pq], tw[pq]);
+  }
+#pragma unroll
+  for (int a = 0; a < C1; a++) {
+    if (VEC == 2) *reinterpret_cast<float4 *>(base + a * ps) = make_float4(e[0][a].x, e[0][a].y, e[VEC - 1][a].x, e[VEC - 1][a].y);
+    else base[a * ps] = e[0][a];
+  }
 }
 
 // ---- 2048-point columns, sixteen per tile: fft2k_cols_kernel (pass 2 of n = 2^21 and 2^22) ----------------------------------
@@ -1819,6 +1900,8 @@ struct tsdgpu_fft {
   unsigned *d_ctr = nullptr;  // n = 2^20: work counter of the dynamic tile hand-out (fft1m_cols_kernel), never reset
   bool cols2k = false;        // four-step plan whose pass 2 (2048-point columns, N2 = 2048) runs on fft2k_cols_kernel
   bool cols2k_p1 = false;     // ... whose pass 1 (N1 = 2048) does
+  int c3 = 0;                 // three-pass plan n = 1024 x c3 x 1024 (c3 = 8, 16, 32; 0: not this plan); d_tp: W_C^(b p) [1024][c3]
+  cpx *d_tp = nullptr;
   unsigned ctr_base = 0;      // its value before the next launch (advanced once a launch pair has been accepted)
   bool ctr_stale = false;     // a launch that used the counter failed: zero it again before the next use
   // even / odd
@@ -2020,7 +2103,10 @@ int plan_init(tsdgpu_fft *p, int n)
       }
       if ((rc = upload(&p->d_thi, hi))) return rc;
       if ((rc = upload(&p->d_tlo, lo))) return rc;
-      if ((p->N2 == 2048 || p->N1 == 2048) && (p->N1 & 15) == 0 && dev_switch("FFT_NO_2K") == nullptr) {
+      // 2^24, 2^25: the three-pass plan; 2^23 keeps the 2048 x 4096 plan unless TSDGPU_FFT_3PASS_23=1 (measured: see DESIGN.md 3.3)
+      const bool use3 = p->logn >= 23 && p->logn <= 25 && dev_switch("FFT_NO_3PASS") == nullptr &&
+                        (p->logn > 23 || dev_switch_int("FFT_3PASS_23", 0) != 0);
+      if (!use3 && (p->N2 == 2048 || p->N1 == 2048) && (p->N1 & 15) == 0 && dev_switch("FFT_NO_2K") == nullptr) {
         // 2048-point column passes on fft2k_cols_kernel: the in-wave engine's tables, W_2048^k0 (64 entries) and the 16 constants
         // W_2048^(64 a + 256 b)
         std::vector<cpx> t1(1024), t2(1024), w2k(96);       // (... and, for the decimation-in-frequency form, W_2048^(64 i), i < 16)
@@ -2069,6 +2155,39 @@ int plan_init(tsdgpu_fft *p, int n)
         (void) hipFuncSetAttribute((const void *) fft2k_cols_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void) hipFuncSetAttribute((const void *) fft2k_cols_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         p->cols2k = p->N2 == 2048;
+      }
+      if (use3) {
+        // three passes of 128-B row segments (fft_planes_kernel): n = 1024 x C1 x 1024
+        const int C1 = 1 << (p->logn - 20), C = C1 * 1024;
+        std::vector<cpx> t1(1024), t2(1024);
+        w1024::fill_twiddles(t1.data(), t2.data());
+        if ((rc = upload(&p->d_w1, t1))) return rc;
+        if ((rc = upload(&p->d_w2, t2))) return rc;
+        auto Wd = [&](int64_t m, int64_t mod) {
+          const double a = -2.0 * PI * (double) (m % mod) / (double) mod;
+          return make_float2((float) std::cos(a), (float) std::sin(a));
+        };
+        {
+          std::vector<cpx> ta((size_t) C * 64), td((size_t) C * 16), tp((size_t) 1024 * C1);
+          for (int c = 0; c < C; c++) {
+            for (int lane = 0; lane < 64; lane++) ta[(size_t) c * 64 + lane] = Wd((int64_t) c * ((lane >> 2) + 16 * (lane & 3)), n);
+            for (int r = 0; r < 16; r++) td[(size_t) c * 16 + r] = Wd((int64_t) c * (64 * (r >> 2) + 256 * (r & 3)), n);
+          }
+          for (int b = 0; b < 1024; b++)
+            for (int q = 0; q < C1; q++) tp[(size_t) b * C1 + q] = Wd((int64_t) b * q, C);
+          if ((rc = upload(&p->d_ta, ta))) return rc;
+          if ((rc = upload(&p->d_td, td))) return rc;
+          if ((rc = upload(&p->d_tp, tp))) return rc;
+        }
+        if (hipMalloc((void **) &p->d_ctr, 256) != hipSuccess || hipMemset(p->d_ctr, 0, 256) != hipSuccess) {
+          (void) hipGetLastError();
+          p->d_ctr = nullptr;
+        }
+        (void) hipFuncSetAttribute((const void *) fft1m_cols_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void) hipFuncSetAttribute((const void *) fft1m_cols_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void) hipFuncSetAttribute((const void *) fft1m_cols_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void) hipFuncSetAttribute((const void *) fft1m_cols_kernel<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        p->c3 = C1;
       }
       // the column tiles use up to ~150 KiB of the CU's 160 KiB LDS
 #define C16_ATTR(P, R) (void) hipFuncSetAttribute((const void *) fft_cols16_kernel<P, R>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
@@ -2202,7 +2321,7 @@ void plan_destroy(tsdgpu_fft *p)
   if (!p) return;
   if (p->sub) plan_destroy(p->sub);
   if (p->d_ctr) (void) hipFree(p->d_ctr);
-  for (cpx *q : {p->d_tw, p->d_tw1, p->d_tw2, p->d_thi, p->d_tlo, p->d_rot, p->d_chirp, p->d_xc, p->d_twf, p->d_w1, p->d_w2, p->d_ta, p->d_td, p->d_wm, p->d_w2k})
+  for (cpx *q : {p->d_tw, p->d_tw1, p->d_tw2, p->d_thi, p->d_tlo, p->d_rot, p->d_chirp, p->d_xc, p->d_twf, p->d_tp, p->d_w1, p->d_w2, p->d_ta, p->d_td, p->d_wm, p->d_w2k})
     if (q) (void) hipFree(q);
   p->work.release();
   p->work2.release();
@@ -2414,14 +2533,14 @@ int step_device(tsdgpu_fft *p, const cpx *x, cpx *y, int batch, int forward, hip
       const unsigned b1 = p->ctr_base, b2 = b1 + (unsigned) ntiles + (unsigned) grid;
       if (ctr) {
         hipLaunchKernelGGL((fft1m_cols_kernel<1, true>), dim3(grid), dim3(1024), F1M_LDS, st, x, z, p->d_w1, p->d_w2, p->d_ta,
-                           p->d_td, inverse, 1.0f, ZP, ntiles, ctr, b1, 6);
+                           p->d_td, inverse, 1.0f, ZP, ntiles, ctr, b1, 6, 0);
         hipLaunchKernelGGL((fft1m_cols_kernel<2, true>), dim3(grid), dim3(1024), F1M_LDS, st, z, y, p->d_w1, p->d_w2, p->d_ta,
-                           p->d_td, inverse, 1.0f / 1024.0f, ZP, ntiles, ctr, b2, 6);
+                           p->d_td, inverse, 1.0f / 1024.0f, ZP, ntiles, ctr, b2, 6, 0);
       } else {
         hipLaunchKernelGGL((fft1m_cols_kernel<1, false>), dim3(grid), dim3(1024), F1M_LDS, st, x, z, p->d_w1, p->d_w2, p->d_ta,
-                           p->d_td, inverse, 1.0f, ZP, ntiles, ctr, b1, 6);
+                           p->d_td, inverse, 1.0f, ZP, ntiles, ctr, b1, 6, 0);
         hipLaunchKernelGGL((fft1m_cols_kernel<2, false>), dim3(grid), dim3(1024), F1M_LDS, st, z, y, p->d_w1, p->d_w2, p->d_ta,
-                           p->d_td, inverse, 1.0f / 1024.0f, ZP, ntiles, ctr, b2, 6);
+                           p->d_td, inverse, 1.0f / 1024.0f, ZP, ntiles, ctr, b2, 6, 0);
       }
       if (const hipError_t le = hipGetLastError(); le != hipSuccess) {
         if (ctr) p->ctr_stale = true;                    // (the device counter and the host base may have parted)
@@ -2459,6 +2578,52 @@ int step_device(tsdgpu_fft *p, const cpx *x, cpx *y, int batch, int forward, hip
           }
 #undef C16_LAUNCH
         };
+        if (p->c3) {
+          const int C1 = p->c3, C = C1 * 1024, zp = 1024 + 16, lc1 = p->logn - 20;
+          rc = p->work.reserve((size_t) batch * C * zp * sizeof(cpx));
+          if (rc) return rc;
+          z = p->work.as<cpx>();
+          const int ncu = cu_count();
+          const int64_t nt1 = (int64_t) (C / 16) * batch, nt2 = (int64_t) 64 * C1 * batch;
+          TSD_CHECK(nt1 <= 0x3fffffff && nt2 <= 0x3fffffff, "fft_step: batch %d too large for n = 2^%d", batch, p->logn);
+          const int g1 = (int) std::min<int64_t>(nt1, ncu), g2 = (int) std::min<int64_t>(nt2, ncu);
+          const bool dyn_ok = p->d_ctr && dev_switch_int("FFT_DYN", 1) != 0 && !stream_is_capturing(st);
+          unsigned *c1 = (dyn_ok && nt1 >= 4 * g1) ? p->d_ctr : nullptr, *c2 = (dyn_ok && nt2 >= 4 * g2) ? p->d_ctr : nullptr;
+          if ((c1 || c2) && p->ctr_stale) {
+            TSD_HIP(hipMemsetAsync(p->d_ctr, 0, 256, st));
+            p->ctr_base = 0;
+            p->ctr_stale = false;
+          }
+          const unsigned b1 = p->ctr_base, b2 = b1 + (c1 ? (unsigned) nt1 + (unsigned) g1 : 0u);
+          int tshift = 0;
+          while ((16 << tshift) < C) tshift++;
+          if (c1)
+            hipLaunchKernelGGL((fft1m_cols_kernel<1, true>), dim3(g1), dim3(1024), F1M_LDS, st, x, z, p->d_w1, p->d_w2, p->d_ta, p->d_td, inverse, 1.0f, zp,
+                               (int) nt1, c1, b1, tshift, 0);
+          else
+            hipLaunchKernelGGL((fft1m_cols_kernel<1, false>), dim3(g1), dim3(1024), F1M_LDS, st, x, z, p->d_w1, p->d_w2, p->d_ta, p->d_td, inverse, 1.0f, zp,
+                               (int) nt1, (unsigned *) nullptr, 0u, tshift, 0);
+          {
+            const int vec = C1 == 32 ? 1 : 2;
+            const int64_t threads = (int64_t) batch * 1024 * (1024 / vec);
+            const unsigned gp = (unsigned) cdiv(threads, 256);
+            if (C1 == 8) hipLaunchKernelGGL((fft_planes_kernel<8, 2>), dim3(gp), dim3(256), 0, st, z, p->d_tp, zp, threads);
+            else if (C1 == 16) hipLaunchKernelGGL((fft_planes_kernel<16, 2>), dim3(gp), dim3(256), 0, st, z, p->d_tp, zp, threads);
+            else hipLaunchKernelGGL((fft_planes_kernel<32, 1>), dim3(gp), dim3(256), 0, st, z, p->d_tp, zp, threads);
+          }
+          if (c2)
+            hipLaunchKernelGGL((fft1m_cols_kernel<2, true>), dim3(g2), dim3(1024), F1M_LDS, st, z, y, p->d_w1, p->d_w2, p->d_ta, p->d_td, inverse, scale, zp,
+                               (int) nt2, c2, b2, 6, lc1);
+          else
+            hipLaunchKernelGGL((fft1m_cols_kernel<2, false>), dim3(g2), dim3(1024), F1M_LDS, st, z, y, p->d_w1, p->d_w2, p->d_ta, p->d_td, inverse, scale, zp,
+                               (int) nt2, (unsigned *) nullptr, 0u, 6, lc1);
+          if (const hipError_t le = hipGetLastError(); le != hipSuccess) {
+            if (c1 || c2) p->ctr_stale = true;
+            return set_err(TSDGPU_ERR_HIP, "fft_step: launch failed: %s", hipGetErrorString(le));
+          }
+          p->ctr_base = b2 + (c2 ? (unsigned) nt2 + (unsigned) g2 : 0u);
+          return TSDGPU_OK;
+        }
         if (p->cols2k || p->cols2k_p1) {
           // 2048-point column passes in sixteen-column tiles held in the register file (fft2k_cols_kernel), persistent grids; the
           // 1024-point pass of 2^21 on the 2^20 plan's column kernel; a padded intermediate when both passes can take one
@@ -2488,10 +2653,10 @@ int step_device(tsdgpu_fft *p, const cpx *x, cpx *y, int batch, int forward, hip
             while ((16 << tshift) < p->N2) tshift++;
             if (c1)
               hipLaunchKernelGGL((fft1m_cols_kernel<1, true>), dim3(g1), dim3(1024), F1M_LDS, st, x, z, p->d_w1, p->d_w2, p->d_ta, p->d_td, inverse, 1.0f, zp,
-                                 nt1, c1, b1, tshift);
+                                 nt1, c1, b1, tshift, 0);
             else
               hipLaunchKernelGGL((fft1m_cols_kernel<1, false>), dim3(g1), dim3(1024), F1M_LDS, st, x, z, p->d_w1, p->d_w2, p->d_ta, p->d_td, inverse, 1.0f, zp,
-                                 nt1, (unsigned *) nullptr, 0u, tshift);
+                                 nt1, (unsigned *) nullptr, 0u, tshift, 0);
           } else if (p1k) {
             if (c1)
               hipLaunchKernelGGL((fft2k_cols_kernel<1, true>), dim3(g1), dim3(512), F1M_LDS, st, x, z, p->d_w1, p->d_w2, p->d_w2k, p->N2, p->N2, zp,

@@ -228,6 +228,38 @@ def test_fft_2k_columns(tg, orc, logn, batch, static, monkeypatch):
     assert float((y2 - p.step(xd)).abs().max() / y2.abs().max()) <= 2e-6
 
 
+# n = 2^24, 2^25 (2^23 by switch): THREE passes of 128-B row segments -- 1024-point columns, a C1-point DFT across C1 planes (fft_planes_kernel,
+# C1 = 8 / 16 / 32), 1024-point columns with rows scattered C1 apart; dynamic and static tile hand-out, forward / inverse in place, and the
+# same transform from the two-pass plan (TSDGPU_FFT_NO_3PASS=1)
+@pytest.mark.parametrize("logn,batch,static", [(24, 1, False), (24, 3, False), (24, 5, True), (25, 1, False), (25, 2, False), (23, 3, False)])
+def test_fft_three_pass(tg, orc, logn, batch, static, monkeypatch):
+    import torch
+    if static:
+        monkeypatch.setenv("TSDGPU_FFT_DYN", "0")
+    if logn == 23:
+        monkeypatch.setenv("TSDGPU_FFT_3PASS_23", "1")
+    n = 1 << logn
+    g = torch.Generator(device="cuda").manual_seed(3 * logn + batch)
+    xd = torch.view_as_complex(torch.randn(batch, n, 2, device="cuda", generator=g))
+    p = tg.Fft(n, batch)
+    yd = p.step(xd)
+    torch.cuda.synchronize()
+    for b in sorted({0, batch - 1}):
+        assert relerr(yd[b].cpu().numpy(), orc.fft(xd[b].cpu().numpy())) <= TOL, b
+    e_in = (xd.abs() ** 2).sum(dim=1)
+    e_out = (yd.abs() ** 2).sum(dim=1)
+    assert torch.allclose(e_in, e_out, rtol=1e-4)                      # Parseval on every transform
+    monkeypatch.setenv("TSDGPU_FFT_NO_3PASS", "1")
+    y2 = tg.Fft(n, batch).step(xd)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("TSDGPU_FFT_NO_3PASS")
+    assert float((y2 - yd).abs().max() / y2.abs().max()) <= 3e-6
+    del y2
+    zd = p.step(yd, False, yd)                                         # inverse, in place
+    torch.cuda.synchronize()
+    assert float((zd - xd).abs().max() / xd.abs().max()) <= TOL
+
+
 # BASELINE configs[2]: 2^20-point complex FFT, batch (bounded here; the bench runs 256)
 def test_cfg3_fft_2p20(tg, orc):
     import torch
