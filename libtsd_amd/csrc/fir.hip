@@ -160,19 +160,24 @@ __global__ __launch_bounds__(THREADS) void fir_direct_kernel(
   }
 
   if (interior) {
-    // a lane's R outputs are 64 contiguous bytes: four 16-B stores straight from the registers.  A wave instruction covers 32
-    // cache lines half a line at a time and the next one completes them (L2 merges the halves); staged back through LDS for
-    // fully coalesced stores the tile cost two more barriers, eight LDS instructions per lane and their index arithmetic --
-    // in a kernel whose vector ALUs are 92 % busy that is time, and the stores are 1/16 of its memory traffic per tap.
-    float4 *ys = reinterpret_cast<float4 *>(y + tile0 + (int64_t) threadIdx.x * R);
+    // outputs go back through LDS so that every global store is a coalesced 16-B access of whole lines.  (Round 4 stored a lane's
+    // 64 contiguous bytes straight from its registers -- four 16-B stores, a wave instruction covering 32 lines half a line at a
+    // time: nothing gained at 127 taps (0.3725 against 0.3727 ms), and the short filters this kernel actually serves lost a fifth:
+    // 0.19 -> 0.22 ms at 31 taps, 0.10 -> 0.14 ms on real data.)
+    __syncthreads();
+    T *Lo = L + threadIdx.x * SP;
 #pragma unroll
     for (int v4 = 0; v4 < R / VEC; v4++) {
       float4 q4;
       T *e = reinterpret_cast<T *>(&q4);
 #pragma unroll
       for (int k = 0; k < VEC; k++) e[k] = acc[v4 * VEC + k];
-      ys[v4] = q4;
+      *reinterpret_cast<float4 *>(Lo + v4 * VEC) = q4;
     }
+    __syncthreads();
+    float4 *ys = reinterpret_cast<float4 *>(y + tile0);
+    for (int c = threadIdx.x; c < TILE / VEC; c += THREADS)
+      ys[c] = *reinterpret_cast<const float4 *>(L + (c / (R / VEC)) * SP + (c % (R / VEC)) * VEC);
   } else {
     const int64_t o0 = tile0 + (int64_t) threadIdx.x * R;
 #pragma unroll

@@ -28,3 +28,13 @@ for w in fir fft sos resample; do
   python3 bench.py --workload $w --steps $steps --warmup 20 > gpurun_out/${TAG}_bench_$w.json 2> gpurun_out/${TAG}_bench_$w.err
   echo "== $w"; tail -c 900 gpurun_out/${TAG}_bench_$w.json; echo
 done
+# the secondary tables of the round (a change tuned on the headline configuration is re-measured where the kernel is actually used:
+# round 4's direct-FIR stores cost nothing at 127 taps and a fifth at 7 ... 31)
+python3 scripts/perf_short_fir.py > gpurun_out/${TAG}_perf_short_fir.txt 2>&1 || true
+python3 scripts/perf_fft_sizes.py > gpurun_out/${TAG}_perf_fft_sizes.txt 2>&1 || true
+python3 scripts/perf_fft_sizes.py 125 131 250 257 375 511 513 1001 2000 3000 4000 6000 8190 >> gpurun_out/${TAG}_perf_fft_sizes.txt 2>&1 || true
+python3 scripts/perf_fft_sizes.py --total 28 1048576 2097152 4194304 8388608 16777216 33554432 65536 262144 1024 4096 > gpurun_out/${TAG}_perf_fft_sizes_2p28.txt 2>&1 || true
+python3 scripts/perf_welch.py 125 250 375 1000 1001 2000 3000 256 1024 4096 > gpurun_out/${TAG}_perf_welch.txt 2>&1 || true
+python3 scripts/perf_secondary.py > gpurun_out/${TAG}_perf_secondary.txt 2>&1 || true
+python3 scripts/perf_polyphase.py > gpurun_out/${TAG}_perf_polyphase.txt 2>&1 || true
+echo "== secondary tables written"
