@@ -1435,7 +1435,7 @@ struct BluArgs {
 };
 // TPT = threads per transform = n2 / 16, a template parameter: the LDS offsets of the exchanges are then immediates (with a run-time tpt
 // half of the kernel's vector instructions were index arithmetic, or -- hoisted -- 256 registers of addresses)
-constexpr int blu_r0(int tpt) { return tpt == 1 || tpt == 16 ? 16 : tpt == 2 || tpt == 32 ? 2 : tpt == 4 || tpt == 64 ? 4 : 8; }
+constexpr int blu_r0(int tpt) { return tpt == 1 || tpt == 16 || tpt == 256 ? 16 : tpt == 2 || tpt == 32 ? 2 : tpt == 4 || tpt == 64 ? 4 : 8; }
 // Arithmetic: PACKED (w1024::v2f -- a complex number in a 64-bit register pair, one or two VOP3P instructions per primitive): the
 // kernel is bound by its vector instructions (PMC, n = 125: 72 % VALU busy in the scalar flavour), unlike the memory-bound
 // kernels where the packed flavour changed nothing.
@@ -1511,7 +1511,7 @@ template <int R0, typename C> __device__ __forceinline__ void bw_pass0_half(C (&
 }
 // s16::transform with (HALF) the pruned first pass and the twiddles of the radix-16 passes READ instead of generated: W[i][q] =
 // W_n^(q i), i < n / 16, in rows of 17 (s16::twiddle_powers spends 11 complex products per pass on the powers of one table value)
-constexpr int BW_TWROW = 17, BW_TAB_MAX_TPT = 32;
+constexpr int BW_TWROW = 17, BW_TAB_MAX_TPT = 32, BW_MAX_TPT = 128;
 // (TAB = false: W[i] = W_n^i, i < n / 16, and generated powers -- where the rows would cost a resident workgroup: n = 1024)
 template <int R0, bool HALF, bool TAB, typename C, typename SYNC>
 __device__ __forceinline__ void bw_transform(C (&v)[16], C *s, const C *__restrict__ W, int n, int j, int tpt, SYNC sync)
@@ -1540,12 +1540,19 @@ __device__ __forceinline__ void bw_transform(C (&v)[16], C *s, const C *__restri
     for (int q = 0; q < 16; q++) s[s16::pad(base + q * Ns)] = v[q];
   }
 }
+// a transform of up to 64 threads lives in one wave (LDS is in order per wave: a fence); 128 threads: the workgroup's barrier
+template <int TPT> __device__ __forceinline__ void bw_sync()
+{
+  if (TPT <= 64) wave_fence();
+  else lds_barrier();
+}
 template <int TPT, bool FRAME>
 __global__ __launch_bounds__(512, 3) void fft_blu_wave_kernel(const BluArgs A)
 {
   extern __shared__ __attribute__((aligned(16))) char bw_raw[];
   constexpr int tpt = TPT, n2 = 16 * TPT, R0 = blu_r0(TPT);
   constexpr bool TAB = TPT <= BW_TAB_MAX_TPT;
+
   constexpr int TWN = TAB ? TPT * BW_TWROW + (TPT & 1) : TPT;
   const int n = A.n, P = 1 << A.logP;
   const int t = threadIdx.x, NT = blockDim.x, T = NT / tpt;
@@ -1626,11 +1633,11 @@ __global__ __launch_bounds__(512, 3) void fft_blu_wave_kernel(const BluArgs A)
       v[m] = pos < n ? c : (bwc){0.f, 0.f};
     }
     if (slot + gridDim.x < nslots) fetch(slot + gridDim.x);
-    bw_transform<R0, true, TAB>(v, img, twL, n2, j, tpt, wave_fence);       // sqrt(n2) * unitary FFT
+    bw_transform<R0, true, TAB>(v, img, twL, n2, j, tpt, bw_sync<TPT>);       // sqrt(n2) * unitary FFT
 #pragma unroll
     for (int q = 0; q < 16; q++) v[q] = bw_conj_mul(v[q], xcL[j + q * tpt]);
-    wave_fence();
-    bw_transform<R0, false, TAB>(v, img, twL, n2, j, tpt, wave_fence);     // conj of n2 * (unitary inverse of the product)
+    bw_sync<TPT>();
+    bw_transform<R0, false, TAB>(v, img, twL, n2, j, tpt, bw_sync<TPT>);     // conj of n2 * (unitary inverse of the product)
     // outputs n - 1 .. 2 n - 2 of the convolution: positions below 4 tpt never qualify (n - 1 >= n2 / 4).  o = conj(v) chirp g [W]
     bwc o[12];
     int kc[12];
@@ -1669,12 +1676,12 @@ __global__ __launch_bounds__(512, 3) void fft_blu_wave_kernel(const BluArgs A)
           y[k] = o[i];
         }
       }
-      wave_fence();                                                    // (the next slot's pass 0 rewrites the image)
+      bw_sync<TPT>();                                                         // (the next slot's pass 0 rewrites the image)
       continue;
     }
     // fused pass 2: the outputs go to the image at their convolution index kk (slot n: a dump nobody reads); the P-point column DFT
     // over the residues of every group of this slot (fft_bluestein_kernel's pass 2) fetches bin k1 from kk = (n - k1) % n when reversed
-    wave_fence();                                                      // (the image is still being read by the transform's last pass)
+    bw_sync<TPT>();                                                           // (the image is still being read by the transform's last pass)
 #pragma unroll
     for (int i = 0; i < 12; i++) img[ok[i] ? kc[i] : n] = o[i];
     lds_barrier();
@@ -2296,7 +2303,7 @@ int plan_init(tsdgpu_fft *p, int n)
 #define BW_ATTR(R)                                                                                                                   \
   (void) hipFuncSetAttribute((const void *) fft_blu_wave_kernel<R, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
   (void) hipFuncSetAttribute((const void *) fft_blu_wave_kernel<R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-      BW_ATTR(1); BW_ATTR(2); BW_ATTR(4); BW_ATTR(8); BW_ATTR(16); BW_ATTR(32); BW_ATTR(64);
+      BW_ATTR(1); BW_ATTR(2); BW_ATTR(4); BW_ATTR(8); BW_ATTR(16); BW_ATTR(32); BW_ATTR(64); BW_ATTR(128);
 #undef BW_ATTR
       (void) hipGetLastError();
     }
@@ -2357,7 +2364,7 @@ int cu_count()
 bool blu_wave_fits(const tsdgpu_fft *p, int P, bool fuse)
 {
   const int tpt = p->n2 / 16;
-  return p->blu_fused && p->d_twf && tpt >= 1 && tpt <= 64 && (P & (P - 1)) == 0 && (!fuse || P * tpt <= 512) && dev_switch("FFT_BLU_OLD") == nullptr;
+  return p->blu_fused && (p->d_twf || tpt > BW_TAB_MAX_TPT) && tpt >= 1 && tpt <= BW_MAX_TPT && (P & (P - 1)) == 0 && (!fuse || P * tpt <= 512) && dev_switch("FFT_BLU_OLD") == nullptr;
 }
 // x: transform (b, r) starts at x + b * bstride + r (element stride P); pw != NULL: |X|^2 out instead of X, win = the window
 // pw_rows != NULL (psd_welch): the kernel sums |X|^2 over the transforms of each workgroup; pw receives *pw_rows partial rows of
@@ -2412,7 +2419,8 @@ int launch_blu_wave(const tsdgpu_fft *p, const cpx *x, cpx *y, float *pw, const 
     case 8: BW_LAUNCH(8); break;
     case 16: BW_LAUNCH(16); break;
     case 32: BW_LAUNCH(32); break;
-    default: BW_LAUNCH(64); break;
+    case 64: BW_LAUNCH(64); break;
+    default: BW_LAUNCH(128); break;
   }
 #undef BW_LAUNCH
   TSD_HIP(hipGetLastError());

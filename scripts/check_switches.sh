@@ -43,4 +43,5 @@ run TSDGPU_SOS_FULL_SCAN=1 tests/test_sos_gpu.py tests/test_sharded_gpu.py
 run "TSDGPU_RS_DYN_MIN=0 TSDGPU_OLS_DYN_MIN=0" tests/test_resample_gpu.py tests/test_fir_gpu.py
 run TSDGPU_FFT_NO_2K=1 tests/test_fft_gpu.py tests/test_large_gpu.py
 run TSDGPU_FFT_BLU_OLD=1 tests/test_fft_gpu.py tests/test_fft_sweep_gpu.py tests/test_ola_gpu.py
+run TSDGPU_FFT_NO_3PASS=1 tests/test_fft_gpu.py tests/test_large_gpu.py
 exit $FAILED

@@ -130,13 +130,14 @@ def test_fft_odd_fused(tg, orc, n):
         assert relerr(z[b], orc.fft(y[b], False)) <= TOL
 
 
-# Bluestein transforms that fit a wave (n2 <= 1024; fft_blu_wave_kernel, round 4): every threads-per-transform count the plans
-# produce (n2 = 64 ... 1024), alone (odd n), with the 2^p-point pass fused (2^p <= 16 within 512 threads) and as pass 1 of the
-# two-kernel plan (2^p = 32 ...), batches that leave the last slot of a persistent workgroup ragged and batches of many slots per
-# workgroup; 16 * 257 and 513 stay on fft_bluestein_kernel.  Forward, inverse, in place.
+# Bluestein transforms of at most 128 threads (n2 <= 2048; fft_blu_wave_kernel, round 4): every threads-per-transform count the plans
+# produce (n2 = 64 ... 1024 inside a wave, 2048 across two waves), alone (odd n), with the 2^p-point pass fused (2^p <= 16 within 512
+# threads) and as pass 1 of the two-kernel plan (2^p = 32 ...), batches that leave the last slot of a persistent workgroup ragged and
+# batches of many slots per workgroup; 16 * 257, 8 * 1001 and 1025 stay on fft_bluestein_kernel.  Forward, inverse, in place.
 @pytest.mark.parametrize("n,batch", [(17, 1), (17, 1000), (37, 77), (67, 5), (125, 3), (125, 40000), (131, 9), (257, 2), (511, 37), (513, 3),
                                      (2 * 37, 33), (4 * 67, 10), (8 * 125, 1), (8 * 125, 2100), (16 * 125, 7), (16 * 131, 5), (8 * 375, 6),
-                                     (2 * 511, 3), (16 * 257, 2), (32 * 37, 9), (64 * 125, 3), (1024 * 67, 1)])
+                                     (2 * 511, 3), (16 * 257, 2), (32 * 37, 9), (64 * 125, 3), (1024 * 67, 1),
+                                     (1001, 1), (1001, 777), (1023, 5), (2 * 1001, 9), (4 * 513, 3), (8 * 1001, 2), (64 * 513, 1), (1025, 2)])
 def test_fft_bluestein_wave_paths(tg, orc, n, batch):
     import torch
     x = crand((batch, n), 7 * n + batch)

@@ -136,8 +136,8 @@ def test_errors():
 
 # psd_welch (freqestim.cc:7-20) on the device: framing, one batched FFT, sum of the periodograms
 # (16 ... 8192: one fused kernel on the LDS transform, 1024: on the in-wave transform; the others: framed transform + sums)
-# (125, 250, 375, 1000, 2000, 3000: framed by the wave-level Bluestein kernel; 1001, 4000, 6000: framed transform + sums)
-@pytest.mark.parametrize("N", [1, 2, 8, 16, 32, 64, 125, 128, 250, 256, 375, 512, 1000, 1001, 1024, 2000, 2048, 3000, 4000, 4096, 6000, 8192, 16384])
+# (125, 250, 375, 1000, 1001, 2000, 2002, 3000: framed by the wave-level Bluestein kernel; 1025, 4000, 6000: framed transform + sums)
+@pytest.mark.parametrize("N", [1, 2, 8, 16, 32, 64, 125, 128, 250, 256, 375, 512, 1000, 1001, 1024, 1025, 2000, 2002, 2048, 3000, 4000, 4096, 6000, 8192, 16384])
 def test_welch_matches_oracle(N):
     rng = np.random.default_rng(N)
     w = ola_oracle.fen_hann_periodique(N) if N > 2 else np.ones(N, np.float32)
