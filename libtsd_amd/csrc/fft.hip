@@ -650,7 +650,10 @@ __global__ __launch_bounds__(256) void fft_odd_dft_kernel(const cpx *__restrict_
 // n = 2^20 = 1024 x 1024, four-step.  One workgroup = 16 waves = 16 adjacent columns of the
 // row-major [1024][1024] matrix; the tile [1024 rows][16 cols] is loaded with 16-B accesses
 // (128-B row segments), staged in LDS at pitch 17 (odd -> the column each wave reads, and the
-// exchange image it then reuses in place, stay bank-conflict free), transformed by the wave.
+// exchange image it then reuses in place, are bank-conflict free; the 16-B fills and read-backs of
+// the tile rows are not -- the hardware serves a 128-bit access in lane groups that straddle two
+// rows: PMC counts 24-28 % of the LDS-active cycles as conflicts, in a kernel that runs at the
+// rate of a copy), transformed by the wave.
 //   PASS 1: out is the transposed matrix, out[c][k] = FFT_c[k] * W_N^(c*k)  (row c contiguous)
 //   PASS 2: out[k][c] = FFT_c[k] * scale (natural order; staged back through LDS)
 // Twiddle W_N^(c*k), k = k0(lane) + 64*(r>>2) + 256*(r&3): TA[c][lane] * TD[c][r] (host tables).
