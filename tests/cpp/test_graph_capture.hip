@@ -128,8 +128,11 @@ int main()
   // FFT 2^20 x 32: the step is stateless and graph-replayable; its kernels hand their tiles out through a
   // never-reset counter whose base is a launch argument, so while the stream records they must take the static partition --
   // a replay with a frozen base would find the counter spent and write nothing.  Two replays on different inputs.
-  {
-    const int nfft = 1 << 20, batch = 32;
+  // (round 4: the same for the three-pass plan of 2^24 -- two dynamic column passes around a plane pass -- and for the persistent
+  // wave-level Bluestein kernels of n = 1000 (fused 8 x 125) and n = 1001, whose grid comes from an occupancy query)
+  const int fft_cases[4][2] = {{1 << 20, 32}, {1 << 24, 2}, {1000, 30000}, {1001, 20000}};
+  for (int fc = 0; fc < 4; fc++) {
+    const int nfft = fft_cases[fc][0], batch = fft_cases[fc][1];
     const size_t tot = (size_t) nfft * batch;
     std::vector<float> hx(2 * tot);
     uint32_t s = 7u;
@@ -162,7 +165,9 @@ int main()
       CK(hipMemcpy(y2.data(), dy2, tot * 8, hipMemcpyDeviceToHost));
       for (size_t i = 0; i < y1.size(); i++) diff += std::memcmp(&y1[i], &y2[i], 4) != 0;
     }
-    printf("%-44s replayed twice: %zu differing floats\n", "fft 2^20 x 32", diff);
+    char label[64];
+    snprintf(label, sizeof label, "fft n = %d x %d", nfft, batch);
+    printf("%-44s replayed twice: %zu differing floats\n", label, diff);
     rc |= diff != 0;
     CK(hipGraphExecDestroy(ge)); CK(hipGraphDestroy(g));
     tsdgpu_fft_destroy(p);
