@@ -480,14 +480,15 @@ template <int PASS, int R0>
 __global__ __launch_bounds__(1024) void fft_cols16_kernel(const cpx *__restrict__ in, cpx *__restrict__ out,
                                                           const cpx *__restrict__ TW, int L, int tpt, int C, int CT,
                                                           const cpx *__restrict__ thi, const cpx *__restrict__ tlo,
-                                                          int inverse, float scale, int ragged)
+                                                          int inverse, float scale, int ragged, int ipitch)
 {
+  // (ipitch: elements between the rows of `in` -- C, or the padded pitch of an intermediate written by fft1m_cols_kernel<1>)
   extern __shared__ __attribute__((aligned(16))) char s16_raw[];
   cpx *lds = reinterpret_cast<cpx *>(s16_raw);
   const int t = threadIdx.x, nthr = blockDim.x;
   const int pn = L + (L >> 4) + 1;
   const size_t boff = (size_t) blockIdx.y * (size_t) L * C;
-  const cpx *x = in + boff;
+  const cpx *x = in + (size_t) blockIdx.y * (size_t) L * ipitch;
   cpx *y = out + boff;
   // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs, so blockIdx.x, +8, +16 ...
   // share an L2.  Tiles narrower than a 128-B line (CT < 16) split cache lines with their
@@ -501,7 +502,7 @@ __global__ __launch_bounds__(1024) void fft_cols16_kernel(const cpx *__restrict_
     for (int q = t; q < L * CT; q += nthr) {
       const int r = q / CT, c = q - r * CT;
       cpx f = cmk(0.f, 0.f);
-      if (c0 + c < C) f = x[(size_t) r * C + c0 + c];
+      if (c0 + c < C) f = x[(size_t) r * ipitch + c0 + c];
       if (PASS == 1 && inverse) f.y = -f.y;
       lds[c * pn + s16::pad(r)] = f;
     }
@@ -512,7 +513,7 @@ __global__ __launch_bounds__(1024) void fft_cols16_kernel(const cpx *__restrict_
 #pragma unroll
     for (int i = 0; i < 8; i++) {
       const int q = t + i * nthr, r = q / h, c = 2 * (q - r * h);
-      f[i] = *reinterpret_cast<const float4 *>(x + (size_t) r * C + c0 + c);
+      f[i] = *reinterpret_cast<const float4 *>(x + (size_t) r * ipitch + c0 + c);
     }
     const float sg = (PASS == 1 && inverse) ? -1.f : 1.f;
 #pragma unroll
@@ -1910,6 +1911,7 @@ struct tsdgpu_fft {
   unsigned *d_ctr = nullptr;  // n = 2^20: work counter of the dynamic tile hand-out (fft1m_cols_kernel), never reset
   bool cols2k = false;        // four-step plan whose pass 2 (2048-point columns, N2 = 2048) runs on fft2k_cols_kernel
   bool cols2k_p1 = false;     // ... whose pass 1 (N1 = 2048) does
+  bool p1k1 = false;          // n = 2^15 .. 2^19 as 1024 x C: pass 1 on fft1m_cols_kernel<1> (padded intermediate), pass 2 on fft_cols16_kernel<2>
   int c3 = 0;                 // three-pass plan n = 1024 x c3 x 1024 (c3 = 8, 16, 32; 0: not this plan); d_tp: W_C^(b p) [1024][c3]
   cpx *d_tp = nullptr;
   unsigned ctr_base = 0;      // its value before the next launch (advanced once a launch pair has been accepted)
@@ -2095,6 +2097,10 @@ int plan_init(tsdgpu_fft *p, int n)
       TSD_CHECK(p->logn <= 28, "fft: n = %d exceeds the four-step limit 2^28 (two passes of at most 16384-point columns)", n);
       p->kind = tsdgpu_fft::POW2_4STEP;
       p->logN1 = p->logn / 2;
+      // n = 2^15 .. 2^19: 1024 x C, so that pass 1 runs on the 2^20 plan's column kernel (in-wave 1024-point FFT, prefetched tiles,
+      // dynamic hand-out: 0.73 ms per 2^28 points against 0.88 for a fft_cols16_kernel pass); TSDGPU_FFT_NO_1K_P1=1: the square split
+      const bool use1k = fast && p->logn >= 15 && p->logn <= 19 && dev_switch("FFT_NO_1K_P1") == nullptr;
+      if (use1k) p->logN1 = 10;
       p->logN2 = p->logn - p->logN1;
       p->N1 = 1 << p->logN1;
       p->N2 = 1 << p->logN2;
@@ -2113,6 +2119,32 @@ int plan_init(tsdgpu_fft *p, int n)
       }
       if ((rc = upload(&p->d_thi, hi))) return rc;
       if ((rc = upload(&p->d_tlo, lo))) return rc;
+      if (use1k) {
+        std::vector<cpx> t1(1024), t2(1024);
+        w1024::fill_twiddles(t1.data(), t2.data());
+        if ((rc = upload(&p->d_w1, t1))) return rc;
+        if ((rc = upload(&p->d_w2, t2))) return rc;
+        std::vector<cpx> ta((size_t) p->N2 * 64), td((size_t) p->N2 * 16);
+        for (int c = 0; c < p->N2; c++) {
+          for (int lane = 0; lane < 64; lane++) {
+            const double a = -2.0 * PI * (double) (((int64_t) c * ((lane >> 2) + 16 * (lane & 3))) % n) / (double) n;
+            ta[(size_t) c * 64 + lane] = make_float2((float) std::cos(a), (float) std::sin(a));
+          }
+          for (int r = 0; r < 16; r++) {
+            const double a = -2.0 * PI * (double) (((int64_t) c * (64 * (r >> 2) + 256 * (r & 3))) % n) / (double) n;
+            td[(size_t) c * 16 + r] = make_float2((float) std::cos(a), (float) std::sin(a));
+          }
+        }
+        if ((rc = upload(&p->d_ta, ta))) return rc;
+        if ((rc = upload(&p->d_td, td))) return rc;
+        if (hipMalloc((void **) &p->d_ctr, 256) != hipSuccess || hipMemset(p->d_ctr, 0, 256) != hipSuccess) {
+          (void) hipGetLastError();
+          p->d_ctr = nullptr;
+        }
+        (void) hipFuncSetAttribute((const void *) fft1m_cols_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void) hipFuncSetAttribute((const void *) fft1m_cols_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        p->p1k1 = true;
+      }
       // 2^24, 2^25: the three-pass plan; 2^23 keeps the 2048 x 4096 plan unless TSDGPU_FFT_3PASS_23=1 (measured: see DESIGN.md 3.3)
       const bool use3 = p->logn >= 23 && p->logn <= 25 && dev_switch("FFT_NO_3PASS") == nullptr &&
                         (p->logn > 23 || dev_switch_int("FFT_3PASS_23", 0) != 0);
@@ -2570,7 +2602,7 @@ int step_device(tsdgpu_fft *p, const cpx *x, cpx *y, int batch, int forward, hip
       // z viewed [N2][N1]: pass 2 = column FFTs (length N2), natural store y[k2 * N1 + k1]
       static const bool generic = dev_switch("FFT_GENERIC") != nullptr;
       if (!generic) {
-        auto launch = [&](int pass, const cpx *src, cpx *dst, const cpx *tw, int L, int logL, int C, float sc) {
+        auto launch = [&](int pass, const cpx *src, cpx *dst, const cpx *tw, int L, int logL, int C, float sc, int ipitch = 0) {
           const int tpt = L / 16;
           int CT = std::min(std::max(16, 256 / tpt), C);
           // 2048-point columns: 8 of them fill the LDS of a CU with ONE workgroup (139 KiB) whose load, transform and store phases
@@ -2581,7 +2613,7 @@ int step_device(tsdgpu_fft *p, const cpx *x, cpx *y, int batch, int forward, hip
           const size_t lds = (size_t) CT * (L + L / 16 + 1) * sizeof(cpx);
           const dim3 grid((unsigned) (C / CT), (unsigned) batch), blk((unsigned) (CT * tpt));
           const int r0 = 1 << ((logL & 3) == 0 ? 4 : (logL & 3));
-#define C16_LAUNCH(P, R) hipLaunchKernelGGL((fft_cols16_kernel<P, R>), grid, blk, lds, st, src, dst, tw, L, tpt, C, CT, p->d_thi, p->d_tlo, inverse, sc, 0)
+#define C16_LAUNCH(P, R) hipLaunchKernelGGL((fft_cols16_kernel<P, R>), grid, blk, lds, st, src, dst, tw, L, tpt, C, CT, p->d_thi, p->d_tlo, inverse, sc, 0, ipitch > 0 ? ipitch : C)
           if (pass == 1) {
             if (r0 == 16) C16_LAUNCH(1, 16); else if (r0 == 8) C16_LAUNCH(1, 8); else if (r0 == 4) C16_LAUNCH(1, 4); else C16_LAUNCH(1, 2);
           } else {
@@ -2589,6 +2621,39 @@ int step_device(tsdgpu_fft *p, const cpx *x, cpx *y, int batch, int forward, hip
           }
 #undef C16_LAUNCH
         };
+        if (p->p1k1) {
+          const int C = p->N2, zp = 1024 + 16;
+          rc = p->work.reserve((size_t) batch * C * zp * sizeof(cpx));
+          if (rc) return rc;
+          z = p->work.as<cpx>();
+          const int ncu = cu_count();
+          const int64_t nt1 = (int64_t) (C / 16) * batch;
+          const int g1 = (int) std::min<int64_t>(nt1, ncu);
+          const bool dyn_ok = p->d_ctr && dev_switch_int("FFT_DYN", 1) != 0 && !stream_is_capturing(st);
+          unsigned *c1 = (dyn_ok && nt1 >= 4 * g1) ? p->d_ctr : nullptr;
+          if (c1 && p->ctr_stale) {
+            TSD_HIP(hipMemsetAsync(p->d_ctr, 0, 256, st));
+            p->ctr_base = 0;
+            p->ctr_stale = false;
+          }
+          const unsigned b1 = p->ctr_base;
+          int tshift = 0;
+          while ((16 << tshift) < C) tshift++;
+          if (c1)
+            hipLaunchKernelGGL((fft1m_cols_kernel<1, true>), dim3(g1), dim3(1024), F1M_LDS, st, x, z, p->d_w1, p->d_w2, p->d_ta, p->d_td, inverse, 1.0f, zp,
+                               (int) nt1, c1, b1, tshift, 0);
+          else
+            hipLaunchKernelGGL((fft1m_cols_kernel<1, false>), dim3(g1), dim3(1024), F1M_LDS, st, x, z, p->d_w1, p->d_w2, p->d_ta, p->d_td, inverse, 1.0f, zp,
+                               (int) nt1, (unsigned *) nullptr, 0u, tshift, 0);
+          if (const hipError_t le = hipGetLastError(); le != hipSuccess) {
+            if (c1) p->ctr_stale = true;
+            return set_err(TSDGPU_ERR_HIP, "fft_step: launch failed: %s", hipGetErrorString(le));
+          }
+          if (c1) p->ctr_base = b1 + (unsigned) nt1 + (unsigned) g1;
+          launch(2, z, y, p->d_tw2, p->N2, p->logN2, p->N1, scale, zp);
+          TSD_HIP(hipGetLastError());
+          return TSDGPU_OK;
+        }
         if (p->c3) {
           const int C1 = p->c3, C = C1 * 1024, zp = 1024 + 16, lc1 = p->logn - 20;
           rc = p->work.reserve((size_t) batch * C * zp * sizeof(cpx));
@@ -2778,7 +2843,7 @@ int step_device(tsdgpu_fft *p, const cpx *x, cpx *y, int batch, int forward, hip
       const size_t lds = (size_t) CT * (P + P / 16 + 1) * sizeof(cpx);
       const dim3 grid((unsigned) cdiv(m, CT), (unsigned) batch), blk((unsigned) (CT * tpt));
       const int r0 = 1 << ((p->logn & 3) == 0 ? 4 : (p->logn & 3));
-#define C16_LAUNCH(R) hipLaunchKernelGGL((fft_cols16_kernel<2, R>), grid, blk, lds, st, z, y, p->d_tw, P, tpt, m, CT, nullptr, nullptr, inverse, s2, 1)
+#define C16_LAUNCH(R) hipLaunchKernelGGL((fft_cols16_kernel<2, R>), grid, blk, lds, st, z, y, p->d_tw, P, tpt, m, CT, nullptr, nullptr, inverse, s2, 1, m)
       if (r0 == 16) C16_LAUNCH(16); else if (r0 == 8) C16_LAUNCH(8); else if (r0 == 4) C16_LAUNCH(4); else C16_LAUNCH(2);
 #undef C16_LAUNCH
       TSD_HIP(hipGetLastError());

@@ -44,4 +44,5 @@ run "TSDGPU_RS_DYN_MIN=0 TSDGPU_OLS_DYN_MIN=0" tests/test_resample_gpu.py tests/
 run TSDGPU_FFT_NO_2K=1 tests/test_fft_gpu.py tests/test_large_gpu.py
 run TSDGPU_FFT_BLU_OLD=1 tests/test_fft_gpu.py tests/test_fft_sweep_gpu.py tests/test_ola_gpu.py
 run TSDGPU_FFT_NO_3PASS=1 tests/test_fft_gpu.py tests/test_large_gpu.py
+run TSDGPU_FFT_NO_1K_P1=1 tests/test_fft_gpu.py tests/test_fft_sweep_gpu.py
 exit $FAILED
