@@ -1911,7 +1911,10 @@ struct tsdgpu_fft {
   unsigned *d_ctr = nullptr;  // n = 2^20: work counter of the dynamic tile hand-out (fft1m_cols_kernel), never reset
   bool cols2k = false;        // four-step plan whose pass 2 (2048-point columns, N2 = 2048) runs on fft2k_cols_kernel
   bool cols2k_p1 = false;     // ... whose pass 1 (N1 = 2048) does
-  bool p1k1 = false;          // n = 2^15 .. 2^19 as 1024 x C: pass 1 on fft1m_cols_kernel<1> (padded intermediate), pass 2 on fft_cols16_kernel<2>
+  bool p1k1 = false;          // n = 2^15 .. 2^19 ALSO planned as 1024 x C (calls of 2^21 points and more): pass 1 on fft1m_cols_kernel<1>
+                              // (padded intermediate), pass 2 = C-point columns on fft_cols16_kernel<2> with the tables d_tw2a
+  int N2a = 0, logN2a = 0;
+  cpx *d_tw2a = nullptr;
   int c3 = 0;                 // three-pass plan n = 1024 x c3 x 1024 (c3 = 8, 16, 32; 0: not this plan); d_tp: W_C^(b p) [1024][c3]
   cpx *d_tp = nullptr;
   unsigned ctr_base = 0;      // its value before the next launch (advanced once a launch pair has been accepted)
@@ -2097,10 +2100,11 @@ int plan_init(tsdgpu_fft *p, int n)
       TSD_CHECK(p->logn <= 28, "fft: n = %d exceeds the four-step limit 2^28 (two passes of at most 16384-point columns)", n);
       p->kind = tsdgpu_fft::POW2_4STEP;
       p->logN1 = p->logn / 2;
-      // n = 2^15 .. 2^19: 1024 x C, so that pass 1 runs on the 2^20 plan's column kernel (in-wave 1024-point FFT, prefetched tiles,
-      // dynamic hand-out: 0.73 ms per 2^28 points against 0.88 for a fft_cols16_kernel pass); TSDGPU_FFT_NO_1K_P1=1: the square split
+      // n = 2^15 .. 2^19: planned a second time as 1024 x C, so that pass 1 of LARGE calls runs on the 2^20 plan's column kernel
+      // (in-wave 1024-point FFT, prefetched tiles, dynamic hand-out: 0.73 ms per 2^28 points against 0.88 for a fft_cols16_kernel
+      // pass); small calls keep the square split (a 128-KiB tile per workgroup costs a single 2^16-point transform 4 us of its 18);
+      // TSDGPU_FFT_NO_1K_P1=1: the square split always
       const bool use1k = fast && p->logn >= 15 && p->logn <= 19 && dev_switch("FFT_NO_1K_P1") == nullptr;
-      if (use1k) p->logN1 = 10;
       p->logN2 = p->logn - p->logN1;
       p->N1 = 1 << p->logN1;
       p->N2 = 1 << p->logN2;
@@ -2120,12 +2124,15 @@ int plan_init(tsdgpu_fft *p, int n)
       if ((rc = upload(&p->d_thi, hi))) return rc;
       if ((rc = upload(&p->d_tlo, lo))) return rc;
       if (use1k) {
+        p->logN2a = p->logn - 10;
+        p->N2a = 1 << p->logN2a;
+        if ((rc = upload(&p->d_tw2a, twiddle_table(p->N2a, p->N2a / 2)))) return rc;
         std::vector<cpx> t1(1024), t2(1024);
         w1024::fill_twiddles(t1.data(), t2.data());
         if ((rc = upload(&p->d_w1, t1))) return rc;
         if ((rc = upload(&p->d_w2, t2))) return rc;
-        std::vector<cpx> ta((size_t) p->N2 * 64), td((size_t) p->N2 * 16);
-        for (int c = 0; c < p->N2; c++) {
+        std::vector<cpx> ta((size_t) p->N2a * 64), td((size_t) p->N2a * 16);
+        for (int c = 0; c < p->N2a; c++) {
           for (int lane = 0; lane < 64; lane++) {
             const double a = -2.0 * PI * (double) (((int64_t) c * ((lane >> 2) + 16 * (lane & 3))) % n) / (double) n;
             ta[(size_t) c * 64 + lane] = make_float2((float) std::cos(a), (float) std::sin(a));
@@ -2363,7 +2370,7 @@ void plan_destroy(tsdgpu_fft *p)
   if (!p) return;
   if (p->sub) plan_destroy(p->sub);
   if (p->d_ctr) (void) hipFree(p->d_ctr);
-  for (cpx *q : {p->d_tw, p->d_tw1, p->d_tw2, p->d_thi, p->d_tlo, p->d_rot, p->d_chirp, p->d_xc, p->d_twf, p->d_tp, p->d_w1, p->d_w2, p->d_ta, p->d_td, p->d_wm, p->d_w2k})
+  for (cpx *q : {p->d_tw, p->d_tw1, p->d_tw2, p->d_thi, p->d_tlo, p->d_rot, p->d_chirp, p->d_xc, p->d_twf, p->d_tp, p->d_tw2a, p->d_w1, p->d_w2, p->d_ta, p->d_td, p->d_wm, p->d_w2k})
     if (q) (void) hipFree(q);
   p->work.release();
   p->work2.release();
@@ -2621,8 +2628,8 @@ int step_device(tsdgpu_fft *p, const cpx *x, cpx *y, int batch, int forward, hip
           }
 #undef C16_LAUNCH
         };
-        if (p->p1k1) {
-          const int C = p->N2, zp = 1024 + 16;
+        if (p->p1k1 && total >= (p->logn >= 18 ? (int64_t) 1 << 19 : (int64_t) 1 << 21)) {
+          const int C = p->N2a, zp = 1024 + 16;
           rc = p->work.reserve((size_t) batch * C * zp * sizeof(cpx));
           if (rc) return rc;
           z = p->work.as<cpx>();
@@ -2650,7 +2657,7 @@ int step_device(tsdgpu_fft *p, const cpx *x, cpx *y, int batch, int forward, hip
             return set_err(TSDGPU_ERR_HIP, "fft_step: launch failed: %s", hipGetErrorString(le));
           }
           if (c1) p->ctr_base = b1 + (unsigned) nt1 + (unsigned) g1;
-          launch(2, z, y, p->d_tw2, p->N2, p->logN2, p->N1, scale, zp);
+          launch(2, z, y, p->d_tw2a, p->N2a, p->logN2a, 1024, scale, zp);
           TSD_HIP(hipGetLastError());
           return TSDGPU_OK;
         }

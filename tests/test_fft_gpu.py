@@ -229,6 +229,36 @@ def test_fft_2k_columns(tg, orc, logn, batch, static, monkeypatch):
     assert float((y2 - p.step(xd)).abs().max() / y2.abs().max()) <= 2e-6
 
 
+# n = 2^15 ... 2^19 hold two plans: the square split (small calls) and 1024 x C -- pass 1 on the 2^20 plan's column kernel, C-point columns
+# with an input pitch -- for calls of 2^21 points and more (2^19 from n = 2^18 on): batches on both sides of the threshold, the static
+# tile hand-out, forward / inverse in place, and the two plans against each other (TSDGPU_FFT_NO_1K_P1=1)
+@pytest.mark.parametrize("logn,batch,static", [(15, 64, False), (15, 3, False), (16, 32, False), (16, 33, True), (17, 16, False), (17, 5, False),
+                                               (18, 2, False), (18, 9, True), (19, 1, False), (19, 6, False)])
+def test_fft_medium_sizes_1k_columns(tg, orc, logn, batch, static, monkeypatch):
+    import torch
+    if static:
+        monkeypatch.setenv("TSDGPU_FFT_DYN", "0")
+    n = 1 << logn
+    g = torch.Generator(device="cuda").manual_seed(5 * logn + batch)
+    xd = torch.view_as_complex(torch.randn(batch, n, 2, device="cuda", generator=g))
+    p = tg.Fft(n, batch)
+    yd = p.step(xd)
+    torch.cuda.synchronize()
+    for b in sorted({0, batch // 2, batch - 1}):
+        assert relerr(yd[b].cpu().numpy(), orc.fft(xd[b].cpu().numpy())) <= TOL, b
+    e_in = (xd.abs() ** 2).sum(dim=1)
+    e_out = (yd.abs() ** 2).sum(dim=1)
+    assert torch.allclose(e_in, e_out, rtol=1e-4)                      # Parseval on every transform
+    monkeypatch.setenv("TSDGPU_FFT_NO_1K_P1", "1")
+    y2 = tg.Fft(n, batch).step(xd)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("TSDGPU_FFT_NO_1K_P1")
+    assert float((y2 - yd).abs().max() / y2.abs().max()) <= 3e-6
+    zd = p.step(yd, False, yd)                                         # inverse, in place
+    torch.cuda.synchronize()
+    assert float((zd - xd).abs().max() / xd.abs().max()) <= TOL
+
+
 # n = 2^24, 2^25 (2^23 by switch): THREE passes of 128-B row segments -- 1024-point columns, a C1-point DFT across C1 planes (fft_planes_kernel,
 # C1 = 8 / 16 / 32), 1024-point columns with rows scattered C1 apart; dynamic and static tile hand-out, forward / inverse in place, and the
 # same transform from the two-pass plan (TSDGPU_FFT_NO_3PASS=1)
