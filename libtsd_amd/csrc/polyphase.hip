@@ -187,6 +187,108 @@ __global__ __launch_bounds__(256) void decim_rows_kernel(const T *__restrict__ x
   }
 }
 
+// ---- decimators of rate 2, 4, 8 and up to 64 taps (the half-band stages of filtre_reechan, filtre_rif_decim): the direct FIR kernel's
+// scheme (fir.hip) evaluated on the kept positions only.  polyfir_fused_kernel spends ~8 instructions per tap (a run-time tap loop, one
+// LDS sample read at a lane stride of R samples -- 2-way conflicts at R = 2 -- and one LDS tap read per product) and runs the 15-tap
+// stages at 0.51-0.60 of 8 TB/s where the same taps at full rate reach 0.73.  Here, as in fir_direct_kernel: a lane owns a 64-B segment
+// of consecutive input positions (segments 80 B apart: conflict-free ds_read_b128), slides a two-segment register window over the taps
+// (wave-uniform scalar loads) and keeps the RS / DEC positions of its segment that survive the decimation -- the tile starts on a kept
+// position, so those are r = 0, DEC, 2 DEC ... at compile time; 16-B global loads, outputs back through LDS for coalesced stores.
+// Same products in the same order (oldest sample first) as the fused kernel.  hrev: the taps reversed and zero-padded to KP.
+template <typename T, int RS, int DEC>
+__global__ __launch_bounds__(256) void decim_direct_kernel(const T *__restrict__ x, const T *__restrict__ hist, T *__restrict__ y,
+                                                           const float *__restrict__ hrev, int KP, int start, int HW, int64_t n, int64_t nout)
+{
+  constexpr int THREADS = 256, TILE = THREADS * RS, VEC = 16 / (int) sizeof(T), P = VEC, SP = RS + P, RO = RS / DEC;
+  static_assert(RS * sizeof(T) == 64 && RS % DEC == 0, "one lane segment is 64 bytes, a whole number of kept positions");
+  extern __shared__ __attribute__((aligned(16))) char dd_raw[];
+  T *L = reinterpret_cast<T *>(dd_raw);
+  const int64_t tile0 = (int64_t) start + (int64_t) blockIdx.x * TILE;      // first position of the tile (a kept one)
+  const int H = KP, total = TILE + H;                                       // staged samples 1 .. total - 1: position tile0 - H + s
+  const bool fast = (((uintptr_t) x) & (sizeof(T) - 1)) == 0 && tile0 - H >= 0 && tile0 + TILE + VEC <= n;
+  if (fast) {
+    struct __attribute__((aligned(4))) f4u { float x, y, z, w; };
+    const f4u *xs = reinterpret_cast<const f4u *>(x + (tile0 - H + 1));
+    const int nchunks = (total - 1 + VEC - 1) / VEC;
+    for (int c0 = threadIdx.x; c0 < nchunks; c0 += 4 * THREADS) {
+      f4u q4[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int c = c0 + u * THREADS;
+        if (c < nchunks) q4[u] = xs[c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int c = c0 + u * THREADS;
+        if (c < nchunks) {
+          const int q = c * VEC;
+          *reinterpret_cast<float4 *>(L + q + (q / RS) * P) = make_float4(q4[u].x, q4[u].y, q4[u].z, q4[u].w);
+        }
+      }
+    }
+  } else {
+    for (int s = threadIdx.x + 1; s < total; s += THREADS) {
+      const int64_t g = tile0 - H + (int64_t) s;
+      T v = pf_zero(T{});
+      if (g < 0) {
+        if (g >= -(int64_t) HW) v = hist[HW + g];
+      } else if (g < n) {
+        v = x[g];
+      }
+      const int q = s - 1;
+      L[q + (q / RS) * P] = v;
+    }
+  }
+  __syncthreads();
+  // lane window: w[i] = sample t RS + 1 + i; kept position r (a multiple of DEC): out = sum_j hrev[j] w[r + j]
+  const T *Lw = L + threadIdx.x * SP;
+  T acc[RO], A[RS], B[RS];
+  auto load_seg = [&](T (&dst)[RS], const T *seg) {
+#pragma unroll
+    for (int v4 = 0; v4 < RS / VEC; v4++) {
+      const float4 q4 = *reinterpret_cast<const float4 *>(seg + v4 * VEC);
+      const T *e = reinterpret_cast<const T *>(&q4);
+#pragma unroll
+      for (int k = 0; k < VEC; k++) dst[v4 * VEC + k] = e[k];
+    }
+  };
+#pragma unroll
+  for (int r = 0; r < RO; r++) acc[r] = pf_zero(T{});
+  load_seg(A, Lw);
+  const int nchunk = KP / RS;                                // even by construction
+  for (int c = 0; c < nchunk; c += 2) {
+    const float *h0 = hrev + c * RS;
+    load_seg(B, Lw + (c + 1) * SP);
+#pragma unroll
+    for (int jj = 0; jj < RS; jj++) {
+      const float hv = h0[jj];
+#pragma unroll
+      for (int r = 0; r < RO; r++) {
+        const int idx = r * DEC + jj;
+        acc[r] = pf_mac(acc[r], hv, idx < RS ? A[idx] : B[idx - RS]);
+      }
+    }
+    load_seg(A, Lw + (c + 2) * SP);                          // (the last refill reads two over-allocated segments, never used)
+#pragma unroll
+    for (int jj = 0; jj < RS; jj++) {
+      const float hv = h0[RS + jj];
+#pragma unroll
+      for (int r = 0; r < RO; r++) {
+        const int idx = r * DEC + jj;
+        acc[r] = pf_mac(acc[r], hv, idx < RS ? B[idx] : A[idx - RS]);
+      }
+    }
+  }
+  // outputs of the tile: positions tile0 + DEC q, q < TILE / DEC -> y[(tile0 - start) / DEC + q]; back through LDS, coalesced
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < RO; r++) L[threadIdx.x * SP + r] = acc[r];
+  __syncthreads();
+  const int64_t ob = (int64_t) blockIdx.x * (TILE / DEC);
+  for (int q = threadIdx.x; q < TILE / DEC; q += THREADS)
+    if (ob + q < nout) y[ob + q] = L[(q / RO) * SP + (q % RO)];
+}
+
 // new_hist = last HW samples of (old_hist ++ x[0..n))
 template <typename T>
 __global__ void pf_hist_update_kernel(const T *__restrict__ x, const T *__restrict__ old_hist, T *__restrict__ new_hist, int HW,
@@ -327,6 +429,8 @@ struct tsdgpu_polyfir {
   bool fused = false;
   int NPH = 1, W = 0, HW = 0, cur = 0, TO = 0;
   float *d_g = nullptr;
+  float *d_hrev = nullptr;          // decim_direct_kernel: the taps reversed, zero-padded to KPd (inside d_g's allocation)
+  int KPd = 0;
   void *d_hist[2] = {nullptr, nullptr};
   DevBuf z, in_stage, out_stage;
 };
@@ -493,12 +597,22 @@ int fused_setup(tsdgpu_polyfir *p, const std::vector<float> &g, int NPH, int W, 
   // ONE allocation -- the taps, then the two (zero) histories, 16-byte aligned -- and ONE upload of its host image (three
   // allocations, a copy, two memsets and a synchronisation before: a third of a one-shot rééchan(x, 4))
   const size_t hb = ((size_t) p->HW * dtype_size(p->data_type) + 15) / 16 * 16, gb = (g.size() * sizeof(float) + 15) / 16 * 16;
-  std::vector<char> image(gb + 2 * hb, 0);
+  // decimators of rate 2 / 4 / 8 up to 64 taps: the reversed, padded taps of decim_direct_kernel behind the histories
+  const int RSd = p->data_type == TSDGPU_F32 ? 16 : 8;
+  const bool direct = NPH == 1 && (stride == 2 || stride == 4 || stride == 8) && W <= 64 && dev_switch("POLY_NO_DIRECT") == nullptr;
+  p->KPd = direct ? (int) (cdiv(W, 2 * RSd) * 2 * RSd) : 0;
+  const size_t rb = (size_t) p->KPd * sizeof(float);
+  std::vector<char> image(gb + 2 * hb + rb, 0);
   std::memcpy(image.data(), g.data(), g.size() * sizeof(float));
+  if (direct) {
+    float *hr = reinterpret_cast<float *>(image.data() + gb + 2 * hb);
+    for (int k = 0; k < W; k++) hr[p->KPd - 1 - k] = g[k];           // hrev[j] = g[KP - 1 - j]: g[0] meets the newest sample
+  }
   if (hipMalloc((void **) &p->d_g, image.size()) != hipSuccess)
     return set_err(TSDGPU_ERR_HIP, "polyfir_create: hipMalloc failed: %s", hipGetErrorString(hipGetLastError()));
   p->d_hist[0] = (char *) p->d_g + gb;
   p->d_hist[1] = (char *) p->d_g + gb + hb;
+  p->d_hrev = direct ? reinterpret_cast<float *>((char *) p->d_g + gb + 2 * hb) : nullptr;
   if (hipMemcpy(p->d_g, image.data(), image.size(), hipMemcpyHostToDevice) != hipSuccess)
     return set_err(TSDGPU_ERR_HIP, "polyfir_create: upload failed: %s", hipGetErrorString(hipGetLastError()));
   (void) hipFuncSetAttribute((const void *) polyfir_fused_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -511,6 +625,19 @@ int fused_setup(tsdgpu_polyfir *p, const std::vector<float> &g, int NPH, int W, 
 template <typename T>
 int fused_step(tsdgpu_polyfir *p, const void *dx, void *dy, int stride, int64_t start, int64_t n, int64_t nout, hipStream_t st)
 {
+  if (nout > 0 && p->d_hrev && p->NPH == 1) {
+    constexpr int RS = 64 / (int) sizeof(T);
+    const int64_t tiles = cdiv(nout, (int64_t) 256 * RS / stride);
+    const size_t lds = ((size_t) (256 * RS + p->KPd) / RS + 3) * 80;
+    if (tiles <= 0x7fffffff) {
+#define DD_LAUNCH(D) hipLaunchKernelGGL((decim_direct_kernel<T, RS, D>), dim3((unsigned) tiles), dim3(256), lds, st, (const T *) dx,     \
+                                        (const T *) p->d_hist[p->cur], (T *) dy, p->d_hrev, p->KPd, (int) start, p->HW, n, nout)
+      if (stride == 2) DD_LAUNCH(2); else if (stride == 4) DD_LAUNCH(4); else DD_LAUNCH(8);
+#undef DD_LAUNCH
+      TSD_HIP(hipGetLastError());
+      nout = 0;                                  // (served; the history update below still runs)
+    }
+  }
   static const bool sans_rangs = dev_switch("POLY_NO_ROWS") != nullptr;
   if (nout > 0 && !sans_rangs && p->NPH == 1 && stride >= 2 && stride <= PF_ROWS_MAXR && p->W >= 32) {
     // decimators of small rate and at least 32 taps: polyphase rows (decim_rows_kernel).  (Shorter filters are bound by the

@@ -45,4 +45,5 @@ run TSDGPU_FFT_NO_2K=1 tests/test_fft_gpu.py tests/test_large_gpu.py
 run TSDGPU_FFT_BLU_OLD=1 tests/test_fft_gpu.py tests/test_fft_sweep_gpu.py tests/test_ola_gpu.py
 run TSDGPU_FFT_NO_3PASS=1 tests/test_fft_gpu.py tests/test_large_gpu.py
 run TSDGPU_FFT_NO_1K_P1=1 tests/test_fft_gpu.py tests/test_fft_sweep_gpu.py
+run TSDGPU_POLY_NO_DIRECT=1 tests/test_polyphase_gpu.py tests/test_resample_gpu.py -k "not direct_kernel"
 exit $FAILED

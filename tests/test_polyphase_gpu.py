@@ -52,6 +52,34 @@ def test_rif_decim(tg, orc, cplx, R, bs):        # test_filtre_rif_decim (test-r
     assert len(y) == len(ref) and relerr(y, ref) <= TOL
 
 
+# decimators of rate 2 / 4 / 8 up to 64 taps run on decim_direct_kernel (round 4: the direct FIR kernel's scheme on the kept positions):
+# tap counts around the 16- / 32-sample window chunks, streams cut in ragged calls (every phase of the decimation counter, tiles that
+# start in the history), one large call (interior tiles, 16-B loads), and THE SAME BITS as the fused kernel it replaces below 32 taps
+# (same products in the same order)
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("R,K", [(2, 1), (2, 7), (2, 15), (2, 16), (2, 17), (2, 33), (2, 64), (4, 15), (4, 31), (4, 64), (8, 15), (8, 47)])
+def test_rif_decim_direct_kernel(tg, orc, cplx, R, K, monkeypatch):
+    rng = np.random.default_rng(100 * R + K)
+    h = rng.standard_normal(K).astype(np.float32) / K
+    n = 300000 + 13
+    x = rand(n, cplx, 7 * R + K)
+    dt = tg.C64 if cplx else tg.F32
+    ref = orc.PolyDecim(h, R, 0).step(x)
+    f = tg.PolyFir(tg.POLY_DECIM, dt, h, R)
+    cuts = [0, 1, 2, 3, 5, 100, 101, 4097, 4100, 70000, 70000 + R + 1, n]
+    y = np.concatenate([f.step(x[a:b].copy()) for a, b in zip(cuts[:-1], cuts[1:])])
+    assert len(y) == len(ref) and relerr(y, ref) <= TOL
+    y1 = tg.PolyFir(tg.POLY_DECIM, dt, h, R).step(x)
+    assert np.array_equal(y1.view(np.uint32), y.view(np.uint32))          # however the stream is cut
+    monkeypatch.setenv("TSDGPU_POLY_NO_DIRECT", "1")
+    y2 = tg.PolyFir(tg.POLY_DECIM, dt, h, R).step(x)
+    monkeypatch.delenv("TSDGPU_POLY_NO_DIRECT")
+    if K < 32:
+        assert np.array_equal(y1.view(np.uint32), y2.view(np.uint32))     # the fused kernel's bits (same products, same order)
+    else:
+        assert relerr(y1, y2) <= 1e-6                                      # (32 taps and more used to go by polyphase rows: another order)
+
+
 @pytest.mark.parametrize("cplx", [False, True])
 @pytest.mark.parametrize("K", [15, 17, 31])
 def test_rif_demi_bande(tg, orc, cplx, K):       # test_filtre_rif_demi_bande (test-ra.cc:166-173)
