@@ -289,6 +289,110 @@ __global__ __launch_bounds__(256) void decim_direct_kernel(const T *__restrict__
     if (ob + q < nout) y[ob + q] = L[(q / RO) * SP + (q % RO)];
 }
 
+// ---- upsamplers of rate 2, 4 (filtre_rif_ups: the interpolating stages of filtre_reechan), branches of up to 32 taps: the same scheme with
+// NPH = RU accumulators per position -- y[a RU + i] = sum_k g[i][k] x[a - k]: the RU branches share the lane's register window.  The
+// RS x RU outputs of a lane (contiguous) return through LDS segments of an odd number of 16-B units for coalesced stores.
+// hrev: RU rows of KP reversed, zero-padded branch taps.
+template <typename T, int RS, int RU>
+__global__ __launch_bounds__(256) void ups_direct_kernel(const T *__restrict__ x, const T *__restrict__ hist, T *__restrict__ y,
+                                                         const float *__restrict__ hrev, int KP, int HW, int64_t n, int64_t nout)
+{
+  constexpr int THREADS = 256, TILE = THREADS * RS, VEC = 16 / (int) sizeof(T), P = VEC, SP = RS + P, OS = RS * RU + VEC;
+  extern __shared__ __attribute__((aligned(16))) char du_raw[];
+  T *L = reinterpret_cast<T *>(du_raw);
+  const int64_t tile0 = (int64_t) blockIdx.x * TILE;
+  const int H = KP, total = TILE + H;
+  const bool fast = tile0 - H >= 0 && tile0 + TILE + VEC <= n && ((((uintptr_t) x) & 15) == 0);
+  if (fast) {
+    struct __attribute__((aligned(4))) f4u { float x, y, z, w; };
+    const f4u *xs = reinterpret_cast<const f4u *>(x + (tile0 - H + 1));
+    const int nchunks = (total - 1 + VEC - 1) / VEC;
+    for (int c0 = threadIdx.x; c0 < nchunks; c0 += 4 * THREADS) {
+      f4u q4[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int c = c0 + u * THREADS;
+        if (c < nchunks) q4[u] = xs[c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int c = c0 + u * THREADS;
+        if (c < nchunks) {
+          const int q = c * VEC;
+          *reinterpret_cast<float4 *>(L + q + (q / RS) * P) = make_float4(q4[u].x, q4[u].y, q4[u].z, q4[u].w);
+        }
+      }
+    }
+  } else {
+    for (int s = threadIdx.x + 1; s < total; s += THREADS) {
+      const int64_t g = tile0 - H + (int64_t) s;
+      T v = pf_zero(T{});
+      if (g < 0) {
+        if (g >= -(int64_t) HW) v = hist[HW + g];
+      } else if (g < n) {
+        v = x[g];
+      }
+      const int q = s - 1;
+      L[q + (q / RS) * P] = v;
+    }
+  }
+  __syncthreads();
+  const T *Lw = L + threadIdx.x * SP;
+  T acc[RU][RS], A[RS], B[RS];
+  auto load_seg = [&](T (&dst)[RS], const T *seg) {
+#pragma unroll
+    for (int v4 = 0; v4 < RS / VEC; v4++) {
+      const float4 q4 = *reinterpret_cast<const float4 *>(seg + v4 * VEC);
+      const T *e = reinterpret_cast<const T *>(&q4);
+#pragma unroll
+      for (int k = 0; k < VEC; k++) dst[v4 * VEC + k] = e[k];
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < RU; i++)
+#pragma unroll
+    for (int r = 0; r < RS; r++) acc[i][r] = pf_zero(T{});
+  load_seg(A, Lw);
+  const int nchunk = KP / RS;                                // even by construction
+  for (int c = 0; c < nchunk; c += 2) {
+    load_seg(B, Lw + (c + 1) * SP);
+#pragma unroll
+    for (int jj = 0; jj < RS; jj++)
+#pragma unroll
+      for (int i = 0; i < RU; i++) {
+        const float hv = hrev[i * KP + c * RS + jj];
+#pragma unroll
+        for (int r = 0; r < RS; r++) {
+          const int idx = r + jj;
+          acc[i][r] = pf_mac(acc[i][r], hv, idx < RS ? A[idx] : B[idx - RS]);
+        }
+      }
+    load_seg(A, Lw + (c + 2) * SP);
+#pragma unroll
+    for (int jj = 0; jj < RS; jj++)
+#pragma unroll
+      for (int i = 0; i < RU; i++) {
+        const float hv = hrev[i * KP + (c + 1) * RS + jj];
+#pragma unroll
+        for (int r = 0; r < RS; r++) {
+          const int idx = r + jj;
+          acc[i][r] = pf_mac(acc[i][r], hv, idx < RS ? B[idx] : A[idx - RS]);
+        }
+      }
+  }
+  // the lane's RS x RU outputs, position-major, through LDS
+  __syncthreads();
+  T *Lo = L + threadIdx.x * OS;
+#pragma unroll
+  for (int r = 0; r < RS; r++)
+#pragma unroll
+    for (int i = 0; i < RU; i++) Lo[r * RU + i] = acc[i][r];
+  __syncthreads();
+  const int64_t ob = (int64_t) blockIdx.x * TILE * RU;
+  for (int q = threadIdx.x; q < TILE * RU; q += THREADS)
+    if (ob + q < nout) y[ob + q] = L[(q / (RS * RU)) * OS + (q % (RS * RU))];
+}
+
 // new_hist = last HW samples of (old_hist ++ x[0..n))
 template <typename T>
 __global__ void pf_hist_update_kernel(const T *__restrict__ x, const T *__restrict__ old_hist, T *__restrict__ new_hist, int HW,
@@ -599,14 +703,17 @@ int fused_setup(tsdgpu_polyfir *p, const std::vector<float> &g, int NPH, int W, 
   const size_t hb = ((size_t) p->HW * dtype_size(p->data_type) + 15) / 16 * 16, gb = (g.size() * sizeof(float) + 15) / 16 * 16;
   // decimators of rate 2 / 4 / 8 up to 64 taps: the reversed, padded taps of decim_direct_kernel behind the histories
   const int RSd = p->data_type == TSDGPU_F32 ? 16 : 8;
-  const bool direct = NPH == 1 && (stride == 2 || stride == 4 || stride == 8) && W <= 64 && dev_switch("POLY_NO_DIRECT") == nullptr;
+  // ... and upsamplers of rate 2 / 4 with branches of up to 32 taps (ups_direct_kernel): one such row per branch
+  const bool updir = stride == 1 && (NPH == 2 || NPH == 4) && W <= 32 && dev_switch("POLY_NO_DIRECT") == nullptr;
+  const bool direct = (NPH == 1 && (stride == 2 || stride == 4 || stride == 8) && W <= 64 && dev_switch("POLY_NO_DIRECT") == nullptr) || updir;
   p->KPd = direct ? (int) (cdiv(W, 2 * RSd) * 2 * RSd) : 0;
-  const size_t rb = (size_t) p->KPd * sizeof(float);
+  const size_t rb = (size_t) p->KPd * NPH * sizeof(float);
   std::vector<char> image(gb + 2 * hb + rb, 0);
   std::memcpy(image.data(), g.data(), g.size() * sizeof(float));
   if (direct) {
     float *hr = reinterpret_cast<float *>(image.data() + gb + 2 * hb);
-    for (int k = 0; k < W; k++) hr[p->KPd - 1 - k] = g[k];           // hrev[j] = g[KP - 1 - j]: g[0] meets the newest sample
+    for (int i = 0; i < NPH; i++)
+      for (int k = 0; k < W; k++) hr[(size_t) i * p->KPd + p->KPd - 1 - k] = g[(size_t) i * W + k];   // hrev[j] = g[KP - 1 - j]: g[0] meets the newest sample
   }
   if (hipMalloc((void **) &p->d_g, image.size()) != hipSuccess)
     return set_err(TSDGPU_ERR_HIP, "polyfir_create: hipMalloc failed: %s", hipGetErrorString(hipGetLastError()));
@@ -625,6 +732,25 @@ int fused_setup(tsdgpu_polyfir *p, const std::vector<float> &g, int NPH, int W, 
 template <typename T>
 int fused_step(tsdgpu_polyfir *p, const void *dx, void *dy, int stride, int64_t start, int64_t n, int64_t nout, hipStream_t st)
 {
+  if (nout > 0 && p->d_hrev && p->NPH > 1 && stride == 1) {
+    constexpr int RS = 64 / (int) sizeof(T);
+    const int64_t tiles = cdiv(n, (int64_t) 256 * RS);
+    const int VECs = 16 / (int) sizeof(T);
+    const size_t lds = std::max(((size_t) (256 * RS + p->KPd) / RS + 3) * 80, (size_t) 256 * (RS * p->NPH + VECs) * sizeof(T));
+    if (tiles <= 0x7fffffff) {
+      if (p->NPH == 2) {
+        (void) hipFuncSetAttribute((const void *) ups_direct_kernel<T, RS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL((ups_direct_kernel<T, RS, 2>), dim3((unsigned) tiles), dim3(256), lds, st, (const T *) dx, (const T *) p->d_hist[p->cur], (T *) dy,
+                           p->d_hrev, p->KPd, p->HW, n, nout);
+      } else {
+        (void) hipFuncSetAttribute((const void *) ups_direct_kernel<T, RS, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL((ups_direct_kernel<T, RS, 4>), dim3((unsigned) tiles), dim3(256), lds, st, (const T *) dx, (const T *) p->d_hist[p->cur], (T *) dy,
+                           p->d_hrev, p->KPd, p->HW, n, nout);
+      }
+      TSD_HIP(hipGetLastError());
+      nout = 0;
+    }
+  }
   if (nout > 0 && p->d_hrev && p->NPH == 1) {
     constexpr int RS = 64 / (int) sizeof(T);
     const int64_t tiles = cdiv(nout, (int64_t) 256 * RS / stride);

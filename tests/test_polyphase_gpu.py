@@ -100,6 +100,29 @@ def test_rif_ups(tg, orc, cplx, R):              # test_filtre_rif_ups (test-ra.
     assert len(y) == len(ref) == len(x) * R and relerr(y, ref) <= TOL
 
 
+# upsamplers of rate 2 / 4 with branches of up to 32 taps run on ups_direct_kernel (round 4): tap counts that leave the last branch
+# short, one tap per branch, the 32-tap limit and beyond it (fused kernel), ragged calls, one large call, the fused kernel's bits
+@pytest.mark.parametrize("cplx", [False, True])
+@pytest.mark.parametrize("R,K", [(2, 1), (2, 2), (2, 15), (2, 31), (2, 33), (2, 64), (2, 65), (4, 15), (4, 30), (4, 127), (4, 129)])
+def test_rif_ups_direct_kernel(tg, orc, cplx, R, K, monkeypatch):
+    rng = np.random.default_rng(10 * R + K)
+    h = rng.standard_normal(K).astype(np.float32) / K
+    n = 200000 + 7
+    x = rand(n, cplx, 3 * R + K)
+    dt = tg.C64 if cplx else tg.F32
+    ref = orc.PolyUps(h, R).step(x)
+    f = tg.PolyFir(tg.POLY_UPS, dt, h, R)
+    cuts = [0, 1, 2, 5, 100, 2048, 2049, 6000, 70001, n]
+    y = np.concatenate([f.step(x[a:b].copy()) for a, b in zip(cuts[:-1], cuts[1:])])
+    assert len(y) == len(ref) == n * R and relerr(y, ref) <= TOL
+    y1 = tg.PolyFir(tg.POLY_UPS, dt, h, R).step(x)
+    assert np.array_equal(y1.view(np.uint32), y.view(np.uint32))          # however the stream is cut
+    monkeypatch.setenv("TSDGPU_POLY_NO_DIRECT", "1")
+    y2 = tg.PolyFir(tg.POLY_UPS, dt, h, R).step(x)
+    monkeypatch.delenv("TSDGPU_POLY_NO_DIRECT")
+    assert np.array_equal(y1.view(np.uint32), y2.view(np.uint32))         # the fused kernel's bits (same products, same order)
+
+
 # rates / tap counts beyond the reference's tests: long decimation (fewer outputs per workgroup),
 # a rate the fused kernel hands back to the composed path (R = 100), many-tap branches, tiny chunks
 @pytest.mark.parametrize("cplx", [False, True])
