@@ -24,6 +24,11 @@ def ops():
     p = t.Fft(1000); p.step(x[:1000]); p.close()
     p = t.Fft(1 << 16); p.step(np.tile(x[:16384], 4)); p.close()
     g = t.PolyFir(t.POLY_DECIM, t.C64, h, 3); g.step(x); del g
+    g = t.PolyFir(t.POLY_DECIM, t.C64, h[:15].copy(), 2); g.step(x); del g              # decim_direct_kernel
+    g = t.PolyFir(t.POLY_UPS, t.F32, h[:15].copy(), 2); g.step(xr); del g                # ups_direct_kernel
+    p = t.Fft(1001); p.step(x[:1001]); p.close()                                          # wave-level Bluestein, two waves per transform
+    p = t.Fft(1 << 15, 64); p.step(np.tile(x[:16384], 128).reshape(64, 1 << 15)); p.close()   # 1024 x C plan
+    t.welch(x, 1000, ola_oracle.fen_hann_periodique(1000))
     q = t.Rii(np.array([1, .5, .2, .1], np.float32), np.array([1, -.5, .3, -.1, .05], np.float32), t.F32); q.step(xr); del q
     o = t.Ola(512, 100, None); o.set_response(np.ones(o.N, np.complex64)); o.step(x); del o
     d = t.Detector(x[:64].copy(), 1024, 0, threshold=0.8); d.step(x[:1024].copy()); del d
@@ -33,8 +38,8 @@ def ops():
 import gc
 for _ in range(20): ops()
 gc.collect(); f0 = free()
-for i in range(300): ops()
+for i in range(int(sys.argv[1]) if len(sys.argv) > 1 else 300): ops()
 gc.collect(); f1 = free()
-print("free before", f0 >> 20, "MiB; after 300 rounds", f1 >> 20, "MiB; delta", (f0 - f1) >> 10, "KiB")
+print("free before", f0 >> 20, "MiB; after the rounds", f1 >> 20, "MiB; delta", (f0 - f1) >> 10, "KiB")
 import resource
 print("host maxrss MiB", resource.getrusage(resource.RUSAGE_SELF).ru_maxrss >> 10)
