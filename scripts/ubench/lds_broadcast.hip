@@ -17,7 +17,9 @@ __global__ __launch_bounds__(1024) void k(float *out, int iters)
   if (MODE == 0) off = lane * 4;                             // 64 distinct consecutive 16-B units
   else if (MODE == 1) off = 0;                               // one address
   else if (MODE == 2) off = (lane >> 2) * 4;                 // 16 addresses, 4 lanes each
-  else off = (int) ((h >> 20) & 127) * 124 + 4;              // random rows of pitch 31 x 16 B (odd), same column
+  else if (MODE == 3) off = (int) ((h >> 20) & 127) * 124 + 4;              // random rows of pitch 31 x 16 B (odd), same column
+  else if (MODE == 4) off = (int) (((lane % 21) * 2654435761u >> 20) & 127) * 124 + 4;   // 21 random rows, lanes l, l + 21, l + 42 share one
+  else off = (int) (((lane / 3) * 2654435761u >> 20) & 127) * 124 + 4;                   // 22 random rows, three adjacent lanes share one
   float4 acc = make_float4(0, 0, 0, 0);
   for (int it = 0; it < iters; it++) {
 #pragma unroll
@@ -60,6 +62,8 @@ int main()
   run<1, 1>("one address (broadcast)");
   run<2, 1>("16 addresses x 4 lanes");
   run<3, 1>("random rows (pitch 31 x 16 B)");
+  run<4, 1>("21 random rows, lanes l / l+21 / l+42 share");
+  run<5, 1>("22 random rows, adjacent triples share");
   run<0, 0>("64 distinct units, conflict-free");
   run<1, 0>("one address (broadcast)");
   run<3, 0>("random rows (pitch 31 x 16 B)");
