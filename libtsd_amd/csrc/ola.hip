@@ -794,14 +794,14 @@ __global__ void welch_sum_kernel(const float *__restrict__ part, float *__restri
 
 // ... of rows in transform order: bin i of the result is bin src(i) of the rows (the fftshift map above).  64 bins x 4 row lanes per
 // workgroup (a row lane adds every fourth row, the four sums are added in lane order): N / 64 workgroups instead of N / 256
-__global__ __launch_bounds__(256) void welch_sum_shift_kernel(const float *__restrict__ part, float *__restrict__ S, int N, int groups)
+__global__ __launch_bounds__(256) void welch_sum_shift_kernel(const float *__restrict__ part, float *__restrict__ S, int N, int groups, int shift)
 {
   __shared__ float red[4][64];
   const int c = threadIdx.x & 63, l = threadIdx.x >> 6, i = blockIdx.x * 64 + c;
   float acc = 0.f;
   if (i < N) {
     const int h = N / 2;
-    const int src = i < h ? N - h + i : i - h;
+    const int src = !shift ? i : i < h ? N - h + i : i - h;       // (shift = 0: rows already in fftshift order)
     for (int g = l; g < groups; g += 4) acc += part[(size_t) g * N + src];
   }
   red[l][c] = acc;
@@ -1332,13 +1332,15 @@ int tsdgpu_welch(const void *x, int64_t n, int N, const float *window, float *S,
     const int64_t rows = cdiv(nseg, per);
     // the rows of the waves are summed in two deterministic stages (a single stage would walk thousands of rows from
     // four workgroups)
-    const int rpg = (int) std::max<int64_t>(1, cdiv(rows, 64)), ngr = (int) cdiv(rows, rpg);
+    // (groups of 8 rows over many workgroups, then 4 row lanes per bin: the 64-group form -- 35 rows per thread from 256 workgroups, then
+    // 64 rows per thread from four -- took 27 + 16 us of the call's 118)
+    const int rpg = (int) std::min<int64_t>(64, std::max<int64_t>(8, cdiv(rows, 96))), ngr = (int) cdiv(rows, rpg);
     if (!rc) rc = part.reserve((size_t) (rows + ngr) * N * sizeof(float));
     float *p1 = part.as<float>(), *p2 = p1 + (size_t) rows * N;
     if (!rc) rc = welch1024_launch((const cpx *) dxv, (const float *) dwv, c->tw.as<cpx>(), p1, nseg, per, st);
     if (!rc) {
       hipLaunchKernelGGL(welch_sum_groups_kernel, dim3(nblk(N), (unsigned) ngr), dim3(256), 0, st, p1, p2, N, (int) rows, rpg);
-      hipLaunchKernelGGL(welch_sum_kernel, dim3(nblk(N)), dim3(256), 0, st, p2, (float *) dS, N, ngr);
+      hipLaunchKernelGGL(welch_sum_shift_kernel, dim3((unsigned) cdiv(N, 64)), dim3(256), 0, st, p2, (float *) dS, N, ngr, 0);
       if (hipGetLastError() != hipSuccess) rc = set_err(TSDGPU_ERR_HIP, "welch: launch failed");
     }
     if (!rc) rc = finish_out(S, (size_t) N * sizeof(float), dS, staged, st);
@@ -1371,13 +1373,13 @@ int tsdgpu_welch(const void *x, int64_t n, int N, const float *window, float *S,
     const int64_t places = (int64_t) cus * (g.threads == 256 ? 3 : 1) * g.T;
     const int per = (int) std::min<int64_t>(64, std::max<int64_t>(1, cdiv(nseg, places)));
     const int64_t rows = cdiv(nseg, per);
-    const int rpg = (int) std::max<int64_t>(1, cdiv(rows, 64)), ngr = (int) cdiv(rows, rpg);
+    const int rpg = (int) std::min<int64_t>(64, std::max<int64_t>(8, cdiv(rows, 96))), ngr = (int) cdiv(rows, rpg);
     if (!rc) rc = part.reserve((size_t) (rows + ngr) * N * sizeof(float));
     float *p1 = part.as<float>(), *p2 = p1 + (size_t) rows * N;
     if (!rc) rc = welch_run_launch((const cpx *) dxv, (const float *) dwv, c->tw.as<cpx>(), p1, N, nseg, per, st);
     if (!rc) {
       hipLaunchKernelGGL(welch_sum_groups_kernel, dim3(nblk(N), (unsigned) ngr), dim3(256), 0, st, p1, p2, N, (int) rows, rpg);
-      hipLaunchKernelGGL(welch_sum_kernel, dim3(nblk(N)), dim3(256), 0, st, p2, (float *) dS, N, ngr);
+      hipLaunchKernelGGL(welch_sum_shift_kernel, dim3((unsigned) cdiv(N, 64)), dim3(256), 0, st, p2, (float *) dS, N, ngr, 0);
       if (hipGetLastError() != hipSuccess) rc = set_err(TSDGPU_ERR_HIP, "welch: launch failed");
     }
     if (!rc) rc = finish_out(S, (size_t) N * sizeof(float), dS, staged, st);
@@ -1402,13 +1404,13 @@ int tsdgpu_welch(const void *x, int64_t n, int N, const float *window, float *S,
     if (!multi) rc = fft_blu_framed_launch(plan, (const cpx *) dxv, pas, (const float *) dwv, nseg, nullptr, 0, &rows, st);
     if (!rc && rows > 0) {
       // (one row per workgroup of the persistent grid: a few hundred; groups of 8 rows, then 4 row lanes per bin)
-      const int rpg = 8, ngr = (int) cdiv(rows, rpg);
+      const int rpg = (int) std::min<int64_t>(64, std::max<int64_t>(8, cdiv(rows, 96))), ngr = (int) cdiv(rows, rpg);
       rc = part.reserve((size_t) (rows + ngr) * N * sizeof(float));
       float *p1 = part.as<float>(), *p2 = p1 + (size_t) rows * N;
       if (!rc) rc = fft_blu_framed_launch(plan, (const cpx *) dxv, pas, (const float *) dwv, nseg, p1, rows, &rows, st);
       if (!rc) {
         hipLaunchKernelGGL(welch_sum_groups_kernel, dim3(nblk(N), (unsigned) ngr), dim3(256), 0, st, p1, p2, N, (int) rows, rpg);
-        hipLaunchKernelGGL(welch_sum_shift_kernel, dim3((unsigned) cdiv(N, 64)), dim3(256), 0, st, p2, (float *) dS, N, ngr);
+        hipLaunchKernelGGL(welch_sum_shift_kernel, dim3((unsigned) cdiv(N, 64)), dim3(256), 0, st, p2, (float *) dS, N, ngr, 1);
         if (hipGetLastError() != hipSuccess) rc = set_err(TSDGPU_ERR_HIP, "welch: launch failed");
       }
       if (!rc) rc = finish_out(S, (size_t) N * sizeof(float), dS, staged, st);
