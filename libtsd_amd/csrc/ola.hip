@@ -1328,7 +1328,7 @@ int tsdgpu_welch(const void *x, int64_t n, int N, const float *window, float *S,
         rc = set_err(TSDGPU_ERR_HIP, "welch: table upload failed");
       if (!rc) c->tw_N = 1024;
     }
-    const int per = (int) std::min<int64_t>(64, std::max<int64_t>(1, nseg / 2048));
+    const int per = (int) std::min<int64_t>(64, std::max<int64_t>(1, cdiv(nseg, 2048)));       // (rounded UP: 2048 waves are resident at once; one more is a second, nearly empty round)
     const int64_t rows = cdiv(nseg, per);
     // the rows of the waves are summed in two deterministic stages (a single stage would walk thousands of rows from
     // four workgroups)

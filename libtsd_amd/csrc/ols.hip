@@ -620,7 +620,7 @@ int ola1024_launch(const cpx *x, cpx *y, const cpx *tables3, const cpx *svg_in, 
   if (B <= 0) return TSDGPU_OK;
   // blocks per wave: short calls spread one block per wave (each recomputes its predecessor: twice the arithmetic, all of it
   // parallel); long ones amortise the recomputed block over a run of up to 16
-  const int per = (int) std::min<int64_t>(16, std::max<int64_t>(1, B / 2048));
+  const int per = (int) std::min<int64_t>(16, std::max<int64_t>(1, cdiv(B, 2048)));      // (rounded up: 2048 waves are resident at once)
   const int64_t grid = cdiv(B, per);
   if (grid > 0x7fffffff) return set_err(TSDGPU_ERR_UNSUPPORTED, "ola: too many blocks in one call");
   hipLaunchKernelGGL(ola1024_kernel, dim3((unsigned) grid), dim3(64), 0, st, x, y, tables3, tables3 + 1024, tables3 + 2048, svg_in, svg_out, B, per);
@@ -762,7 +762,7 @@ int olaw512_launch(const cpx *blk0, int nrest, const cpx *x, cpx *y, const cpx *
 {
   if (B <= 0) return TSDGPU_OK;
   // blocks per wave: a run costs per + 2 passes; short calls spread out, long ones amortise the two warm-up passes over 16 blocks
-  const int per = (int) std::min<int64_t>(16, std::max<int64_t>(2, B / 2048));
+  const int per = (int) std::min<int64_t>(16, std::max<int64_t>(2, cdiv(B, 2048)));
   const int64_t grid = cdiv(B, per);
   if (grid > 0x7fffffff) return set_err(TSDGPU_ERR_UNSUPPORTED, "ola: too many blocks in one call");
   hipLaunchKernelGGL(olaw512_kernel, dim3((unsigned) grid), dim3(64), 0, st, blk0, nrest, x, y, tables, tables + 512, tables + 512 + 1024, fen, svg_in,
