@@ -46,7 +46,7 @@ for n in (15, 125, 1001, 2187, 8191, 1000, 3000, 15360, 12345):
         x64 = x.astype(np.complex128)
         f = (np.fft.fft(x64) if fwd else np.fft.ifft(x64) * n) / np.sqrt(n)
         worst = [max(worst[0], rel(g, o)), max(worst[1], rel(o, f)), max(worst[2], rel(g, f))]
-    line(f"fft n = {n} (odd part {n // (n & -n)})", *worst, "2e-5 (test_fft_gpu, test_fft_sweep_gpu, test_fuzz_gpu)")
+    line(f"fft n = {n} (odd part {n // (n & -n)})", *worst, "was 2e-5, now 1e-5 (test_fft_gpu, test_fft_sweep_gpu, test_fuzz_gpu)")
 
 # ---- 2. OLA engine: windowed identity, FiltreFFTRIF through the engine
 Ne = 512
@@ -58,7 +58,7 @@ rw = oo.Ola(Ne, 0, oo.fen_hann_periodique(Ne), lambda X: X)
 yo = rw.step(x)
 d = Ne // 2
 exact = 0.5 * x[:len(y) - d].astype(np.complex128)
-line("ola windowed identity (Hann, Ne = 512): 0.5 x delayed", rel(y[d:], yo[d:]), rel(yo[d:], exact), rel(y[d:], exact), "2e-5 (test_ola_gpu)")
+line("ola windowed identity (Hann, Ne = 512): 0.5 x delayed", rel(y[d:], yo[d:]), rel(yo[d:], exact), rel(y[d:], exact), "was 2e-5, now 1e-5 (test_ola_gpu)")
 for Ne, K in ((512, 127), (1000, 24), (4096, 1025)):
     g = t.Ola(Ne, K, None)
     h = (rng.standard_normal(K) * np.hanning(K)).astype(np.float32)
@@ -72,7 +72,7 @@ for Ne, K in ((512, 127), (1000, 24), (4096, 1025)):
     yo = ro.step(x)
     dd = Ne - K
     f64 = np.convolve(x.astype(np.complex128), h.astype(np.float64))[:len(y) - dd]
-    line(f"filtre_rif_fft through the engine, Ne = {Ne}, K = {K}", rel(y[dd:], yo[dd:]), rel(yo[dd:], f64), rel(y[dd:], f64), "2e-5 (test_ola_gpu)")
+    line(f"filtre_rif_fft through the engine, Ne = {Ne}, K = {K}", rel(y[dd:], yo[dd:]), rel(yo[dd:], f64), rel(y[dd:], f64), "was 2e-5, now 1e-5 (test_ola_gpu)")
 
 # ---- 3. rt_spectrum (linear scale)
 for BS, nsubs, nmeans in ((1024, 1, 10), (4096, 4, 3), (3000, 3, 2)):
@@ -92,7 +92,7 @@ for BS, nsubs, nmeans in ((1024, 1, 10), (4096, 4, 3), (3000, 3, 2)):
     lin64 = acc / (nmeans * nsubs * Nf)
     lin = lambda db: 10.0 ** (db.astype(np.float64) / 10)
     line(f"rt_spectrum BS = {BS}, nsubs = {nsubs}, nmeans = {nmeans} (linear power)", rel(lin(got), lin(want)), rel(lin(want), lin64), rel(lin(got), lin64),
-         "2e-5 (test_spectrum_gpu)")
+         "was 2e-5, now 1e-5 (test_spectrum_gpu)")
 
 # ---- 4. xcorr
 for n, m in ((1000, 1000), (4096, 1), (777, 300)):
@@ -105,7 +105,7 @@ for n, m in ((1000, 1000), (4096, 1), (777, 300)):
     f64 = np.array([np.sum(a64[max(0, l):n + min(0, l)] * np.conj(b64[max(0, -l):n - max(0, l)])) / n for l in lags])
     e_o = min(rel(ro, f64), rel(ro, np.conj(f64[::-1])))
     e_g = min(rel(gg, f64), rel(gg, np.conj(f64[::-1])))
-    line(f"xcorrb n = {n}, m = {m}", rel(gg, ro), e_o, e_g, "2e-5 (test_detect_gpu, test_fuzz_gpu)")
+    line(f"xcorrb n = {n}, m = {m}", rel(gg, ro), e_o, e_g, "was 2e-5, now 1e-5 (test_detect_gpu, test_fuzz_gpu)")
 
 # ---- 5. analytic Lagrange interpolators (taps from the float phase; the K^2 constant divisions of itrp.cc:96-133 folded
 #         into one host-computed reciprocal per tap on the device)
@@ -113,7 +113,7 @@ for deg in (3, 5, 7):
     for ratio in (160.0 / 147.0, 0.77):
         x = crand(60000)
         ref, g = orc.Resampler(ratio, analytic=("lagrange", deg)), t.Resampler(ratio, t.C64, analytic=("lagrange", deg))
-        line(f"lagrange degree {deg}, ratio {ratio:.4f}", rel(g.step(x), ref.step(x)), float("nan"), float("nan"), "5e-5 (test_fuzz_gpu), 1e-5 in test_resample_gpu")
+        line(f"lagrange degree {deg}, ratio {ratio:.4f}", rel(g.step(x), ref.step(x)), float("nan"), float("nan"), "was 5e-5 (test_fuzz_gpu), now 1e-5 as in test_resample_gpu")
 
 # ---- 6. long-memory first-order smoother through FiltreRII (exact carry)
 from scipy.signal import lfilter      # noqa: E402
